@@ -1,0 +1,162 @@
+/*
+ * lagassign.h -- C ABI of the MI355X-native lag-based partition assignor.
+ *
+ * This is the drop-in boundary: the Java host (a ConsumerPartitionAssignor with the
+ * same configure()/name()/assign() surface as the reference) does everything that is
+ * string- or container-shaped and calls these functions through a thin JNI shim
+ * (see INTEGRATION.md).  Everything below is plain pointers and sizes.
+ *
+ * "Main.java:N" =
+ *   reference src/main/java/com/github/grantneale/kafka/LagBasedPartitionAssignor.java:N
+ *
+ * What each entry point replaces:
+ *   la_compute_lag          static long computePartitionLag(...)            Main.java:376-404
+ *   la_assign_batch         readTopicPartitionLags' per-partition lag call  Main.java:344-356
+ *                           + the per-topic loop of assign(Map,Map)         Main.java:177-184
+ *                           + assignTopic (sort + greedy + update)          Main.java:204-266
+ *   la_assign_batch_lags    static assign(Map,Map) on precomputed lags      Main.java:166-188
+ *   la_assign_batch_device  the same two, on buffers already resident in HBM
+ *
+ * Data model (SoA; TopicPartitionLag, Main.java:431-455, flattened):
+ *   topic t owns partitions [part_off[t], part_off[t+1]) of the per-partition arrays and
+ *   consumers  [cons_off[t], cons_off[t+1]) of cons_rank.
+ *
+ *   cons_rank[k] is the subscribing member's rank under java.lang.String.compareTo over
+ *   all memberIds (0 = smallest).  Within one topic's segment the ranks MUST be strictly
+ *   ascending (sorted, de-duplicated); the host does this once per rebalance.  The
+ *   device never sees strings: "lowest memberId" (Main.java:259) == "lowest rank".
+ *
+ * Results, per topic segment, in the order the reference appends them (Main.java:264):
+ *   out_partition[i]    partition id of the i-th assignment (lag desc, id asc)
+ *   out_member_rank[i]  rank of the member that received it (-1: topic has no consumers,
+ *                       Main.java:211-213)
+ *   out_total_lag[k]    final consumerTotalLags of consumer k of that topic
+ *                       (Main.java:265, the value the debug summary prints, :283-291)
+ *
+ * Arithmetic is Java's: 64-bit two's-complement wrap on subtract/add, signed compares.
+ * Results are bit-identical to the reference for every input, including negative lags
+ * and overflowing totals.
+ *
+ * Threading: a la_ctx is single-threaded (one per assignor instance, like the
+ * reference's own non-thread-safe state, Main.java:89).  No global mutable state.
+ * Errors: every function returns LA_OK or a negative code and never throws or aborts;
+ * la_last_error() gives the text.  There is NO CPU fallback in this library: without a
+ * usable gfx950 device la_create fails and the caller (the Java host) decides.
+ */
+#ifndef LAGASSIGN_H
+#define LAGASSIGN_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LA_OK        0
+#define LA_EINVAL   (-1)  /* bad argument (NULL, negative size, unsorted cons_rank, ...) */
+#define LA_ENOMEM   (-2)  /* host or device allocation failed                           */
+#define LA_EHIP     (-3)  /* a HIP runtime call or kernel failed                        */
+#define LA_ENODEV   (-4)  /* no usable gfx950 device                                    */
+#define LA_ESHAPE   (-5)  /* a topic exceeds the shape hint given for a device batch    */
+
+/* auto.offset.reset as the reference reads it (Main.java:391-396): "latest"
+ * (equalsIgnoreCase) -> LA_RESET_LATEST; EVERY other string, "none" included, behaves
+ * as earliest. */
+#define LA_RESET_LATEST   0
+#define LA_RESET_EARLIEST 1
+
+/* committed_off value meaning "no committed offset" (partitionMetadata == null,
+ * Main.java:384).  Any negative value is treated the same; OffsetAndMetadata cannot
+ * hold one. */
+#define LA_NO_COMMITTED (-1)
+
+/* la_device_batch.algo */
+#define LA_ALGO_AUTO    0  /* round-structured greedy (default, fastest)                */
+#define LA_ALGO_ROUNDS  1  /* force the round-structured greedy                         */
+#define LA_ALGO_ARGMIN  2  /* literal per-partition wavefront argmin over the bins      */
+
+typedef struct la_ctx la_ctx;
+
+/* Creates a context on HIP device `device_id` (streams, scratch, kernels). */
+int la_create(la_ctx **out, int device_id, unsigned flags);
+void la_destroy(la_ctx *ctx);
+/* Text of the last error on this context ("" if none).  ctx may be NULL: returns the
+ * text of the last la_create failure on the calling thread. */
+const char *la_last_error(const la_ctx *ctx);
+/* ABI version: major*10000 + minor*100 + patch. */
+int la_version(void);
+
+/* computePartitionLag over n partitions (host buffers).  begin_off may be NULL when
+ * reset_mode == LA_RESET_LATEST.  Main.java:376-404. */
+int la_compute_lag(la_ctx *ctx, int64_t n,
+                   const int64_t *begin_off, const int64_t *end_off,
+                   const int64_t *committed_off, int32_t reset_mode,
+                   int64_t *out_lag);
+
+/* One rebalance: lag from offsets, then sort + greedy per topic.  All pointers are
+ * caller-owned host memory, valid for the duration of the call.  N = part_off[T],
+ * K = cons_off[T].  out_total_lag may be NULL. */
+int la_assign_batch(la_ctx *ctx, int32_t n_topics,
+                    const int64_t *part_off,       /* [T+1]                              */
+                    const int32_t *partition_id,   /* [N]                                */
+                    const int64_t *begin_off,      /* [N]  NULL allowed iff LATEST       */
+                    const int64_t *end_off,        /* [N]                                */
+                    const int64_t *committed_off,  /* [N]  <0 == none                    */
+                    int32_t reset_mode,
+                    const int64_t *cons_off,       /* [T+1]                              */
+                    const int32_t *cons_rank,      /* [K]  ascending within each topic   */
+                    int32_t *out_partition,        /* [N]                                */
+                    int32_t *out_member_rank,      /* [N]                                */
+                    int64_t *out_total_lag);       /* [K]  or NULL                       */
+
+/* Same, on precomputed lags: the static assign(Map,Map) seam the reference's own tests
+ * use (Test.java:127-128).  lag[] may hold any int64, negatives included. */
+int la_assign_batch_lags(la_ctx *ctx, int32_t n_topics,
+                         const int64_t *part_off, const int32_t *partition_id,
+                         const int64_t *lag,
+                         const int64_t *cons_off, const int32_t *cons_rank,
+                         int32_t *out_partition, int32_t *out_member_rank,
+                         int64_t *out_total_lag);
+
+/* A batch whose bulk arrays already live in device memory (HBM). */
+typedef struct la_device_batch {
+    int32_t n_topics;
+    int32_t reset_mode;
+    int32_t algo;                    /* LA_ALGO_*                                        */
+    int32_t reserved;
+    int64_t n_partitions;            /* N                                                */
+    int64_t n_consumers;             /* K                                                */
+    /* Shape hint: upper bounds over the batch.  A topic that exceeds them is reported
+     * as LA_ESHAPE by la_sync(); nothing is written for it. */
+    int64_t max_partitions_per_topic;
+    int64_t max_consumers_per_topic;
+    /* device pointers */
+    const int64_t *d_part_off;       /* [T+1]                                            */
+    const int32_t *d_partition_id;   /* [N]                                              */
+    const int64_t *d_begin_off;      /* [N] or NULL (LATEST only)                        */
+    const int64_t *d_end_off;        /* [N] (ignored when d_lag != NULL)                 */
+    const int64_t *d_committed_off;  /* [N] (ignored when d_lag != NULL)                 */
+    const int64_t *d_lag;            /* [N] or NULL: precomputed lags instead of offsets */
+    const int64_t *d_cons_off;       /* [T+1]                                            */
+    const int32_t *d_cons_rank;      /* [K]                                              */
+    int32_t *d_out_partition;        /* [N]                                              */
+    int32_t *d_out_member_rank;      /* [N]                                              */
+    int64_t *d_out_total_lag;        /* [K] or NULL                                      */
+    /* host copies of the two offset arrays; required only when the shape hint exceeds
+     * what one wavefront tile holds (1024 partitions or 64 consumers per topic), where
+     * topics are dispatched one by one.  NULL otherwise. */
+    const int64_t *h_part_off;
+    const int64_t *h_cons_off;
+} la_device_batch;
+
+/* Enqueues the whole batch on `stream` (a hipStream_t; NULL = the context's own
+ * stream) and returns without waiting.  Device-detected errors surface in la_sync. */
+int la_assign_batch_device(la_ctx *ctx, const la_device_batch *batch, void *stream);
+
+/* Waits for `stream` and returns LA_OK or the first device-detected error. */
+int la_sync(la_ctx *ctx, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LAGASSIGN_H */

@@ -1,0 +1,181 @@
+"""ctypes binding of the C ABI in include/lagassign.h (liblagassign.so).
+
+This is the same boundary a JNI shim binds.  There is no fallback: if
+the shared object is missing or no gfx950 device is usable, calls raise.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from typing import Optional, Tuple
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liblagassign.so")
+
+LA_OK = 0
+LA_EINVAL, LA_ENOMEM, LA_EHIP, LA_ENODEV, LA_ESHAPE = -1, -2, -3, -4, -5
+LA_RESET_LATEST, LA_RESET_EARLIEST = 0, 1
+LA_ALGO_AUTO, LA_ALGO_ROUNDS, LA_ALGO_ARGMIN = 0, 1, 2
+
+EXPORTED_SYMBOLS = (
+    "la_create", "la_destroy", "la_last_error", "la_version", "la_compute_lag",
+    "la_assign_batch", "la_assign_batch_lags", "la_assign_batch_device", "la_sync",
+)
+
+_i64p = ctypes.POINTER(ctypes.c_int64)
+_i32p = ctypes.POINTER(ctypes.c_int32)
+
+
+class LagAssignError(RuntimeError):
+    def __init__(self, code: int, message: str):
+        super().__init__("liblagassign error %d: %s" % (code, message))
+        self.code = code
+
+
+class DeviceBatch(ctypes.Structure):
+    """struct la_device_batch"""
+    _fields_ = [
+        ("n_topics", ctypes.c_int32), ("reset_mode", ctypes.c_int32),
+        ("algo", ctypes.c_int32), ("reserved", ctypes.c_int32),
+        ("n_partitions", ctypes.c_int64), ("n_consumers", ctypes.c_int64),
+        ("max_partitions_per_topic", ctypes.c_int64), ("max_consumers_per_topic", ctypes.c_int64),
+        ("d_part_off", ctypes.c_void_p), ("d_partition_id", ctypes.c_void_p),
+        ("d_begin_off", ctypes.c_void_p), ("d_end_off", ctypes.c_void_p),
+        ("d_committed_off", ctypes.c_void_p), ("d_lag", ctypes.c_void_p),
+        ("d_cons_off", ctypes.c_void_p), ("d_cons_rank", ctypes.c_void_p),
+        ("d_out_partition", ctypes.c_void_p), ("d_out_member_rank", ctypes.c_void_p),
+        ("d_out_total_lag", ctypes.c_void_p),
+        ("h_part_off", _i64p), ("h_cons_off", _i64p),
+    ]
+
+
+_lib: Optional[ctypes.CDLL] = None
+
+
+def load() -> ctypes.CDLL:
+    """Loads liblagassign.so; raises if it has not been built (no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "%s is missing: build it with `python -m kafka_lag_based_assignor_amd.build` "
+            "(needs hipcc). There is no CPU fallback." % LIB_PATH)
+    L = ctypes.CDLL(LIB_PATH)
+    L.la_version.restype = ctypes.c_int
+    L.la_create.restype = ctypes.c_int
+    L.la_create.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, ctypes.c_uint]
+    L.la_destroy.restype = None
+    L.la_destroy.argtypes = [ctypes.c_void_p]
+    L.la_last_error.restype = ctypes.c_char_p
+    L.la_last_error.argtypes = [ctypes.c_void_p]
+    L.la_compute_lag.restype = ctypes.c_int
+    L.la_compute_lag.argtypes = [ctypes.c_void_p, ctypes.c_int64, _i64p, _i64p, _i64p, ctypes.c_int32, _i64p]
+    L.la_assign_batch.restype = ctypes.c_int
+    L.la_assign_batch.argtypes = [ctypes.c_void_p, ctypes.c_int32, _i64p, _i32p, _i64p, _i64p, _i64p,
+                                  ctypes.c_int32, _i64p, _i32p, _i32p, _i32p, _i64p]
+    L.la_assign_batch_lags.restype = ctypes.c_int
+    L.la_assign_batch_lags.argtypes = [ctypes.c_void_p, ctypes.c_int32, _i64p, _i32p, _i64p, _i64p, _i32p,
+                                       _i32p, _i32p, _i64p]
+    L.la_assign_batch_device.restype = ctypes.c_int
+    L.la_assign_batch_device.argtypes = [ctypes.c_void_p, ctypes.POINTER(DeviceBatch), ctypes.c_void_p]
+    L.la_sync.restype = ctypes.c_int
+    L.la_sync.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+    _lib = L
+    return L
+
+
+def _a64(x) -> np.ndarray:
+    return np.ascontiguousarray(x, dtype=np.int64)
+
+
+def _a32(x) -> np.ndarray:
+    return np.ascontiguousarray(x, dtype=np.int32)
+
+
+def _p64(a: Optional[np.ndarray]):
+    return None if a is None else a.ctypes.data_as(_i64p)
+
+
+def _p32(a: Optional[np.ndarray]):
+    return None if a is None else a.ctypes.data_as(_i32p)
+
+
+class Context:
+    """RAII wrapper of la_ctx (one per assignor instance; not thread-safe)."""
+
+    def __init__(self, device_id: int = 0):
+        self._lib = load()
+        h = ctypes.c_void_p()
+        rc = self._lib.la_create(ctypes.byref(h), device_id, 0)
+        if rc != LA_OK:
+            raise LagAssignError(rc, self._lib.la_last_error(None).decode())
+        self._h = h
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            self._lib.la_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def _check(self, rc: int) -> None:
+        if rc != LA_OK:
+            raise LagAssignError(rc, self._lib.la_last_error(self._h).decode())
+
+    # -- host-buffer entry points ------------------------------------------------
+    def compute_lag(self, begin, end, committed, reset_mode: int) -> np.ndarray:
+        end, committed = _a64(end), _a64(committed)
+        begin = None if begin is None else _a64(begin)
+        out = np.empty_like(end)
+        self._check(self._lib.la_compute_lag(self._h, end.size, _p64(begin), _p64(end), _p64(committed),
+                                             reset_mode, _p64(out)))
+        return out
+
+    def assign_batch(self, part_off, partition_id, begin, end, committed, reset_mode: int,
+                     cons_off, cons_rank, want_totals: bool = True
+                     ) -> Tuple[np.ndarray, np.ndarray, Optional[np.ndarray]]:
+        part_off, cons_off = _a64(part_off), _a64(cons_off)
+        partition_id, cons_rank = _a32(partition_id), _a32(cons_rank)
+        end, committed = _a64(end), _a64(committed)
+        begin = None if begin is None else _a64(begin)
+        out_p = np.empty(partition_id.size, dtype=np.int32)
+        out_m = np.empty(partition_id.size, dtype=np.int32)
+        out_t = np.zeros(cons_rank.size, dtype=np.int64) if want_totals else None
+        self._check(self._lib.la_assign_batch(self._h, part_off.size - 1, _p64(part_off), _p32(partition_id),
+                                              _p64(begin), _p64(end), _p64(committed), reset_mode,
+                                              _p64(cons_off), _p32(cons_rank), _p32(out_p), _p32(out_m),
+                                              _p64(out_t)))
+        return out_p, out_m, out_t
+
+    def assign_batch_lags(self, part_off, partition_id, lag, cons_off, cons_rank, want_totals: bool = True
+                          ) -> Tuple[np.ndarray, np.ndarray, Optional[np.ndarray]]:
+        part_off, cons_off = _a64(part_off), _a64(cons_off)
+        partition_id, cons_rank, lag = _a32(partition_id), _a32(cons_rank), _a64(lag)
+        out_p = np.empty(partition_id.size, dtype=np.int32)
+        out_m = np.empty(partition_id.size, dtype=np.int32)
+        out_t = np.zeros(cons_rank.size, dtype=np.int64) if want_totals else None
+        self._check(self._lib.la_assign_batch_lags(self._h, part_off.size - 1, _p64(part_off),
+                                                   _p32(partition_id), _p64(lag), _p64(cons_off),
+                                                   _p32(cons_rank), _p32(out_p), _p32(out_m), _p64(out_t)))
+        return out_p, out_m, out_t
+
+    # -- device-resident entry point ------------------------------------------------
+    def assign_batch_device(self, batch: DeviceBatch, stream: int = 0) -> None:
+        self._check(self._lib.la_assign_batch_device(self._h, ctypes.byref(batch),
+                                                     ctypes.c_void_p(stream) if stream else None))
+
+    def sync(self, stream: int = 0) -> None:
+        self._check(self._lib.la_sync(self._h, ctypes.c_void_p(stream) if stream else None))

@@ -1,0 +1,406 @@
+// la_api.hip -- the C ABI of include/lagassign.h over the HIP kernels.
+//
+// There is no CPU fallback here by design: if the device or a kernel is unavailable the
+// call fails with a negative code and the caller decides what to do.
+#include "../../include/lagassign.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "la_kernels.h"
+
+#define LA_API extern "C" __attribute__((visibility("default")))
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+};
+
+}  // namespace
+
+struct la_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    uint32_t* d_status = nullptr;
+    std::string err;
+    // grow-only device scratch for the host-buffer entry points
+    DevBuf part_off, pid, begin, end, committed, cons_off, cons_rank, out_pid, out_rank, out_total;
+    // scratch of the large-topic path
+    la::LargeScratch large;
+};
+
+namespace {
+
+int fail(la_ctx* ctx, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (ctx) ctx->err = buf; else g_create_error = buf;
+    return code;
+}
+
+#define LA_HIP(ctx, expr)                                                                    \
+    do {                                                                                     \
+        hipError_t e_ = (expr);                                                              \
+        if (e_ != hipSuccess)                                                                \
+            return fail(ctx, e_ == hipErrorOutOfMemory ? LA_ENOMEM : LA_EHIP, "%s: %s", #expr, \
+                        hipGetErrorString(e_));                                              \
+    } while (0)
+
+int reserve(la_ctx* ctx, DevBuf& b, size_t bytes) {
+    if (bytes <= b.cap) return LA_OK;
+    if (b.p) { LA_HIP(ctx, hipFree(b.p)); b.p = nullptr; b.cap = 0; }
+    size_t want = bytes + bytes / 4 + 256;
+    LA_HIP(ctx, hipMalloc(&b.p, want));
+    b.cap = want;
+    return LA_OK;
+}
+
+void release(DevBuf& b) {
+    if (b.p) (void)hipFree(b.p);
+    b.p = nullptr;
+    b.cap = 0;
+}
+
+struct Shape {
+    int64_t n = 0, k = 0, max_p = 0, max_c = 0;
+};
+
+// Validates offsets (and, if given, the ascending-rank contract) on the host.
+int scan_shape(la_ctx* ctx, int32_t T, const int64_t* part_off, const int64_t* cons_off,
+               const int32_t* cons_rank, Shape* s) {
+    if (part_off[0] != 0 || cons_off[0] != 0) return fail(ctx, LA_EINVAL, "part_off[0] and cons_off[0] must be 0");
+    for (int32_t t = 0; t < T; ++t) {
+        const int64_t p = part_off[t + 1] - part_off[t], c = cons_off[t + 1] - cons_off[t];
+        if (p < 0 || c < 0) return fail(ctx, LA_EINVAL, "offsets of topic %d decrease", t);
+        if (p > s->max_p) s->max_p = p;
+        if (c > s->max_c) s->max_c = c;
+        if (cons_rank)
+            for (int64_t k = cons_off[t] + 1; k < cons_off[t + 1]; ++k)
+                if (cons_rank[k - 1] >= cons_rank[k])
+                    return fail(ctx, LA_EINVAL,
+                                "cons_rank of topic %d is not strictly ascending at %lld", t, (long long)k);
+    }
+    s->n = part_off[T];
+    s->k = cons_off[T];
+    return LA_OK;
+}
+
+// The dispatcher shared by the host and device entry points.
+int enqueue_batch(la_ctx* ctx, const la_device_batch* b, hipStream_t stream) {
+    if (b->n_topics < 0 || b->n_partitions < 0 || b->n_consumers < 0)
+        return fail(ctx, LA_EINVAL, "negative size");
+    if (b->n_topics == 0) return LA_OK;
+    if (!b->d_part_off || !b->d_cons_off || !b->d_out_partition || !b->d_out_member_rank)
+        return fail(ctx, LA_EINVAL, "null offsets or outputs");
+    if (b->n_partitions > 0 && (!b->d_partition_id || (!b->d_lag && (!b->d_end_off || !b->d_committed_off))))
+        return fail(ctx, LA_EINVAL, "null per-partition input");
+    if (b->n_consumers > 0 && !b->d_cons_rank) return fail(ctx, LA_EINVAL, "null cons_rank");
+    if (!b->d_lag && b->reset_mode != LA_RESET_LATEST && !b->d_begin_off && b->n_partitions > 0)
+        return fail(ctx, LA_EINVAL, "begin_off is required unless reset_mode is LA_RESET_LATEST");
+    if (b->algo != LA_ALGO_AUTO && b->algo != LA_ALGO_ROUNDS && b->algo != LA_ALGO_ARGMIN)
+        return fail(ctx, LA_EINVAL, "unknown algo %d", b->algo);
+
+    la::TileArgs a{};
+    a.n_topics = b->n_topics;
+    a.part_off = b->d_part_off;
+    a.pid = b->d_partition_id;
+    a.begin = b->d_begin_off;
+    a.end = b->d_end_off;
+    a.committed = b->d_committed_off;
+    a.lag = b->d_lag;
+    a.cons_off = b->d_cons_off;
+    a.cons_rank = b->d_cons_rank;
+    a.out_pid = b->d_out_partition;
+    a.out_rank = b->d_out_member_rank;
+    a.out_total = b->d_out_total_lag;
+    a.status = ctx->d_status;
+    a.reset_latest = (b->reset_mode == LA_RESET_LATEST) ? 1 : 0;
+    const bool argmin = (b->algo == LA_ALGO_ARGMIN);
+
+    if (la::wave_tile_fits(b->max_partitions_per_topic, b->max_consumers_per_topic)) {
+        LA_HIP(ctx, la::wave_tile_launch(a, b->max_partitions_per_topic, b->max_consumers_per_topic, argmin, stream));
+        return LA_OK;
+    }
+
+    // Mixed or large shapes: walk the topics on the host.  Runs of tile-sized topics go to
+    // the wave-tile kernel in one launch each; every larger topic takes the large path.
+    if (!b->h_part_off || !b->h_cons_off)
+        return fail(ctx, LA_EINVAL,
+                    "shape hint exceeds one wave tile (%lld partitions / %lld consumers per topic): "
+                    "h_part_off and h_cons_off are required",
+                    (long long)la::kTileMaxPartitions, (long long)la::kTileMaxConsumers);
+    const int64_t T = b->n_topics;
+    int64_t t = 0;
+    while (t < T) {
+        auto psize = [&](int64_t i) { return b->h_part_off[i + 1] - b->h_part_off[i]; };
+        auto csize = [&](int64_t i) { return b->h_cons_off[i + 1] - b->h_cons_off[i]; };
+        if (la::wave_tile_fits(psize(t), csize(t))) {
+            int64_t u = t, mp = 0, mc = 0;
+            while (u < T && la::wave_tile_fits(psize(u), csize(u))) {
+                if (psize(u) > mp) mp = psize(u);
+                if (csize(u) > mc) mc = csize(u);
+                ++u;
+            }
+            la::TileArgs run = a;
+            run.n_topics = u - t;
+            run.part_off = b->d_part_off + t;
+            run.cons_off = b->d_cons_off + t;
+            LA_HIP(ctx, la::wave_tile_launch(run, mp, mc, argmin, stream));
+            t = u;
+        } else {
+            la::LargeArgs g{};
+            g.p0 = b->h_part_off[t];
+            g.n_part = psize(t);
+            g.c0 = b->h_cons_off[t];
+            g.n_cons = csize(t);
+            g.pid = b->d_partition_id;
+            g.begin = b->d_begin_off;
+            g.end = b->d_end_off;
+            g.committed = b->d_committed_off;
+            g.lag = b->d_lag;
+            g.cons_rank = b->d_cons_rank;
+            g.out_pid = b->d_out_partition;
+            g.out_rank = b->d_out_member_rank;
+            g.out_total = b->d_out_total_lag;
+            g.reset_latest = a.reset_latest;
+            g.status = ctx->d_status;
+            hipError_t e = la::large_topic_launch(ctx->large, g, argmin, stream);
+            if (e != hipSuccess)
+                return fail(ctx, e == hipErrorOutOfMemory ? LA_ENOMEM : LA_EHIP, "large topic %lld: %s",
+                            (long long)t, hipGetErrorString(e));
+            ++t;
+        }
+    }
+    return LA_OK;
+}
+
+int sync_status(la_ctx* ctx, hipStream_t stream) {
+    LA_HIP(ctx, hipStreamSynchronize(stream));
+    uint32_t st = 0;
+    LA_HIP(ctx, hipMemcpy(&st, ctx->d_status, sizeof st, hipMemcpyDeviceToHost));
+    if (st) {
+        LA_HIP(ctx, hipMemset(ctx->d_status, 0, sizeof st));
+        if (st & la::kStatusUnsorted)
+            return fail(ctx, LA_EINVAL, "a topic's cons_rank segment is not strictly ascending");
+        return fail(ctx, LA_ESHAPE, "a topic exceeds the batch's shape hint");
+    }
+    return LA_OK;
+}
+
+int assign_host(la_ctx* ctx, int32_t T, const int64_t* part_off, const int32_t* pid, const int64_t* begin,
+                const int64_t* end, const int64_t* committed, const int64_t* lag, int32_t reset_mode,
+                const int64_t* cons_off, const int32_t* cons_rank, int32_t* out_pid, int32_t* out_rank,
+                int64_t* out_total) {
+    if (!ctx) return LA_EINVAL;
+    if (T < 0) return fail(ctx, LA_EINVAL, "n_topics < 0");
+    if (T == 0) return LA_OK;
+    if (!part_off || !cons_off) return fail(ctx, LA_EINVAL, "null offsets");
+    Shape s;
+    if (int rc = scan_shape(ctx, T, part_off, cons_off, cons_rank, &s)) return rc;
+    if (s.n > 0 && (!pid || !out_pid || !out_rank || (!lag && (!end || !committed))))
+        return fail(ctx, LA_EINVAL, "null per-partition buffer");
+    if (s.k > 0 && !cons_rank) return fail(ctx, LA_EINVAL, "null cons_rank");
+    if (!lag && reset_mode != LA_RESET_LATEST && !begin && s.n > 0)
+        return fail(ctx, LA_EINVAL, "begin_off is required unless reset_mode is LA_RESET_LATEST");
+    LA_HIP(ctx, hipSetDevice(ctx->device));
+
+    const size_t nb8 = (size_t)s.n * 8, nb4 = (size_t)s.n * 4, kb8 = (size_t)s.k * 8, kb4 = (size_t)s.k * 4;
+    const size_t tb = (size_t)(T + 1) * 8;
+    const bool use_begin = !lag && begin && reset_mode != LA_RESET_LATEST;
+    int rc;
+    if ((rc = reserve(ctx, ctx->part_off, tb)) || (rc = reserve(ctx, ctx->cons_off, tb)) ||
+        (rc = reserve(ctx, ctx->pid, nb4 + 16)) || (rc = reserve(ctx, ctx->end, nb8 + 16)) ||
+        (rc = reserve(ctx, ctx->committed, lag ? 16 : nb8 + 16)) ||
+        (rc = reserve(ctx, ctx->begin, use_begin ? nb8 + 16 : 16)) ||
+        (rc = reserve(ctx, ctx->cons_rank, kb4 + 16)) || (rc = reserve(ctx, ctx->out_pid, nb4 + 16)) ||
+        (rc = reserve(ctx, ctx->out_rank, nb4 + 16)) || (rc = reserve(ctx, ctx->out_total, kb8 + 16)))
+        return rc;
+
+    hipStream_t st = ctx->stream;
+    LA_HIP(ctx, hipMemcpyAsync(ctx->part_off.p, part_off, tb, hipMemcpyHostToDevice, st));
+    LA_HIP(ctx, hipMemcpyAsync(ctx->cons_off.p, cons_off, tb, hipMemcpyHostToDevice, st));
+    if (s.n) LA_HIP(ctx, hipMemcpyAsync(ctx->pid.p, pid, nb4, hipMemcpyHostToDevice, st));
+    if (s.k) LA_HIP(ctx, hipMemcpyAsync(ctx->cons_rank.p, cons_rank, kb4, hipMemcpyHostToDevice, st));
+    if (s.n) {
+        if (lag) {
+            LA_HIP(ctx, hipMemcpyAsync(ctx->end.p, lag, nb8, hipMemcpyHostToDevice, st));
+        } else {
+            LA_HIP(ctx, hipMemcpyAsync(ctx->end.p, end, nb8, hipMemcpyHostToDevice, st));
+            LA_HIP(ctx, hipMemcpyAsync(ctx->committed.p, committed, nb8, hipMemcpyHostToDevice, st));
+            if (use_begin) LA_HIP(ctx, hipMemcpyAsync(ctx->begin.p, begin, nb8, hipMemcpyHostToDevice, st));
+        }
+    }
+
+    la_device_batch b{};
+    b.n_topics = T;
+    b.reset_mode = reset_mode == LA_RESET_LATEST ? LA_RESET_LATEST : LA_RESET_EARLIEST;
+    b.algo = LA_ALGO_AUTO;
+    b.n_partitions = s.n;
+    b.n_consumers = s.k;
+    b.max_partitions_per_topic = s.max_p;
+    b.max_consumers_per_topic = s.max_c;
+    b.d_part_off = (const int64_t*)ctx->part_off.p;
+    b.d_partition_id = (const int32_t*)ctx->pid.p;
+    b.d_begin_off = use_begin ? (const int64_t*)ctx->begin.p : nullptr;
+    b.d_end_off = (const int64_t*)ctx->end.p;
+    b.d_committed_off = (const int64_t*)ctx->committed.p;
+    b.d_lag = lag ? (const int64_t*)ctx->end.p : nullptr;
+    b.d_cons_off = (const int64_t*)ctx->cons_off.p;
+    b.d_cons_rank = (const int32_t*)ctx->cons_rank.p;
+    b.d_out_partition = (int32_t*)ctx->out_pid.p;
+    b.d_out_member_rank = (int32_t*)ctx->out_rank.p;
+    b.d_out_total_lag = out_total ? (int64_t*)ctx->out_total.p : nullptr;
+    b.h_part_off = part_off;
+    b.h_cons_off = cons_off;
+    if ((rc = enqueue_batch(ctx, &b, st))) return rc;
+
+    if (s.n) {
+        LA_HIP(ctx, hipMemcpyAsync(out_pid, ctx->out_pid.p, nb4, hipMemcpyDeviceToHost, st));
+        LA_HIP(ctx, hipMemcpyAsync(out_rank, ctx->out_rank.p, nb4, hipMemcpyDeviceToHost, st));
+    }
+    if (out_total && s.k) LA_HIP(ctx, hipMemcpyAsync(out_total, ctx->out_total.p, kb8, hipMemcpyDeviceToHost, st));
+    return sync_status(ctx, st);
+}
+
+}  // namespace
+
+// ---- C ABI --------------------------------------------------------------------------------------
+LA_API int la_version(void) { return 100; }   // 0.1.0
+
+LA_API const char* la_last_error(const la_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+LA_API int la_create(la_ctx** out, int device_id, unsigned flags) {
+    (void)flags;
+    if (!out) return fail(nullptr, LA_EINVAL, "out is NULL");
+    *out = nullptr;
+    try {
+        int count = 0;
+        hipError_t e = hipGetDeviceCount(&count);
+        if (e != hipSuccess || count <= 0)
+            return fail(nullptr, LA_ENODEV, "no HIP device (%s)", e == hipSuccess ? "count = 0" : hipGetErrorString(e));
+        if (device_id < 0 || device_id >= count) return fail(nullptr, LA_ENODEV, "device %d of %d", device_id, count);
+        hipDeviceProp_t prop;
+        if ((e = hipGetDeviceProperties(&prop, device_id)) != hipSuccess)
+            return fail(nullptr, LA_EHIP, "hipGetDeviceProperties: %s", hipGetErrorString(e));
+        if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+            return fail(nullptr, LA_ENODEV, "device %d is %s; this library is built for gfx950 only", device_id,
+                        prop.gcnArchName);
+        la_ctx* ctx = new (std::nothrow) la_ctx();
+        if (!ctx) return fail(nullptr, LA_ENOMEM, "out of host memory");
+        ctx->device = device_id;
+        if ((e = hipSetDevice(device_id)) != hipSuccess ||
+            (e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess ||
+            (e = hipMalloc((void**)&ctx->d_status, 256)) != hipSuccess ||
+            (e = hipMemset(ctx->d_status, 0, 256)) != hipSuccess) {
+            int rc = fail(nullptr, LA_EHIP, "context setup: %s", hipGetErrorString(e));
+            la_destroy(ctx);
+            return rc;
+        }
+        *out = ctx;
+        return LA_OK;
+    } catch (...) {
+        return fail(nullptr, LA_ENOMEM, "exception in la_create");
+    }
+}
+
+LA_API void la_destroy(la_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    for (DevBuf* b : {&ctx->part_off, &ctx->pid, &ctx->begin, &ctx->end, &ctx->committed, &ctx->cons_off,
+                      &ctx->cons_rank, &ctx->out_pid, &ctx->out_rank, &ctx->out_total})
+        release(*b);
+    la::large_scratch_release(ctx->large);
+    if (ctx->d_status) (void)hipFree(ctx->d_status);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+LA_API int la_compute_lag(la_ctx* ctx, int64_t n, const int64_t* begin_off, const int64_t* end_off,
+                          const int64_t* committed_off, int32_t reset_mode, int64_t* out_lag) {
+    if (!ctx) return LA_EINVAL;
+    try {
+        if (n < 0) return fail(ctx, LA_EINVAL, "n < 0");
+        if (n == 0) return LA_OK;
+        if (!end_off || !committed_off || !out_lag) return fail(ctx, LA_EINVAL, "null buffer");
+        const bool latest = reset_mode == LA_RESET_LATEST;
+        if (!latest && !begin_off) return fail(ctx, LA_EINVAL, "begin_off is required unless reset_mode is LA_RESET_LATEST");
+        LA_HIP(ctx, hipSetDevice(ctx->device));
+        const size_t nb = (size_t)n * 8;
+        int rc;
+        if ((rc = reserve(ctx, ctx->end, nb)) || (rc = reserve(ctx, ctx->committed, nb)) ||
+            (rc = reserve(ctx, ctx->begin, latest ? 16 : nb)) || (rc = reserve(ctx, ctx->out_total, nb)))
+            return rc;
+        hipStream_t st = ctx->stream;
+        LA_HIP(ctx, hipMemcpyAsync(ctx->end.p, end_off, nb, hipMemcpyHostToDevice, st));
+        LA_HIP(ctx, hipMemcpyAsync(ctx->committed.p, committed_off, nb, hipMemcpyHostToDevice, st));
+        if (!latest) LA_HIP(ctx, hipMemcpyAsync(ctx->begin.p, begin_off, nb, hipMemcpyHostToDevice, st));
+        LA_HIP(ctx, la::lag_launch(n, latest ? nullptr : (const int64_t*)ctx->begin.p, (const int64_t*)ctx->end.p,
+                                   (const int64_t*)ctx->committed.p, latest, (int64_t*)ctx->out_total.p, st));
+        LA_HIP(ctx, hipMemcpyAsync(out_lag, ctx->out_total.p, nb, hipMemcpyDeviceToHost, st));
+        LA_HIP(ctx, hipStreamSynchronize(st));
+        return LA_OK;
+    } catch (...) {
+        return fail(ctx, LA_ENOMEM, "exception in la_compute_lag");
+    }
+}
+
+LA_API int la_assign_batch(la_ctx* ctx, int32_t n_topics, const int64_t* part_off, const int32_t* partition_id,
+                           const int64_t* begin_off, const int64_t* end_off, const int64_t* committed_off,
+                           int32_t reset_mode, const int64_t* cons_off, const int32_t* cons_rank,
+                           int32_t* out_partition, int32_t* out_member_rank, int64_t* out_total_lag) {
+    try {
+        return assign_host(ctx, n_topics, part_off, partition_id, begin_off, end_off, committed_off, nullptr,
+                           reset_mode, cons_off, cons_rank, out_partition, out_member_rank, out_total_lag);
+    } catch (...) {
+        return ctx ? fail(ctx, LA_ENOMEM, "exception in la_assign_batch") : LA_EINVAL;
+    }
+}
+
+LA_API int la_assign_batch_lags(la_ctx* ctx, int32_t n_topics, const int64_t* part_off, const int32_t* partition_id,
+                                const int64_t* lag, const int64_t* cons_off, const int32_t* cons_rank,
+                                int32_t* out_partition, int32_t* out_member_rank, int64_t* out_total_lag) {
+    try {
+        if (ctx && !lag && n_topics > 0 && part_off && part_off[n_topics] > 0)
+            return fail(ctx, LA_EINVAL, "lag is NULL");
+        static const int64_t dummy = 0;
+        return assign_host(ctx, n_topics, part_off, partition_id, nullptr, nullptr, nullptr, lag ? lag : &dummy,
+                           LA_RESET_LATEST, cons_off, cons_rank, out_partition, out_member_rank, out_total_lag);
+    } catch (...) {
+        return ctx ? fail(ctx, LA_ENOMEM, "exception in la_assign_batch_lags") : LA_EINVAL;
+    }
+}
+
+LA_API int la_assign_batch_device(la_ctx* ctx, const la_device_batch* batch, void* stream) {
+    if (!ctx) return LA_EINVAL;
+    try {
+        if (!batch) return fail(ctx, LA_EINVAL, "batch is NULL");
+        LA_HIP(ctx, hipSetDevice(ctx->device));
+        return enqueue_batch(ctx, batch, stream ? (hipStream_t)stream : ctx->stream);
+    } catch (...) {
+        return fail(ctx, LA_ENOMEM, "exception in la_assign_batch_device");
+    }
+}
+
+LA_API int la_sync(la_ctx* ctx, void* stream) {
+    if (!ctx) return LA_EINVAL;
+    try {
+        LA_HIP(ctx, hipSetDevice(ctx->device));
+        return sync_status(ctx, stream ? (hipStream_t)stream : ctx->stream);
+    } catch (...) {
+        return fail(ctx, LA_ENOMEM, "exception in la_sync");
+    }
+}

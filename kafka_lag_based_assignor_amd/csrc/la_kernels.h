@@ -1,0 +1,71 @@
+// la_kernels.h -- host-visible declarations of the kernel launchers (internal to the library).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace la {
+
+// device status word bits (la_ctx::d_status)
+constexpr uint32_t kStatusShape = 1u;      // a topic exceeded the shape hint
+constexpr uint32_t kStatusUnsorted = 2u;   // a topic's cons_rank segment is not strictly ascending
+
+constexpr int64_t kTileMaxPartitions = 1024;   // 64 lanes x 16 records
+constexpr int64_t kTileMaxConsumers = 64;      // one consumer bin per lane
+
+// Arguments of the fused wave-tile kernel (all device pointers).
+struct TileArgs {
+    int64_t n_topics;
+    const int64_t* part_off;
+    const int32_t* pid;
+    const int64_t* begin;       // may be null (treated as 0; only read when !reset_latest)
+    const int64_t* end;
+    const int64_t* committed;
+    const int64_t* lag;         // non-null: precomputed lags, offsets ignored
+    const int64_t* cons_off;
+    const int32_t* cons_rank;
+    int32_t* out_pid;
+    int32_t* out_rank;
+    int64_t* out_total;         // may be null
+    uint32_t* status;
+    int32_t reset_latest;
+    int32_t lc;                 // pow2ceil(max consumers per topic), set by the launcher
+};
+
+bool wave_tile_fits(int64_t max_p, int64_t max_c);
+void wave_tile_pick(int64_t max_p, int64_t max_c, int* L, int* E);
+hipError_t wave_tile_launch(TileArgs a, int64_t max_p, int64_t max_c, bool argmin, hipStream_t stream);
+
+// Elementwise lag: out_lag[i] = computePartitionLag(...)   (Main.java:376-404)
+hipError_t lag_launch(int64_t n, const int64_t* begin, const int64_t* end, const int64_t* committed,
+                      bool reset_latest, int64_t* out_lag, hipStream_t stream);
+
+// Checks that every topic's cons_rank segment is strictly ascending; sets kStatusUnsorted.
+hipError_t check_consumers_launch(int64_t n_topics, const int64_t* cons_off, const int32_t* cons_rank,
+                                  uint32_t* status, hipStream_t stream);
+
+// ---- large-topic path (device-wide radix sort + one-workgroup greedy) ---------------------
+struct LargeScratch {
+    void* buf = nullptr;
+    size_t cap = 0;
+};
+
+struct LargeArgs {
+    int64_t p0, n_part;         // partition segment of the topic
+    int64_t c0, n_cons;         // consumer segment of the topic
+    const int32_t* pid;
+    const int64_t* begin;
+    const int64_t* end;
+    const int64_t* committed;
+    const int64_t* lag;
+    const int32_t* cons_rank;
+    int32_t* out_pid;
+    int32_t* out_rank;
+    int64_t* out_total;
+    uint32_t* status;
+    int32_t reset_latest;
+};
+
+hipError_t large_topic_launch(LargeScratch& scratch, const LargeArgs& a, bool argmin, hipStream_t stream);
+void large_scratch_release(LargeScratch& scratch);
+
+}  // namespace la

@@ -183,7 +183,15 @@ static int assign_topic(const member_cmp_t *mc, int64_t np, const int32_t *parti
                         const int64_t *lag, int64_t nc, const int32_t *consumers,
                         int32_t *out_partition, int32_t *out_member, int64_t *out_total) {
     if (nc == 0) {                                                    /* Main.java:211-213 */
-        for (int64_t i = 0; i < np; ++i) { out_partition[i] = partition[i]; out_member[i] = -1; }
+        /* The reference returns before sorting and assigns nothing.  The flat ABI still
+         * has to fill the segment: member = -1, partitions in (lag desc, id asc) order. */
+        tpl_t *s0 = (tpl_t *)malloc((size_t)(np ? np : 1) * sizeof(tpl_t));
+        tpl_t *t0 = (tpl_t *)malloc((size_t)(np ? np : 1) * sizeof(tpl_t));
+        if (!s0 || !t0) { free(s0); free(t0); return -1; }
+        for (int64_t i = 0; i < np; ++i) { s0[i].partition = partition[i]; s0[i].lag = lag[i]; }
+        merge_sort(s0, t0, np);
+        for (int64_t i = 0; i < np; ++i) { out_partition[i] = s0[i].partition; out_member[i] = -1; }
+        free(s0); free(t0);
         return 0;
     }
     /* consumerTotalLags / consumerTotalPartitions, Main.java:216-225; keyed maps de-dup */
