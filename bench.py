@@ -1,0 +1,247 @@
+#!/usr/bin/env python3
+"""bench.py -- partition-assignments/sec of the lag-based assignor hot path on MI355X.
+
+One "step" = one pass of the whole hot path (lag compute -> sort by lag desc -> greedy
+assignment) over one batch of synthetic topics that is already resident in HBM when the
+timed region starts.  Default workload at N=1 is the configuration BASELINE.json quotes
+its metric on: 100 000 topics x 256 partitions x 32 consumers, Zipf(1.1) lags.
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Multi-GPU: topics are independent, so they shard across ranks with no data-path
+collective (weak scaling: every rank owns a full per-GPU batch).  `--gather` adds the
+north star's RCCL all-gather of the result arrays inside the timed region.
+
+Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X spec, /opt/skills/guides/MI355X_MICROARCH.md:35
+BYTES_PER_PARTITION = 36       # 28 B read + 8 B written
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--topics", type=int, default=100000)
+    ap.add_argument("--partitions", type=int, default=256)
+    ap.add_argument("--consumers", type=int, default=32)
+    ap.add_argument("--reset-mode", choices=["latest", "earliest"], default="latest")
+    ap.add_argument("--algo", choices=["auto", "argmin"], default="auto")
+    ap.add_argument("--gather", action="store_true", help="all-gather the result arrays (RCCL) in the timed region")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg (rank 0, N=1)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    return ap.parse_args()
+
+
+def make_device_workload(torch, dev, T, P, C, seed):
+    """Target-config inputs generated on the device: Zipf(1.1) lags shuffled over the
+    partitions of each topic, shuffled partition ids, offsets built from the lag."""
+    from kafka_lag_based_assignor_amd import synth
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    base = torch.from_numpy(synth.zipf_lags(P)).to(dev)                       # [P] int64
+    order = torch.rand(T, P, device=dev, generator=g).argsort(dim=1)
+    lag = base[order].reshape(-1).contiguous()
+    pid = torch.rand(T, P, device=dev, generator=g).argsort(dim=1).to(torch.int32).reshape(-1).contiguous()
+    del order
+    com = torch.randint(0, 1 << 20, (T * P,), device=dev, generator=g, dtype=torch.int64)
+    end = com + lag
+    none = torch.rand(T * P, device=dev, generator=g) < 0.01
+    com = torch.where(none, torch.full_like(com, -1), com)
+    begin = torch.zeros(T * P, device=dev, dtype=torch.int64)
+    part_off = torch.arange(T + 1, device=dev, dtype=torch.int64) * P
+    cons_off = torch.arange(T + 1, device=dev, dtype=torch.int64) * C
+    cons_rank = torch.arange(C, device=dev, dtype=torch.int32).repeat(T).contiguous()
+    return dict(part_off=part_off, pid=pid, begin=begin, end=end, committed=com, lag=lag,
+                cons_off=cons_off, cons_rank=cons_rank)
+
+
+def main():
+    args = parse_args()
+    import torch
+    import torch.distributed as dist
+
+    from kafka_lag_based_assignor_amd import _native as N
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+    if args.gpus != world and rank == 0:
+        print("warning: --gpus %d but WORLD_SIZE=%d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
+
+    T, P, C = args.topics, args.partitions, args.consumers
+    n_part = T * P
+    w = make_device_workload(torch, dev, T, P, C, seed=0x5EED + rank)
+    out_pid = torch.empty(n_part, device=dev, dtype=torch.int32)
+    out_rank = torch.empty(n_part, device=dev, dtype=torch.int32)
+    out_total = torch.empty(T * C, device=dev, dtype=torch.int64)
+    if args.gather and world > 1:
+        gathered_pid = torch.empty(world * n_part, device=dev, dtype=torch.int32)
+        gathered_rank = torch.empty(world * n_part, device=dev, dtype=torch.int32)
+
+    ctx = N.Context(local_rank)
+    latest = args.reset_mode == "latest"
+    b = N.DeviceBatch()
+    b.n_topics = T
+    b.reset_mode = N.LA_RESET_LATEST if latest else N.LA_RESET_EARLIEST
+    b.algo = N.LA_ALGO_ARGMIN if args.algo == "argmin" else N.LA_ALGO_AUTO
+    b.n_partitions = n_part
+    b.n_consumers = T * C
+    b.max_partitions_per_topic = P
+    b.max_consumers_per_topic = C
+    b.d_part_off = w["part_off"].data_ptr()
+    b.d_partition_id = w["pid"].data_ptr()
+    b.d_begin_off = None if latest else w["begin"].data_ptr()
+    b.d_end_off = w["end"].data_ptr()
+    b.d_committed_off = w["committed"].data_ptr()
+    b.d_lag = None
+    b.d_cons_off = w["cons_off"].data_ptr()
+    b.d_cons_rank = w["cons_rank"].data_ptr()
+    b.d_out_partition = out_pid.data_ptr()
+    b.d_out_member_rank = out_rank.data_ptr()
+    b.d_out_total_lag = out_total.data_ptr()
+    if P > 1024 or C > 64:
+        h_part = w["part_off"].cpu().numpy()
+        h_cons = w["cons_off"].cpu().numpy()
+        b.h_part_off = h_part.ctypes.data_as(ctypes.POINTER(ctypes.c_int64))
+        b.h_cons_off = h_cons.ctypes.data_as(ctypes.POINTER(ctypes.c_int64))
+
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step():
+        ctx.assign_batch_device(b, stream)
+        if args.gather and world > 1:
+            dist.all_gather_into_tensor(gathered_pid, out_pid)
+            dist.all_gather_into_tensor(gathered_rank, out_rank)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    ctx.sync(stream)
+
+    # timed region: exactly K steps, bracketed by barrier + synchronize on both sides
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    barrier()
+    t0 = time.perf_counter()
+    for s in range(args.steps):
+        ev[s][0].record()
+        step()
+        ev[s][1].record()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    ctx.sync(stream)
+
+    # HIP-event duration of the assign launch on the stream it runs on (one kernel per step)
+    kern_ms = float(np.mean([a.elapsed_time(z) for a, z in ev]))
+
+    t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    ms_per_step = elapsed / args.steps * 1e3
+    total_units = world * n_part * args.steps
+    value = total_units / elapsed
+
+    achieved = BYTES_PER_PARTITION * n_part / (kern_ms * 1e-3) / 1e9
+    roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "kernel": "wave_tile_assign_kernel", "kernel_ms": round(kern_ms, 4),
+                "algorithmic_bytes_per_partition": BYTES_PER_PARTITION}
+
+    # ---- parity spot check + cpu_baseline (oracle; test infrastructure, timed on host cores) ----
+    cpu = None
+    parity = None
+    if not args.no_cpu_baseline and world == 1:
+        from oracle import oracle
+        h = {k: v.cpu().numpy() for k, v in w.items()}
+        g_pid, g_rank, g_tot = out_pid.cpu().numpy(), out_rank.cpu().numpy(), out_total.cpu().numpy()
+        chunk = max(1, min(T, 2000))
+        done = 0
+        spent = 0.0
+        ok = True
+        while done < T and spent < args.cpu_seconds:
+            t1 = min(T, done + chunk)
+            sl = slice(done * P, t1 * P)
+            c0 = time.perf_counter()
+            lag = oracle.compute_lags(h["begin"][sl], h["end"][sl], h["committed"][sl], latest)
+            e_pid, e_rank, e_tot = oracle.assign_flat(h["part_off"][done:t1 + 1] - done * P, h["pid"][sl], lag,
+                                                      h["cons_off"][done:t1 + 1] - done * C,
+                                                      h["cons_rank"][done * C:t1 * C])
+            spent += time.perf_counter() - c0
+            ok &= bool(np.array_equal(e_pid, g_pid[sl]) and np.array_equal(e_rank, g_rank[sl]) and
+                       np.array_equal(e_tot, g_tot[done * C:t1 * C]))
+            done = t1
+        parity = {"checked_topics": done, "bit_exact": ok}
+        cpu = {"value": round(done * P / spent, 1), "unit": "partition-assignments/sec", "cores": 1,
+               "kind": "port",
+               "sample": "first %d of %d topics of the same batch, C oracle (oracle/lag_oracle.c, literal "
+                         "per-step min), 1 thread, %.1f s" % (done, T, spent),
+               "host_cpus": os.cpu_count()}
+        if not ok:
+            print("PARITY FAILURE against the oracle", file=sys.stderr)
+
+    line = {
+        "metric": "partition-assignments/sec (whole node)",
+        "value": round(value, 1),
+        "unit": "partition-assignments/sec",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 4),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "int64",
+        "data": "synthetic",
+        "config": {"workload": "%d topics x %d partitions x %d consumers per GPU, Zipf(1.1) lags, "
+                               "shuffled partition ids, 1%% no committed offset, auto.offset.reset=%s"
+                               % (T, P, C, args.reset_mode),
+                   "topics_per_gpu": T, "partitions_per_topic": P, "consumers_per_topic": C,
+                   "gather": bool(args.gather and world > 1), "algo": args.algo},
+        "roofline": roofline,
+        "cpu_baseline": cpu,
+        "parity": parity,
+    }
+    print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+    if parity is not None and not parity["bit_exact"]:
+        sys.exit(2)
+
+
+if __name__ == "__main__":
+    main()

@@ -149,12 +149,16 @@ typedef struct la_device_batch {
     const int64_t *h_cons_off;
 } la_device_batch;
 
-/* Enqueues the whole batch on `stream` (a hipStream_t; NULL = the context's own
- * stream) and returns without waiting.  Device-detected errors surface in la_sync. */
+/* Enqueues the whole batch on `stream` and returns without waiting.  `stream` is a
+ * hipStream_t used exactly as given (NULL = HIP's default stream); la_stream() gives
+ * the context's own stream.  Device-detected errors surface in la_sync. */
 int la_assign_batch_device(la_ctx *ctx, const la_device_batch *batch, void *stream);
 
 /* Waits for `stream` and returns LA_OK or the first device-detected error. */
 int la_sync(la_ctx *ctx, void *stream);
+
+/* The context's own (non-blocking) hipStream_t, used by the host-buffer entry points. */
+void *la_stream(la_ctx *ctx);
 
 #ifdef __cplusplus
 }

@@ -21,7 +21,7 @@ LA_ALGO_AUTO, LA_ALGO_ROUNDS, LA_ALGO_ARGMIN = 0, 1, 2
 
 EXPORTED_SYMBOLS = (
     "la_create", "la_destroy", "la_last_error", "la_version", "la_compute_lag",
-    "la_assign_batch", "la_assign_batch_lags", "la_assign_batch_device", "la_sync",
+    "la_assign_batch", "la_assign_batch_lags", "la_assign_batch_device", "la_sync", "la_stream",
 )
 
 _i64p = ctypes.POINTER(ctypes.c_int64)
@@ -63,6 +63,15 @@ def load() -> ctypes.CDLL:
         raise ImportError(
             "%s is missing: build it with `python -m kafka_lag_based_assignor_amd.build` "
             "(needs hipcc). There is no CPU fallback." % LIB_PATH)
+    # One HIP runtime per process: PyTorch bundles its own libamdhip64.so.7.  Importing torch
+    # first makes liblagassign's NEEDED libamdhip64.so.7 resolve to that already-loaded copy,
+    # so torch tensors, torch streams and our kernels share one runtime.  (Two runtimes in one
+    # process fail at device discovery.)  Without torch -- e.g. under a JVM -- the system
+    # ROCm runtime is used.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = ctypes.CDLL(LIB_PATH)
     L.la_version.restype = ctypes.c_int
     L.la_create.restype = ctypes.c_int
@@ -83,6 +92,8 @@ def load() -> ctypes.CDLL:
     L.la_assign_batch_device.argtypes = [ctypes.c_void_p, ctypes.POINTER(DeviceBatch), ctypes.c_void_p]
     L.la_sync.restype = ctypes.c_int
     L.la_sync.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+    L.la_stream.restype = ctypes.c_void_p
+    L.la_stream.argtypes = [ctypes.c_void_p]
     _lib = L
     return L
 
@@ -174,8 +185,12 @@ class Context:
 
     # -- device-resident entry point ------------------------------------------------
     def assign_batch_device(self, batch: DeviceBatch, stream: int = 0) -> None:
-        self._check(self._lib.la_assign_batch_device(self._h, ctypes.byref(batch),
-                                                     ctypes.c_void_p(stream) if stream else None))
+        """Enqueue on `stream` (a hipStream_t handle as an int; 0 = HIP's default stream)."""
+        self._check(self._lib.la_assign_batch_device(self._h, ctypes.byref(batch), ctypes.c_void_p(stream)))
 
     def sync(self, stream: int = 0) -> None:
-        self._check(self._lib.la_sync(self._h, ctypes.c_void_p(stream) if stream else None))
+        self._check(self._lib.la_sync(self._h, ctypes.c_void_p(stream)))
+
+    @property
+    def stream(self) -> int:
+        return int(self._lib.la_stream(self._h) or 0)

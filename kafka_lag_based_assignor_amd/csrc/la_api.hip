@@ -389,17 +389,19 @@ LA_API int la_assign_batch_device(la_ctx* ctx, const la_device_batch* batch, voi
     try {
         if (!batch) return fail(ctx, LA_EINVAL, "batch is NULL");
         LA_HIP(ctx, hipSetDevice(ctx->device));
-        return enqueue_batch(ctx, batch, stream ? (hipStream_t)stream : ctx->stream);
+        return enqueue_batch(ctx, batch, (hipStream_t)stream);
     } catch (...) {
         return fail(ctx, LA_ENOMEM, "exception in la_assign_batch_device");
     }
 }
 
+LA_API void* la_stream(la_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+
 LA_API int la_sync(la_ctx* ctx, void* stream) {
     if (!ctx) return LA_EINVAL;
     try {
         LA_HIP(ctx, hipSetDevice(ctx->device));
-        return sync_status(ctx, stream ? (hipStream_t)stream : ctx->stream);
+        return sync_status(ctx, (hipStream_t)stream);
     } catch (...) {
         return fail(ctx, LA_ENOMEM, "exception in la_sync");
     }
