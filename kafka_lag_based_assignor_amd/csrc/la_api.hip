@@ -161,6 +161,12 @@ int enqueue_batch(la_ctx* ctx, const la_device_batch* b, hipStream_t stream) {
             LA_HIP(ctx, la::wave_tile_launch(run, mp, mc, argmin, stream));
             t = u;
         } else {
+            if (csize(t) > la::kLargeMaxConsumers)
+                return fail(ctx, LA_ESHAPE, "topic %lld has %lld consumers; at most %lld are supported",
+                            (long long)t, (long long)csize(t), (long long)la::kLargeMaxConsumers);
+            if (psize(t) > 0x7FFFFFFF)
+                return fail(ctx, LA_ESHAPE, "topic %lld has %lld partitions; at most 2^31-1 are supported",
+                            (long long)t, (long long)psize(t));
             la::LargeArgs g{};
             g.p0 = b->h_part_off[t];
             g.n_part = psize(t);

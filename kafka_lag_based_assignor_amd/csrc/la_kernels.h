@@ -11,6 +11,7 @@ constexpr uint32_t kStatusUnsorted = 2u;   // a topic's cons_rank segment is not
 
 constexpr int64_t kTileMaxPartitions = 1024;   // 64 lanes x 16 records
 constexpr int64_t kTileMaxConsumers = 64;      // one consumer bin per lane
+constexpr int64_t kLargeMaxConsumers = 8192;   // large path: 8 bins per thread x 1024 threads
 
 // Arguments of the fused wave-tile kernel (all device pointers).
 struct TileArgs {

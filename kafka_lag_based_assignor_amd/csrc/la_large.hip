@@ -1,9 +1,497 @@
-// la_large.hip -- topics larger than one wave tile.  (stub: filled in next)
+// la_large.hip -- topics that do not fit one wave tile (> 1024 partitions or > 64 consumers).
+//
+// Three phases per topic, all on the device, no host round trip in between:
+//
+//   kernel 1  build_keys     lag from offsets (Main.java:376-404), 64-bit sort key + 32-bit id,
+//                            and the 12 digit histograms of the 96-bit composite in one read.
+//   kernel 2  radix sort     LSD, 8 bits per pass, stable, over (key64, id32):
+//                            id digits first, then key digits -> (lag desc, id asc), the
+//                            comparator of Main.java:228-235.  A pass whose digit is constant
+//                            over the whole topic is skipped on the device (plan kernel), so
+//                            lags < 2^40 with ids < 2^24 cost 8 passes, not 12; input that is
+//                            already in id order skips the 4 id passes.
+//                            per pass: tile digit counts -> per-digit scan over tiles -> stable
+//                            scatter (wave-level match ranking, no atomics on the data path).
+//   kernel 3  greedy         ONE workgroup (the chain of rounds is serial): consumer bins live in
+//                            registers, E per thread; each round bitonic-sorts the bins by
+//                            (total lag, member) -- in registers, across lanes with DPP, across
+//                            waves through LDS -- and hands the round's C partitions out in
+//                            that order.  ceil(P/C) rounds instead of P argmins.
+//                            LA_ALGO_ARGMIN keeps the literal form: bins (count, total) in LDS,
+//                            one wavefront-argmin + LDS combine per partition.
 #include "la_kernels.h"
+#include "la_device.h"
 
 namespace la {
 
-hipError_t large_topic_launch(LargeScratch&, const LargeArgs&, bool, hipStream_t) { return hipErrorNotSupported; }
+namespace {
+
+constexpr int kDigits = 12;            // 4 id digits + 8 key digits
+constexpr int kRadix = 256;
+constexpr int kSortThreads = 256;
+constexpr int kSortWaves = kSortThreads / kWave;
+constexpr int kItems = 16;
+constexpr int kTile = kSortThreads * kItems;     // 4096 elements per workgroup
+
+struct SortCtl {
+    uint32_t skip[kDigits];
+    uint32_t cur[kDigits + 1];         // which buffer (0/1) holds the data before pass d
+    uint32_t unsorted_ids;             // != 0: input ids are not ascending
+    uint32_t pad[6];
+};
+
+struct SortBufs {
+    SortCtl* ctl;
+    uint32_t* hist;                    // [kDigits][256]
+    uint64_t* key[2];
+    uint32_t* val[2];
+    uint32_t* tile_off;                // [256][n_tiles] (digit-major)
+    int64_t n;
+    int n_tiles;
+};
+
+__device__ __forceinline__ uint32_t digit_of(int pass, uint64_t key, uint32_t val) {
+    return pass < 4 ? (val >> (8 * pass)) & 0xFFu : (uint32_t)(key >> (8 * (pass - 4))) & 0xFFu;
+}
+
+// ---- kernel 1: keys + all digit histograms ---------------------------------------------------
+__global__ __launch_bounds__(256) void build_keys_kernel(LargeArgs a, SortBufs b) {
+    __shared__ uint32_t h[kDigits * kRadix];
+    for (int i = threadIdx.x; i < kDigits * kRadix; i += blockDim.x) h[i] = 0;
+    __syncthreads();
+    const bool latest = a.reset_latest != 0;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t base = (int64_t)blockIdx.x * blockDim.x; base < b.n; base += stride) {
+        const int64_t i = base + threadIdx.x;
+        const bool valid = i < b.n;
+        uint64_t key = 0;
+        uint32_t val = 0;
+        if (valid) {
+            const int64_t g = a.p0 + i;
+            int64_t lag;
+            if (a.lag) lag = a.lag[g];
+            else lag = partition_lag(a.begin ? a.begin[g] : 0, a.end[g], a.committed[g], latest);
+            key = (uint64_t)lag ^ kLagKeyFlip;
+            const int32_t id = a.pid[g];
+            val = (uint32_t)id ^ kPidBias;
+            b.key[0][i] = key;
+            b.val[0][i] = val;
+            if (i + 1 < b.n && a.pid[g + 1] < id) b.ctl->unsorted_ids = 1;
+        }
+        const uint64_t vmask = __ballot(valid);
+#pragma unroll
+        for (int p = 0; p < kDigits; ++p) {
+            const uint32_t d = digit_of(p, key, val);
+            // common case for the high digits: the whole wave agrees -> one add
+            const uint32_t d0 = __builtin_amdgcn_readfirstlane(d);
+            const uint64_t same = __ballot(valid && d == d0);
+            if (same == vmask) {
+                if (valid && (int)__lane_id() == __ffsll((unsigned long long)vmask) - 1)
+                    atomicAdd(&h[p * kRadix + d0], (uint32_t)__popcll(vmask));
+            } else if (valid) {
+                atomicAdd(&h[p * kRadix + d], 1u);
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < kDigits * kRadix; i += blockDim.x)
+        if (h[i]) atomicAdd(&b.hist[i], h[i]);
+}
+
+// ---- plan: which passes are no-ops, where the data lives before each pass --------------------
+__global__ void plan_kernel(SortBufs b) {
+    __shared__ uint32_t skip[kDigits];
+    if (threadIdx.x < kDigits) skip[threadIdx.x] = 0;
+    __syncthreads();
+    for (int p = 0; p < kDigits; ++p)
+        if (b.hist[p * kRadix + threadIdx.x] == (uint32_t)b.n) skip[p] = 1;   // one bin holds everything
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t cur = 0;
+        for (int p = 0; p < kDigits; ++p) {
+            uint32_t s = skip[p];
+            if (p < 4 && b.ctl->unsorted_ids == 0) s = 1;     // stable passes keep the input's id order
+            b.ctl->skip[p] = s;
+            b.ctl->cur[p] = cur;
+            cur ^= (s ? 0u : 1u);
+        }
+        b.ctl->cur[kDigits] = cur;
+    }
+}
+
+// ---- per pass: tile digit counts ------------------------------------------------------------------
+__global__ __launch_bounds__(kSortThreads) void tile_count_kernel(SortBufs b, int pass) {
+    if (b.ctl->skip[pass]) return;
+    __shared__ uint32_t h[kRadix];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t cur = b.ctl->cur[pass];
+    const uint64_t* key = b.key[cur];
+    const uint32_t* val = b.val[cur];
+    const int64_t t0 = (int64_t)blockIdx.x * kTile;
+#pragma unroll 4
+    for (int it = 0; it < kItems; ++it) {
+        const int64_t i = t0 + it * kSortThreads + threadIdx.x;
+        if (i < b.n) {
+            const uint32_t d = pass < 4 ? digit_of(pass, 0, val[i]) : digit_of(pass, key[i], 0);
+            atomicAdd(&h[d], 1u);
+        }
+    }
+    __syncthreads();
+    b.tile_off[(int64_t)threadIdx.x * b.n_tiles + blockIdx.x] = h[threadIdx.x];
+}
+
+// ---- per pass: exclusive scan of each digit's tile counts, plus the digit's global base -----------
+__global__ __launch_bounds__(256) void tile_scan_kernel(SortBufs b, int pass) {
+    if (b.ctl->skip[pass]) return;
+    __shared__ uint32_t wsum[4];
+    __shared__ uint32_t carry_s;
+    const int d = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // global base of digit d = number of elements with a smaller digit
+    uint32_t v = ((int)threadIdx.x < d) ? b.hist[pass * kRadix + threadIdx.x] : 0;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+    if (lane == 0) wsum[wave] = v;
+    __syncthreads();
+    uint32_t carry = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    __syncthreads();
+    uint32_t* col = b.tile_off + (int64_t)d * b.n_tiles;
+    for (int base = 0; base < b.n_tiles; base += 256) {
+        const int t = base + threadIdx.x;
+        const uint32_t x = t < b.n_tiles ? col[t] : 0;
+        uint32_t incl = x;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t y = __shfl_up(incl, o);
+            if (lane >= o) incl += y;
+        }
+        if (lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        uint32_t woff = 0;
+        for (int w = 0; w < wave; ++w) woff += wsum[w];
+        if (t < b.n_tiles) col[t] = carry + woff + incl - x;
+        if (threadIdx.x == 255) carry_s = carry + woff + incl;
+        __syncthreads();
+        carry = carry_s;
+    }
+}
+
+// ---- per pass: stable scatter ----------------------------------------------------------------------
+// Order inside a tile = (wave, item, lane); elements are loaded wave-striped so every load is a
+// 64-element contiguous run.  Rank among equal digits: wave-level match (8 ballots), running
+// per-wave digit counters in LDS, then an exclusive scan of those counters over the waves.
+__global__ __launch_bounds__(kSortThreads) void tile_scatter_kernel(SortBufs b, int pass) {
+    if (b.ctl->skip[pass]) return;
+    __shared__ uint32_t cnt[kSortWaves][kRadix];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int i = threadIdx.x; i < kSortWaves * kRadix; i += kSortThreads) (&cnt[0][0])[i] = 0;
+    __syncthreads();
+    const uint32_t cur = b.ctl->cur[pass];
+    const uint64_t* kin = b.key[cur];
+    const uint32_t* vin = b.val[cur];
+    uint64_t* kout = b.key[cur ^ 1];
+    uint32_t* vout = b.val[cur ^ 1];
+    const int64_t w0 = (int64_t)blockIdx.x * kTile + (int64_t)wave * kItems * kWave;
+    const uint64_t lt = ((uint64_t)1 << lane) - 1;
+
+    uint64_t key[kItems];
+    uint32_t val[kItems];
+    uint32_t loc[kItems];       // digit << 16 | rank inside (wave, digit)   (rank < 1024)
+#pragma unroll
+    for (int it = 0; it < kItems; ++it) {
+        const int64_t i = w0 + it * kWave + lane;
+        const bool valid = i < b.n;
+        key[it] = valid ? kin[i] : 0;
+        val[it] = valid ? vin[i] : 0;
+    }
+#pragma unroll
+    for (int it = 0; it < kItems; ++it) {
+        const int64_t i = w0 + it * kWave + lane;
+        const bool valid = i < b.n;
+        const uint32_t d = digit_of(pass, key[it], val[it]);
+        uint64_t peers = __ballot(valid);
+#pragma unroll
+        for (int bit = 0; bit < 8; ++bit) {
+            const bool one = (d >> bit) & 1;
+            const uint64_t bal = __ballot(one);
+            peers &= one ? bal : ~bal;
+        }
+        uint32_t old = 0;
+        if (valid) old = cnt[wave][d];                       // same address for all peers: broadcast
+        wave_lds_fence();
+        if (valid && (peers & lt) == 0) cnt[wave][d] = old + (uint32_t)__popcll(peers);   // group leader
+        wave_lds_fence();
+        loc[it] = (d << 16) | (old + (uint32_t)__popcll(peers & lt));
+    }
+    __syncthreads();
+    {   // exclusive scan over the waves + the tile's global base for this digit
+        const int d = threadIdx.x;
+        uint32_t run = b.tile_off[(int64_t)d * b.n_tiles + blockIdx.x];
+#pragma unroll
+        for (int w = 0; w < kSortWaves; ++w) {
+            const uint32_t c = cnt[w][d];
+            cnt[w][d] = run;
+            run += c;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < kItems; ++it) {
+        const int64_t i = w0 + it * kWave + lane;
+        if (i < b.n) {
+            const uint32_t pos = cnt[wave][loc[it] >> 16] + (loc[it] & 0xFFFFu);
+            kout[pos] = key[it];
+            vout[pos] = val[it];
+        }
+    }
+}
+
+// ---- outputs that do not depend on the greedy ----------------------------------------------------
+__global__ __launch_bounds__(256) void emit_ids_kernel(LargeArgs a, SortBufs b, int fill_rank_minus1) {
+    const uint32_t* val = b.val[b.ctl->cur[kDigits]];
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < b.n; i += stride) {
+        a.out_pid[a.p0 + i] = (int32_t)(val[i] ^ kPidBias);
+        if (fill_rank_minus1) a.out_rank[a.p0 + i] = -1;
+    }
+}
+
+// ---- kernel 3: round-structured greedy, one workgroup -----------------------------------------------
+// n = EC * blockDim.x consumer slots (power of two >= C); slot i = tid*EC + r.
+template <int EC>
+__global__ __launch_bounds__(1024) void greedy_rounds_kernel(LargeArgs a, SortBufs b) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    const int tid = threadIdx.x;
+    const int n = EC * blockDim.x;
+    uint32_t* s_hi = smem;
+    uint32_t* s_lo = smem + n;
+    uint32_t* s_tb = smem + 2 * n;
+    const uint64_t* key = b.key[b.ctl->cur[kDigits]];
+    const int64_t P = a.n_part;
+    const int C = (int)a.n_cons;
+
+    Rec rec[EC];
+#pragma unroll
+    for (int r = 0; r < EC; ++r) {
+        const int i = tid * EC + r;
+        if (i < C) { rec[r].hi = (uint32_t)(kTotalBias >> 32); rec[r].lo = 0; rec[r].tb = (uint32_t)i; }
+        else rec[r].hi = rec[r].lo = rec[r].tb = 0xFFFFFFFFu;
+    }
+    const int64_t rounds = (P + C - 1) / C;
+    for (int64_t q = 0; q < rounds; ++q) {
+        if (q > 0) {
+            // bitonic sort of the n bins, ascending by (biased total, index)
+            for (int k = 2; k <= n; k <<= 1) {
+                for (int j = k >> 1; j >= 64 * EC; j >>= 1) {            // across waves: LDS
+#pragma unroll
+                    for (int r = 0; r < EC; ++r) {
+                        const int i = tid * EC + r;
+                        s_hi[i] = rec[r].hi; s_lo[i] = rec[r].lo; s_tb[i] = rec[r].tb;
+                    }
+                    __syncthreads();
+#pragma unroll
+                    for (int r = 0; r < EC; ++r) {
+                        const int i = tid * EC + r;
+                        Rec o;
+                        o.hi = s_hi[i ^ j]; o.lo = s_lo[i ^ j]; o.tb = s_tb[i ^ j];
+                        const bool keep_min = (((i & j) == 0) == ((i & k) == 0));
+                        const bool take = (rec_less(o, rec[r]) == keep_min);
+                        rec[r].hi = take ? o.hi : rec[r].hi;
+                        rec[r].lo = take ? o.lo : rec[r].lo;
+                        rec[r].tb = take ? o.tb : rec[r].tb;
+                    }
+                    __syncthreads();
+                }
+                for (int jl = 32; jl >= 1; jl >>= 1) {                    // across lanes: DPP
+                    const int j = jl * EC;
+                    if (j < k) {
+#pragma unroll
+                        for (int r = 0; r < EC; ++r) {
+                            const int i = tid * EC + r;
+                            cmpx_lanes_dyn(rec[r], jl, (((i & j) == 0) == ((i & k) == 0)));
+                        }
+                    }
+                }
+#pragma unroll
+                for (int J = EC / 2; J >= 1; J >>= 1) {                   // inside the lane: registers
+                    if (J < k) {
+#pragma unroll
+                        for (int r = 0; r < EC; ++r)
+                            if ((r & J) == 0) cmpx_regs(rec[r], rec[r | J], ((tid * EC + r) & k) == 0);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < EC; ++r) {
+            const int k = tid * EC + r;
+            const int64_t s = q * C + k;
+            if (k < C && s < P) {
+                const uint64_t lag = key[s] ^ kLagKeyFlip;
+                const uint64_t t = (((uint64_t)rec[r].hi << 32) | rec[r].lo) + lag;      // Main.java:265
+                rec[r].hi = (uint32_t)(t >> 32);
+                rec[r].lo = (uint32_t)t;
+                a.out_rank[a.p0 + s] = a.cons_rank[a.c0 + rec[r].tb];
+            }
+        }
+    }
+    if (a.out_total) {
+#pragma unroll
+        for (int r = 0; r < EC; ++r)
+            if (rec[r].tb < (uint32_t)C)
+                a.out_total[a.c0 + rec[r].tb] = (int64_t)((((uint64_t)rec[r].hi << 32) | rec[r].lo) ^ kTotalBias);
+    }
+}
+
+// ---- kernel 3, literal form: bins in LDS, wavefront argmin per partition ------------------------------
+__global__ __launch_bounds__(1024) void greedy_argmin_kernel(LargeArgs a, SortBufs b) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    const int C = (int)a.n_cons;
+    uint32_t* s_cnt = smem;                 // assigned count per bin
+    uint32_t* s_hi = smem + C;              // biased assigned lag, high / low dword
+    uint32_t* s_lo = smem + 2 * C;
+    uint32_t* w_best = smem + 3 * C;        // [16 waves][4]
+    const uint64_t* key = b.key[b.ctl->cur[kDigits]];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
+    for (int i = tid; i < C; i += blockDim.x) { s_cnt[i] = 0; s_hi[i] = (uint32_t)(kTotalBias >> 32); s_lo[i] = 0; }
+    __syncthreads();
+    for (int64_t s = 0; s < a.n_part; ++s) {
+        uint32_t bc = 0xFFFFFFFFu;
+        Rec best; best.hi = best.lo = best.tb = 0xFFFFFFFFu;
+        for (int i = tid; i < C; i += blockDim.x) {          // comparator of Main.java:243-261
+            Rec c; c.hi = s_hi[i]; c.lo = s_lo[i]; c.tb = (uint32_t)i;
+            const uint32_t cc = s_cnt[i];
+            const bool take = (cc < bc) | ((cc == bc) & rec_less(c, best));
+            bc = take ? cc : bc; best.hi = take ? c.hi : best.hi; best.lo = take ? c.lo : best.lo;
+            best.tb = take ? c.tb : best.tb;
+        }
+        for (int j = 1; j < 64; j <<= 1) {                   // wavefront argmin
+            const Rec o = shfl_xor_dyn(best, j);
+            const uint32_t oc = (uint32_t)__shfl_xor((int)bc, j);
+            const bool take = (oc < bc) | ((oc == bc) & rec_less(o, best));
+            bc = take ? oc : bc; best.hi = take ? o.hi : best.hi; best.lo = take ? o.lo : best.lo;
+            best.tb = take ? o.tb : best.tb;
+        }
+        if (lane == 0) { w_best[wave * 4] = bc; w_best[wave * 4 + 1] = best.hi; w_best[wave * 4 + 2] = best.lo; w_best[wave * 4 + 3] = best.tb; }
+        __syncthreads();
+        if (tid == 0) {
+            for (int w = 1; w < nw; ++w) {
+                Rec o; o.hi = w_best[w * 4 + 1]; o.lo = w_best[w * 4 + 2]; o.tb = w_best[w * 4 + 3];
+                const uint32_t oc = w_best[w * 4];
+                const bool take = (oc < bc) | ((oc == bc) & rec_less(o, best));
+                if (take) { bc = oc; best = o; }
+            }
+            const uint32_t m = best.tb;
+            const uint64_t t = (((uint64_t)s_hi[m] << 32) | s_lo[m]) + (key[s] ^ kLagKeyFlip);
+            s_hi[m] = (uint32_t)(t >> 32);
+            s_lo[m] = (uint32_t)t;
+            s_cnt[m] += 1;
+            a.out_rank[a.p0 + s] = a.cons_rank[a.c0 + m];
+        }
+        __syncthreads();
+    }
+    if (a.out_total)
+        for (int i = tid; i < C; i += blockDim.x)
+            a.out_total[a.c0 + i] = (int64_t)((((uint64_t)s_hi[i] << 32) | s_lo[i]) ^ kTotalBias);
+}
+
+template <int EC>
+hipError_t launch_rounds(const LargeArgs& a, const SortBufs& b, int threads, hipStream_t stream) {
+    const size_t lds = (size_t)3 * EC * threads * sizeof(uint32_t);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)greedy_rounds_kernel<EC>,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((greedy_rounds_kernel<EC>), dim3(1), dim3(threads), lds, stream, a, b);
+    return hipGetLastError();
+}
+
+size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+}  // namespace
+
+hipError_t large_topic_launch(LargeScratch& scratch, const LargeArgs& a, bool argmin, hipStream_t stream) {
+    const int64_t n = a.n_part;
+    if (n <= 0) return hipSuccess;
+    if (n > 0x7FFFFFFF || a.n_cons > kLargeMaxConsumers) return hipErrorInvalidValue;
+    const int n_tiles = (int)((n + kTile - 1) / kTile);
+
+    // scratch carve-up
+    size_t off = 0;
+    auto carve = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
+    const size_t o_ctl = carve(sizeof(SortCtl));
+    const size_t o_hist = carve(sizeof(uint32_t) * kDigits * kRadix);
+    const size_t zero_bytes = off;                                  // ctl + hist are zeroed per topic
+    const size_t o_k0 = carve(sizeof(uint64_t) * n), o_k1 = carve(sizeof(uint64_t) * n);
+    const size_t o_v0 = carve(sizeof(uint32_t) * n), o_v1 = carve(sizeof(uint32_t) * n);
+    const size_t o_to = carve(sizeof(uint32_t) * kRadix * (size_t)n_tiles);
+    if (off > scratch.cap) {
+        hipError_t e;
+        if (scratch.buf) {
+            if ((e = hipStreamSynchronize(stream)) != hipSuccess) return e;   // earlier topics may still use it
+            if ((e = hipFree(scratch.buf)) != hipSuccess) return e;
+            scratch.buf = nullptr;
+            scratch.cap = 0;
+        }
+        const size_t want = off + off / 4;
+        if ((e = hipMalloc(&scratch.buf, want)) != hipSuccess) return e;
+        scratch.cap = want;
+    }
+    char* base = (char*)scratch.buf;
+    SortBufs b{};
+    b.ctl = (SortCtl*)(base + o_ctl);
+    b.hist = (uint32_t*)(base + o_hist);
+    b.key[0] = (uint64_t*)(base + o_k0);
+    b.key[1] = (uint64_t*)(base + o_k1);
+    b.val[0] = (uint32_t*)(base + o_v0);
+    b.val[1] = (uint32_t*)(base + o_v1);
+    b.tile_off = (uint32_t*)(base + o_to);
+    b.n = n;
+    b.n_tiles = n_tiles;
+
+    hipError_t e;
+    if ((e = hipMemsetAsync(base, 0, zero_bytes, stream)) != hipSuccess) return e;
+    int grid = (int)((n + 255) / 256);
+    if (grid > 2048) grid = 2048;
+    hipLaunchKernelGGL(build_keys_kernel, dim3(grid), dim3(256), 0, stream, a, b);
+    hipLaunchKernelGGL(plan_kernel, dim3(1), dim3(256), 0, stream, b);
+    for (int p = 0; p < kDigits; ++p) {
+        hipLaunchKernelGGL(tile_count_kernel, dim3(n_tiles), dim3(kSortThreads), 0, stream, b, p);
+        hipLaunchKernelGGL(tile_scan_kernel, dim3(kRadix), dim3(256), 0, stream, b, p);
+        hipLaunchKernelGGL(tile_scatter_kernel, dim3(n_tiles), dim3(kSortThreads), 0, stream, b, p);
+    }
+    hipLaunchKernelGGL(emit_ids_kernel, dim3(grid), dim3(256), 0, stream, a, b, a.n_cons == 0 ? 1 : 0);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+    if (a.n_cons == 0) return hipSuccess;
+
+    if (argmin) {
+        const int C = (int)a.n_cons;
+        int threads = 64;
+        while (threads < C && threads < 1024) threads <<= 1;
+        const size_t lds = sizeof(uint32_t) * ((size_t)3 * C + 16 * 4);
+        static bool attr_set = false;
+        if (!attr_set) {
+            if ((e = hipFuncSetAttribute((const void*)greedy_argmin_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         160 * 1024)) != hipSuccess)
+                return e;
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(greedy_argmin_kernel, dim3(1), dim3(threads), lds, stream, a, b);
+        return hipGetLastError();
+    }
+    int cp2 = 64;
+    while (cp2 < a.n_cons) cp2 <<= 1;
+    if (cp2 <= 1024) return launch_rounds<1>(a, b, cp2, stream);
+    switch (cp2 / 1024) {
+        case 2: return launch_rounds<2>(a, b, 1024, stream);
+        case 4: return launch_rounds<4>(a, b, 1024, stream);
+        default: return launch_rounds<8>(a, b, 1024, stream);
+    }
+}
 
 void large_scratch_release(LargeScratch& s) {
     if (s.buf) (void)hipFree(s.buf);

@@ -120,3 +120,142 @@ def test_unsorted_consumers_rejected(ctx):
     with pytest.raises(N.LagAssignError) as ei:
         ctx.assign_batch_lags([0, 2], [0, 1], [5, 6], [0, 2], [3, 1])
     assert ei.value.code == N.LA_EINVAL
+
+
+# ---- large path: device radix sort + one-workgroup greedy ----------------------------------------------
+def _single_topic(seed, p, c, kind, shuffled=True, negative=False):
+    rng = np.random.default_rng(seed)
+    pid = rng.permutation(p).astype(np.int32) if shuffled else np.arange(p, dtype=np.int32)
+    if kind == "u63":
+        lag = rng.integers(0, (1 << 63) - 1, p)
+    elif kind == "u40":
+        lag = rng.integers(0, 1 << 40, p)
+    elif kind == "ties":
+        lag = rng.integers(0, 5, p) * 1000
+    elif kind == "zero":
+        lag = np.zeros(p, dtype=np.int64)
+    else:
+        lag = rng.integers(-(1 << 63), (1 << 63) - 1, p)
+    if not negative:
+        lag = np.where(lag < 0, ~lag, lag)
+    ranks = np.sort(rng.choice(3 * c + 1, c, replace=False)).astype(np.int32)
+    return [0, p], pid, lag.astype(np.int64), [0, c], ranks
+
+
+@pytest.mark.parametrize("p,c,kind", [
+    (1025, 3, "u40"), (2000, 65, "u40"), (4096, 64, "ties"), (5000, 100, "zero"), (10000, 128, "u63"),
+    (10000, 128, "u40"), (12345, 1000, "full"), (50, 100, "u40"), (70000, 2048, "u40"), (8193, 8192, "ties"),
+])
+def test_large_single_topic(ctx, p, c, kind):
+    po, pid, lag, co, ranks = _single_topic(p + c, p, c, kind, negative=(kind == "full"))
+    exp = oracle.assign_flat(po, pid, lag, co, ranks)
+    got = ctx.assign_batch_lags(po, pid, lag, co, ranks)
+    for g, e, what in zip(got, exp, ("partition order", "member", "totals")):
+        np.testing.assert_array_equal(g, e, err_msg=what)
+
+
+def test_large_ids_already_sorted_and_sparse(ctx):
+    po, pid, lag, co, ranks = _single_topic(9, 3000, 70, "ties", shuffled=False)
+    for ids in (pid, (pid * 1000 - 500000).astype(np.int32)):       # dense sorted, sparse with negatives
+        exp = oracle.assign_flat(po, ids, lag, co, ranks)
+        got = ctx.assign_batch_lags(po, ids, lag, co, ranks)
+        for g, e in zip(got, exp):
+            np.testing.assert_array_equal(g, e)
+
+
+def test_mixed_batch_small_and_large_topics(ctx):
+    rng = np.random.default_rng(3)
+    ps = [10, 2000, 0, 300, 1500, 64, 5000, 7]
+    cs = [2, 5, 3, 64, 100, 0, 200, 8]
+    part_off = np.concatenate([[0], np.cumsum(ps)])
+    cons_off = np.concatenate([[0], np.cumsum(cs)])
+    pid = np.concatenate([rng.permutation(p) for p in ps]).astype(np.int32)
+    lag = rng.integers(0, 1 << 30, part_off[-1]).astype(np.int64)
+    ranks = np.concatenate([np.sort(rng.choice(1000, c, replace=False)) for c in cs]).astype(np.int32)
+    exp = oracle.assign_flat(part_off, pid, lag, cons_off, ranks)
+    got = ctx.assign_batch_lags(part_off, pid, lag, cons_off, ranks)
+    for g, e in zip(got, exp):
+        np.testing.assert_array_equal(g, e)
+
+
+def test_cfg2_full_size_offsets(ctx):
+    for name in ("cfg2a", "cfg2b"):
+        w = synth.config(name)
+        if name == "cfg2a":
+            _check_lags(ctx, w, name)          # totals overflow by design: lag entry point
+        else:
+            _check_offsets(ctx, w, N.LA_RESET_LATEST, name)
+            _check_offsets(ctx, w, N.LA_RESET_EARLIEST, name)
+
+
+def test_cfg5_scaled(ctx):
+    w = synth.config("cfg5", 1.0 / 16)            # 65 536 partitions x 8 192 consumers
+    _check_offsets(ctx, w, N.LA_RESET_EARLIEST, "cfg5/16")
+
+
+# ---- device-resident entry point; round form == literal wavefront argmin ------------------------------
+def _run_device(ctx, w, algo, use_lag=False, latest=True):
+    import ctypes
+    import torch
+    dev = torch.device("cuda", 0)
+    d = {k: torch.from_numpy(np.ascontiguousarray(getattr(w, k))).to(dev) for k in
+         ("part_off", "partition_id", "begin", "end", "committed", "lag", "cons_off", "cons_rank")}
+    out_pid = torch.full((w.n_partitions,), -7, device=dev, dtype=torch.int32)
+    out_rank = torch.full((w.n_partitions,), -7, device=dev, dtype=torch.int32)
+    out_total = torch.zeros(w.cons_rank.size, device=dev, dtype=torch.int64)
+    b = N.DeviceBatch()
+    b.n_topics = w.n_topics
+    b.reset_mode = N.LA_RESET_LATEST if latest else N.LA_RESET_EARLIEST
+    b.algo = algo
+    b.n_partitions = w.n_partitions
+    b.n_consumers = w.cons_rank.size
+    b.max_partitions_per_topic = w.max_partitions
+    b.max_consumers_per_topic = w.max_consumers
+    b.d_part_off = d["part_off"].data_ptr()
+    b.d_partition_id = d["partition_id"].data_ptr()
+    b.d_begin_off = d["begin"].data_ptr()
+    b.d_end_off = d["end"].data_ptr()
+    b.d_committed_off = d["committed"].data_ptr()
+    b.d_lag = d["lag"].data_ptr() if use_lag else None
+    b.d_cons_off = d["cons_off"].data_ptr()
+    b.d_cons_rank = d["cons_rank"].data_ptr()
+    b.d_out_partition = out_pid.data_ptr()
+    b.d_out_member_rank = out_rank.data_ptr()
+    b.d_out_total_lag = out_total.data_ptr()
+    po = np.ascontiguousarray(w.part_off, dtype=np.int64)
+    co = np.ascontiguousarray(w.cons_off, dtype=np.int64)
+    b.h_part_off = po.ctypes.data_as(ctypes.POINTER(ctypes.c_int64))
+    b.h_cons_off = co.ctypes.data_as(ctypes.POINTER(ctypes.c_int64))
+    stream = torch.cuda.current_stream().cuda_stream
+    ctx.assign_batch_device(b, stream)
+    ctx.sync(stream)
+    return out_pid.cpu().numpy(), out_rank.cpu().numpy(), out_total.cpu().numpy()
+
+
+@pytest.mark.parametrize("max_p,max_c", [(64, 8), (256, 32), (700, 64)])
+def test_device_entry_rounds_equals_argmin_equals_oracle(ctx, max_p, max_c):
+    w = synth.ragged(max_p + 11, 150, max_p, max_c, negative=True)
+    exp = oracle.assign_flat(w.part_off, w.partition_id, w.lag, w.cons_off, w.cons_rank)
+    for algo in (N.LA_ALGO_ROUNDS, N.LA_ALGO_ARGMIN):
+        got = _run_device(ctx, w, algo, use_lag=True)
+        for g, e in zip(got, exp):
+            np.testing.assert_array_equal(g, e)
+
+
+def test_device_entry_large_argmin(ctx):
+    po, pid, lag, co, ranks = _single_topic(4, 3000, 300, "u40")
+    w = synth.Workload("one", 1, np.array(po), pid, np.zeros_like(lag), lag, np.zeros_like(lag), lag,
+                       np.array(co), ranks, 3000, 300)
+    exp = oracle.assign_flat(po, pid, lag, co, ranks)
+    for algo in (N.LA_ALGO_ROUNDS, N.LA_ALGO_ARGMIN):
+        got = _run_device(ctx, w, algo, use_lag=True)
+        for g, e in zip(got, exp):
+            np.testing.assert_array_equal(g, e)
+
+
+def test_device_entry_shape_hint_violation_is_reported(ctx):
+    w = synth.ragged(2, 50, 100, 16)
+    w.max_partitions = 8           # lie about the shape
+    with pytest.raises(N.LagAssignError) as ei:
+        _run_device(ctx, w, N.LA_ALGO_AUTO, use_lag=True)
+    assert ei.value.code == N.LA_ESHAPE
