@@ -1,9 +1,11 @@
-"""Builds liblagassign.so (HIP, gfx950 only) in-tree with hipcc.
+"""Builds the native code in-tree.
 
     python -m kafka_lag_based_assignor_amd.build [--force]
 
-The shared object has no Python or torch dependency: it is the C-ABI library of
-include/lagassign.h that a JNI shim or ctypes loads.
+* liblagassign.so  -- the HIP kernels + C ABI of include/lagassign.h (gfx950 only, hipcc).
+                      No Python or torch dependency: it is what a JNI shim or ctypes loads.
+* _host.*.so       -- the C++ host mirror of the reference's plugin class, bound with pybind11.
+                      It links liblagassign.so and uses nothing but its C ABI.
 """
 from __future__ import annotations
 
@@ -11,13 +13,16 @@ import os
 import shutil
 import subprocess
 import sys
+import sysconfig
 from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(HERE, "liblagassign.so")
+HOST = os.path.join(HERE, "_host" + (sysconfig.get_config_var("EXT_SUFFIX") or ".so"))
 SOURCES = ["la_api.hip", "la_lag.hip", "la_wave_tile.hip", "la_large.hip"]
+HOST_SOURCES = ["host/lag_based_partition_assignor.cpp", "host/pybind_host.cpp"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden",
          "-Wall", "-Wextra", "-Wno-unused-parameter"]
 
@@ -36,11 +41,20 @@ def _stale(target: str, deps) -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
+def _headers():
+    hs = []
+    for root, _, files in os.walk(CSRC):
+        if os.path.basename(root) == "build":
+            continue
+        hs += [os.path.join(root, f) for f in files if f.endswith((".h", ".hpp"))]
+    hs.append(os.path.join(os.path.dirname(HERE), "include", "lagassign.h"))
+    return hs
+
+
+def build(force: bool = False, verbose: bool = False, host: bool = True) -> str:
     hipcc = _hipcc()
     os.makedirs(OBJ, exist_ok=True)
-    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
-    headers.append(os.path.join(os.path.dirname(HERE), "include", "lagassign.h"))
+    headers = _headers()
     jobs = []
     objs = []
     for src in SOURCES:
@@ -59,7 +73,23 @@ def build(force: bool = False, verbose: bool = False) -> str:
         list(ex.map(run, jobs))
     if force or jobs or _stale(LIB, objs):
         run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs])
+    if host:
+        build_host(force=force, verbose=verbose)
     return LIB
+
+
+def build_host(force: bool = False, verbose: bool = False) -> str:
+    import pybind11
+    srcs = [os.path.join(CSRC, s) for s in HOST_SOURCES]
+    if force or _stale(HOST, srcs + _headers() + [LIB]):
+        cxx = shutil.which("g++") or "g++"
+        cmd = [cxx, "-O2", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden", "-Wall",
+               "-I" + sysconfig.get_paths()["include"], "-I" + pybind11.get_include(),
+               *srcs, "-o", HOST, "-L" + HERE, "-llagassign", "-Wl,-rpath,$ORIGIN"]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    return HOST
 
 
 if __name__ == "__main__":

@@ -1,0 +1,308 @@
+// lag_based_partition_assignor.cpp -- see the header.  Host-side container/string work only;
+// all arithmetic goes through the C ABI (include/lagassign.h) to the HIP kernels.
+#include "lag_based_partition_assignor.hpp"
+
+#include <algorithm>
+#include <mutex>
+#include <numeric>
+#include <unordered_map>
+
+#include "../../../include/lagassign.h"
+#include "java_compat.hpp"
+
+namespace kafka_lag {
+
+namespace {
+
+// One process-wide native context for the static entry points (the reference's statics carry
+// no state either); guarded because la_ctx is single-threaded.
+std::mutex g_ctx_mutex;
+la_ctx* g_ctx = nullptr;
+
+la_ctx* shared_ctx_locked() {
+    if (!g_ctx) {
+        int rc = la_create(&g_ctx, 0, 0);
+        if (rc != LA_OK) {
+            g_ctx = nullptr;
+            throw std::runtime_error(std::string("liblagassign: ") + la_last_error(nullptr));
+        }
+    }
+    return g_ctx;
+}
+
+void check(la_ctx* ctx, int rc) {
+    if (rc == LA_OK) return;
+    const std::string msg = std::string("liblagassign error ") + std::to_string(rc) + ": " + la_last_error(ctx);
+    if (rc == LA_EINVAL) throw std::invalid_argument(msg);
+    throw std::runtime_error(msg);
+}
+
+// The subscription side of one rebalance, resolved to ranks and topic order.
+struct Plan {
+    std::vector<std::string> members;              // unique memberIds, caller's iteration order
+    std::vector<int32_t> rank_of_member;           // String.compareTo rank of members[i]
+    std::vector<int> member_of_rank;
+    std::vector<std::string> topics;               // consumersPerTopic.entrySet() order
+    std::vector<std::vector<int32_t>> topic_ranks; // per topic: sorted unique subscriber ranks
+    bool order_exact = true;
+};
+
+Plan make_plan(const GroupSubscription& subscriptions) {
+    Plan p;
+    std::unordered_map<std::string, int> member_index;
+    std::vector<const std::vector<std::string>*> member_topics;
+    for (const auto& kv : subscriptions) {                      // a Map has unique keys: last wins
+        auto it = member_index.find(kv.first);
+        if (it == member_index.end()) {
+            member_index.emplace(kv.first, (int)p.members.size());
+            p.members.push_back(kv.first);
+            member_topics.push_back(&kv.second);
+        } else {
+            member_topics[it->second] = &kv.second;
+        }
+    }
+    p.rank_of_member = rankMembers(p.members);
+    p.member_of_rank.assign(p.members.size(), 0);
+    for (size_t i = 0; i < p.members.size(); ++i) p.member_of_rank[p.rank_of_member[i]] = (int)i;
+
+    // consumersPerTopic, Main.java:410-426: HashMap + computeIfAbsent, walked in entry order
+    JavaHashMapOrder order;
+    std::unordered_map<std::string, int> topic_index;
+    std::vector<std::string> names;
+    std::vector<std::vector<int32_t>> ranks;
+    for (size_t m = 0; m < p.members.size(); ++m) {
+        for (const std::string& topic : *member_topics[m]) {
+            auto it = topic_index.find(topic);
+            int ti;
+            if (it == topic_index.end()) {
+                ti = (int)names.size();
+                topic_index.emplace(topic, ti);
+                names.push_back(topic);
+                ranks.emplace_back();
+                order.compute_if_absent_new(ti, java_string_hash(topic));
+            } else {
+                ti = it->second;
+            }
+            ranks[ti].push_back(p.rank_of_member[m]);          // duplicates allowed here ...
+        }
+    }
+    for (int ti : order.order()) {
+        std::vector<int32_t> r = ranks[ti];
+        std::sort(r.begin(), r.end());
+        r.erase(std::unique(r.begin(), r.end()), r.end());     // ... the keyed bins de-dup, Main.java:216-225
+        p.topics.push_back(names[ti]);
+        p.topic_ranks.push_back(std::move(r));
+    }
+    p.order_exact = order.order_exact();
+    return p;
+}
+
+// Per-topic partition data in SoA form, ready for the C ABI.
+struct TopicData {
+    std::vector<int32_t> partition;
+    std::vector<std::string> element_topic;   // TopicPartitionLag.topic of each element (Main.java:264)
+    std::vector<int64_t> lag;                 // lag mode
+    std::vector<int64_t> begin, end, committed;   // offset mode
+};
+
+struct Flat {
+    std::vector<int64_t> part_off{0}, cons_off{0};
+    std::vector<int32_t> pid, cons_rank;
+    std::vector<int64_t> lag, begin, end, committed;
+};
+
+Assignment run_native(const Plan& plan, const std::vector<const TopicData*>& data, bool offsets_mode,
+                      int32_t reset_mode, std::map<std::string, std::map<std::string, int64_t>>* totals_out) {
+    Flat f;
+    for (size_t t = 0; t < plan.topics.size(); ++t) {
+        const TopicData* d = data[t];
+        if (d) {
+            f.pid.insert(f.pid.end(), d->partition.begin(), d->partition.end());
+            if (offsets_mode) {
+                f.begin.insert(f.begin.end(), d->begin.begin(), d->begin.end());
+                f.end.insert(f.end.end(), d->end.begin(), d->end.end());
+                f.committed.insert(f.committed.end(), d->committed.begin(), d->committed.end());
+            } else {
+                f.lag.insert(f.lag.end(), d->lag.begin(), d->lag.end());
+            }
+        }
+        f.part_off.push_back((int64_t)f.pid.size());
+        f.cons_rank.insert(f.cons_rank.end(), plan.topic_ranks[t].begin(), plan.topic_ranks[t].end());
+        f.cons_off.push_back((int64_t)f.cons_rank.size());
+    }
+    const size_t n = f.pid.size(), k = f.cons_rank.size();
+    std::vector<int32_t> out_pid(n), out_rank(n);
+    std::vector<int64_t> out_total(k);
+    if (!plan.topics.empty()) {
+        std::lock_guard<std::mutex> lock(g_ctx_mutex);
+        la_ctx* ctx = shared_ctx_locked();
+        int rc;
+        if (offsets_mode)
+            rc = la_assign_batch(ctx, (int32_t)plan.topics.size(), f.part_off.data(), f.pid.data(), f.begin.data(),
+                                 f.end.data(), f.committed.data(), reset_mode, f.cons_off.data(), f.cons_rank.data(),
+                                 out_pid.data(), out_rank.data(), out_total.data());
+        else
+            rc = la_assign_batch_lags(ctx, (int32_t)plan.topics.size(), f.part_off.data(), f.pid.data(), f.lag.data(),
+                                      f.cons_off.data(), f.cons_rank.data(), out_pid.data(), out_rank.data(),
+                                      out_total.data());
+        check(ctx, rc);
+    }
+
+    Assignment assignment;
+    for (const std::string& m : plan.members) assignment[m];            // a list for EVERY member, :171-174
+    for (size_t t = 0; t < plan.topics.size(); ++t) {
+        const TopicData* d = data[t];
+        // partition id -> the element's own topic string (normally the map key)
+        std::unordered_map<int32_t, const std::string*> topic_of;
+        if (d)
+            for (size_t i = 0; i < d->partition.size(); ++i) topic_of.emplace(d->partition[i], &d->element_topic[i]);
+        for (int64_t i = f.part_off[t]; i < f.part_off[t + 1]; ++i) {
+            if (out_rank[i] < 0) continue;
+            const std::string& member = plan.members[plan.member_of_rank[out_rank[i]]];
+            assignment[member].push_back(TopicPartition{*topic_of.at(out_pid[i]), out_pid[i]});   // :264
+        }
+        if (totals_out) {
+            auto& per = (*totals_out)[plan.topics[t]];
+            for (int64_t c = f.cons_off[t]; c < f.cons_off[t + 1]; ++c)
+                per[plan.members[plan.member_of_rank[f.cons_rank[c]]]] = out_total[c];
+        }
+    }
+    return assignment;
+}
+
+}  // namespace
+
+// String.compareTo ranks (0 = smallest).  Equal ids share a rank slot order by position, but
+// callers pass unique ids.
+std::vector<int32_t> rankMembers(const std::vector<std::string>& memberIds) {
+    std::vector<std::u16string> u;
+    u.reserve(memberIds.size());
+    for (const auto& m : memberIds) u.push_back(utf8_to_utf16(m));
+    std::vector<int> idx(memberIds.size());
+    std::iota(idx.begin(), idx.end(), 0);
+    std::stable_sort(idx.begin(), idx.end(), [&](int a, int b) { return java_compare(u[a], u[b]) < 0; });
+    std::vector<int32_t> rank(memberIds.size());
+    for (size_t r = 0; r < idx.size(); ++r) rank[idx[r]] = (int32_t)r;
+    return rank;
+}
+
+std::vector<std::string> consumersPerTopicOrder(const GroupSubscription& subscriptions) {
+    return make_plan(subscriptions).topics;
+}
+
+LagBasedPartitionAssignor::LagBasedPartitionAssignor() = default;
+LagBasedPartitionAssignor::~LagBasedPartitionAssignor() = default;
+
+void LagBasedPartitionAssignor::configure(const std::map<std::string, std::string>& configs) {
+    consumer_group_props_ = configs;                                             // Main.java:101-104
+    auto gid = consumer_group_props_.find("group.id");
+    if (gid == consumer_group_props_.end())                                      // :107-113
+        throw std::invalid_argument("group.id cannot be null when using partition.assignment.strategy=" +
+                                    std::string("LagBasedPartitionAssignor"));
+    metadata_consumer_props_ = consumer_group_props_;                            // :116-120
+    metadata_consumer_props_["enable.auto.commit"] = "false";
+    metadata_consumer_props_["client.id"] = gid->second + ".assignor";
+}
+
+int64_t LagBasedPartitionAssignor::computePartitionLag(const std::optional<OffsetAndMetadata>& partitionMetadata,
+                                                       int64_t beginOffset, int64_t endOffset,
+                                                       const std::string& autoOffsetResetMode) {
+    const int64_t committed = partitionMetadata ? partitionMetadata->offset : LA_NO_COMMITTED;
+    const int32_t mode = equals_ignore_case_latest(autoOffsetResetMode) ? LA_RESET_LATEST : LA_RESET_EARLIEST;
+    int64_t lag = 0;
+    std::lock_guard<std::mutex> lock(g_ctx_mutex);
+    la_ctx* ctx = shared_ctx_locked();
+    check(ctx, la_compute_lag(ctx, 1, &beginOffset, &endOffset, &committed, mode, &lag));
+    return lag;
+}
+
+Assignment LagBasedPartitionAssignor::assign(const OrderedMap<std::vector<TopicPartitionLag>>& partitionLagPerTopic,
+                                             const GroupSubscription& subscriptions) {
+    const Plan plan = make_plan(subscriptions);
+    std::unordered_map<std::string, TopicData> by_topic;
+    for (const auto& kv : partitionLagPerTopic) {
+        TopicData d;
+        for (const TopicPartitionLag& e : kv.second) {
+            d.partition.push_back(e.partition);
+            d.element_topic.push_back(e.topic);
+            d.lag.push_back(e.lag);
+        }
+        by_topic[kv.first] = std::move(d);                                       // later duplicate key wins
+    }
+    std::vector<const TopicData*> data;
+    for (const std::string& t : plan.topics) {
+        auto it = by_topic.find(t);
+        data.push_back(it == by_topic.end() ? nullptr : &it->second);            // getOrDefault(..., emptyList()), :182
+    }
+    return run_native(plan, data, false, LA_RESET_LATEST, nullptr);
+}
+
+Assignment LagBasedPartitionAssignor::assign(const Cluster& metadata, const GroupSubscription& subscriptions,
+                                             OffsetSource& offsets) {
+    // topicSubscriptions is a HashMap<memberId, topics> filled with put (Main.java:141-146);
+    // the static assign then walks it in HashMap order.
+    GroupSubscription hashed;
+    {
+        JavaHashMapOrder order;
+        std::unordered_map<std::string, int> seen;
+        std::vector<const std::pair<std::string, std::vector<std::string>>*> entries;
+        for (const auto& kv : subscriptions) {
+            auto it = seen.find(kv.first);
+            if (it == seen.end()) {
+                seen.emplace(kv.first, (int)entries.size());
+                order.put_new((int)entries.size(), java_string_hash(kv.first));
+                entries.push_back(&kv);
+            } else {
+                entries[it->second] = &kv;
+            }
+        }
+        for (int i : order.order()) hashed.push_back(*entries[i]);
+    }
+    const Plan plan = make_plan(hashed);
+
+    // readTopicPartitionLags, Main.java:317-365 -- batched: one request per kind for all topics
+    std::vector<TopicPartition> all;
+    std::unordered_map<std::string, TopicData> by_topic;
+    for (const std::string& topic : plan.topics) {
+        auto it = metadata.find(topic);
+        if (it == metadata.end() || it->second.empty()) {
+            warn("Skipping assignment for topic " + topic + " since no metadata is available");   // :359
+            continue;
+        }
+        TopicData d;
+        for (int32_t p : it->second) {
+            d.partition.push_back(p);
+            d.element_topic.push_back(topic);
+            all.push_back(TopicPartition{topic, p});
+        }
+        by_topic[topic] = std::move(d);
+    }
+    const auto begin = offsets.beginningOffsets(all);                            // :339
+    const auto end = offsets.endOffsets(all);                                    // :340
+    const auto committed = offsets.committed(all);                               // :342
+    for (auto& kv : by_topic) {
+        TopicData& d = kv.second;
+        for (int32_t p : d.partition) {
+            const TopicPartition tp{kv.first, p};
+            auto b = begin.find(tp);
+            auto e = end.find(tp);
+            auto c = committed.find(tp);
+            d.begin.push_back(b == begin.end() ? 0 : b->second);                 // getOrDefault(.., 0L), :350
+            d.end.push_back(e == end.end() ? 0 : e->second);                     // :351
+            d.committed.push_back(c == committed.end() || !c->second ? LA_NO_COMMITTED : c->second->offset);
+        }
+    }
+    auto mode_it = consumer_group_props_.find("auto.offset.reset");              // default "latest", :346-347
+    const std::string mode = mode_it == consumer_group_props_.end() ? "latest" : mode_it->second;
+    const int32_t reset = equals_ignore_case_latest(mode) ? LA_RESET_LATEST : LA_RESET_EARLIEST;
+
+    std::vector<const TopicData*> data;
+    for (const std::string& t : plan.topics) {
+        auto it = by_topic.find(t);
+        data.push_back(it == by_topic.end() ? nullptr : &it->second);
+    }
+    last_totals_.clear();
+    return run_native(plan, data, true, reset, &last_totals_);                   // wrap: :152-156
+}
+
+}  // namespace kafka_lag

@@ -1,0 +1,118 @@
+// lag_based_partition_assignor.hpp -- C++ host mirror of the reference's plugin class.
+//
+// The real drop-in host is Java (java/ in this repo, JNI over include/lagassign.h); no JVM
+// exists in the build image, so this C++ class is the host that is compiled, run and tested
+// here.  It keeps the reference's names, argument meaning and error behaviour:
+//
+//   reference (Main.java)                                   here
+//   ------------------------------------------------------  ------------------------------------
+//   class LagBasedPartitionAssignor            :83          kafka_lag::LagBasedPartitionAssignor
+//   void configure(Map<String,?>)              :97-130      configure(map)   throws invalid_argument
+//   String name() -> "lag"                     :132-135     name()
+//   GroupAssignment assign(Cluster, GroupSubscription)      assign(cluster, subscriptions)
+//                                              :137-157
+//   static assign(Map lags, Map subscriptions) :166-188     static assign(lags, subscriptions)
+//   static computePartitionLag(...)            :376-404     static computePartitionLag(...)
+//   readTopicPartitionLags                     :317-365     (inside assign; ONE batched offset
+//                                                            request for all topics)
+//   TopicPartitionLag                          :431-455     struct TopicPartitionLag
+//
+// Everything string- or container-shaped happens here; every number is computed by the HIP
+// kernels behind the C ABI (there is no host arithmetic fallback).
+#pragma once
+#include <cstdint>
+#include <functional>
+#include <map>
+#include <memory>
+#include <optional>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+namespace kafka_lag {
+
+struct TopicPartition {
+    std::string topic;
+    int32_t partition = 0;
+    bool operator==(const TopicPartition& o) const { return partition == o.partition && topic == o.topic; }
+    bool operator<(const TopicPartition& o) const { return topic != o.topic ? topic < o.topic : partition < o.partition; }
+};
+
+struct TopicPartitionLag {                    // Main.java:431-455
+    std::string topic;
+    int32_t partition = 0;
+    int64_t lag = 0;
+};
+
+struct OffsetAndMetadata {                    // org.apache.kafka.clients.consumer.OffsetAndMetadata
+    int64_t offset = 0;
+    explicit OffsetAndMetadata(int64_t off) : offset(off) {
+        if (off < 0) throw std::invalid_argument("Invalid negative offset");   // as the Kafka class does
+    }
+};
+
+// Insertion-ordered String -> V map: what the caller's java.util.Map iterates like.
+template <typename V>
+using OrderedMap = std::vector<std::pair<std::string, V>>;
+
+// Stand-in for the side KafkaConsumer the reference builds lazily (Main.java:89, :322-324).
+// One call per kind for ALL requested partitions (the reference issues three per topic).
+struct OffsetSource {
+    virtual ~OffsetSource() = default;
+    // Missing keys mean "lookup failed" and default to 0 (Main.java:350-351).
+    virtual std::map<TopicPartition, int64_t> beginningOffsets(const std::vector<TopicPartition>& tps) = 0;
+    virtual std::map<TopicPartition, int64_t> endOffsets(const std::vector<TopicPartition>& tps) = 0;
+    // Missing keys / nullopt mean "no committed offset" (partitionMetadata == null, :384).
+    virtual std::map<TopicPartition, std::optional<OffsetAndMetadata>> committed(const std::vector<TopicPartition>& tps) = 0;
+};
+
+// Cluster.partitionsForTopic (Main.java:329): topic -> partition ids; absent or empty = no metadata.
+using Cluster = std::map<std::string, std::vector<int32_t>>;
+// GroupSubscription: memberId -> subscribed topics, in the caller's iteration order.
+using GroupSubscription = OrderedMap<std::vector<std::string>>;
+// GroupAssignment / the static assign's result: memberId -> partitions in the reference's list order.
+using Assignment = std::map<std::string, std::vector<TopicPartition>>;
+
+class LagBasedPartitionAssignor {
+ public:
+    LagBasedPartitionAssignor();
+    ~LagBasedPartitionAssignor();
+
+    // Main.java:97-130.  Requires group.id (std::invalid_argument == IllegalArgumentException).
+    void configure(const std::map<std::string, std::string>& configs);
+    std::string name() const { return "lag"; }            // Main.java:132-135
+
+    // Main.java:137-157.  `offsets` plays the metadata consumer.
+    Assignment assign(const Cluster& metadata, const GroupSubscription& subscriptions, OffsetSource& offsets);
+
+    // Main.java:166-188 (package-private static in the reference; the seam its tests use).
+    static Assignment assign(const OrderedMap<std::vector<TopicPartitionLag>>& partitionLagPerTopic,
+                             const GroupSubscription& subscriptions);
+
+    // Main.java:376-404.
+    static int64_t computePartitionLag(const std::optional<OffsetAndMetadata>& partitionMetadata,
+                                       int64_t beginOffset, int64_t endOffset,
+                                       const std::string& autoOffsetResetMode);
+
+    // Properties the side consumer would get (Main.java:116-120), for inspection/tests.
+    const std::map<std::string, std::string>& metadataConsumerProps() const { return metadata_consumer_props_; }
+
+    // Per-topic consumer totals of the last instance-level assign (the debug summary's
+    // numbers, Main.java:279-306): topic -> (memberId -> total lag).
+    const std::map<std::string, std::map<std::string, int64_t>>& lastTopicTotals() const { return last_totals_; }
+
+    // Hook for log lines the reference emits through slf4j (warn on missing metadata, :359).
+    std::function<void(const std::string&)> warn = [](const std::string&) {};
+
+ private:
+    std::map<std::string, std::string> consumer_group_props_;
+    std::map<std::string, std::string> metadata_consumer_props_;
+    std::map<std::string, std::map<std::string, int64_t>> last_totals_;
+};
+
+// Exposed for tests of the host-side string logic (no GPU involved).
+std::vector<int32_t> rankMembers(const std::vector<std::string>& memberIds);
+std::vector<std::string> consumersPerTopicOrder(const GroupSubscription& subscriptions);
+
+}  // namespace kafka_lag

@@ -1,0 +1,155 @@
+"""The reference's own seven JUnit tests (LagBasedPartitionAssignorTest.java:21-228), restated
+against the host mirror.  Every number below is computed on the MI355X behind the C ABI."""
+import random
+
+import pytest
+
+from kafka_lag_based_assignor_amd import (LagBasedPartitionAssignor, OffsetAndMetadata, TopicPartition,
+                                          TopicPartitionLag)
+from oracle import oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def test_compute_partition_lag():                                     # Test.java:21-33
+    lag = LagBasedPartitionAssignor.compute_partition_lag(OffsetAndMetadata(5555), 1111, 9999, "none")
+    assert lag == 4444
+
+
+def test_compute_partition_lag_no_end_offset():                       # Test.java:38-50
+    assert LagBasedPartitionAssignor.compute_partition_lag(OffsetAndMetadata(5555), 0, 0, "none") == 0
+
+
+def test_compute_partition_lag_no_committed_offset_reset_mode_latest():   # Test.java:52-64
+    assert LagBasedPartitionAssignor.compute_partition_lag(None, 1111, 9999, "latest") == 0
+
+
+def test_compute_partition_lag_no_committed_offset_reset_mode_earliest():  # Test.java:66-80
+    begin, end = 1111, 9999
+    assert LagBasedPartitionAssignor.compute_partition_lag(None, begin, end, "earliest") == end - begin
+
+
+def test_assign():                                                    # Test.java:82-132
+    partition_lag_per_topic = {
+        "topic1": [TopicPartitionLag("topic1", 0, 100000), TopicPartitionLag("topic1", 1, 100000),
+                   TopicPartitionLag("topic1", 2, 500), TopicPartitionLag("topic1", 3, 1)],
+        "topic2": [TopicPartitionLag("topic2", 0, 900000), TopicPartitionLag("topic2", 1, 100000)],
+    }
+    subscriptions = {"consumer-1": ["topic1", "topic2"], "consumer-2": ["topic1"]}
+    expected = {
+        "consumer-1": [TopicPartition("topic1", 0), TopicPartition("topic1", 2),
+                       TopicPartition("topic2", 0), TopicPartition("topic2", 1)],
+        "consumer-2": [TopicPartition("topic1", 1), TopicPartition("topic1", 3)],
+    }
+    assert LagBasedPartitionAssignor.assign_lags(partition_lag_per_topic, subscriptions) == expected
+
+
+def test_assign_with_zero_lags():                                     # Test.java:134-175
+    lags = {"topic1": [TopicPartitionLag("topic1", p, 0) for p in range(7)]}
+    subs = {"consumer-1": ["topic1"], "consumer-2": ["topic1"]}
+    actual = LagBasedPartitionAssignor.assign_lags(lags, subs)
+    sizes = [len(v) for v in actual.values()]
+    assert max(sizes) <= min(sizes) + 1
+
+
+def test_assign_with_heavily_skewed_lags():                           # Test.java:177-228
+    values = [360, 359, 230, 118, 444, 122, 65, 111, 455000, 424000]
+    lags = {"topic1": [TopicPartitionLag("topic1", p, v) for p, v in enumerate(values)]}
+    subs = {"consumer-%d" % i: ["topic1"] for i in (1, 2, 3)}
+    actual = LagBasedPartitionAssignor.assign_lags(lags, subs)
+    sizes = [len(v) for v in actual.values()]
+    assert max(sizes) <= min(sizes) + 1
+
+
+# ---- beyond the reference's tests: same API, checked against the oracle's container model ----
+def test_readme_example():                                            # README.md:42-57
+    lags = {"t0": [TopicPartitionLag("t0", 0, 100000), TopicPartitionLag("t0", 1, 50000),
+                   TopicPartitionLag("t0", 2, 60000)]}
+    got = LagBasedPartitionAssignor.assign_lags(lags, {"C0": ["t0"], "C1": ["t0"]})
+    assert got == {"C0": [("t0", 0)], "C1": [("t0", 2), ("t0", 1)]}
+
+
+def test_static_assign_fuzz_list_order_matches_oracle():
+    rng = random.Random(11)
+    for trial in range(25):
+        topics = ["topic-%d" % i for i in range(rng.randint(1, 40))]
+        members = ["consumer-%d" % i for i in range(rng.randint(1, 15))]
+        rng.shuffle(members)
+        lags = {}
+        for t in topics:
+            if rng.random() < 0.9:
+                ids = list(range(rng.randint(0, 50)))
+                rng.shuffle(ids)
+                lags[t] = [TopicPartitionLag(t, p, rng.choice([0, 0, 5, rng.randint(0, 1 << 40)])) for p in ids]
+        subs = {m: rng.sample(topics + ["ghost"], rng.randint(0, len(topics))) for m in members}
+        if rng.random() < 0.3 and subs[members[0]]:
+            subs[members[0]] = subs[members[0]] + [subs[members[0]][0]]          # duplicate topic
+        got = LagBasedPartitionAssignor.assign_lags(lags, subs)
+        exp = oracle.assign_named({t: [tuple(e) for e in v] for t, v in lags.items()}, subs)
+        assert got == exp, trial
+
+
+class FakeOffsets:
+    """Plays the side KafkaConsumer: one call per kind for ALL partitions."""
+
+    def __init__(self, begin, end, committed):
+        self.begin, self.end, self.com = begin, end, committed
+        self.calls = []
+
+    def beginning_offsets(self, tps):
+        self.calls.append(("begin", len(tps)))
+        return {tp: self.begin[tp] for tp in tps if tp in self.begin}
+
+    def end_offsets(self, tps):
+        self.calls.append(("end", len(tps)))
+        return {tp: self.end[tp] for tp in tps if tp in self.end}
+
+    def committed(self, tps):
+        self.calls.append(("committed", len(tps)))
+        return {tp: self.com.get(tp) for tp in tps}
+
+
+@pytest.mark.parametrize("mode", ["latest", "earliest", None, "none"])
+def test_plugin_level_assign_with_offsets(mode):
+    rng = random.Random(5)
+    metadata = {"orders": list(range(12)), "payments": list(range(5)), "empty": []}
+    begin, end, com = {}, {}, {}
+    for t, ps in metadata.items():
+        for p in ps:
+            b = rng.randint(0, 100)
+            e = b + rng.randint(0, 10000)
+            begin[(t, p)], end[(t, p)] = b, e
+            if rng.random() < 0.7:
+                com[(t, p)] = rng.randint(b, e)
+    del end[("orders", 3)]                                             # failed lookup -> 0 (Main.java:351)
+    subs = {"app-2": ["orders", "payments", "nometa"], "app-10": ["orders"], "app-1": ["payments", "empty"]}
+    a = LagBasedPartitionAssignor()
+    cfg = {"group.id": "g"}
+    if mode is not None:
+        cfg["auto.offset.reset"] = mode
+    a.configure(cfg)
+    warnings = []
+    a.set_warn(warnings.append)
+    src = FakeOffsets(begin, end, com)
+    got = a.assign(metadata, subs, src)
+    assert sorted(c[0] for c in src.calls) == ["begin", "committed", "end"]     # batched: 3 calls total
+    assert len(warnings) == 2 and all("no metadata" in w for w in warnings)     # "nometa" and "empty"
+
+    # expectation through the oracle: lag per partition, then the container model.  The plugin
+    # level walks members in HashMap order (Main.java:141-146).
+    eff_mode = "latest" if mode is None else mode
+    lags = {}
+    for t, ps in metadata.items():
+        if ps:
+            lags[t] = [(t, p, oracle.compute_partition_lag(com.get((t, p)), begin.get((t, p), 0),
+                                                           end.get((t, p), 0), eff_mode)) for p in ps]
+    from oracle.java_collections import JavaHashMap
+    hm = JavaHashMap()
+    for m, ts in subs.items():
+        hm.put(m, ts)
+    exp = oracle.assign_named(lags, dict(hm.items()))
+    assert got == exp
+    totals = a.last_topic_totals()
+    for t in ("orders", "payments"):
+        assigned = {m: sum(l for (tt, p, l) in lags[t] if (tt, p) in got[m]) for m in totals[t]}
+        assert totals[t] == assigned
