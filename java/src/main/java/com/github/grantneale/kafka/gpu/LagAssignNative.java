@@ -1,0 +1,43 @@
+package com.github.grantneale.kafka.gpu;
+
+import java.nio.ByteBuffer;
+
+/**
+ * JNI face of include/lagassign.h (liblagassign.so).  SOURCE ONLY: there is no JDK in the
+ * build image, so this file and jni/lagassign_jni.c have not been compiled here.
+ *
+ * All buffers are DIRECT ByteBuffers in native byte order; the shim passes their addresses
+ * straight to the C ABI (GetDirectBufferAddress), so nothing is copied on the Java side.
+ */
+final class LagAssignNative {
+
+    static {
+        System.loadLibrary("lagassign_jni");   // links liblagassign.so
+    }
+
+    static final int RESET_LATEST = 0;
+    static final int RESET_EARLIEST = 1;
+    static final long NO_COMMITTED = -1L;
+
+    private LagAssignNative() { }
+
+    /** la_create; returns the context handle or throws IllegalStateException(la_last_error). */
+    static native long create(int deviceId);
+
+    /** la_destroy */
+    static native void destroy(long ctx);
+
+    /**
+     * la_assign_batch.  partOff/consOff: int64[T+1]; partitionId/consRank: int32;
+     * begin/end/committed: int64[N] (begin may be null for RESET_LATEST);
+     * outPartition/outMemberRank: int32[N]; outTotalLag: int64[K] or null.
+     * Returns the la_* status code (0 = ok); lastError(ctx) has the text.
+     */
+    static native int assignBatch(long ctx, int nTopics, ByteBuffer partOff, ByteBuffer partitionId,
+                                  ByteBuffer begin, ByteBuffer end, ByteBuffer committed, int resetMode,
+                                  ByteBuffer consOff, ByteBuffer consRank, ByteBuffer outPartition,
+                                  ByteBuffer outMemberRank, ByteBuffer outTotalLag);
+
+    /** la_last_error */
+    static native String lastError(long ctx);
+}

