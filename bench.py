@@ -31,7 +31,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X spec, /opt/skills/guides/MI355X_MICROARCH.md:35
-BYTES_PER_PARTITION = 36       # 28 B read + 8 B written
+# read begin 8 + end 8 + committed 8 + partition id 4, write id-in-assignment-order 4 +
+# member rank 4 = 36 B/partition.  auto.offset.reset=latest never reads `begin`: 28 B/partition there.
+BYTES_PER_PARTITION = {"earliest": 36, "latest": 28}
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "traffic.json")   # written by tools/pmc_parse.py (separate --pmc passes)
 
 
 def parse_args():
@@ -42,23 +45,28 @@ def parse_args():
     ap.add_argument("--topics", type=int, default=100000)
     ap.add_argument("--partitions", type=int, default=256)
     ap.add_argument("--consumers", type=int, default=32)
-    ap.add_argument("--reset-mode", choices=["latest", "earliest"], default="latest")
-    ap.add_argument("--algo", choices=["auto", "argmin"], default="auto")
+    ap.add_argument("--reset-mode", choices=["latest", "earliest"], default="earliest",
+                    help="earliest reads all four marshalled arrays (the 36 B/partition of SURVEY 8d)")
+    ap.add_argument("--algo", choices=["auto", "wide", "argmin"], default="auto")
     ap.add_argument("--gather", action="store_true", help="all-gather the result arrays (RCCL) in the timed region")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg (rank 0, N=1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     return ap.parse_args()
 
 
-def make_device_workload(torch, dev, T, P, C, seed):
+def make_device_workload(torch, dev, T, P, C, seed, dist="zipf"):
     """Target-config inputs generated on the device: Zipf(1.1) lags shuffled over the
     partitions of each topic, shuffled partition ids, offsets built from the lag."""
     from kafka_lag_based_assignor_amd import synth
     g = torch.Generator(device=dev)
     g.manual_seed(seed)
-    base = torch.from_numpy(synth.zipf_lags(P)).to(dev)                       # [P] int64
-    order = torch.rand(T, P, device=dev, generator=g).argsort(dim=1)
-    lag = base[order].reshape(-1).contiguous()
+    if dist == "zipf":
+        base = torch.from_numpy(synth.zipf_lags(P)).to(dev)                       # [P] int64
+        order = torch.rand(T, P, device=dev, generator=g).argsort(dim=1)
+        lag = base[order].reshape(-1).contiguous()
+    else:                                                                         # uniform on [0, 2^40)
+        order = None
+        lag = torch.randint(0, 1 << 40, (T * P,), device=dev, generator=g, dtype=torch.int64)
     pid = torch.rand(T, P, device=dev, generator=g).argsort(dim=1).to(torch.int32).reshape(-1).contiguous()
     del order
     com = torch.randint(0, 1 << 20, (T * P,), device=dev, generator=g, dtype=torch.int64)
@@ -71,6 +79,57 @@ def make_device_workload(torch, dev, T, P, C, seed):
     cons_rank = torch.arange(C, device=dev, dtype=torch.int32).repeat(T).contiguous()
     return dict(part_off=part_off, pid=pid, begin=begin, end=end, committed=com, lag=lag,
                 cons_off=cons_off, cons_rank=cons_rank)
+
+
+def alloc_outputs(torch, dev, T, P, C):
+    return dict(pid=torch.empty(T * P, device=dev, dtype=torch.int32),
+                rank=torch.empty(T * P, device=dev, dtype=torch.int32),
+                total=torch.empty(T * C, device=dev, dtype=torch.int64))
+
+
+def make_batch(N, w, outs, T, P, C, latest, algo):
+    """la_device_batch over device-resident tensors; returns (batch, objects to keep alive)."""
+    b = N.DeviceBatch()
+    b.n_topics = T
+    b.reset_mode = N.LA_RESET_LATEST if latest else N.LA_RESET_EARLIEST
+    b.algo = {"auto": N.LA_ALGO_AUTO, "wide": N.LA_ALGO_ROUNDS_WIDE, "argmin": N.LA_ALGO_ARGMIN}[algo]
+    b.n_partitions = T * P
+    b.n_consumers = T * C
+    b.max_partitions_per_topic = P
+    b.max_consumers_per_topic = C
+    b.d_part_off = w["part_off"].data_ptr()
+    b.d_partition_id = w["pid"].data_ptr()
+    b.d_begin_off = None if latest else w["begin"].data_ptr()
+    b.d_end_off = w["end"].data_ptr()
+    b.d_committed_off = w["committed"].data_ptr()
+    b.d_lag = None
+    b.d_cons_off = w["cons_off"].data_ptr()
+    b.d_cons_rank = w["cons_rank"].data_ptr()
+    b.d_out_partition = outs["pid"].data_ptr()
+    b.d_out_member_rank = outs["rank"].data_ptr()
+    b.d_out_total_lag = outs["total"].data_ptr()
+    keep = []
+    if P > 1024 or C > 64:
+        h_part = w["part_off"].cpu().numpy()
+        h_cons = w["cons_off"].cpu().numpy()
+        b.h_part_off = h_part.ctypes.data_as(ctypes.POINTER(ctypes.c_int64))
+        b.h_cons_off = h_cons.ctypes.data_as(ctypes.POINTER(ctypes.c_int64))
+        keep = [h_part, h_cons]
+    return b, keep
+
+
+def measured_traffic(T, P, C, mode, algo):
+    """HBM bytes per launch from the PMC passes (tools/pmc_probe.py + tools/pmc_parse.py), if a
+    summary for exactly this workload is committed; rocprofv3 cannot wrap itself from inside here."""
+    try:
+        with open(TRAFFIC_FILE) as fh:
+            t = json.load(fh)
+        for e in t.get("entries", []):
+            if (e["topics"], e["partitions"], e["consumers"], e["reset_mode"], e["algo"]) == (T, P, C, mode, algo):
+                return e
+    except (OSError, ValueError, KeyError):
+        pass
+    return None
 
 
 def main():
@@ -95,39 +154,15 @@ def main():
     T, P, C = args.topics, args.partitions, args.consumers
     n_part = T * P
     w = make_device_workload(torch, dev, T, P, C, seed=0x5EED + rank)
-    out_pid = torch.empty(n_part, device=dev, dtype=torch.int32)
-    out_rank = torch.empty(n_part, device=dev, dtype=torch.int32)
-    out_total = torch.empty(T * C, device=dev, dtype=torch.int64)
+    outs = alloc_outputs(torch, dev, T, P, C)
+    out_pid, out_rank, out_total = outs["pid"], outs["rank"], outs["total"]
     if args.gather and world > 1:
         gathered_pid = torch.empty(world * n_part, device=dev, dtype=torch.int32)
         gathered_rank = torch.empty(world * n_part, device=dev, dtype=torch.int32)
 
     ctx = N.Context(local_rank)
     latest = args.reset_mode == "latest"
-    b = N.DeviceBatch()
-    b.n_topics = T
-    b.reset_mode = N.LA_RESET_LATEST if latest else N.LA_RESET_EARLIEST
-    b.algo = N.LA_ALGO_ARGMIN if args.algo == "argmin" else N.LA_ALGO_AUTO
-    b.n_partitions = n_part
-    b.n_consumers = T * C
-    b.max_partitions_per_topic = P
-    b.max_consumers_per_topic = C
-    b.d_part_off = w["part_off"].data_ptr()
-    b.d_partition_id = w["pid"].data_ptr()
-    b.d_begin_off = None if latest else w["begin"].data_ptr()
-    b.d_end_off = w["end"].data_ptr()
-    b.d_committed_off = w["committed"].data_ptr()
-    b.d_lag = None
-    b.d_cons_off = w["cons_off"].data_ptr()
-    b.d_cons_rank = w["cons_rank"].data_ptr()
-    b.d_out_partition = out_pid.data_ptr()
-    b.d_out_member_rank = out_rank.data_ptr()
-    b.d_out_total_lag = out_total.data_ptr()
-    if P > 1024 or C > 64:
-        h_part = w["part_off"].cpu().numpy()
-        h_cons = w["cons_off"].cpu().numpy()
-        b.h_part_off = h_part.ctypes.data_as(ctypes.POINTER(ctypes.c_int64))
-        b.h_cons_off = h_cons.ctypes.data_as(ctypes.POINTER(ctypes.c_int64))
+    b, _keep = make_batch(N, w, outs, T, P, C, latest, args.algo)
 
     stream = torch.cuda.current_stream().cuda_stream
 
@@ -176,11 +211,18 @@ def main():
     total_units = world * n_part * args.steps
     value = total_units / elapsed
 
-    achieved = BYTES_PER_PARTITION * n_part / (kern_ms * 1e-3) / 1e9
+    bpp = BYTES_PER_PARTITION[args.reset_mode]
+    achieved = bpp * n_part / (kern_ms * 1e-3) / 1e9
+    tr = measured_traffic(T, P, C, args.reset_mode, args.algo)
     roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                "kernel": "wave_tile_assign_kernel", "kernel_ms": round(kern_ms, 4),
-                "algorithmic_bytes_per_partition": BYTES_PER_PARTITION}
+                "frac": round(achieved / HBM_PEAK_GBS, 4),
+                "traffic": tr["hbm_bytes_per_launch"] if tr else None,
+                "kernel": "wave_tile_assign_kernel" if (P <= 1024 and C <= 64) else "large-topic path (all kernels)",
+                "kernel_ms": round(kern_ms, 4),
+                "algorithmic_bytes_per_partition": bpp,
+                "algorithmic_bytes_per_launch": bpp * n_part}
+    if tr:
+        roofline["traffic_source"] = tr.get("source")
 
     # ---- parity spot check + cpu_baseline (oracle; test infrastructure, timed on host cores) ----
     cpu = None

@@ -74,6 +74,8 @@ extern "C" {
 #define LA_ALGO_AUTO    0  /* round-structured greedy (default, fastest)                */
 #define LA_ALGO_ROUNDS  1  /* force the round-structured greedy                         */
 #define LA_ALGO_ARGMIN  2  /* literal per-partition wavefront argmin over the bins      */
+#define LA_ALGO_ROUNDS_WIDE 3 /* rounds, but never the packed 64-bit record format (tile path);
+                              * results are identical, this exists so tests can run both  */
 
 typedef struct la_ctx la_ctx;
 

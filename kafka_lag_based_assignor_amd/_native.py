@@ -17,7 +17,7 @@ LIB_PATH = os.path.join(_HERE, "liblagassign.so")
 LA_OK = 0
 LA_EINVAL, LA_ENOMEM, LA_EHIP, LA_ENODEV, LA_ESHAPE = -1, -2, -3, -4, -5
 LA_RESET_LATEST, LA_RESET_EARLIEST = 0, 1
-LA_ALGO_AUTO, LA_ALGO_ROUNDS, LA_ALGO_ARGMIN = 0, 1, 2
+LA_ALGO_AUTO, LA_ALGO_ROUNDS, LA_ALGO_ARGMIN, LA_ALGO_ROUNDS_WIDE = 0, 1, 2, 3
 
 EXPORTED_SYMBOLS = (
     "la_create", "la_destroy", "la_last_error", "la_version", "la_compute_lag",

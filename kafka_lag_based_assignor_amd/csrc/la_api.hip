@@ -110,7 +110,7 @@ int enqueue_batch(la_ctx* ctx, const la_device_batch* b, hipStream_t stream) {
     if (b->n_consumers > 0 && !b->d_cons_rank) return fail(ctx, LA_EINVAL, "null cons_rank");
     if (!b->d_lag && b->reset_mode != LA_RESET_LATEST && !b->d_begin_off && b->n_partitions > 0)
         return fail(ctx, LA_EINVAL, "begin_off is required unless reset_mode is LA_RESET_LATEST");
-    if (b->algo != LA_ALGO_AUTO && b->algo != LA_ALGO_ROUNDS && b->algo != LA_ALGO_ARGMIN)
+    if (b->algo != LA_ALGO_AUTO && b->algo != LA_ALGO_ROUNDS && b->algo != LA_ALGO_ARGMIN && b->algo != LA_ALGO_ROUNDS_WIDE)
         return fail(ctx, LA_EINVAL, "unknown algo %d", b->algo);
 
     la::TileArgs a{};
@@ -129,9 +129,10 @@ int enqueue_batch(la_ctx* ctx, const la_device_batch* b, hipStream_t stream) {
     a.status = ctx->d_status;
     a.reset_latest = (b->reset_mode == LA_RESET_LATEST) ? 1 : 0;
     const bool argmin = (b->algo == LA_ALGO_ARGMIN);
+    const int tile_mode = argmin ? 2 : (b->algo == LA_ALGO_ROUNDS_WIDE ? 1 : 0);
 
     if (la::wave_tile_fits(b->max_partitions_per_topic, b->max_consumers_per_topic)) {
-        LA_HIP(ctx, la::wave_tile_launch(a, b->max_partitions_per_topic, b->max_consumers_per_topic, argmin, stream));
+        LA_HIP(ctx, la::wave_tile_launch(a, b->max_partitions_per_topic, b->max_consumers_per_topic, tile_mode, stream));
         return LA_OK;
     }
 
@@ -158,7 +159,7 @@ int enqueue_batch(la_ctx* ctx, const la_device_batch* b, hipStream_t stream) {
             run.n_topics = u - t;
             run.part_off = b->d_part_off + t;
             run.cons_off = b->d_cons_off + t;
-            LA_HIP(ctx, la::wave_tile_launch(run, mp, mc, argmin, stream));
+            LA_HIP(ctx, la::wave_tile_launch(run, mp, mc, tile_mode, stream));
             t = u;
         } else {
             if (csize(t) > la::kLargeMaxConsumers)

@@ -34,7 +34,8 @@ struct TileArgs {
 
 bool wave_tile_fits(int64_t max_p, int64_t max_c);
 void wave_tile_pick(int64_t max_p, int64_t max_c, int* L, int* E);
-hipError_t wave_tile_launch(TileArgs a, int64_t max_p, int64_t max_c, bool argmin, hipStream_t stream);
+// mode: 0 = rounds, record format picked per wavefront; 1 = rounds, wide records forced; 2 = literal argmin
+hipError_t wave_tile_launch(TileArgs a, int64_t max_p, int64_t max_c, int mode, hipStream_t stream);
 
 // Elementwise lag: out_lag[i] = computePartitionLag(...)   (Main.java:376-404)
 hipError_t lag_launch(int64_t n, const int64_t* begin, const int64_t* end, const int64_t* committed,

@@ -109,6 +109,72 @@ def test_tile_hard_distributions(ctx, dist):
     _check_lags(ctx, w, dist)
 
 
+# ---- packed 64-bit record format (chosen per wavefront) vs the wide format -----------------------------
+def _uniform_batch(seed, t, p, c, lag_hi, pid_hi, lag_lo=0):
+    """T topics x P partitions x C consumers; lags uniform on [lag_lo, lag_hi], ids distinct in [0, pid_hi]."""
+    rng = np.random.default_rng(seed)
+    lag = rng.integers(lag_lo, lag_hi, t * p, endpoint=True).astype(np.int64)
+    lag[rng.integers(0, t * p, max(1, t * p // 50))] = lag_hi            # make sure the bound is hit
+    pid = np.empty(t * p, dtype=np.int64)
+    for i in range(t):
+        ids = np.append(rng.choice(min(pid_hi, 8 * p + 8), p - 1, replace=False), pid_hi)
+        pid[i * p:(i + 1) * p] = rng.permutation(ids)
+    zeros = np.zeros(t * p, dtype=np.int64)
+    return synth.Workload("uniform", t, np.arange(t + 1, dtype=np.int64) * p, pid.astype(np.int32), zeros, lag.copy(),
+                          zeros, lag, np.arange(t + 1, dtype=np.int64) * c,
+                          np.tile(np.arange(c, dtype=np.int32) * 3 + 1, t), p, c)
+
+
+@pytest.mark.parametrize("dist", ["zero", "ties", "small", "u40"])
+@pytest.mark.parametrize("max_p,max_c", [(8, 8), (30, 3), (64, 8), (128, 16), (256, 32), (500, 64), (1024, 40)])
+def test_tile_packed_records_ragged(ctx, dist, max_p, max_c):
+    # narrow lags: (almost) every wavefront takes the packed format; the wide one must agree
+    w = synth.ragged(31 * max_p + max_c, 260, max_p, max_c, dist=dist)
+    exp = oracle.assign_flat(w.part_off, w.partition_id, w.lag, w.cons_off, w.cons_rank)
+    for algo in (N.LA_ALGO_AUTO, N.LA_ALGO_ROUNDS_WIDE):
+        got = _run_device(ctx, w, algo, use_lag=True)
+        for g, e, what in zip(got, exp, ("partition order", "member", "totals")):
+            np.testing.assert_array_equal(g, e, err_msg="%s algo %d" % (what, algo))
+
+
+@pytest.mark.parametrize("p,c", [(64, 8), (256, 32), (1024, 64)])
+@pytest.mark.parametrize("pid_bits", [0, 12, 20, 31])      # 0: ids are exactly 0..P-1
+def test_tile_packed_boundary(ctx, p, c, pid_bits):
+    # the packing rule: lag < 2^min(63 - sh, 57 - log2(tile)) with sh = bits of the largest id.
+    # One below the limit packs, the limit itself must fall back to wide records; both exact.
+    cap_bits = int(np.ceil(np.log2(p)))
+    pid_bits = pid_bits or cap_bits
+    lb = min(63 - pid_bits, 57 - cap_bits)
+    for lag_hi in ((1 << lb) - 1, 1 << lb, (1 << lb) + 12345):
+        w = _uniform_batch(pid_bits * 1000 + p, 40, p, c, lag_hi, (1 << pid_bits) - 1, lag_lo=lag_hi // 2)
+        exp = oracle.assign_flat(w.part_off, w.partition_id, w.lag, w.cons_off, w.cons_rank)
+        for algo in (N.LA_ALGO_AUTO, N.LA_ALGO_ROUNDS_WIDE):
+            got = _run_device(ctx, w, algo, use_lag=True)
+            for g, e, what in zip(got, exp, ("partition order", "member", "totals")):
+                np.testing.assert_array_equal(g, e, err_msg="%s lag_hi=%d algo %d" % (what, lag_hi, algo))
+
+
+def test_tile_packed_negative_id_or_lag_falls_back(ctx):
+    w = _uniform_batch(77, 64, 256, 32, 1 << 30, 255)
+    w.partition_id[5] = -3                      # one negative id in the first wavefront
+    w.lag[256 * 9 + 17] = -1                    # one negative lag in another
+    exp = oracle.assign_flat(w.part_off, w.partition_id, w.lag, w.cons_off, w.cons_rank)
+    got = _run_device(ctx, w, N.LA_ALGO_AUTO, use_lag=True)
+    for g, e in zip(got, exp):
+        np.testing.assert_array_equal(g, e)
+
+
+def test_target_shape_packed_equals_wide_equals_oracle(ctx):
+    w = synth.config("target", 0.05)             # 5 000 topics x 256 x 32
+    for latest in (True, False):
+        lag = oracle.compute_lags(w.begin, w.end, w.committed, latest)
+        exp = oracle.assign_flat(w.part_off, w.partition_id, lag, w.cons_off, w.cons_rank)
+        for algo in (N.LA_ALGO_AUTO, N.LA_ALGO_ROUNDS_WIDE):
+            got = _run_device(ctx, w, algo, use_lag=False, latest=latest)
+            for g, e in zip(got, exp):
+                np.testing.assert_array_equal(g, e)
+
+
 def test_named_configs_scaled(ctx):
     for name, scale in (("cfg3", 1.0), ("cfg4", 0.02), ("target", 0.01)):
         w = synth.config(name, scale)
