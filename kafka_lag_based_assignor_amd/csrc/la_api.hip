@@ -37,6 +37,10 @@ struct la_ctx {
     DevBuf part_off, pid, begin, end, committed, cons_off, cons_rank, out_pid, out_rank, out_total;
     // scratch of the large-topic path
     la::LargeScratch large;
+    // tile path: list of tiles the packed kernel leaves to the wide kernel, and which of the two
+    // counters (d_status + 16 / + 17 words) the next launch uses
+    DevBuf defer;
+    unsigned launches = 0;
 };
 
 namespace {
@@ -128,10 +132,29 @@ int enqueue_batch(la_ctx* ctx, const la_device_batch* b, hipStream_t stream) {
     a.out_total = b->d_out_total_lag;
     a.status = ctx->d_status;
     a.reset_latest = (b->reset_mode == LA_RESET_LATEST) ? 1 : 0;
+    a.n_total = b->n_partitions;
+    a.k_total = b->n_consumers;
+    if (int rc = reserve(ctx, ctx->defer, la::wave_tile_defer_bytes(b->n_topics))) return rc;
+    a.defer_list = (int32_t*)ctx->defer.p;
     const bool argmin = (b->algo == LA_ALGO_ARGMIN);
     const int tile_mode = argmin ? 2 : (b->algo == LA_ALGO_ROUNDS_WIDE ? 1 : 0);
 
+    // The counter pair alternates per LA_ALGO_AUTO launch: such a launch counts into one and its wide
+    // kernel zeroes the other (idle by stream order), so no memset node sits between launches.
+    auto next_counters = [&](la::TileArgs& t) {
+        int32_t* pair = (int32_t*)(ctx->d_status + 16);
+        t.defer_count = pair + (ctx->launches & 1u);
+        t.defer_count_next = pair + ((ctx->launches + 1u) & 1u);
+        if (tile_mode == 0) ++ctx->launches;
+    };
+    if (b->n_partitions == 0) {
+        // nothing to assign; consumers of partition-less topics still report a total of 0
+        if (b->d_out_total_lag && b->n_consumers > 0)
+            LA_HIP(ctx, hipMemsetAsync(b->d_out_total_lag, 0, (size_t)b->n_consumers * sizeof(int64_t), stream));
+        return LA_OK;
+    }
     if (la::wave_tile_fits(b->max_partitions_per_topic, b->max_consumers_per_topic)) {
+        next_counters(a);
         LA_HIP(ctx, la::wave_tile_launch(a, b->max_partitions_per_topic, b->max_consumers_per_topic, tile_mode, stream));
         return LA_OK;
     }
@@ -159,6 +182,7 @@ int enqueue_batch(la_ctx* ctx, const la_device_batch* b, hipStream_t stream) {
             run.n_topics = u - t;
             run.part_off = b->d_part_off + t;
             run.cons_off = b->d_cons_off + t;
+            next_counters(run);
             LA_HIP(ctx, la::wave_tile_launch(run, mp, mc, tile_mode, stream));
             t = u;
         } else {
@@ -328,7 +352,7 @@ LA_API void la_destroy(la_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     for (DevBuf* b : {&ctx->part_off, &ctx->pid, &ctx->begin, &ctx->end, &ctx->committed, &ctx->cons_off,
-                      &ctx->cons_rank, &ctx->out_pid, &ctx->out_rank, &ctx->out_total})
+                      &ctx->cons_rank, &ctx->out_pid, &ctx->out_rank, &ctx->out_total, &ctx->defer})
         release(*b);
     la::large_scratch_release(ctx->large);
     if (ctx->d_status) (void)hipFree(ctx->d_status);

@@ -16,6 +16,8 @@ constexpr int64_t kLargeMaxConsumers = 8192;   // large path: 8 bins per thread 
 // Arguments of the fused wave-tile kernel (all device pointers).
 struct TileArgs {
     int64_t n_topics;
+    int64_t n_total;            // partitions in the whole batch (loads are clamped to it)
+    int64_t k_total;            // consumer entries in the whole batch
     const int64_t* part_off;
     const int32_t* pid;
     const int64_t* begin;       // may be null (treated as 0; only read when !reset_latest)
@@ -30,7 +32,15 @@ struct TileArgs {
     uint32_t* status;
     int32_t reset_latest;
     int32_t lc;                 // pow2ceil(max consumers per topic), set by the launcher
+    // tiles the packed kernel leaves to the wide kernel (LA_ALGO_AUTO): a counter pair that alternates
+    // per launch (the wide kernel zeroes the other one), and the list of tile ids
+    int32_t* defer_count;
+    int32_t* defer_count_next;
+    int32_t* defer_list;
 };
+
+// bytes of defer_list a launch over n_topics topics may need (one tile holds >= 1 topic)
+inline size_t wave_tile_defer_bytes(int64_t n_topics) { return (size_t)(n_topics > 0 ? n_topics : 1) * sizeof(int32_t); }
 
 bool wave_tile_fits(int64_t max_p, int64_t max_c);
 void wave_tile_pick(int64_t max_p, int64_t max_c, int* L, int* E);

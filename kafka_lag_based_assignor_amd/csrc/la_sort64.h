@@ -1,0 +1,298 @@
+// la_sort64.h -- compare-exchange networks on packed 64-bit records, written at the instruction level.
+//
+// A record is one 64-bit unsigned word kept as two VGPRs (P64).  Everything here is the inner loop of
+// the wave-tile kernel: the sort of a topic's partitions (Main.java:228-235) and, per greedy round, the
+// sort of its consumer bins (the comparator of Main.java:243-261 minus the count, which the round
+// structure removes).  hipcc's own code for `(o < mine) == keep_min ? o : mine` on uint64 is
+// 2 v_mov_dpp + v_cmp_lt_u64 + s_xor + s_nop + 2 v_cndmask (and TWO 64-bit compares for an in-register
+// exchange, because it canonicalises to umin/umax).  The forms below fold the lane move into the
+// arithmetic (DPP source operands), use the borrow of a 64-bit subtract as the compare, and keep the
+// mask in VCC:
+//
+//     v_sub_co_u32_dpp   t, vcc, lo, lo  <lane^J>        ; t = lo[lane^J] - lo
+//     v_subb_co_u32_dpp  t, vcc, hi, hi, vcc <lane^J>    ; vcc = rec[lane^J] < rec
+//     s_xor_b64          vcc, vcc, KEEP_MIN              ; vcc = "keep my own record"
+//     v_cndmask_b32_dpp  lo, lo, lo, vcc <lane^J>        ; lo = vcc ? lo : lo[lane^J]
+//     v_cndmask_b32_dpp  hi, hi, hi, vcc <lane^J>
+//
+// 4 full-rate VALU + 1 SALU per compare-exchange.  KEEP_MIN is a compile-time 64-bit lane mask
+// (direction-free bitonic network: the lower index always keeps the smaller record, and "lower" is
+// one bit of the lane id).
+//
+// Hazards (the compiler does not look inside an asm statement; rules from the CDNA4 guides, §5.7 / T21):
+//   * a VALU write of a VGPR needs 2 wait states before a DPP or v_permlane*_swap read of it.
+//     Inside a block the instruction order provides them; between blocks the callers' register
+//     order does (see the notes at bitonic_sort_tile_p64), and blocks that may directly follow a write
+//     of their DPP source take PAD = 1 (s_nop 0) or 2 (s_nop 1).
+//   * VCC: v_sub_co -> v_subb_co is a carry chain (no wait); SALU write of VCC -> VALU read needs none.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "la_device.h"
+
+namespace la {
+
+struct P64 {
+    uint32_t lo, hi;
+};
+
+__device__ __forceinline__ P64 p64_from(uint64_t x) { P64 p; p.lo = (uint32_t)x; p.hi = (uint32_t)(x >> 32); return p; }
+__device__ __forceinline__ uint64_t p64_value(const P64& p) { return ((uint64_t)p.hi << 32) | p.lo; }
+
+// keep-min lane masks: lanes whose bit `J` of the lane id is clear
+template <int J>
+struct KeepMin {
+    static_assert(J == 1 || J == 2 || J == 4 || J == 8 || J == 16 || J == 32, "bad lane bit");
+    static constexpr uint64_t value = J == 1 ? 0x5555555555555555ull : J == 2 ? 0x3333333333333333ull
+                                    : J == 4 ? 0x0F0F0F0F0F0F0F0Full : J == 8 ? 0x00FF00FF00FF00FFull
+                                    : J == 16 ? 0x0000FFFF0000FFFFull : 0x00000000FFFFFFFFull;
+};
+
+#define LA_DPP_TAIL " row_mask:0xf bank_mask:0xf"
+#define LA_PAD0 ""
+#define LA_PAD1 "s_nop 0\n\t"
+#define LA_PAD2 "s_nop 1\n\t"
+
+// ---- (a) rec <-> the same register of lane^(pattern), single-DPP patterns -------------------------------
+#define LA_SAME_ASM(PADSTR, CTRL)                                                          \
+    asm volatile(PADSTR                                                                    \
+                 "v_sub_co_u32_dpp %2, vcc, %0, %0 " CTRL LA_DPP_TAIL "\n\t"                 \
+                 "v_subb_co_u32_dpp %2, vcc, %1, %1, vcc " CTRL LA_DPP_TAIL "\n\t"           \
+                 "s_xor_b64 vcc, vcc, %3\n\t"                                              \
+                 "v_cndmask_b32_dpp %0, %0, %0, vcc " CTRL LA_DPP_TAIL "\n\t"                \
+                 "v_cndmask_b32_dpp %1, %1, %1, vcc " CTRL LA_DPP_TAIL                       \
+                 : "+v"(r.lo), "+v"(r.hi), "=&v"(t)                                         \
+                 : "s"(keep)                                                               \
+                 : "vcc")
+
+#define LA_SAME_PADS(CTRL)                                  \
+    do {                                                    \
+        if constexpr (PAD == 0) LA_SAME_ASM(LA_PAD0, CTRL);  \
+        else if constexpr (PAD == 1) LA_SAME_ASM(LA_PAD1, CTRL); \
+        else LA_SAME_ASM(LA_PAD2, CTRL);                     \
+    } while (0)
+
+// lane ^ 4: no single DPP control; half-mirror into temporaries, then quad reverse as the DPP source
+#define LA_SAME_X4_ASM(PADSTR)                                                                 \
+    asm volatile(PADSTR                                                                        \
+                 "v_mov_b32_dpp %2, %0 row_half_mirror" LA_DPP_TAIL "\n\t"                       \
+                 "v_mov_b32_dpp %3, %1 row_half_mirror" LA_DPP_TAIL "\n\t"                       \
+                 "s_nop 0\n\t"                                                                 \
+                 "v_sub_co_u32_dpp %4, vcc, %2, %0 quad_perm:[3,2,1,0]" LA_DPP_TAIL "\n\t"       \
+                 "v_subb_co_u32_dpp %4, vcc, %3, %1, vcc quad_perm:[3,2,1,0]" LA_DPP_TAIL "\n\t" \
+                 "s_xor_b64 vcc, vcc, %5\n\t"                                                  \
+                 "v_cndmask_b32_dpp %0, %2, %0, vcc quad_perm:[3,2,1,0]" LA_DPP_TAIL "\n\t"      \
+                 "v_cndmask_b32_dpp %1, %3, %1, vcc quad_perm:[3,2,1,0]" LA_DPP_TAIL             \
+                 : "+v"(r.lo), "+v"(r.hi), "=&v"(t), "=&v"(u), "=&v"(w)                          \
+                 : "s"(keep)                                                                   \
+                 : "vcc")
+
+// lane ^ 16 / lane ^ 32: v_permlane*_swap gives both lanes of a pair (A, B) = (lower's, upper's)
+// record; each keeps A or B.  keep-min lanes keep A iff A < B.
+#define LA_SAME_SWAP_ASM(PADSTR, SWAP)                       \
+    asm volatile(PADSTR                                      \
+                 "v_mov_b32 %2, %0\n\t"                      \
+                 "v_mov_b32 %3, %1\n\t"                      \
+                 "s_nop 1\n\t"                               \
+                 SWAP " %0, %2\n\t"                          \
+                 SWAP " %1, %3\n\t"                          \
+                 "v_sub_co_u32 %4, vcc, %0, %2\n\t"          \
+                 "v_subb_co_u32 %4, vcc, %1, %3, vcc\n\t"    \
+                 "s_xor_b64 vcc, vcc, %5\n\t"                \
+                 "v_cndmask_b32 %0, %0, %2, vcc\n\t"         \
+                 "v_cndmask_b32 %1, %1, %3, vcc"             \
+                 : "+v"(r.lo), "+v"(r.hi), "=&v"(t), "=&v"(u), "=&v"(w) \
+                 : "s"(keep)                                 \
+                 : "vcc")
+
+// rec <- min or max of (rec, record of lane ^ J), min where bit J of the lane id is clear
+template <int J, int PAD>
+__device__ __forceinline__ void cmpx_same_xor(P64& r) {
+    const uint64_t keep = KeepMin<J>::value;
+    uint32_t t;
+    if constexpr (J == 1) LA_SAME_PADS("quad_perm:[1,0,3,2]");
+    else if constexpr (J == 2) LA_SAME_PADS("quad_perm:[2,3,0,1]");
+    else if constexpr (J == 8) LA_SAME_PADS("row_ror:8");
+    else if constexpr (J == 4) {
+        uint32_t u, w;
+        if constexpr (PAD == 0) LA_SAME_X4_ASM(LA_PAD0);
+        else if constexpr (PAD == 1) LA_SAME_X4_ASM(LA_PAD1);
+        else LA_SAME_X4_ASM(LA_PAD2);
+    } else {
+        uint32_t u, w;
+        // after the swaps: %0/%1 = A (lower lane's record), %2/%3 = B; vcc = (A<B) ^ keepmin; 1 -> B
+        if constexpr (J == 16) LA_SAME_SWAP_ASM(LA_PAD2, "v_permlane16_swap_b32");
+        else LA_SAME_SWAP_ASM(LA_PAD2, "v_permlane32_swap_b32");
+    }
+}
+
+// rec <- min or max of (rec, record of lane ^ (M-1)), min where bit M/2 of the lane id is clear.
+// Single-register form (one record per lane: the consumer bins).
+template <int M, int PAD>
+__device__ __forceinline__ void cmpx_same_mirror(P64& r) {
+    static_assert(M == 2 || M == 4 || M == 8 || M == 16 || M == 32 || M == 64, "bad mirror width");
+    if constexpr (M == 2) {
+        cmpx_same_xor<1, PAD>(r);
+    } else if constexpr (M == 4 || M == 8 || M == 16) {
+        const uint64_t keep = KeepMin<M / 2>::value;
+        uint32_t t;
+        if constexpr (M == 4) LA_SAME_PADS("quad_perm:[3,2,1,0]");
+        else if constexpr (M == 8) LA_SAME_PADS("row_half_mirror");
+        else LA_SAME_PADS("row_mirror");
+    } else {
+        // lane ^ 31 = row_mirror then lane ^ 16; lane ^ 63 additionally lane ^ 32.  Rare (once per sort):
+        // move first, then a plain (non-DPP) select.
+        P64 o;
+        o.lo = shfl_mirror<M>(r.lo);
+        o.hi = shfl_mirror<M>(r.hi);
+        const uint64_t keep = KeepMin<M / 2>::value;
+        uint32_t t;
+        asm volatile("v_sub_co_u32 %2, vcc, %3, %0\n\t"
+                     "v_subb_co_u32 %2, vcc, %4, %1, vcc\n\t"
+                     "s_xor_b64 vcc, vcc, %5\n\t"
+                     "v_cndmask_b32 %0, %3, %0, vcc\n\t"
+                     "v_cndmask_b32 %1, %4, %1, vcc"
+                     : "+v"(r.lo), "+v"(r.hi), "=&v"(t)
+                     : "v"(o.lo), "v"(o.hi), "s"(keep)
+                     : "vcc");
+    }
+}
+
+// ---- (b) mirror step between registers: my r <-> partner's q and my q <-> partner's r ---------------------
+#define LA_CROSS_ASM(PADSTR, CTRL)                                                          \
+    asm volatile(PADSTR                                                                     \
+                 "v_sub_co_u32_dpp %2, vcc, %0, %5 " CTRL LA_DPP_TAIL "\n\t"                  \
+                 "v_subb_co_u32_dpp %2, vcc, %1, %6, vcc " CTRL LA_DPP_TAIL "\n\t"            \
+                 "s_xor_b64 vcc, vcc, %7\n\t"                                               \
+                 "v_cndmask_b32_dpp %3, %0, %5, vcc " CTRL LA_DPP_TAIL "\n\t"                 \
+                 "v_cndmask_b32_dpp %4, %1, %6, vcc " CTRL LA_DPP_TAIL "\n\t"                 \
+                 "v_sub_co_u32_dpp %2, vcc, %5, %0 " CTRL LA_DPP_TAIL "\n\t"                  \
+                 "v_subb_co_u32_dpp %2, vcc, %6, %1, vcc " CTRL LA_DPP_TAIL "\n\t"            \
+                 "s_xor_b64 vcc, vcc, %7\n\t"                                               \
+                 "v_cndmask_b32_dpp %0, %5, %0, vcc " CTRL LA_DPP_TAIL "\n\t"                 \
+                 "v_cndmask_b32_dpp %1, %6, %1, vcc " CTRL LA_DPP_TAIL                        \
+                 : "+v"(q.lo), "+v"(q.hi), "=&v"(t), "=&v"(n.lo), "=&v"(n.hi)                       \
+                 : "v"(r.lo), "v"(r.hi), "s"(keep)                                          \
+                 : "vcc")
+
+#define LA_CROSS_PADS(CTRL)                                   \
+    do {                                                      \
+        if constexpr (PAD == 0) LA_CROSS_ASM(LA_PAD0, CTRL);   \
+        else if constexpr (PAD == 1) LA_CROSS_ASM(LA_PAD1, CTRL); \
+        else LA_CROSS_ASM(LA_PAD2, CTRL);                      \
+    } while (0)
+
+// plain (already moved) select: r <- keep-min lanes min(r, o), others max(r, o)
+__device__ __forceinline__ void select_minmax(P64& r, const P64& o, uint64_t keep) {
+    uint32_t t;
+    asm volatile("v_sub_co_u32 %2, vcc, %3, %0\n\t"
+                 "v_subb_co_u32 %2, vcc, %4, %1, vcc\n\t"
+                 "s_xor_b64 vcc, vcc, %5\n\t"
+                 "v_cndmask_b32 %0, %3, %0, vcc\n\t"
+                 "v_cndmask_b32 %1, %4, %1, vcc"
+                 : "+v"(r.lo), "+v"(r.hi), "=&v"(t)
+                 : "v"(o.lo), "v"(o.hi), "s"(keep)
+                 : "vcc");
+}
+
+template <int M, int PAD>
+__device__ __forceinline__ void cmpx_cross_mirror(P64& r, P64& q) {
+    static_assert(M == 2 || M == 4 || M == 8 || M == 16 || M == 32 || M == 64, "bad mirror width");
+    const uint64_t keep = KeepMin<M / 2>::value;
+    if constexpr (M <= 16) {
+        uint32_t t;
+        P64 n;
+        if constexpr (M == 2) LA_CROSS_PADS("quad_perm:[1,0,3,2]");
+        else if constexpr (M == 4) LA_CROSS_PADS("quad_perm:[3,2,1,0]");
+        else if constexpr (M == 8) LA_CROSS_PADS("row_half_mirror");
+        else LA_CROSS_PADS("row_mirror");
+        r = n;
+    } else {
+        P64 oq, orr;
+        oq.lo = shfl_mirror<M>(q.lo); oq.hi = shfl_mirror<M>(q.hi);
+        orr.lo = shfl_mirror<M>(r.lo); orr.hi = shfl_mirror<M>(r.hi);
+        select_minmax(r, oq, keep);
+        select_minmax(q, orr, keep);
+    }
+}
+
+// ---- (c) two registers of one lane: a <= b afterwards ---------------------------------------------------------
+__device__ __forceinline__ void cmpx_regs_p64(P64& a, P64& b) {
+    uint32_t t;
+    P64 n;
+    asm volatile("v_sub_co_u32 %2, vcc, %0, %5\n\t"             // b - a
+                 "v_subb_co_u32 %2, vcc, %1, %6, vcc\n\t"       // vcc = b < a
+                 "v_cndmask_b32 %3, %5, %0, vcc\n\t"            // n = vcc ? b : a   (min)
+                 "v_cndmask_b32 %4, %6, %1, vcc\n\t"
+                 "v_cndmask_b32 %0, %0, %5, vcc\n\t"            // b = vcc ? a : b   (max)
+                 "v_cndmask_b32 %1, %1, %6, vcc"
+                 : "+v"(b.lo), "+v"(b.hi), "=&v"(t), "=&v"(n.lo), "=&v"(n.hi)
+                 : "v"(a.lo), "v"(a.hi)
+                 : "vcc");
+    a = n;
+}
+
+// ---- networks ---------------------------------------------------------------------------------------------------
+// Element index i = gl*E + r (L lanes per group, E registers per lane); ascending on exit.
+//
+// Register order between blocks (the 2-wait-state DPP rule).  With E >= 4 a lane stage walks r = 0..E-1,
+// so a register is touched again E-1 blocks later; an in-register stage is followed by the mirror stage
+// of the next merge, whose first block must not DPP-read the register the last in-register block just
+// wrote: the mirror walks pairs from the middle outwards ((E/2-1, E/2) first), and the in-register stage
+// finishes on (E-2, E-1).  E <= 2 cannot be ordered that way and pads every DPP block.
+
+template <int L, int E, int J, bool FIRST>
+__device__ __forceinline__ void clean_p64(P64 (&rec)[E]) {
+    if constexpr (J >= 1) {
+        if constexpr (J >= E) {
+            constexpr int PADN = (E <= 2) ? 1 : 0;
+#pragma unroll
+            for (int r = 0; r < E; ++r) cmpx_same_xor<J / E, PADN>(rec[r]);
+        } else {
+#pragma unroll
+            for (int r = 0; r < E; ++r)
+                if ((r & J) == 0) cmpx_regs_p64(rec[r], rec[r | J]);
+        }
+        clean_p64<L, E, J / 2, false>(rec);
+    }
+}
+
+template <int L, int E, int K, bool FIRST>
+__device__ __forceinline__ void merge_p64(P64 (&rec)[E]) {
+    if constexpr (K <= L * E) {
+        if constexpr (K <= E) {
+#pragma unroll
+            for (int r = 0; r < E; ++r)
+                if ((r & (K >> 1)) == 0) cmpx_regs_p64(rec[r], rec[r ^ (K - 1)]);
+        } else {
+            constexpr int M = K / E;
+            if constexpr (E == 1) {
+                cmpx_same_mirror<M, FIRST ? 2 : 1>(rec[0]);
+            } else {
+                constexpr int PADN = FIRST ? 2 : ((E <= 2) ? 1 : 0);
+#pragma unroll
+                for (int r = E / 2 - 1; r >= 0; --r) cmpx_cross_mirror<M, PADN>(rec[r], rec[E - 1 - r]);
+            }
+        }
+        clean_p64<L, E, K / 4, false>(rec);
+        merge_p64<L, E, K * 2, false>(rec);
+    }
+}
+
+template <int L, int E>
+__device__ __forceinline__ void bitonic_sort_tile_p64(P64 (&rec)[E]) {
+    // the first DPP block may directly follow compiler-generated writes of its sources: PAD 2
+    if constexpr (E == 1) merge_p64<L, E, 2, true>(rec);
+    else merge_p64<L, E, 2, false>(rec);
+}
+
+// One record per lane (consumer bins), ascending over each group of L lanes.
+template <int L>
+__device__ __forceinline__ void bitonic_sort_lanes_p64(P64& rec) {
+    P64 r1[1] = {rec};
+    merge_p64<L, 1, 2, true>(r1);
+    rec = r1[0];
+}
+
+}  // namespace la

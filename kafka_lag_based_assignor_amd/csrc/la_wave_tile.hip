@@ -38,10 +38,24 @@
 // byte is read once, every output byte written once, nothing spills to HBM in between.
 #include "la_kernels.h"
 #include "la_device.h"
+#include "la_sort64.h"
+#include "la_sort32.h"
+#ifdef LA_LAB
+#include <cstdio>
+#include <cstdlib>
+#endif
 
 namespace la {
 
 enum : int { kModeAuto = 0, kModeWide = 1, kModeArgmin = 2 };
+
+// Ablation hooks for tools/tile_lab.hip (phase timing on the GPU); always 0 in the library.
+//   1: no sort, no greedy (memory only)   2: no global loads / stores (compute only)
+//   3: sort but no greedy                 4: greedy but no sort
+#ifndef LA_ABLATE
+#define LA_ABLATE 0
+#endif
+constexpr int kAblate = LA_ABLATE;
 
 template <int L, int E>
 struct TileCfg {
@@ -69,92 +83,232 @@ __device__ __forceinline__ int load_index(int v, int gl) {
 }
 
 // ---- 1. load + lag ------------------------------------------------------------------------------
+// The loads of a tile are split from their use so the kernel can keep the NEXT tile's loads in flight
+// while it sorts the current one (software pipeline, see the kernel).  Raw holds what is in flight.
+//
+// Every load is unconditional: lanes beyond their topic's partitions (and groups beyond the last topic)
+// read a CLAMPED in-bounds element and ignore it.  Branches around loads make hipcc wait for each load
+// before issuing the next (one HBM round trip per branch); straight-line loads all go out back to back.
+template <int E>
+struct Raw {
+    I64x2 en[(E + 1) / 2];      // end offsets (or precomputed lags)
+    I64x2 cm[(E + 1) / 2];      // committed offsets; after stage 2 (earliest mode): the offset to subtract
+    I32x2 id[(E + 1) / 2];      // partition ids
+};
+
+struct TopicDesc {
+    int64_t p0, c0;
+    int P, C;
+};
+
+// element index of a lane's v-th pair, clamped so that a 2-element load stays inside [0, n_total)
 template <int L, int E>
-__device__ __forceinline__ void load_lags(const TileArgs& a, int64_t p0, int P, int gl, int64_t (&lag)[E],
-                                          int32_t (&pid)[E]) {
-    const bool latest = a.reset_latest != 0;
-    if constexpr (E >= 2) {
+__device__ __forceinline__ int64_t clamped_index(const TileArgs& a, const TopicDesc& d, int v, int gl) {
+    const int64_t g = d.p0 + load_index<L, E>(v, gl);
+    const int64_t hi = a.n_total - (E >= 2 ? 2 : 1);
+    return g < hi ? g : hi;
+}
+
+// stage 1: everything that does not depend on data.  Committed offsets first: stage 2 needs only them.
+template <int L, int E>
+__device__ __forceinline__ void issue_loads(const TileArgs& a, const TopicDesc& d, int gl, Raw<E>& raw) {
+    if constexpr (kAblate == 2) return;
+    constexpr int NP = (E + 1) / 2;
+    const int64_t* src_en = a.lag ? a.lag : a.end;
+    if (!a.lag) {
 #pragma unroll
-        for (int v = 0; v < E; v += 2) {
-            const int e = load_index<L, E>(v, gl);
-            lag[v] = lag[v + 1] = 0;
-            pid[v] = pid[v + 1] = 0;
-            if (e + 1 < P) {
-                const int64_t g = p0 + e;
-                const I32x2 id = *reinterpret_cast<const I32x2*>(a.pid + g);
-                pid[v] = id.x; pid[v + 1] = id.y;
-                if (a.lag) {
-                    const I64x2 l = *reinterpret_cast<const I64x2*>(a.lag + g);
-                    lag[v] = l.x; lag[v + 1] = l.y;
-                } else {
-                    const I64x2 en = *reinterpret_cast<const I64x2*>(a.end + g);
-                    const I64x2 cm = *reinterpret_cast<const I64x2*>(a.committed + g);
-                    I64x2 bg; bg.x = bg.y = 0;
-                    if (!latest && a.begin) bg = *reinterpret_cast<const I64x2*>(a.begin + g);
-                    lag[v] = partition_lag(bg.x, en.x, cm.x, latest);
-                    lag[v + 1] = partition_lag(bg.y, en.y, cm.y, latest);
-                }
-            } else if (e < P) {
-                const int64_t g = p0 + e;
-                pid[v] = a.pid[g];
-                if (a.lag) lag[v] = a.lag[g];
-                else lag[v] = partition_lag((!latest && a.begin) ? a.begin[g] : 0, a.end[g], a.committed[g], latest);
-            }
+        for (int k = 0; k < NP; ++k) {
+            const int64_t g = clamped_index<L, E>(a, d, 2 * k, gl);
+            if constexpr (E >= 2) raw.cm[k] = *reinterpret_cast<const I64x2*>(a.committed + g);
+            else { raw.cm[k].x = a.committed[g]; raw.cm[k].y = 0; }
         }
     } else {
-        lag[0] = 0; pid[0] = 0;
-        if (gl < P) {
-            const int64_t g = p0 + gl;
-            pid[0] = a.pid[g];
-            if (a.lag) lag[0] = a.lag[g];
-            else lag[0] = partition_lag((!latest && a.begin) ? a.begin[g] : 0, a.end[g], a.committed[g], latest);
+#pragma unroll
+        for (int k = 0; k < NP; ++k) raw.cm[k].x = raw.cm[k].y = 0;
+    }
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+        const int64_t g = clamped_index<L, E>(a, d, 2 * k, gl);
+        if constexpr (E >= 2) {
+            raw.en[k] = *reinterpret_cast<const I64x2*>(src_en + g);
+            raw.id[k] = *reinterpret_cast<const I32x2*>(a.pid + g);
+        } else {
+            raw.en[k].x = src_en[g]; raw.en[k].y = 0;
+            raw.id[k].x = a.pid[g]; raw.id[k].y = 0;
         }
     }
 }
 
-// ---- packed path ------------------------------------------------------------------------------------
+// stage 2: the beginning offset is needed only where there is no committed offset and auto.offset.reset is
+// not "latest" (Main.java:384-396).  Lanes that need it read `begin`; every other lane re-reads its own
+// `committed` element (a cache hit, no HBM traffic), so the loads stay unconditional and batched, and the
+// result lands in the committed offset's own registers: afterwards cm is the "next offset" of
+// Main.java:386-396 itself.  A topic whose partitions all have committed offsets never touches `begin`.
 template <int L, int E>
-__device__ __forceinline__ void assign_packed(const TileArgs& a, uint64_t* slice, int32_t* rank_tab, int64_t p0,
-                                              int64_t c0, int P, int C, int gl, const int64_t (&lag)[E],
-                                              const int32_t (&pid)[E], int sh) {
-    const uint64_t lag_max = (~0ull >> 1) >> sh;                    // 2^(63-sh) - 1
-    const uint32_t pid_mask = (uint32_t)((1ull << sh) - 1);
+__device__ __forceinline__ bool second_stage_needed(const TileArgs& a) {
+    return !a.lag && !a.reset_latest && a.begin;                        // wave-uniform
+}
 
-    // ---- records; empty slots sort last ---------------------------------------------------------
-    uint64_t rec[E];
+template <int L, int E>
+__device__ __forceinline__ void issue_begin_loads(const TileArgs& a, const TopicDesc& d, int gl, Raw<E>& raw) {
+    if constexpr (kAblate == 2) return;
+    constexpr int NP = (E + 1) / 2;
+    if (!second_stage_needed<L, E>(a)) return;
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+        const int64_t g = clamped_index<L, E>(a, d, 2 * k, gl);
+        const int64_t* sx = raw.cm[k].x < 0 ? a.begin : a.committed;
+        raw.cm[k].x = sx[g];
+        if constexpr (E >= 2) {
+            const int64_t* sy = raw.cm[k].y < 0 ? a.begin : a.committed;
+            raw.cm[k].y = sy[g + 1];
+        }
+    }
+}
+
+// computePartitionLag (Main.java:376-404) on what the two stages fetched
+template <int L, int E>
+__device__ __forceinline__ void finish_lags(const TileArgs& a, const TopicDesc& d, int gl, const Raw<E>& raw,
+                                            int64_t (&lag)[E], int32_t (&pid)[E]) {
+    const bool latest = a.reset_latest != 0;
+    if constexpr (kAblate == 2) {
+#pragma unroll
+        for (int v = 0; v < E; ++v) {
+            const uint32_t h = ((uint32_t)d.p0 + (uint32_t)(v * L + gl)) * 2654435761u;
+            lag[v] = (int64_t)(h >> 2) + a.reset_latest;
+            pid[v] = (int32_t)((v * L + gl) * 77 + 13) & (L * E - 1);
+        }
+        return;
+    }
+    constexpr int NP = (E + 1) / 2;
+    // after stage 2 the cm registers hold the offset to subtract; otherwise "none" (< 0) means `end`
+    // (latest) or 0 (earliest without a begin array)
+    const bool cm_is_next = second_stage_needed<L, E>(a);
+    auto lag_of = [&](int64_t en, int64_t cm) -> int64_t {
+        if (a.lag) return en;
+        if (cm_is_next) { const int64_t dlt = (int64_t)((uint64_t)en - (uint64_t)cm); return dlt > 0 ? dlt : 0; }
+        return partition_lag(0, en, cm, latest);
+    };
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+        const int e = load_index<L, E>(2 * k, gl);
+        // a pair clamped back by one element holds this lane's first element in .y (only the very last
+        // element of the batch can be in that position)
+        const bool shifted = (E >= 2) && (d.p0 + e == a.n_total - 1);
+        const int64_t en_x = shifted ? raw.en[k].y : raw.en[k].x;
+        const int64_t cm_x = shifted ? raw.cm[k].y : raw.cm[k].x;
+        pid[2 * k] = shifted ? raw.id[k].y : raw.id[k].x;
+        lag[2 * k] = lag_of(en_x, cm_x);
+        if constexpr (E >= 2) {
+            pid[2 * k + 1] = raw.id[k].y;
+            lag[2 * k + 1] = lag_of(raw.en[k].y, raw.cm[k].y);
+        }
+    }
+    // slots past the topic's partitions: lag 0, id 0 (they must not influence the format decision)
+#pragma unroll
+    for (int v = 0; v < E; ++v) {
+        const bool valid = load_index<L, E>(v, gl) < d.P;
+        lag[v] = valid ? lag[v] : 0;
+        pid[v] = valid ? pid[v] : 0;
+    }
+}
+
+// ---- packed path ------------------------------------------------------------------------------------
+// records of the packed format:  ((2^lbw - 1 - lag) << sh) | id,  empty slots all ones (sort last)
+template <int L, int E>
+__device__ __forceinline__ void pack_records(int P, int gl, const int64_t (&lag)[E], const int32_t (&pid)[E], int sh,
+                                             uint64_t lag_max, P64 (&rec)[E]) {
 #pragma unroll
     for (int v = 0; v < E; ++v) {
         const int e = load_index<L, E>(v, gl);
-        rec[v] = (e < P) ? (((lag_max - (uint64_t)lag[v]) << sh) | (uint32_t)pid[v]) : ~0ull;
+        rec[v] = p64_from((e < P) ? (((lag_max - (uint64_t)lag[v]) << sh) | (uint32_t)pid[v]) : ~0ull);
     }
+}
 
-    // ---- 2. sort (lag desc, partition asc) -------------------------------------------------------
-    bitonic_sort_tile64<L, E>(rec, gl);
-
-    // ---- 3. sorted position s = gl*E + r -> LDS -----------------------------------------------------
+// ---- 2. sort (lag desc, partition asc), leaving the sorted records in the LDS slice ---------------------
+// Fast form: sort 32-bit keys  (top bits of the record) << idx_bits | slot,  then fetch each record from
+// the slice by its slot.  Two records whose kept bits are equal would be ordered by slot instead of by
+// their dropped bits, so the sorted keys are checked for equal neighbours; if the wavefront has one, it
+// re-sorts the full 64-bit records (la_sort64.h).  When the record needs no more bits than the key
+// keeps, nothing is dropped and the check cannot fail.
+template <int L, int E>
+__device__ __forceinline__ void sort_into_slice(uint64_t* slice, int gl, P64 (&rec)[E], int rec_bits) {
+    using Cfg = TileCfg<L, E>;
+    constexpr int kIdxBits = Cfg::kLog2Cap;
+    constexpr int kKeep = 31 - kIdxBits;                     // key < 2^31: the all-ones sentinel stays largest
+    if constexpr (kAblate == 1 || kAblate == 4) {
 #pragma unroll
-    for (int r = 0; r < E; ++r) slice[slot_of(gl * E + r)] = rec[r];
-    if (gl < C) rank_tab[gl] = a.cons_rank[c0 + gl];
+        for (int r = 0; r < E; ++r) slice[slot_of(gl * E + r)] = p64_value(rec[r]);
+        return;
+    }
+    const int drop = rec_bits > kKeep ? rec_bits - kKeep : 0;            // wave-uniform
+    uint32_t key[E];
+#pragma unroll
+    for (int v = 0; v < E; ++v) {
+        const int e = load_index<L, E>(v, gl);
+        const uint64_t r = p64_value(rec[v]);
+        slice[slot_of(e)] = r;                                            // unsorted, by slot
+        key[v] = (r == ~0ull) ? 0xFFFFFFFFu : (((uint32_t)(r >> drop) << kIdxBits) | (uint32_t)e);
+    }
+    bitonic_sort_tile_u32<L, E>(key);
+
+    bool tie = false;
+    if (drop > 0) {
+        // neighbours in sorted order: position s = gl*E + r
+#pragma unroll
+        for (int r = 0; r + 1 < E; ++r)
+            tie |= ((key[r] ^ key[r + 1]) >> kIdxBits) == 0 && key[r + 1] != 0xFFFFFFFFu;
+        const uint32_t nxt = (uint32_t)__shfl_down((int)key[0], 1);
+        tie |= gl != L - 1 && ((key[E - 1] ^ nxt) >> kIdxBits) == 0 && nxt != 0xFFFFFFFFu;
+    }
+    wave_lds_fence();
+    if (__builtin_amdgcn_ballot_w64(tie) != 0) {
+        // full records, full network
+#pragma unroll
+        for (int v = 0; v < E; ++v) rec[v] = p64_from(slice[slot_of(load_index<L, E>(v, gl))]);
+        bitonic_sort_tile_p64<L, E>(rec);
+    } else {
+#pragma unroll
+        for (int r = 0; r < E; ++r) {
+            const uint64_t x = slice[slot_of((int)(key[r] & (uint32_t)(Cfg::kCap - 1)))];
+            rec[r] = p64_from(key[r] == 0xFFFFFFFFu ? ~0ull : x);
+        }
+    }
+    wave_lds_fence();
+#pragma unroll
+    for (int r = 0; r < E; ++r) slice[slot_of(gl * E + r)] = p64_value(rec[r]);
+}
+
+// ---- 3..5: greedy rounds over the sorted slice, outputs ------------------------------------------------------
+template <int L, int E>
+__device__ __forceinline__ void assign_packed(const TileArgs& a, uint64_t* slice, int32_t* rank_tab, int64_t p0,
+                                              int64_t c0, int P, int C, int gl, int sh, uint64_t lag_max,
+                                              int32_t my_rank) {
+    const uint32_t pid_mask = (uint32_t)((1ull << sh) - 1);
+
+    if (gl < C) rank_tab[gl] = my_rank;
     wave_lds_fence();
 
     // ---- 4. greedy rounds: bin = (total << 6) | index in the rank-sorted consumer list ----------------
-    uint64_t bin = (gl < C) ? (uint64_t)gl : ~0ull;
+    P64 bin = p64_from((gl < C) ? (uint64_t)gl : ~0ull);
     const int rounds = (C > 0) ? (P + C - 1) / C : 0;
-    const int max_rounds = __builtin_amdgcn_readfirstlane(wave_max_i32(rounds));
+    int max_rounds = __builtin_amdgcn_readfirstlane(wave_max_i32(rounds));
+    if constexpr (kAblate == 1 || kAblate == 3) max_rounds = 0;
     for (int q = 0; q < max_rounds; ++q) {
         // round 0 starts sorted: all totals 0, indices ascending
-        if (q > 0) bitonic_sort_lanes64<L>(bin, gl);
+        if (q > 0) bitonic_sort_lanes_p64<L>(bin);
         const int s = q * C + gl;
         if (gl < C && s < P) {
             const uint64_t r = slice[slot_of(s)];
-            bin += (lag_max - (r >> sh)) << 6;                                   // Main.java:265
-            slice[slot_of(s)] = ((uint64_t)((uint32_t)bin & 63u) << 32) | ((uint32_t)r & pid_mask);
+            const uint64_t nb = p64_value(bin) + ((lag_max - (r >> sh)) << 6);                  // Main.java:265
+            bin = p64_from(nb);
+            slice[slot_of(s)] = ((uint64_t)(bin.lo & 63u) << 32) | ((uint32_t)r & pid_mask);
         }
     }
     wave_lds_fence();
 
     // ---- 5. outputs ------------------------------------------------------------------------------------
-    if (a.out_total && gl < C && bin != ~0ull) a.out_total[c0 + ((uint32_t)bin & 63u)] = (int64_t)(bin >> 6);
+    if (a.out_total && gl < C) a.out_total[c0 + (bin.lo & 63u)] = (int64_t)(p64_value(bin) >> 6);
     if constexpr (E >= 4) {
         // four consecutive positions per lane: 16-byte stores
 #pragma unroll
@@ -167,6 +321,7 @@ __device__ __forceinline__ void assign_packed(const TileArgs& a, uint64_t* slice
                 op[i] = (int32_t)((uint32_t)w & pid_mask);
                 om[i] = (C > 0) ? rank_tab[(uint32_t)(w >> 32) & 63u] : -1;
             }
+            if (kAblate == 2 && (op[0] ^ om[1] ^ op[2] ^ om[3]) != 0x7FFFFFF1) continue;
             if (s0 + 3 < P) {
                 struct __attribute__((aligned(4))) I32x4 { int32_t x, y, z, w; };
                 I32x4 vp; vp.x = op[0]; vp.y = op[1]; vp.z = op[2]; vp.w = op[3];
@@ -285,8 +440,61 @@ __device__ __forceinline__ void assign_wide(const TileArgs& a, uint64_t* slice, 
     }
 }
 
-template <int L, int E, int MODE>
-__global__ __launch_bounds__(256) void wave_tile_assign_kernel(TileArgs a) {
+// Tile -> topic descriptor of this lane's group.
+// Tile -> topic descriptor of this lane's group.  Unconditional loads (clamped topic index); the words are
+// fetched one step (fetch_desc) and interpreted another (make_desc), so a prefetched descriptor is not
+// waited for where it is issued.
+struct DescWords {
+    int64_t p0, p1, c0, c1;
+    bool exists;
+};
+
+template <int L, int E>
+__device__ __forceinline__ DescWords fetch_desc(const TileArgs& a, int64_t t, int64_t n_tiles, int grp) {
+    using Cfg = TileCfg<L, E>;
+    const int64_t topic = t * Cfg::kGroupsPerWave + grp;
+    DescWords w;
+    w.exists = t < n_tiles && topic < a.n_topics;
+    const int64_t tc = w.exists ? topic : a.n_topics - 1;
+    w.p0 = a.part_off[tc]; w.p1 = a.part_off[tc + 1];
+    w.c0 = a.cons_off[tc]; w.c1 = a.cons_off[tc + 1];
+    return w;
+}
+
+template <int L, int E>
+__device__ __forceinline__ TopicDesc make_desc(const TileArgs& a, const DescWords& w, int gl) {
+    using Cfg = TileCfg<L, E>;
+    TopicDesc d;
+    d.p0 = w.p0;
+    d.c0 = w.c0;
+    const int64_t Pl = w.p1 - w.p0, Cl = w.c1 - w.c0;
+    const bool bad = Pl > Cfg::kCap || Cl > L || Pl < 0 || Cl < 0;
+    if (w.exists && bad && gl == 0) atomicOr(a.status, kStatusShape);    // hint was wrong; leave outputs alone
+    d.P = (w.exists && !bad) ? (int)Pl : 0;
+    d.C = (w.exists && !bad) ? (int)Cl : 0;
+    return d;
+}
+
+template <int L, int E>
+__device__ __forceinline__ TopicDesc load_desc(const TileArgs& a, int64_t t, int64_t n_tiles, int grp, int gl) {
+    return make_desc<L, E>(a, fetch_desc<L, E>(a, t, n_tiles, grp), gl);
+}
+
+// ---- kernel 1: packed records, software-pipelined -------------------------------------------------------
+// One wavefront walks tiles t = w, w + W, w + 2W, .. (W = wavefronts in the grid; the grid is sized to what
+// is resident, see the launcher).  Per tile: finish the lags from loads that were issued one tile ago,
+// pack, issue the next tile's loads into the registers that just became free, then sort / greedy / store.
+// The HBM latency of tile i+1 hides under the ~2 000 VALU instructions of tile i inside the SAME
+// wavefront, instead of relying on other wavefronts being in a different phase.
+// A tile whose records do not fit the packed format is appended to the deferred list and left to kernel 2.
+#ifndef LA_WPS
+#define LA_WPS 1
+#endif
+#ifndef LA_GRID_MULT
+#define LA_GRID_MULT 1
+#endif
+template <int L, int E>
+__global__ __launch_bounds__(256, LA_WPS) void wave_tile_packed_kernel(TileArgs a) {
     using Cfg = TileCfg<L, E>;
     __shared__ uint64_t lds[Cfg::kTopicsPerBlock * Cfg::kSlots];
     __shared__ int32_t rank_lds[Cfg::kTopicsPerBlock * L];
@@ -295,61 +503,139 @@ __global__ __launch_bounds__(256) void wave_tile_assign_kernel(TileArgs a) {
     const int wave = threadIdx.x >> 6;
     const int gl = lane & (L - 1);            // lane within group
     const int grp = lane / L;                 // group within wave
-    const int64_t topic = ((int64_t)blockIdx.x * Cfg::kWavesPerBlock + wave) * Cfg::kGroupsPerWave + grp;
     uint64_t* slice = lds + (wave * Cfg::kGroupsPerWave + grp) * Cfg::kSlots;
     int32_t* rank_tab = rank_lds + (wave * Cfg::kGroupsPerWave + grp) * L;
 
-    // ---- topic descriptor ------------------------------------------------------------
-    int64_t p0 = 0, c0 = 0;
-    int P = 0, C = 0;
-    if (topic < a.n_topics) {
-        p0 = a.part_off[topic];
-        c0 = a.cons_off[topic];
-        const int64_t Pl = a.part_off[topic + 1] - p0, Cl = a.cons_off[topic + 1] - c0;
-        if (Pl > Cfg::kCap || Cl > L || Pl < 0 || Cl < 0) {
-            if (gl == 0) atomicOr(a.status, kStatusShape);   // hint was wrong; leave outputs alone
-        } else {
-            P = (int)Pl;
-            C = (int)Cl;
+    const int64_t n_tiles = (a.n_topics + Cfg::kGroupsPerWave - 1) / Cfg::kGroupsPerWave;
+    const int64_t n_waves = (int64_t)gridDim.x * Cfg::kWavesPerBlock;
+    int64_t tile = (int64_t)blockIdx.x * Cfg::kWavesPerBlock + wave;
+    if (tile >= n_tiles) return;
+
+    for (; tile < n_tiles; tile += n_waves) {
+        const TopicDesc cur = load_desc<L, E>(a, tile, n_tiles, grp, gl);
+        Raw<E> raw;
+        issue_loads<L, E>(a, cur, gl, raw);
+        // consumer ranks of the topic, used only at the very end: fetched with everything else
+        int32_t my_rank = 0;
+        if constexpr (kAblate != 2) {
+            const int64_t kc = cur.c0 + gl < a.k_total ? cur.c0 + gl : (a.k_total > 0 ? a.k_total - 1 : 0);
+            if (a.k_total > 0) my_rank = a.cons_rank[kc];
         }
-    }
+        issue_begin_loads<L, E>(a, cur, gl, raw);
 
-    int64_t lag[E];
-    int32_t pid[E];
-    load_lags<L, E>(a, p0, P, gl, lag, pid);
-
-    if constexpr (MODE == kModeAuto) {
-        // can this wavefront's records be packed into 64 bits?  (empty slots hold lag 0, id 0)
-        uint32_t id_or = 0;
-        uint64_t lag_or = 0;
+        P64 rec[E];
+        int sh, lbw;
+        bool fits;
+        uint64_t lag_max;
+        {
+            int64_t lag[E];
+            int32_t pid[E];
+            finish_lags<L, E>(a, cur, gl, raw, lag, pid);
+            // can this wavefront's records be packed into 64 bits?  (empty slots hold lag 0, id 0)
+            uint32_t id_or = 0;
+            uint64_t lag_or = 0;
 #pragma unroll
-        for (int v = 0; v < E; ++v) { id_or |= (uint32_t)pid[v]; lag_or |= (uint64_t)lag[v]; }
-        id_or = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave_or_u32(id_or));
-        const int sh = 32 - __builtin_clz(id_or | 1u);                   // 1..32 (32: a negative id)
-        int lb = 63 - sh;
-        if (lb > 57 - Cfg::kLog2Cap) lb = 57 - Cfg::kLog2Cap;
-        const bool fits = (sh < 32) && ((lag_or >> lb) == 0);
-        if (__builtin_amdgcn_ballot_w64(!fits) == 0) {
-            assign_packed<L, E>(a, slice, rank_tab, p0, c0, P, C, gl, lag, pid, sh);
-            return;
+            for (int v = 0; v < E; ++v) { id_or |= (uint32_t)pid[v]; lag_or |= (uint64_t)lag[v]; }
+            id_or = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave_or_u32(id_or));
+            sh = 32 - __builtin_clz(id_or | 1u);                             // 1..32 (32: a negative id)
+            // bits of the wavefront's largest lag (64: a negative lag)
+            const uint32_t hi = (uint32_t)(lag_or >> 32), lo = (uint32_t)lag_or;
+            const int my_bits = hi ? 64 - __builtin_clz(hi) : (lo ? 32 - __builtin_clz(lo) : 0);
+            lbw = __builtin_amdgcn_readfirstlane(wave_max_i32(my_bits));
+            int lim = 63 - sh;
+            if (lim > 57 - Cfg::kLog2Cap) lim = 57 - Cfg::kLog2Cap;
+            fits = sh < 32 && lbw <= lim;                                    // wave-uniform
+            lag_max = lbw >= 64 ? ~0ull : (((uint64_t)1 << lbw) - 1);
+            if (fits) pack_records<L, E>(cur.P, gl, lag, pid, sh, lag_max, rec);
         }
+        if (fits) {
+            sort_into_slice<L, E>(slice, gl, rec, lbw + sh);
+            assign_packed<L, E>(a, slice, rank_tab, cur.p0, cur.c0, cur.P, cur.C, gl, sh, lag_max, my_rank);
+        } else if (lane == 0) {
+            a.defer_list[atomicAdd(a.defer_count, 1)] = (int32_t)tile;
+        }
+        break;      // one tile per wavefront: the grid covers all tiles (a resident-sized grid looping over
+                    // tiles measured 15-20 % slower: more live registers, fewer wavefronts per SIMD)
     }
-    assign_wide<L, E, MODE == kModeArgmin>(a, slice, p0, c0, P, C, gl, lag, pid);
 }
 
-// ---- launcher ---------------------------------------------------------------------------------
+// ---- kernel 2: wide records (and the literal argmin form) ------------------------------------------------------
+// Tiles come from the deferred list of kernel 1 (LA_ALGO_AUTO) or are all tiles (forced wide / argmin).
+template <int L, int E, bool ARGMIN>
+__global__ __launch_bounds__(256) void wave_tile_wide_kernel(TileArgs a, int from_list) {
+    using Cfg = TileCfg<L, E>;
+    __shared__ uint64_t lds[Cfg::kTopicsPerBlock * Cfg::kSlots];
+
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = threadIdx.x >> 6;
+    const int gl = lane & (L - 1);
+    const int grp = lane / L;
+    uint64_t* slice = lds + (wave * Cfg::kGroupsPerWave + grp) * Cfg::kSlots;
+
+    const int64_t n_tiles = (a.n_topics + Cfg::kGroupsPerWave - 1) / Cfg::kGroupsPerWave;
+    const int64_t n_waves = (int64_t)gridDim.x * Cfg::kWavesPerBlock;
+    const int64_t count = from_list ? (int64_t)*a.defer_count : n_tiles;
+    // the other counter of the pair is the next launch's: it is idle now (stream order), reset it here
+    if (from_list && blockIdx.x == 0 && threadIdx.x == 0) *a.defer_count_next = 0;
+    for (int64_t i = (int64_t)blockIdx.x * Cfg::kWavesPerBlock + wave; i < count; i += n_waves) {
+        const int64_t tile = from_list ? (int64_t)a.defer_list[i] : i;
+        const TopicDesc d = load_desc<L, E>(a, tile, n_tiles, grp, gl);
+        Raw<E> raw;
+        issue_loads<L, E>(a, d, gl, raw);
+        issue_begin_loads<L, E>(a, d, gl, raw);
+        int64_t lag[E];
+        int32_t pid[E];
+        finish_lags<L, E>(a, d, gl, raw, lag, pid);
+        assign_wide<L, E, ARGMIN>(a, slice, d.p0, d.c0, d.P, d.C, gl, lag, pid);
+        wave_lds_fence();
+    }
+}
+
+// Grid = what is resident: CUs x (workgroups per CU the kernel's registers / LDS admit), at most one
+// workgroup per four tiles.  Nothing depends on co-residency (no inter-workgroup communication); a
+// smaller or larger grid only changes speed.
+template <typename K>
+static hipError_t resident_blocks(K kernel, int threads, int* out) {
+    int dev = 0, cus = 0, per_cu = 0;
+    hipError_t e;
+    if ((e = hipGetDevice(&dev)) != hipSuccess) return e;
+    if ((e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev)) != hipSuccess) return e;
+    if ((e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, threads, 0)) != hipSuccess) return e;
+    if (per_cu < 1) per_cu = 1;
+    *out = cus * per_cu;
+    return hipSuccess;
+}
+
 template <int L, int E>
 static hipError_t launch_one(const TileArgs& a, int mode, hipStream_t stream) {
     using Cfg = TileCfg<L, E>;
     const int64_t blocks = (a.n_topics + Cfg::kTopicsPerBlock - 1) / Cfg::kTopicsPerBlock;
     if (blocks <= 0) return hipSuccess;
-    const dim3 g((unsigned)blocks), b(Cfg::kThreads);
-    if (mode == kModeArgmin)
-        hipLaunchKernelGGL((wave_tile_assign_kernel<L, E, kModeArgmin>), g, b, 0, stream, a);
-    else if (mode == kModeWide)
-        hipLaunchKernelGGL((wave_tile_assign_kernel<L, E, kModeWide>), g, b, 0, stream, a);
-    else
-        hipLaunchKernelGGL((wave_tile_assign_kernel<L, E, kModeAuto>), g, b, 0, stream, a);
+    static int res_packed = 0, res_wide = 0, res_argmin = 0;       // per instantiation; one device family
+    hipError_t e;
+    if (res_packed == 0) {
+        if ((e = resident_blocks(wave_tile_packed_kernel<L, E>, Cfg::kThreads, &res_packed)) != hipSuccess) return e;
+        if ((e = resident_blocks(wave_tile_wide_kernel<L, E, false>, Cfg::kThreads, &res_wide)) != hipSuccess) return e;
+        if ((e = resident_blocks(wave_tile_wide_kernel<L, E, true>, Cfg::kThreads, &res_argmin)) != hipSuccess) return e;
+#ifdef LA_LAB
+        printf("resident blocks: packed %d wide %d argmin %d (needed %lld)\n", res_packed, res_wide, res_argmin, (long long)blocks);
+#endif
+    }
+    const dim3 b(Cfg::kThreads);
+    auto grid = [&](int resident) { return dim3((unsigned)(blocks < resident ? blocks : resident)); };
+    if (mode == kModeArgmin) {
+        hipLaunchKernelGGL((wave_tile_wide_kernel<L, E, true>), grid(res_argmin), b, 0, stream, a, 0);
+    } else if (mode == kModeWide) {
+        hipLaunchKernelGGL((wave_tile_wide_kernel<L, E, false>), grid(res_wide), b, 0, stream, a, 0);
+    } else {
+        if (!a.defer_count || !a.defer_count_next || !a.defer_list) return hipErrorInvalidValue;
+        hipLaunchKernelGGL((wave_tile_packed_kernel<L, E>), dim3((unsigned)blocks), b, 0, stream, a);
+        // usually nothing was deferred: every wavefront reads the count and leaves
+#ifdef LA_LAB
+        if (getenv("LA_NO_WIDE")) return hipGetLastError();
+#endif
+        hipLaunchKernelGGL((wave_tile_wide_kernel<L, E, false>), grid(res_wide), b, 0, stream, a, 1);
+    }
     return hipGetLastError();
 }
 
@@ -388,6 +674,8 @@ void wave_tile_pick(int64_t max_p, int64_t max_c, int* L, int* E) {
 
 hipError_t wave_tile_launch(TileArgs a, int64_t max_p, int64_t max_c, int mode, hipStream_t stream) {
     int L, E;
+    if (a.n_total <= 0) return hipSuccess;
+    if (max_p > a.n_total) max_p = a.n_total;      // no topic holds more than the batch (E >= 2 needs 2 elements)
     wave_tile_pick(max_p, max_c, &L, &E);
     a.lc = pow2ceil(max_c > 1 ? max_c : 1);
     switch (L) {
