@@ -40,8 +40,9 @@ TRAFFIC_FILE = os.path.join(ROOT, "profiles", "traffic.json")   # written by too
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=20,
+                    help="the chip settles to its power-capped clock after ~15 back-to-back launches")
     ap.add_argument("--topics", type=int, default=100000)
     ap.add_argument("--partitions", type=int, default=256)
     ap.add_argument("--consumers", type=int, default=32)
@@ -217,7 +218,8 @@ def main():
     roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "traffic": tr["hbm_bytes_per_launch"] if tr else None,
-                "kernel": "wave_tile_assign_kernel" if (P <= 1024 and C <= 64) else "large-topic path (all kernels)",
+                "kernel": ("wave_tile_packed_kernel (+ the wide-record kernel over its deferred-tile list, empty here)"
+                           if (P <= 1024 and C <= 64) else "large-topic path (all kernels)"),
                 "kernel_ms": round(kern_ms, 4),
                 "algorithmic_bytes_per_partition": bpp,
                 "algorithmic_bytes_per_launch": bpp * n_part}

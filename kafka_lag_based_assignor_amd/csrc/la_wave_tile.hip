@@ -226,57 +226,79 @@ __device__ __forceinline__ void pack_records(int P, int gl, const int64_t (&lag)
 }
 
 // ---- 2. sort (lag desc, partition asc), leaving the sorted records in the LDS slice ---------------------
-// Fast form: sort 32-bit keys  (top bits of the record) << idx_bits | slot,  then fetch each record from
-// the slice by its slot.  Two records whose kept bits are equal would be ordered by slot instead of by
-// their dropped bits, so the sorted keys are checked for equal neighbours; if the wavefront has one, it
-// re-sorts the full 64-bit records (la_sort64.h).  When the record needs no more bits than the key
-// keeps, nothing is dropped and the check cannot fail.
+// Fast form: sort 32-bit keys that are a monotone function of the record "almost always", fetch each
+// record from the slice through the index carried in the key's low bits, then CHECK that the fetched
+// records are strictly ascending.  If any neighbour pair in the wavefront is not, the wavefront re-sorts
+// the full 64-bit records (la_sort64.h).  Two key layouts (wave-uniform choice):
+//   ids dense (every id < tile capacity):  key = (lag part, low bits dropped to fit) << sh | id, record stored
+//        at slot `id`.  Equal lags -- the common tie, e.g. many partitions with lag 0 -- are ordered by id
+//        inside the key itself, exactly as Main.java:231-234 orders them.
+//   otherwise:  key = (top bits of the record) << idx_bits | slot, record stored at its load slot.
+// Dropped low bits (and duplicate ids, which would collide in a slot) can only make the check fail, never
+// pass wrongly: the check is on the full records.
 template <int L, int E>
-__device__ __forceinline__ void sort_into_slice(uint64_t* slice, int gl, P64 (&rec)[E], int rec_bits) {
+__device__ __forceinline__ void sort_into_slice(uint64_t* slice, int gl, P64 (&rec)[E], int lbw, int sh) {
     using Cfg = TileCfg<L, E>;
-    constexpr int kIdxBits = Cfg::kLog2Cap;
-    constexpr int kKeep = 31 - kIdxBits;                     // key < 2^31: the all-ones sentinel stays largest
     if constexpr (kAblate == 1 || kAblate == 4) {
 #pragma unroll
         for (int r = 0; r < E; ++r) slice[slot_of(gl * E + r)] = p64_value(rec[r]);
         return;
     }
-    const int drop = rec_bits > kKeep ? rec_bits - kKeep : 0;            // wave-uniform
+    const bool by_id = sh <= Cfg::kLog2Cap;                               // wave-uniform
+    const int idx_bits = by_id ? sh : Cfg::kLog2Cap;
+    const uint32_t idx_mask = (1u << idx_bits) - 1;
+    const int top_bits = by_id ? lbw : lbw + sh;                          // bits above the index field's source
+    const int keep = 31 - idx_bits;                                       // key < 2^31: all-ones stays largest
+    const int drop = (by_id ? sh : 0) + (top_bits > keep ? top_bits - keep : 0);
     uint32_t key[E];
+    if (by_id && drop == sh) {
+        // nothing dropped: the key IS the record (it is shorter than 31 bits); no fetch, no check
+#pragma unroll
+        for (int v = 0; v < E; ++v) key[v] = rec[v].hi == 0xFFFFFFFFu ? 0xFFFFFFFFu : rec[v].lo;
+        bitonic_sort_tile_u32<L, E>(key);
+#pragma unroll
+        for (int r = 0; r < E; ++r)
+            slice[slot_of(gl * E + r)] = key[r] == 0xFFFFFFFFu ? ~0ull : (uint64_t)key[r];
+        return;
+    }
 #pragma unroll
     for (int v = 0; v < E; ++v) {
-        const int e = load_index<L, E>(v, gl);
         const uint64_t r = p64_value(rec[v]);
-        slice[slot_of(e)] = r;                                            // unsorted, by slot
-        key[v] = (r == ~0ull) ? 0xFFFFFFFFu : (((uint32_t)(r >> drop) << kIdxBits) | (uint32_t)e);
+        const bool valid = r != ~0ull;
+        const uint32_t idx = by_id ? ((uint32_t)r & idx_mask) : (uint32_t)load_index<L, E>(v, gl);
+        if (valid) slice[slot_of((int)idx)] = r;
+        key[v] = valid ? (((uint32_t)(r >> drop) << idx_bits) | idx) : 0xFFFFFFFFu;
     }
+    wave_lds_fence();
     bitonic_sort_tile_u32<L, E>(key);
 
-    bool tie = false;
-    if (drop > 0) {
-        // neighbours in sorted order: position s = gl*E + r
+    P64 got[E];
 #pragma unroll
-        for (int r = 0; r + 1 < E; ++r)
-            tie |= ((key[r] ^ key[r + 1]) >> kIdxBits) == 0 && key[r + 1] != 0xFFFFFFFFu;
-        const uint32_t nxt = (uint32_t)__shfl_down((int)key[0], 1);
-        tie |= gl != L - 1 && ((key[E - 1] ^ nxt) >> kIdxBits) == 0 && nxt != 0xFFFFFFFFu;
+    for (int r = 0; r < E; ++r) {
+        const uint64_t x = slice[slot_of((int)(key[r] & idx_mask))];
+        got[r] = p64_from(key[r] == 0xFFFFFFFFu ? ~0ull : x);
+    }
+    // strictly ascending?  position s = gl*E + r; all-ones records (empty slots) are all at the end
+    bool bad = false;
+#pragma unroll
+    for (int r = 0; r + 1 < E; ++r) {
+        const uint64_t x = p64_value(got[r]), y = p64_value(got[r + 1]);
+        bad |= (x >= y) && (y != ~0ull);
+    }
+    {
+        const uint64_t x = p64_value(got[E - 1]);
+        const uint64_t y = ((uint64_t)(uint32_t)__shfl_down((int)got[0].hi, 1) << 32) | (uint32_t)__shfl_down((int)got[0].lo, 1);
+        bad |= (gl != L - 1) && (x >= y) && (y != ~0ull);
     }
     wave_lds_fence();
-    if (__builtin_amdgcn_ballot_w64(tie) != 0) {
-        // full records, full network
+    if (__builtin_amdgcn_ballot_w64(bad) != 0) {
+        bitonic_sort_tile_p64<L, E>(rec);                                 // full records, full network
 #pragma unroll
-        for (int v = 0; v < E; ++v) rec[v] = p64_from(slice[slot_of(load_index<L, E>(v, gl))]);
-        bitonic_sort_tile_p64<L, E>(rec);
+        for (int r = 0; r < E; ++r) slice[slot_of(gl * E + r)] = p64_value(rec[r]);
     } else {
 #pragma unroll
-        for (int r = 0; r < E; ++r) {
-            const uint64_t x = slice[slot_of((int)(key[r] & (uint32_t)(Cfg::kCap - 1)))];
-            rec[r] = p64_from(key[r] == 0xFFFFFFFFu ? ~0ull : x);
-        }
+        for (int r = 0; r < E; ++r) slice[slot_of(gl * E + r)] = p64_value(got[r]);
     }
-    wave_lds_fence();
-#pragma unroll
-    for (int r = 0; r < E; ++r) slice[slot_of(gl * E + r)] = p64_value(rec[r]);
 }
 
 // ---- 3..5: greedy rounds over the sorted slice, outputs ------------------------------------------------------
@@ -549,7 +571,7 @@ __global__ __launch_bounds__(256, LA_WPS) void wave_tile_packed_kernel(TileArgs 
             if (fits) pack_records<L, E>(cur.P, gl, lag, pid, sh, lag_max, rec);
         }
         if (fits) {
-            sort_into_slice<L, E>(slice, gl, rec, lbw + sh);
+            sort_into_slice<L, E>(slice, gl, rec, lbw, sh);
             assign_packed<L, E>(a, slice, rank_tab, cur.p0, cur.c0, cur.P, cur.C, gl, sh, lag_max, my_rank);
         } else if (lane == 0) {
             a.defer_list[atomicAdd(a.defer_count, 1)] = (int32_t)tile;
@@ -633,6 +655,9 @@ static hipError_t launch_one(const TileArgs& a, int mode, hipStream_t stream) {
         // usually nothing was deferred: every wavefront reads the count and leaves
 #ifdef LA_LAB
         if (getenv("LA_NO_WIDE")) return hipGetLastError();
+#endif
+#ifdef LA_LAB
+        if (getenv("LA_WIDE_GRID")) { hipLaunchKernelGGL((wave_tile_wide_kernel<L, E, false>), grid(atoi(getenv("LA_WIDE_GRID"))), b, 0, stream, a, 1); return hipGetLastError(); }
 #endif
         hipLaunchKernelGGL((wave_tile_wide_kernel<L, E, false>), grid(res_wide), b, 0, stream, a, 1);
     }

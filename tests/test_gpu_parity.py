@@ -164,6 +164,73 @@ def test_tile_packed_negative_id_or_lag_falls_back(ctx):
         np.testing.assert_array_equal(g, e)
 
 
+@pytest.mark.parametrize("p,c", [(64, 8), (256, 32), (1000, 48)])
+@pytest.mark.parametrize("ids", ["dense", "sparse", "offset"])
+def test_tile_many_equal_lags_among_large_ones(ctx, p, c, ids):
+    # The fast sort orders 32-bit keys and then checks the full records.  Equal lags (here: most
+    # partitions at 0, the auto.offset.reset=latest situation) next to lags that need > 23 bits are
+    # exactly what a truncated key cannot order by itself: the id tie-break and the fallback must.
+    rng = np.random.default_rng(p * 31 + len(ids))
+    t = 120
+    lag = np.where(rng.random(t * p) < 0.6, 0, rng.integers(1, 1 << 40, t * p)).astype(np.int64)
+    lag[rng.integers(0, t * p, t * p // 10)] = 123456789012          # equal non-zero lags too
+    pid = np.concatenate([rng.permutation(p) for _ in range(t)]).astype(np.int64)
+    if ids == "sparse":
+        pid = pid * 1009 + 7
+    elif ids == "offset":
+        pid = pid + 5000
+    zeros = np.zeros(t * p, dtype=np.int64)
+    w = synth.Workload("ties", t, np.arange(t + 1, dtype=np.int64) * p, pid.astype(np.int32), zeros, lag.copy(), zeros,
+                       lag, np.arange(t + 1, dtype=np.int64) * c, np.tile(np.arange(c, dtype=np.int32), t), p, c)
+    exp = oracle.assign_flat(w.part_off, w.partition_id, w.lag, w.cons_off, w.cons_rank)
+    for algo in (N.LA_ALGO_AUTO, N.LA_ALGO_ROUNDS_WIDE):
+        got = _run_device(ctx, w, algo, use_lag=True)
+        for g, e, what in zip(got, exp, ("partition order", "member", "totals")):
+            np.testing.assert_array_equal(g, e, err_msg="%s algo %d" % (what, algo))
+
+
+def test_tile_duplicate_partition_ids(ctx):
+    # not something Kafka produces, but the reference would simply sort and assign the records it is
+    # given; two records with one id collide in the id-indexed slice and must be caught by the check
+    rng = np.random.default_rng(99)
+    t, p, c = 64, 256, 32
+    pid = np.concatenate([rng.permutation(p) for _ in range(t)]).astype(np.int32)
+    pid[rng.integers(0, t * p, 200)] = 7
+    lag = rng.integers(0, 1 << 33, t * p).astype(np.int64)
+    zeros = np.zeros(t * p, dtype=np.int64)
+    w = synth.Workload("dups", t, np.arange(t + 1, dtype=np.int64) * p, pid, zeros, lag.copy(), zeros, lag,
+                       np.arange(t + 1, dtype=np.int64) * c, np.tile(np.arange(c, dtype=np.int32), t), p, c)
+    exp = oracle.assign_flat(w.part_off, w.partition_id, w.lag, w.cons_off, w.cons_rank)
+    got = _run_device(ctx, w, N.LA_ALGO_AUTO, use_lag=True)
+    for g, e in zip(got, exp):
+        np.testing.assert_array_equal(g, e)
+
+
+def test_last_element_of_batch_is_a_lone_pair_tail(ctx):
+    # loads are 2-element and clamped to the batch: the very last partition of the batch can sit in the
+    # second half of a clamped pair; odd sizes at the end of the arrays exercise that
+    for p_last in (1, 2, 3, 9, 17, 255):
+        ps = [256, 31, p_last]
+        cs = [32, 5, 4]
+        rng = np.random.default_rng(p_last)
+        part_off = np.concatenate([[0], np.cumsum(ps)]).astype(np.int64)
+        cons_off = np.concatenate([[0], np.cumsum(cs)]).astype(np.int64)
+        n = int(part_off[-1])
+        pid = np.concatenate([rng.permutation(q) for q in ps]).astype(np.int32)
+        com = rng.integers(-1, 1000, n).astype(np.int64)
+        end = com.clip(0) + rng.integers(0, 1 << 30, n)
+        begin = rng.integers(0, 50, n).astype(np.int64)
+        ranks = np.concatenate([np.arange(q) for q in cs]).astype(np.int32)
+        w = synth.Workload("tail", 3, part_off, pid, begin, end.astype(np.int64), com, np.zeros(n, dtype=np.int64),
+                           cons_off, ranks, max(ps), max(cs))
+        for latest in (True, False):
+            lag = oracle.compute_lags(w.begin, w.end, w.committed, latest)
+            exp = oracle.assign_flat(w.part_off, w.partition_id, lag, w.cons_off, w.cons_rank)
+            got = _run_device(ctx, w, N.LA_ALGO_AUTO, use_lag=False, latest=latest)
+            for g, e in zip(got, exp):
+                np.testing.assert_array_equal(g, e)
+
+
 def test_target_shape_packed_equals_wide_equals_oracle(ctx):
     w = synth.config("target", 0.05)             # 5 000 topics x 256 x 32
     for latest in (True, False):
