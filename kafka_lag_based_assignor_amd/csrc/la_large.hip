@@ -22,6 +22,8 @@
 #include "la_kernels.h"
 #include "la_device.h"
 
+#include <type_traits>
+
 namespace la {
 
 namespace {
@@ -32,6 +34,7 @@ constexpr int kSortThreads = 256;
 constexpr int kSortWaves = kSortThreads / kWave;
 constexpr int kItems = 16;
 constexpr int kTile = kSortThreads * kItems;     // 4096 elements per workgroup
+constexpr int kScanRows = 32;                    // tiles per workgroup of the offset scan
 
 struct SortCtl {
     uint32_t skip[kDigits];
@@ -45,10 +48,19 @@ struct SortBufs {
     uint32_t* hist;                    // [kDigits][256]
     uint64_t* key[2];
     uint32_t* val[2];
-    uint32_t* tile_off;                // [256][n_tiles] (digit-major)
+    uint32_t* tile_off;                // [n_tiles][256] (a tile's 256 digit counts / offsets are one 1 KB row)
+    uint32_t* group_sum;               // [n_groups][256] digit counts of kScanRows consecutive tiles
     int64_t n;
     int n_tiles;
+    int n_groups;
 };
+
+// bijection [0, n) -> [0, n): workgroups with equal (w % 8) get consecutive results
+__device__ __forceinline__ int xcd_contiguous(int w, int n) {
+    const int per = n / 8, rem = n % 8;                  // XCD x owns per (+1 if x < rem) values
+    const int x = w % 8, k = w / 8;
+    return x * per + (x < rem ? x : rem) + k;
+}
 
 __device__ __forceinline__ uint32_t digit_of(int pass, uint64_t key, uint32_t val) {
     return pass < 4 ? (val >> (8 * pass)) & 0xFFu : (uint32_t)(key >> (8 * (pass - 4))) & 0xFFu;
@@ -120,70 +132,128 @@ __global__ void plan_kernel(SortBufs b) {
 }
 
 // ---- per pass: tile digit counts ------------------------------------------------------------------
-__global__ __launch_bounds__(kSortThreads) void tile_count_kernel(SortBufs b, int pass) {
-    if (b.ctl->skip[pass]) return;
-    __shared__ uint32_t h[kRadix];
-    h[threadIdx.x] = 0;
-    __syncthreads();
+// A resident-sized grid walks the tiles; the next tile's loads (16 B per lane, whole tile) are issued before
+// the current tile's histogram updates, one private histogram per wavefront (LDS atomics contend only inside
+// a wavefront).  Only the array that carries the pass's digit is read: 8 B (key passes) or 4 B (id passes)
+// per element.
+template <bool IDS>
+__device__ __forceinline__ void count_tiles(const SortBufs& b, int pass, uint32_t (*h)[kRadix]) {
+    using Vec = typename std::conditional<IDS, uint4, ulonglong2>::type;
+    constexpr int PER = IDS ? 4 : 2;                              // elements per 16-byte load
+    constexpr int N = kTile / (PER * kSortThreads);
+    const int wave = threadIdx.x >> 6;
     const uint32_t cur = b.ctl->cur[pass];
-    const uint64_t* key = b.key[cur];
-    const uint32_t* val = b.val[cur];
-    const int64_t t0 = (int64_t)blockIdx.x * kTile;
-#pragma unroll 4
-    for (int it = 0; it < kItems; ++it) {
-        const int64_t i = t0 + it * kSortThreads + threadIdx.x;
-        if (i < b.n) {
-            const uint32_t d = pass < 4 ? digit_of(pass, 0, val[i]) : digit_of(pass, key[i], 0);
-            atomicAdd(&h[d], 1u);
+    const char* src = IDS ? (const char*)b.val[cur] : (const char*)b.key[cur];
+    const int esz = IDS ? 4 : 8;
+    const int sh = IDS ? 8 * pass : 8 * (pass - 4);
+    auto digit = [&](const Vec& v, int k) -> uint32_t {
+        if constexpr (IDS) return ((k == 0 ? v.x : k == 1 ? v.y : k == 2 ? v.z : v.w) >> sh) & 0xFFu;
+        else return (uint32_t)((k == 0 ? v.x : v.y) >> sh) & 0xFFu;
+    };
+    Vec v[N];
+    auto load_tile = [&](int tile) {
+        const int64_t t0 = (int64_t)tile * kTile;
+        if (t0 + kTile <= b.n) {
+#pragma unroll
+            for (int k = 0; k < N; ++k)
+                v[k] = *reinterpret_cast<const Vec*>(src + (t0 + PER * (k * kSortThreads + (int)threadIdx.x)) * esz);
         }
+    };
+    int tile = blockIdx.x;
+    if (tile < b.n_tiles) load_tile(tile);
+    for (; tile < b.n_tiles; tile += gridDim.x) {
+        for (int i = threadIdx.x; i < kSortWaves * kRadix; i += kSortThreads) (&h[0][0])[i] = 0;
+        __syncthreads();
+        const int64_t t0 = (int64_t)tile * kTile;
+        if (t0 + kTile <= b.n) {
+            Vec w[N];
+#pragma unroll
+            for (int k = 0; k < N; ++k) w[k] = v[k];
+            if (tile + (int)gridDim.x < b.n_tiles) load_tile(tile + gridDim.x);
+#pragma unroll
+            for (int k = 0; k < N; ++k)
+#pragma unroll
+                for (int e = 0; e < PER; ++e) atomicAdd(&h[wave][digit(w[k], e)], 1u);
+        } else {
+            for (int64_t i = t0 + threadIdx.x; i < b.n; i += kSortThreads) {
+                const uint32_t d = IDS ? digit_of(pass, 0, b.val[cur][i]) : digit_of(pass, b.key[cur][i], 0);
+                atomicAdd(&h[wave][d], 1u);
+            }
+        }
+        __syncthreads();
+        uint32_t c = 0;
+#pragma unroll
+        for (int w2 = 0; w2 < kSortWaves; ++w2) c += h[w2][threadIdx.x];
+        b.tile_off[(int64_t)tile * kRadix + threadIdx.x] = c;
+        __syncthreads();
     }
-    __syncthreads();
-    b.tile_off[(int64_t)threadIdx.x * b.n_tiles + blockIdx.x] = h[threadIdx.x];
 }
 
-// ---- per pass: exclusive scan of each digit's tile counts, plus the digit's global base -----------
-__global__ __launch_bounds__(256) void tile_scan_kernel(SortBufs b, int pass) {
+__global__ __launch_bounds__(kSortThreads) void tile_count_kernel(SortBufs b, int pass) {
     if (b.ctl->skip[pass]) return;
-    __shared__ uint32_t wsum[4];
-    __shared__ uint32_t carry_s;
-    const int d = blockIdx.x;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    // global base of digit d = number of elements with a smaller digit
-    uint32_t v = ((int)threadIdx.x < d) ? b.hist[pass * kRadix + threadIdx.x] : 0;
+    __shared__ uint32_t h[kSortWaves][kRadix];
+    if (pass < 4) count_tiles<true>(b, pass, h);
+    else count_tiles<false>(b, pass, h);
+}
+
+// ---- per pass: exclusive scan over the tiles of every digit's count, plus the digit's global base --------
+// tile_off is [tile][digit]: the count kernel writes and the scatter kernel reads one contiguous 1 KB row
+// per tile.  The scan walks columns: thread d owns digit d, a workgroup owns kScanRows consecutive tiles
+// (every row access is a coalesced 1 KB).  Kernel A: the group's column sums.  Kernel B: every group adds up
+// the sums of the groups before it (L2-resident, <= 256 KB per group) and rewrites its rows as offsets.
+__global__ __launch_bounds__(kRadix) void scan_group_sums_kernel(SortBufs b, int pass) {
+    if (b.ctl->skip[pass]) return;
+    const int r0 = blockIdx.x * kScanRows;
+    const int r1 = r0 + kScanRows < b.n_tiles ? r0 + kScanRows : b.n_tiles;
+    uint32_t sum = 0;
+    for (int r = r0; r < r1; ++r) sum += b.tile_off[(int64_t)r * kRadix + threadIdx.x];
+    b.group_sum[(int64_t)blockIdx.x * kRadix + threadIdx.x] = sum;
+}
+
+__global__ __launch_bounds__(kRadix) void scan_offsets_kernel(SortBufs b, int pass) {
+    if (b.ctl->skip[pass]) return;
+    __shared__ uint32_t wsum[kRadix / kWave];
+    const int d = threadIdx.x, lane = d & 63, wave = d >> 6;
+    // global base of digit d = number of elements with a smaller digit (exclusive scan of the histogram)
+    const uint32_t hcount = b.hist[pass * kRadix + d];
+    uint32_t incl = hcount;
 #pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
-    if (lane == 0) wsum[wave] = v;
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t y = __shfl_up(incl, o);
+        if (lane >= o) incl += y;
+    }
+    if (lane == 63) wsum[wave] = incl;
     __syncthreads();
-    uint32_t carry = wsum[0] + wsum[1] + wsum[2] + wsum[3];
-    __syncthreads();
-    uint32_t* col = b.tile_off + (int64_t)d * b.n_tiles;
-    for (int base = 0; base < b.n_tiles; base += 256) {
-        const int t = base + threadIdx.x;
-        const uint32_t x = t < b.n_tiles ? col[t] : 0;
-        uint32_t incl = x;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const uint32_t y = __shfl_up(incl, o);
-            if (lane >= o) incl += y;
-        }
-        if (lane == 63) wsum[wave] = incl;
-        __syncthreads();
-        uint32_t woff = 0;
-        for (int w = 0; w < wave; ++w) woff += wsum[w];
-        if (t < b.n_tiles) col[t] = carry + woff + incl - x;
-        if (threadIdx.x == 255) carry_s = carry + woff + incl;
-        __syncthreads();
-        carry = carry_s;
+    uint32_t run = incl - hcount;
+    for (int w = 0; w < wave; ++w) run += wsum[w];
+    // + this digit's elements in the groups before this one (independent loads: keep many in flight)
+#pragma unroll 16
+    for (int g = 0; g < (int)blockIdx.x; ++g) run += b.group_sum[(int64_t)g * kRadix + d];
+    const int r0 = blockIdx.x * kScanRows;
+    const int r1 = r0 + kScanRows < b.n_tiles ? r0 + kScanRows : b.n_tiles;
+    for (int r = r0; r < r1; ++r) {
+        uint32_t* p = b.tile_off + (int64_t)r * kRadix + d;
+        const uint32_t x = *p;
+        *p = run;
+        run += x;
     }
 }
 
 // ---- per pass: stable scatter ----------------------------------------------------------------------
 // Order inside a tile = (wave, item, lane); elements are loaded wave-striped so every load is a
 // 64-element contiguous run.  Rank among equal digits: wave-level match (8 ballots), running
-// per-wave digit counters in LDS, then an exclusive scan of those counters over the waves.
+// per-wave digit counters in LDS, then an exclusive scan of those counters over the waves (stable; no
+// atomics on the data path).  The tile is then REORDERED IN LDS by digit, so that consecutive lanes write
+// consecutive addresses of a digit's output run (a tile holds ~16 elements per digit: 128 B runs of keys,
+// 64 B of ids) instead of 64 unrelated 8-byte writes per wavefront.
 __global__ __launch_bounds__(kSortThreads) void tile_scatter_kernel(SortBufs b, int pass) {
     if (b.ctl->skip[pass]) return;
+    static_assert(kSortThreads == kRadix, "one thread per digit in the offset phase");
     __shared__ uint32_t cnt[kSortWaves][kRadix];
+    __shared__ uint32_t bin_start[kRadix];            // tile-local position of the digit's first element
+    __shared__ uint32_t bin_base[kRadix];             // global position of it, minus bin_start
+    __shared__ uint32_t wsum[kSortWaves];
+    __shared__ uint64_t s_stage[kTile];               // the tile reordered by digit: one array at a time
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int i = threadIdx.x; i < kSortWaves * kRadix; i += kSortThreads) (&cnt[0][0])[i] = 0;
     __syncthreads();
@@ -192,7 +262,13 @@ __global__ __launch_bounds__(kSortThreads) void tile_scatter_kernel(SortBufs b, 
     const uint32_t* vin = b.val[cur];
     uint64_t* kout = b.key[cur ^ 1];
     uint32_t* vout = b.val[cur ^ 1];
-    const int64_t w0 = (int64_t)blockIdx.x * kTile + (int64_t)wave * kItems * kWave;
+    // Workgroup w runs on XCD w % 8 (observed dispatch order; only speed depends on it).  Neighbouring tiles
+    // write neighbouring runs of every digit's output: give each XCD a CONTIGUOUS range of tiles so that the
+    // partial cache lines at the run boundaries meet in one L2 instead of being written back twice.
+    const int tile = xcd_contiguous(blockIdx.x, gridDim.x);
+    const int64_t t0 = (int64_t)tile * kTile;
+    const int64_t w0 = t0 + (int64_t)wave * kItems * kWave;
+    const int n_here = (int)((b.n - t0) < kTile ? (b.n - t0) : kTile);
     const uint64_t lt = ((uint64_t)1 << lane) - 1;
 
     uint64_t key[kItems];
@@ -225,24 +301,87 @@ __global__ __launch_bounds__(kSortThreads) void tile_scatter_kernel(SortBufs b, 
         loc[it] = (d << 16) | (old + (uint32_t)__popcll(peers & lt));
     }
     __syncthreads();
-    {   // exclusive scan over the waves + the tile's global base for this digit
+    {   // thread d: exclusive scan of digit d's counters over the waves, then of the tile's digit counts
         const int d = threadIdx.x;
-        uint32_t run = b.tile_off[(int64_t)d * b.n_tiles + blockIdx.x];
+        uint32_t run = 0;
 #pragma unroll
         for (int w = 0; w < kSortWaves; ++w) {
             const uint32_t c = cnt[w][d];
             cnt[w][d] = run;
             run += c;
         }
+        uint32_t incl = run;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t y = __shfl_up(incl, o);
+            if (lane >= o) incl += y;
+        }
+        if (lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        uint32_t woff = 0;
+        for (int w = 0; w < wave; ++w) woff += wsum[w];
+        const uint32_t start = woff + incl - run;
+        bin_start[d] = start;
+        bin_base[d] = b.tile_off[(int64_t)tile * kRadix + d] - start;
     }
     __syncthreads();
+    // tile-local sorted position of every element
 #pragma unroll
     for (int it = 0; it < kItems; ++it) {
-        const int64_t i = w0 + it * kWave + lane;
-        if (i < b.n) {
-            const uint32_t pos = cnt[wave][loc[it] >> 16] + (loc[it] & 0xFFFFu);
-            kout[pos] = key[it];
-            vout[pos] = val[it];
+        const uint32_t d = loc[it] >> 16;
+        loc[it] = bin_start[d] + cnt[wave][d] + (loc[it] & 0xFFFFu);
+    }
+    // The array that carries the pass's digit goes through the staging buffer first: the global position of
+    // tile-local position j is bin_base[digit of the element at j] + j.
+    uint32_t* s_val = reinterpret_cast<uint32_t*>(s_stage);
+    uint32_t gpos[kItems];
+    if (pass < 4) {
+#pragma unroll
+        for (int it = 0; it < kItems; ++it)
+            if (w0 + it * kWave + lane < b.n) s_val[loc[it]] = val[it];
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < kItems; ++it) {
+            const int j = it * kSortThreads + threadIdx.x;
+            if (j < n_here) {
+                const uint32_t v = s_val[j];
+                gpos[it] = bin_base[digit_of(pass, 0, v)] + (uint32_t)j;
+                vout[gpos[it]] = v;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < kItems; ++it)
+            if (w0 + it * kWave + lane < b.n) s_stage[loc[it]] = key[it];
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < kItems; ++it) {
+            const int j = it * kSortThreads + threadIdx.x;
+            if (j < n_here) kout[gpos[it]] = s_stage[j];
+        }
+    } else {
+#pragma unroll
+        for (int it = 0; it < kItems; ++it)
+            if (w0 + it * kWave + lane < b.n) s_stage[loc[it]] = key[it];
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < kItems; ++it) {
+            const int j = it * kSortThreads + threadIdx.x;
+            if (j < n_here) {
+                const uint64_t k = s_stage[j];
+                gpos[it] = bin_base[digit_of(pass, k, 0)] + (uint32_t)j;
+                kout[gpos[it]] = k;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < kItems; ++it)
+            if (w0 + it * kWave + lane < b.n) s_val[loc[it]] = val[it];
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < kItems; ++it) {
+            const int j = it * kSortThreads + threadIdx.x;
+            if (j < n_here) vout[gpos[it]] = s_val[j];
         }
     }
 }
@@ -429,6 +568,8 @@ hipError_t large_topic_launch(LargeScratch& scratch, const LargeArgs& a, bool ar
     const size_t o_k0 = carve(sizeof(uint64_t) * n), o_k1 = carve(sizeof(uint64_t) * n);
     const size_t o_v0 = carve(sizeof(uint32_t) * n), o_v1 = carve(sizeof(uint32_t) * n);
     const size_t o_to = carve(sizeof(uint32_t) * kRadix * (size_t)n_tiles);
+    const int n_groups = (n_tiles + kScanRows - 1) / kScanRows;
+    const size_t o_gs = carve(sizeof(uint32_t) * kRadix * (size_t)n_groups);
     if (off > scratch.cap) {
         hipError_t e;
         if (scratch.buf) {
@@ -450,8 +591,10 @@ hipError_t large_topic_launch(LargeScratch& scratch, const LargeArgs& a, bool ar
     b.val[0] = (uint32_t*)(base + o_v0);
     b.val[1] = (uint32_t*)(base + o_v1);
     b.tile_off = (uint32_t*)(base + o_to);
+    b.group_sum = (uint32_t*)(base + o_gs);
     b.n = n;
     b.n_tiles = n_tiles;
+    b.n_groups = n_groups;
 
     hipError_t e;
     if ((e = hipMemsetAsync(base, 0, zero_bytes, stream)) != hipSuccess) return e;
@@ -460,8 +603,9 @@ hipError_t large_topic_launch(LargeScratch& scratch, const LargeArgs& a, bool ar
     hipLaunchKernelGGL(build_keys_kernel, dim3(grid), dim3(256), 0, stream, a, b);
     hipLaunchKernelGGL(plan_kernel, dim3(1), dim3(256), 0, stream, b);
     for (int p = 0; p < kDigits; ++p) {
-        hipLaunchKernelGGL(tile_count_kernel, dim3(n_tiles), dim3(kSortThreads), 0, stream, b, p);
-        hipLaunchKernelGGL(tile_scan_kernel, dim3(kRadix), dim3(256), 0, stream, b, p);
+        hipLaunchKernelGGL(tile_count_kernel, dim3(n_tiles < 2048 ? n_tiles : 2048), dim3(kSortThreads), 0, stream, b, p);
+        hipLaunchKernelGGL(scan_group_sums_kernel, dim3(n_groups), dim3(kRadix), 0, stream, b, p);
+        hipLaunchKernelGGL(scan_offsets_kernel, dim3(n_groups), dim3(kRadix), 0, stream, b, p);
         hipLaunchKernelGGL(tile_scatter_kernel, dim3(n_tiles), dim3(kSortThreads), 0, stream, b, p);
     }
     hipLaunchKernelGGL(emit_ids_kernel, dim3(grid), dim3(256), 0, stream, a, b, a.n_cons == 0 ? 1 : 0);
