@@ -16,6 +16,7 @@
  *                           + assignTopic (sort + greedy + update)          Main.java:204-266
  *   la_assign_batch_lags    static assign(Map,Map) on precomputed lags      Main.java:166-188
  *   la_assign_batch_device  the same two, on buffers already resident in HBM
+ *   la_group_by_member      building every member's List<TopicPartition>      Main.java:171-174, :264
  *
  * Data model (SoA; TopicPartitionLag, Main.java:431-455, flattened):
  *   topic t owns partitions [part_off[t], part_off[t+1]) of the per-partition arrays and
@@ -161,6 +162,27 @@ int la_sync(la_ctx *ctx, void *stream);
 
 /* The context's own (non-blocking) hipStream_t, used by the host-buffer entry points. */
 void *la_stream(la_ctx *ctx);
+
+/* Assignment -> per-member lists: the wrap step of the reference (every member's list is created at
+ * Main.java:171-174 and appended to at :264, topic by topic in the order the topics were given, inside a
+ * topic in assignment order; Main.java:152-156 then wraps each list).  Input: the result arrays of an
+ * assign call.  Output, with M = n_members (ranks 0..M-1):
+ *   member_off[r] .. member_off[r+1]   member r's slice of the grouped arrays (member_off has M+1 entries);
+ *                                      positions before member_off[0] hold the entries of topics that had no
+ *                                      consumer (rank -1), which the reference leaves unassigned
+ *   grouped_topic[j], grouped_partition[j]   topic index (into part_off) and partition id of the j-th entry,
+ *                                      in exactly the order the reference's list for that member holds them
+ * It is a stable device radix sort of the entry indices by member rank.  grouped_topic may be NULL. */
+int la_group_by_member(la_ctx *ctx, int32_t n_topics, const int64_t *part_off,
+                       const int32_t *out_partition, const int32_t *out_member_rank, int32_t n_members,
+                       int64_t *member_off, int32_t *grouped_topic, int32_t *grouped_partition);
+
+/* Same on device buffers (N = n_partitions entries); enqueues on `stream` and returns. */
+int la_group_by_member_device(la_ctx *ctx, int32_t n_topics, int64_t n_partitions,
+                              const int64_t *d_part_off, const int32_t *d_out_partition,
+                              const int32_t *d_out_member_rank, int32_t n_members,
+                              int64_t *d_member_off, int32_t *d_grouped_topic, int32_t *d_grouped_partition,
+                              void *stream);
 
 #ifdef __cplusplus
 }

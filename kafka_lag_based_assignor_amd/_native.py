@@ -22,6 +22,7 @@ LA_ALGO_AUTO, LA_ALGO_ROUNDS, LA_ALGO_ARGMIN, LA_ALGO_ROUNDS_WIDE = 0, 1, 2, 3
 EXPORTED_SYMBOLS = (
     "la_create", "la_destroy", "la_last_error", "la_version", "la_compute_lag",
     "la_assign_batch", "la_assign_batch_lags", "la_assign_batch_device", "la_sync", "la_stream",
+    "la_group_by_member", "la_group_by_member_device",
 )
 
 _i64p = ctypes.POINTER(ctypes.c_int64)
@@ -94,6 +95,13 @@ def load() -> ctypes.CDLL:
     L.la_sync.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
     L.la_stream.restype = ctypes.c_void_p
     L.la_stream.argtypes = [ctypes.c_void_p]
+    L.la_group_by_member.restype = ctypes.c_int
+    L.la_group_by_member.argtypes = [ctypes.c_void_p, ctypes.c_int32, _i64p, _i32p, _i32p, ctypes.c_int32,
+                                     _i64p, _i32p, _i32p]
+    L.la_group_by_member_device.restype = ctypes.c_int
+    L.la_group_by_member_device.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_void_p,
+                                            ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p,
+                                            ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
     _lib = L
     return L
 
@@ -182,6 +190,27 @@ class Context:
                                                    _p32(partition_id), _p64(lag), _p64(cons_off),
                                                    _p32(cons_rank), _p32(out_p), _p32(out_m), _p64(out_t)))
         return out_p, out_m, out_t
+
+    def group_by_member(self, part_off, out_partition, out_member_rank, n_members: int
+                        ) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+        """(member_off [M+1], grouped_topic [N], grouped_partition [N]): every member's list in the
+        reference's order; entries before member_off[0] belong to topics without consumers."""
+        part_off = _a64(part_off)
+        out_partition, out_member_rank = _a32(out_partition), _a32(out_member_rank)
+        off = np.zeros(n_members + 1, dtype=np.int64)
+        g_t = np.empty(out_partition.size, dtype=np.int32)
+        g_p = np.empty(out_partition.size, dtype=np.int32)
+        self._check(self._lib.la_group_by_member(self._h, part_off.size - 1, _p64(part_off), _p32(out_partition),
+                                                 _p32(out_member_rank), n_members, _p64(off), _p32(g_t), _p32(g_p)))
+        return off, g_t, g_p
+
+    def group_by_member_device(self, n_topics: int, n_partitions: int, d_part_off: int, d_out_partition: int,
+                               d_out_member_rank: int, n_members: int, d_member_off: int, d_grouped_topic: int,
+                               d_grouped_partition: int, stream: int = 0) -> None:
+        self._check(self._lib.la_group_by_member_device(self._h, n_topics, n_partitions, d_part_off,
+                                                        d_out_partition, d_out_member_rank, n_members,
+                                                        d_member_off, d_grouped_topic, d_grouped_partition,
+                                                        ctypes.c_void_p(stream)))
 
     # -- device-resident entry point ------------------------------------------------
     def assign_batch_device(self, batch: DeviceBatch, stream: int = 0) -> None:

@@ -428,6 +428,71 @@ LA_API int la_assign_batch_device(la_ctx* ctx, const la_device_batch* batch, voi
 
 LA_API void* la_stream(la_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
 
+LA_API int la_group_by_member_device(la_ctx* ctx, int32_t n_topics, int64_t n_partitions, const int64_t* d_part_off,
+                                     const int32_t* d_out_partition, const int32_t* d_out_member_rank,
+                                     int32_t n_members, int64_t* d_member_off, int32_t* d_grouped_topic,
+                                     int32_t* d_grouped_partition, void* stream) {
+    if (!ctx) return LA_EINVAL;
+    try {
+        if (n_topics < 0 || n_partitions < 0 || n_members < 0) return fail(ctx, LA_EINVAL, "negative size");
+        if (!d_member_off) return fail(ctx, LA_EINVAL, "member_off is NULL");
+        if (n_partitions > 0 && (!d_out_partition || !d_out_member_rank || !d_grouped_partition ||
+                                 (d_grouped_topic && !d_part_off)))
+            return fail(ctx, LA_EINVAL, "null buffer");
+        if (n_partitions > 0x7FFFFFFF) return fail(ctx, LA_ESHAPE, "at most 2^31-1 entries are supported");
+        LA_HIP(ctx, hipSetDevice(ctx->device));
+        hipError_t e = la::group_by_member_launch(ctx->large, n_partitions, n_members, n_topics, d_part_off,
+                                                  d_out_partition, d_out_member_rank, d_member_off,
+                                                  d_grouped_topic, d_grouped_partition, nullptr, (hipStream_t)stream);
+        if (e != hipSuccess)
+            return fail(ctx, e == hipErrorOutOfMemory ? LA_ENOMEM : LA_EHIP, "group_by_member: %s", hipGetErrorString(e));
+        return LA_OK;
+    } catch (...) {
+        return fail(ctx, LA_ENOMEM, "exception in la_group_by_member_device");
+    }
+}
+
+LA_API int la_group_by_member(la_ctx* ctx, int32_t n_topics, const int64_t* part_off, const int32_t* out_partition,
+                              const int32_t* out_member_rank, int32_t n_members, int64_t* member_off,
+                              int32_t* grouped_topic, int32_t* grouped_partition) {
+    if (!ctx) return LA_EINVAL;
+    try {
+        if (n_topics < 0 || n_members < 0) return fail(ctx, LA_EINVAL, "negative size");
+        if (!member_off || (n_topics > 0 && !part_off)) return fail(ctx, LA_EINVAL, "null buffer");
+        const int64_t n = n_topics > 0 ? part_off[n_topics] : 0;
+        if (n < 0) return fail(ctx, LA_EINVAL, "part_off decreases");
+        if (n > 0 && (!out_partition || !out_member_rank || !grouped_partition)) return fail(ctx, LA_EINVAL, "null buffer");
+        LA_HIP(ctx, hipSetDevice(ctx->device));
+        const size_t nb4 = (size_t)n * 4, tb = (size_t)(n_topics + 1) * 8, mb = ((size_t)n_members + 1) * 8;
+        int rc;
+        // scratch reuse: out_pid <- out_partition, out_rank <- member ranks, pid <- grouped_partition,
+        // cons_rank <- grouped_topic, out_total <- member_off
+        if ((rc = reserve(ctx, ctx->part_off, tb + 16)) || (rc = reserve(ctx, ctx->out_pid, nb4 + 16)) ||
+            (rc = reserve(ctx, ctx->out_rank, nb4 + 16)) || (rc = reserve(ctx, ctx->pid, nb4 + 16)) ||
+            (rc = reserve(ctx, ctx->cons_rank, nb4 + 16)) || (rc = reserve(ctx, ctx->out_total, mb + 16)))
+            return rc;
+        hipStream_t st = ctx->stream;
+        if (n_topics > 0) LA_HIP(ctx, hipMemcpyAsync(ctx->part_off.p, part_off, tb, hipMemcpyHostToDevice, st));
+        if (n) {
+            LA_HIP(ctx, hipMemcpyAsync(ctx->out_pid.p, out_partition, nb4, hipMemcpyHostToDevice, st));
+            LA_HIP(ctx, hipMemcpyAsync(ctx->out_rank.p, out_member_rank, nb4, hipMemcpyHostToDevice, st));
+        }
+        rc = la_group_by_member_device(ctx, n_topics, n, (const int64_t*)ctx->part_off.p, (const int32_t*)ctx->out_pid.p,
+                                       (const int32_t*)ctx->out_rank.p, n_members, (int64_t*)ctx->out_total.p,
+                                       grouped_topic ? (int32_t*)ctx->cons_rank.p : nullptr, (int32_t*)ctx->pid.p, st);
+        if (rc) return rc;
+        LA_HIP(ctx, hipMemcpyAsync(member_off, ctx->out_total.p, mb, hipMemcpyDeviceToHost, st));
+        if (n) {
+            LA_HIP(ctx, hipMemcpyAsync(grouped_partition, ctx->pid.p, nb4, hipMemcpyDeviceToHost, st));
+            if (grouped_topic) LA_HIP(ctx, hipMemcpyAsync(grouped_topic, ctx->cons_rank.p, nb4, hipMemcpyDeviceToHost, st));
+        }
+        LA_HIP(ctx, hipStreamSynchronize(st));
+        return LA_OK;
+    } catch (...) {
+        return fail(ctx, LA_ENOMEM, "exception in la_group_by_member");
+    }
+}
+
 LA_API int la_sync(la_ctx* ctx, void* stream) {
     if (!ctx) return LA_EINVAL;
     try {

@@ -172,16 +172,11 @@ __device__ __forceinline__ void bitonic_sort_lanes(Rec& rec, int gl, int n) {
     }
 }
 
-// ---- packed 64-bit records ---------------------------------------------------------------
-// When a wavefront's lags and partition ids are narrow enough, a whole sort record fits one
-// 64-bit word (see la_wave_tile.hip): one v_cmp_lt_u64 per compare-exchange instead of three
-// compares, two selects instead of three, two lane moves instead of three.
-//
-// The networks below are the direction-free form of the bitonic sorter: the first step of a
-// merge of size K pairs element i with i ^ (K-1) (mirror), every later step pairs i with i ^ j,
-// and the lower index always keeps the smaller record.  "Lower index" is one bit of the lane id,
-// so a stage's keep-min mask is one v_and + v_cmp, shared by all registers of the stage.
-// lane ^ (M-1): quad_perm / row_half_mirror / row_mirror are single DPP moves.
+// ---- lane ^ (M-1) moves ------------------------------------------------------------------------
+// The networks of la_sort32.h / la_sort64.h are the direction-free form of the bitonic sorter: the first
+// step of a merge of size K pairs element i with i ^ (K-1) (mirror), every later step pairs i with i ^ j,
+// and the lower index always keeps the smaller record.  quad_perm / row_half_mirror / row_mirror are
+// single DPP moves; wider mirrors add v_permlane*_swap steps.
 
 __device__ __forceinline__ uint32_t dpp_row_mirror(uint32_t x) {
     return (uint32_t)__builtin_amdgcn_mov_dpp((int)x, 0x140, 0xF, 0xF, false);
@@ -196,107 +191,6 @@ __device__ __forceinline__ uint32_t shfl_mirror(uint32_t x) {
     else if constexpr (M == 16) return dpp_row_mirror(x);
     else if constexpr (M == 32) return shfl_xor<16>(dpp_row_mirror(x));
     else return shfl_xor<32>(shfl_xor<16>(dpp_row_mirror(x)));
-}
-
-template <int J>
-__device__ __forceinline__ uint64_t shfl_xor64(uint64_t x) {
-    return ((uint64_t)shfl_xor<J>((uint32_t)(x >> 32)) << 32) | shfl_xor<J>((uint32_t)x);
-}
-
-template <int M>
-__device__ __forceinline__ uint64_t shfl_mirror64(uint64_t x) {
-    return ((uint64_t)shfl_mirror<M>((uint32_t)(x >> 32)) << 32) | shfl_mirror<M>((uint32_t)x);
-}
-
-// mine <- min or max of (mine, record of lane ^ J)
-template <int J>
-__device__ __forceinline__ void cmpx_lanes64(uint64_t& mine, bool keep_min) {
-    if constexpr (J == 16 || J == 32) {
-        // v_permlane*_swap hands both lanes of a pair the same (A, B) = (lower lane's, upper
-        // lane's) record; each lane keeps A or B by its own keep_min.  No per-word select to
-        // rebuild "the other lane's" record first.
-        const uint32_t lo = (uint32_t)mine, hi = (uint32_t)(mine >> 32);
-        uint64_t A, B;
-        if constexpr (J == 16) {
-            auto l = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
-            auto h = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
-            A = ((uint64_t)h[0] << 32) | l[0];
-            B = ((uint64_t)h[1] << 32) | l[1];
-        } else {
-            auto l = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
-            auto h = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
-            A = ((uint64_t)h[0] << 32) | l[0];
-            B = ((uint64_t)h[1] << 32) | l[1];
-        }
-        mine = ((A < B) == keep_min) ? A : B;
-    } else {
-        const uint64_t o = shfl_xor64<J>(mine);
-        mine = ((o < mine) == keep_min) ? o : mine;
-    }
-}
-
-__device__ __forceinline__ void cmpx_regs64(uint64_t& a, uint64_t& b) {   // a <= b afterwards
-    const bool sw = b < a;
-    const uint64_t ta = a, tb = b;
-    a = sw ? tb : ta;
-    b = sw ? ta : tb;
-}
-
-// half cleaners of a merge: i <-> i ^ J for J, J/2, .., 1   (element index i = gl*E + r)
-template <int L, int E, int J>
-__device__ __forceinline__ void clean64(uint64_t (&rec)[E], int gl) {
-    if constexpr (J >= 1) {
-        if constexpr (J >= E) {
-            const bool keep_min = (gl & (J / E)) == 0;
-#pragma unroll
-            for (int r = 0; r < E; ++r) cmpx_lanes64<J / E>(rec[r], keep_min);
-        } else {
-#pragma unroll
-            for (int r = 0; r < E; ++r)
-                if ((r & J) == 0) cmpx_regs64(rec[r], rec[r | J]);
-        }
-        clean64<L, E, J / 2>(rec, gl);
-    }
-}
-
-// merges of size K, 2K, .., L*E
-template <int L, int E, int K>
-__device__ __forceinline__ void merge64(uint64_t (&rec)[E], int gl) {
-    if constexpr (K <= L * E) {
-        // mirror step: i <-> i ^ (K-1)
-        if constexpr (K <= E) {
-#pragma unroll
-            for (int r = 0; r < E; ++r)
-                if ((r & (K >> 1)) == 0) cmpx_regs64(rec[r], rec[r ^ (K - 1)]);
-        } else {
-            constexpr int M = K / E;                      // lane ^ (M-1), register E-1-r
-            const bool keep_min = (gl & (M >> 1)) == 0;
-#pragma unroll
-            for (int r = 0; r < (E + 1) / 2; ++r) {
-                const int q = E - 1 - r;
-                const uint64_t oa = shfl_mirror64<M>(rec[q]);
-                const uint64_t ob = shfl_mirror64<M>(rec[r]);
-                rec[r] = ((oa < rec[r]) == keep_min) ? oa : rec[r];
-                if (q != r) rec[q] = ((ob < rec[q]) == keep_min) ? ob : rec[q];
-            }
-        }
-        clean64<L, E, K / 4>(rec, gl);
-        merge64<L, E, K * 2>(rec, gl);
-    }
-}
-
-// L lanes x E registers, element index i = gl*E + r, ascending on exit.
-template <int L, int E>
-__device__ __forceinline__ void bitonic_sort_tile64(uint64_t (&rec)[E], int gl) {
-    merge64<L, E, 2>(rec, gl);
-}
-
-// One record per lane, ascending over each group of L lanes.
-template <int L>
-__device__ __forceinline__ void bitonic_sort_lanes64(uint64_t& rec, int gl) {
-    uint64_t r1[1] = {rec};
-    merge64<L, 1, 2>(r1, gl);
-    rec = r1[0];
 }
 
 // OR over the whole wavefront, result in every lane (idempotent, so a butterfly is enough).

@@ -80,4 +80,10 @@ struct LargeArgs {
 hipError_t large_topic_launch(LargeScratch& scratch, const LargeArgs& a, bool argmin, hipStream_t stream);
 void large_scratch_release(LargeScratch& scratch);
 
+// Stable grouping of the n assignment entries by member rank (see la_group_by_member in lagassign.h).
+hipError_t group_by_member_launch(LargeScratch& scratch, int64_t n, int32_t n_members, int64_t n_topics,
+                                  const int64_t* part_off, const int32_t* out_partition, const int32_t* member_rank,
+                                  int64_t* member_off, int32_t* grouped_topic, int32_t* grouped_partition,
+                                  int32_t* grouped_entry, hipStream_t stream);
+
 }  // namespace la

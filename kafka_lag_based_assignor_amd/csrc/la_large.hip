@@ -549,31 +549,87 @@ hipError_t launch_rounds(const LargeArgs& a, const SortBufs& b, int threads, hip
     return hipGetLastError();
 }
 
+
+// ---- assignment -> per-member lists (the wrap step of Main.java:152-156, 171-174, 264) -------
+// The reference appends to each member's list topic by topic, and inside a topic in assignment order: that is
+// the order of the output arrays.  Grouping by member is therefore a STABLE sort of the entry indices by member
+// rank: key = rank + 1 (0 = "topic had no consumers": those entries come first and are dropped), payload =
+// entry index, already ascending, so only the key's ceil(log2(M+1)/8) digit passes run.
+__global__ __launch_bounds__(256) void member_keys_kernel(const int32_t* member_rank, SortBufs b) {
+    __shared__ uint32_t h[kDigits * kRadix];
+    for (int i = threadIdx.x; i < kDigits * kRadix; i += blockDim.x) h[i] = 0;
+    __syncthreads();
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t base = (int64_t)blockIdx.x * blockDim.x; base < b.n; base += stride) {
+        const int64_t i = base + threadIdx.x;
+        if (i < b.n) {
+            const uint64_t key = (uint64_t)(uint32_t)(member_rank[i] + 1);
+            b.key[0][i] = key;
+            b.val[0][i] = (uint32_t)i;
+#pragma unroll
+            for (int p = 4; p < 8; ++p) atomicAdd(&h[p * kRadix + ((uint32_t)(key >> (8 * (p - 4))) & 0xFFu)], 1u);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < kDigits * kRadix; i += blockDim.x)
+        if (h[i]) atomicAdd(&b.hist[i], h[i]);
+    // digits the loop did not count: ids are ascending (skipped by the plan), key bits 32..63 are zero
+    if (blockIdx.x == 0 && threadIdx.x < kDigits && (threadIdx.x < 4 || threadIdx.x >= 8))
+        b.hist[threadIdx.x * kRadix] = (uint32_t)b.n;
+}
+
+// member_off[r] = first grouped position of member r (r = 0..M); grouped_* = the entries in grouped order
+__global__ __launch_bounds__(256) void member_emit_kernel(SortBufs b, int32_t n_members, int64_t n_topics,
+                                                          const int64_t* part_off, const int32_t* out_partition,
+                                                          int64_t* member_off, int32_t* grouped_topic,
+                                                          int32_t* grouped_partition, int32_t* grouped_entry) {
+    const uint32_t fin = b.ctl->cur[kDigits];
+    const uint64_t* key = b.key[fin];
+    const uint32_t* val = b.val[fin];
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i <= b.n; i += stride) {
+        // boundaries: key k (= rank + 1) starts at the first i with key[i] >= k
+        const int64_t k_prev = i > 0 ? (int64_t)key[i - 1] : 0;
+        const int64_t k_here = i < b.n ? (int64_t)key[i] : (int64_t)n_members + 1;
+        for (int64_t k = k_prev + 1; k <= k_here; ++k)
+            if (k >= 1 && k <= (int64_t)n_members + 1) member_off[k - 1] = i;
+        if (i < b.n) {
+            const uint32_t e = val[i];
+            if (grouped_entry) grouped_entry[i] = (int32_t)e;
+            if (grouped_partition) grouped_partition[i] = out_partition[e];
+            if (grouped_topic) {
+                int64_t lo = 0, hi = n_topics;                   // largest t with part_off[t] <= e
+                while (hi - lo > 1) {
+                    const int64_t mid = (lo + hi) >> 1;
+                    if (part_off[mid] <= (int64_t)e) lo = mid; else hi = mid;
+                }
+                grouped_topic[i] = (int32_t)lo;
+            }
+        }
+    }
+}
+
 size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 }  // namespace
 
-hipError_t large_topic_launch(LargeScratch& scratch, const LargeArgs& a, bool argmin, hipStream_t stream) {
-    const int64_t n = a.n_part;
-    if (n <= 0) return hipSuccess;
-    if (n > 0x7FFFFFFF || a.n_cons > kLargeMaxConsumers) return hipErrorInvalidValue;
+// Carves the sort's working set for n elements out of the grow-only scratch and zeroes ctl + hist.
+static hipError_t sort_prepare(LargeScratch& scratch, int64_t n, hipStream_t stream, SortBufs* out) {
     const int n_tiles = (int)((n + kTile - 1) / kTile);
-
-    // scratch carve-up
     size_t off = 0;
     auto carve = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
     const size_t o_ctl = carve(sizeof(SortCtl));
     const size_t o_hist = carve(sizeof(uint32_t) * kDigits * kRadix);
-    const size_t zero_bytes = off;                                  // ctl + hist are zeroed per topic
+    const size_t zero_bytes = off;                                  // ctl + hist are zeroed per sort
     const size_t o_k0 = carve(sizeof(uint64_t) * n), o_k1 = carve(sizeof(uint64_t) * n);
     const size_t o_v0 = carve(sizeof(uint32_t) * n), o_v1 = carve(sizeof(uint32_t) * n);
     const size_t o_to = carve(sizeof(uint32_t) * kRadix * (size_t)n_tiles);
     const int n_groups = (n_tiles + kScanRows - 1) / kScanRows;
     const size_t o_gs = carve(sizeof(uint32_t) * kRadix * (size_t)n_groups);
+    hipError_t e;
     if (off > scratch.cap) {
-        hipError_t e;
         if (scratch.buf) {
-            if ((e = hipStreamSynchronize(stream)) != hipSuccess) return e;   // earlier topics may still use it
+            if ((e = hipStreamSynchronize(stream)) != hipSuccess) return e;   // earlier work may still use it
             if ((e = hipFree(scratch.buf)) != hipSuccess) return e;
             scratch.buf = nullptr;
             scratch.cap = 0;
@@ -595,19 +651,32 @@ hipError_t large_topic_launch(LargeScratch& scratch, const LargeArgs& a, bool ar
     b.n = n;
     b.n_tiles = n_tiles;
     b.n_groups = n_groups;
+    *out = b;
+    return hipMemsetAsync(base, 0, zero_bytes, stream);
+}
 
+// plan + the 12 (mostly skipped) passes; keys/vals/hist/unsorted flag must already be in buffer 0
+static void sort_run_passes(const SortBufs& b, hipStream_t stream) {
+    hipLaunchKernelGGL(plan_kernel, dim3(1), dim3(256), 0, stream, b);
+    for (int p = 0; p < kDigits; ++p) {
+        hipLaunchKernelGGL(tile_count_kernel, dim3(b.n_tiles < 2048 ? b.n_tiles : 2048), dim3(kSortThreads), 0, stream, b, p);
+        hipLaunchKernelGGL(scan_group_sums_kernel, dim3(b.n_groups), dim3(kRadix), 0, stream, b, p);
+        hipLaunchKernelGGL(scan_offsets_kernel, dim3(b.n_groups), dim3(kRadix), 0, stream, b, p);
+        hipLaunchKernelGGL(tile_scatter_kernel, dim3(b.n_tiles), dim3(kSortThreads), 0, stream, b, p);
+    }
+}
+
+hipError_t large_topic_launch(LargeScratch& scratch, const LargeArgs& a, bool argmin, hipStream_t stream) {
+    const int64_t n = a.n_part;
+    if (n <= 0) return hipSuccess;
+    if (n > 0x7FFFFFFF || a.n_cons > kLargeMaxConsumers) return hipErrorInvalidValue;
+    SortBufs b{};
     hipError_t e;
-    if ((e = hipMemsetAsync(base, 0, zero_bytes, stream)) != hipSuccess) return e;
+    if ((e = sort_prepare(scratch, n, stream, &b)) != hipSuccess) return e;
     int grid = (int)((n + 255) / 256);
     if (grid > 2048) grid = 2048;
     hipLaunchKernelGGL(build_keys_kernel, dim3(grid), dim3(256), 0, stream, a, b);
-    hipLaunchKernelGGL(plan_kernel, dim3(1), dim3(256), 0, stream, b);
-    for (int p = 0; p < kDigits; ++p) {
-        hipLaunchKernelGGL(tile_count_kernel, dim3(n_tiles < 2048 ? n_tiles : 2048), dim3(kSortThreads), 0, stream, b, p);
-        hipLaunchKernelGGL(scan_group_sums_kernel, dim3(n_groups), dim3(kRadix), 0, stream, b, p);
-        hipLaunchKernelGGL(scan_offsets_kernel, dim3(n_groups), dim3(kRadix), 0, stream, b, p);
-        hipLaunchKernelGGL(tile_scatter_kernel, dim3(n_tiles), dim3(kSortThreads), 0, stream, b, p);
-    }
+    sort_run_passes(b, stream);
     hipLaunchKernelGGL(emit_ids_kernel, dim3(grid), dim3(256), 0, stream, a, b, a.n_cons == 0 ? 1 : 0);
     if ((e = hipGetLastError()) != hipSuccess) return e;
     if (a.n_cons == 0) return hipSuccess;
@@ -635,6 +704,24 @@ hipError_t large_topic_launch(LargeScratch& scratch, const LargeArgs& a, bool ar
         case 4: return launch_rounds<4>(a, b, 1024, stream);
         default: return launch_rounds<8>(a, b, 1024, stream);
     }
+}
+
+hipError_t group_by_member_launch(LargeScratch& scratch, int64_t n, int32_t n_members, int64_t n_topics,
+                                  const int64_t* part_off, const int32_t* out_partition, const int32_t* member_rank,
+                                  int64_t* member_off, int32_t* grouped_topic, int32_t* grouped_partition,
+                                  int32_t* grouped_entry, hipStream_t stream) {
+    if (n < 0 || n > 0x7FFFFFFF || n_members < 0) return hipErrorInvalidValue;
+    hipError_t e;
+    if (n == 0) return hipMemsetAsync(member_off, 0, sizeof(int64_t) * ((size_t)n_members + 1), stream);
+    SortBufs b{};
+    if ((e = sort_prepare(scratch, n, stream, &b)) != hipSuccess) return e;
+    int grid = (int)((n + 255) / 256);
+    if (grid > 2048) grid = 2048;
+    hipLaunchKernelGGL(member_keys_kernel, dim3(grid), dim3(256), 0, stream, member_rank, b);
+    sort_run_passes(b, stream);
+    hipLaunchKernelGGL(member_emit_kernel, dim3(grid), dim3(256), 0, stream, b, n_members, n_topics, part_off,
+                       out_partition, member_off, grouped_topic, grouped_partition, grouped_entry);
+    return hipGetLastError();
 }
 
 void large_scratch_release(LargeScratch& s) {

@@ -7,12 +7,13 @@
 // carries 64/L topics, a 256-thread workgroup 4x that.  Each lane holds E partition
 // records in registers (L*E >= partitions of the topic, L >= consumers of the topic).
 //
-//   1. load      begin/end/committed/partition id, 16 B per lane per array where the tile
-//                allows it (the order records enter the sorter is irrelevant, so a lane takes
-//                pairs of neighbours); lag in registers.                     [28 B/partition]
-//   2. sort      bitonic network over the L*E records: strides < E in registers, larger
-//                strides via DPP / v_permlane swaps.  No LDS, no HBM.
-//   3. transpose sorted records through the group's LDS slice (padded, conflict-free writes).
+//   1. load      committed / end / partition id, 16 B per lane per array, unconditional and clamped, all
+//                issued back to back; `begin` only where there is no committed offset; lag in registers.
+//   2. format    per wavefront: packed 64-bit records if ids and lags are narrow enough (kernel 1), else
+//                the tile is deferred to the wide-record kernel (kernel 2).
+//   3. sort      32-bit keys (top bits of the record, id as tie-break) through a bitonic network of DPP
+//                min/max; records fetched from the LDS slice by the key's index and CHECKED to be strictly
+//                ascending; the full 64-bit network only if the check fails.  No HBM.
 //   4. greedy    ROUND-STRUCTURED: the count is the comparator's first key (Main.java:246-250),
 //                so assignment proceeds in rounds of C partitions; in a round the k-th
 //                partition goes to the k-th consumer in (total lag, memberId) order as of
@@ -20,22 +21,21 @@
 //                bins (one bin per lane, in registers) + one add.  ceil(P/C) dependent
 //                steps instead of P.  LA_ALGO_ARGMIN keeps the literal per-partition
 //                wavefront argmin for cross-checking.
-//   5. store     partition ids in assignment order + chosen member rank.     [8 B/partition]
+//   5. store     partition ids in assignment order + chosen member rank, 16 B per lane.  [8 B/partition]
 //
-// Two record formats, chosen per wavefront at run time (wave-uniform branch):
+// Record formats:
 //
-//   packed   one 64-bit word per record.  With sh = bits needed by the wave's largest
-//            partition id:   rec = ((2^(63-sh)-1 - lag) << sh) | id     ascending == (lag desc, id asc)
-//            and consumer bins  bin = (total << 6) | index.  Taken when every lag of the wave
-//            satisfies 0 <= lag < 2^min(63-sh, 57-log2(L*E)) and no id is negative; then no
-//            total can reach 2^57, nothing wraps, and the packed order is exactly the
-//            reference's.  One 64-bit compare + two selects per compare-exchange.
+//   packed   one 64-bit word per record.  With sh = bits of the wavefront's largest partition id and
+//            lbw = bits of its largest lag:   rec = ((2^lbw - 1 - lag) << sh) | id     ascending == (lag desc, id asc)
+//            and consumer bins  bin = (total << 6) | index.  Taken when no id or lag is negative and
+//            lbw <= min(63-sh, 57-log2(L*E)); then no total can reach 2^57, nothing wraps, and the
+//            packed order is exactly the reference's.
 //   wide     (key64, tie-break32) records, biased so that unsigned order == Java's signed
 //            order; totals wrap like Java's long.  Any int64 lag, any int32 id.
 //            LA_ALGO_ROUNDS_WIDE forces it (tests run both on the same inputs).
 //
-// HBM traffic is exactly the algorithmic 36 B/partition (+ ~2% descriptors): every input
-// byte is read once, every output byte written once, nothing spills to HBM in between.
+// HBM traffic is at most the algorithmic 36 B/partition (+ ~2% descriptors): every input byte is read at
+// most once (`begin` usually not at all), every output byte written once, nothing spills in between.
 #include "la_kernels.h"
 #include "la_device.h"
 #include "la_sort64.h"
@@ -502,21 +502,12 @@ __device__ __forceinline__ TopicDesc load_desc(const TileArgs& a, int64_t t, int
     return make_desc<L, E>(a, fetch_desc<L, E>(a, t, n_tiles, grp), gl);
 }
 
-// ---- kernel 1: packed records, software-pipelined -------------------------------------------------------
-// One wavefront walks tiles t = w, w + W, w + 2W, .. (W = wavefronts in the grid; the grid is sized to what
-// is resident, see the launcher).  Per tile: finish the lags from loads that were issued one tile ago,
-// pack, issue the next tile's loads into the registers that just became free, then sort / greedy / store.
-// The HBM latency of tile i+1 hides under the ~2 000 VALU instructions of tile i inside the SAME
-// wavefront, instead of relying on other wavefronts being in a different phase.
-// A tile whose records do not fit the packed format is appended to the deferred list and left to kernel 2.
-#ifndef LA_WPS
-#define LA_WPS 1
-#endif
-#ifndef LA_GRID_MULT
-#define LA_GRID_MULT 1
-#endif
+// ---- kernel 1: packed records -------------------------------------------------------------------------
+// One tile per wavefront.  Loads (all issued back to back) -> lags -> format decision -> 32-bit key sort ->
+// greedy rounds -> stores.  A tile whose records do not fit the packed format is appended to the deferred
+// list and left to kernel 2.
 template <int L, int E>
-__global__ __launch_bounds__(256, LA_WPS) void wave_tile_packed_kernel(TileArgs a) {
+__global__ __launch_bounds__(256) void wave_tile_packed_kernel(TileArgs a) {
     using Cfg = TileCfg<L, E>;
     __shared__ uint64_t lds[Cfg::kTopicsPerBlock * Cfg::kSlots];
     __shared__ int32_t rank_lds[Cfg::kTopicsPerBlock * L];
@@ -529,11 +520,12 @@ __global__ __launch_bounds__(256, LA_WPS) void wave_tile_packed_kernel(TileArgs 
     int32_t* rank_tab = rank_lds + (wave * Cfg::kGroupsPerWave + grp) * L;
 
     const int64_t n_tiles = (a.n_topics + Cfg::kGroupsPerWave - 1) / Cfg::kGroupsPerWave;
-    const int64_t n_waves = (int64_t)gridDim.x * Cfg::kWavesPerBlock;
-    int64_t tile = (int64_t)blockIdx.x * Cfg::kWavesPerBlock + wave;
+    // one tile per wavefront: the grid covers all tiles (a resident-sized grid looping over tiles, with or
+    // without the next tile's loads prefetched into registers, measured 10-25 % slower: more live
+    // registers, fewer wavefronts per SIMD)
+    const int64_t tile = (int64_t)blockIdx.x * Cfg::kWavesPerBlock + wave;
     if (tile >= n_tiles) return;
-
-    for (; tile < n_tiles; tile += n_waves) {
+    {
         const TopicDesc cur = load_desc<L, E>(a, tile, n_tiles, grp, gl);
         Raw<E> raw;
         issue_loads<L, E>(a, cur, gl, raw);
@@ -576,8 +568,6 @@ __global__ __launch_bounds__(256, LA_WPS) void wave_tile_packed_kernel(TileArgs 
         } else if (lane == 0) {
             a.defer_list[atomicAdd(a.defer_count, 1)] = (int32_t)tile;
         }
-        break;      // one tile per wavefront: the grid covers all tiles (a resident-sized grid looping over
-                    // tiles measured 15-20 % slower: more live registers, fewer wavefronts per SIMD)
     }
 }
 
@@ -655,9 +645,6 @@ static hipError_t launch_one(const TileArgs& a, int mode, hipStream_t stream) {
         // usually nothing was deferred: every wavefront reads the count and leaves
 #ifdef LA_LAB
         if (getenv("LA_NO_WIDE")) return hipGetLastError();
-#endif
-#ifdef LA_LAB
-        if (getenv("LA_WIDE_GRID")) { hipLaunchKernelGGL((wave_tile_wide_kernel<L, E, false>), grid(atoi(getenv("LA_WIDE_GRID"))), b, 0, stream, a, 1); return hipGetLastError(); }
 #endif
         hipLaunchKernelGGL((wave_tile_wide_kernel<L, E, false>), grid(res_wide), b, 0, stream, a, 1);
     }

@@ -392,3 +392,46 @@ def test_device_entry_shape_hint_violation_is_reported(ctx):
     with pytest.raises(N.LagAssignError) as ei:
         _run_device(ctx, w, N.LA_ALGO_AUTO, use_lag=True)
     assert ei.value.code == N.LA_ESHAPE
+
+
+# ---- assignment -> per-member lists (la_group_by_member) -------------------------------------------------
+def _expected_groups(part_off, out_p, out_m, n_members):
+    order = np.argsort(out_m, kind="stable")                 # rank -1 first, then members in rank order
+    topic_of = np.searchsorted(part_off, np.arange(out_p.size), side="right") - 1
+    counts = np.bincount(out_m + 1, minlength=n_members + 1)
+    return np.cumsum(counts)[: n_members + 1].astype(np.int64), topic_of[order].astype(np.int32), out_p[order]
+
+
+@pytest.mark.parametrize("shape", [(1, 3, 2), (50, 64, 8), (300, 256, 32), (3, 5000, 300)])
+def test_group_by_member_matches_stable_sort(ctx, shape):
+    t, max_p, max_c = shape
+    w = synth.ragged(7 * t + max_p, t, max_p, max_c, dist="small")
+    out_p, out_m, _ = ctx.assign_batch_lags(w.part_off, w.partition_id, w.lag, w.cons_off, w.cons_rank)
+    n_members = int(w.cons_rank.max()) + 1 if w.cons_rank.size else 0
+    off, g_t, g_p = ctx.group_by_member(w.part_off, out_p, out_m, n_members)
+    e_off, e_t, e_p = _expected_groups(np.asarray(w.part_off), out_p, out_m, n_members)
+    np.testing.assert_array_equal(off, e_off)
+    np.testing.assert_array_equal(g_t, e_t)
+    np.testing.assert_array_equal(g_p, e_p)
+
+
+def test_group_by_member_reference_vector(ctx):              # Test.java:82-132: the exact lists
+    out_p, out_m, _ = ctx.assign_batch_lags([0, 4, 6], [0, 1, 2, 3, 0, 1], [100000, 100000, 500, 1, 900000, 100000],
+                                            [0, 2, 3], [0, 1, 0])
+    off, g_t, g_p = ctx.group_by_member([0, 4, 6], out_p, out_m, 2)
+    lists = [[(int(g_t[j]), int(g_p[j])) for j in range(off[r], off[r + 1])] for r in range(2)]
+    assert lists[0] == [(0, 0), (0, 2), (1, 0), (1, 1)]          # consumer-1: topic1-0, topic1-2, topic2-0, topic2-1
+    assert lists[1] == [(0, 1), (0, 3)]                          # consumer-2: topic1-1, topic1-3
+
+
+def test_group_by_member_many_members(ctx):
+    rng = np.random.default_rng(5)
+    n, m = 200000, 70000
+    out_m = rng.integers(-1, m, n).astype(np.int32)
+    out_p = rng.integers(0, 1 << 20, n).astype(np.int32)
+    part_off = np.array([0, 1000, 1000, n], dtype=np.int64)
+    off, g_t, g_p = ctx.group_by_member(part_off, out_p, out_m, m)
+    e_off, e_t, e_p = _expected_groups(part_off, out_p, out_m, m)
+    np.testing.assert_array_equal(off, e_off)
+    np.testing.assert_array_equal(g_t, e_t)
+    np.testing.assert_array_equal(g_p, e_p)
