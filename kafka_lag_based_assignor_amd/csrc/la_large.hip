@@ -21,6 +21,7 @@
 //                            one wavefront-argmin + LDS combine per partition.
 #include "la_kernels.h"
 #include "la_device.h"
+#include "la_sort64.h"
 
 #include <type_traits>
 
@@ -396,6 +397,90 @@ __global__ __launch_bounds__(256) void emit_ids_kernel(LargeArgs a, SortBufs b, 
     }
 }
 
+// ---- kernel 3, packed form: bins are one 64-bit word -----------------------------------------------------
+// (total << idx_bits) | index, ascending = (total, member) ascending, the comparator of Main.java:253-259.
+// Element i = tid*EC + r.  Strides inside a wavefront run through the instruction-level networks of
+// la_sort64.h (registers, DPP); strides across wavefronts go through LDS: 10 exchanges per round at 8 192 bins.
+template <int EC>
+__device__ __forceinline__ void dpp_fence(P64 (&rec)[EC]) {
+    // the next instruction-level block reads these registers through DPP: 2 wait states after their last
+    // (compiler-generated) write
+#pragma unroll
+    for (int r = 0; r < EC; ++r) asm volatile("s_nop 1" : "+v"(rec[r].lo), "+v"(rec[r].hi));
+}
+
+template <int EC>
+__device__ __forceinline__ void cross_wave_step(P64 (&rec)[EC], uint64_t* s_bin, int tid, int mask, int min_bit) {
+#pragma unroll
+    for (int r = 0; r < EC; ++r) s_bin[tid * EC + r] = p64_value(rec[r]);
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < EC; ++r) {
+        const int i = tid * EC + r;
+        const uint64_t o = s_bin[i ^ mask], x = p64_value(rec[r]);
+        const bool keep_min = (i & min_bit) == 0;
+        const uint64_t lo = o < x ? o : x, hi = o < x ? x : o;
+        rec[r] = p64_from(keep_min ? lo : hi);
+    }
+    __syncthreads();
+}
+
+template <int EC>
+__device__ void greedy_rounds_packed(const LargeArgs& a, const uint64_t* key, int64_t P, int C, int64_t rounds,
+                                     int idx_bits, uint64_t* s_bin) {
+    const int tid = threadIdx.x;
+    const int n = EC * blockDim.x;
+    constexpr int kSpan = 64 * EC;                       // elements of one wavefront
+    const uint32_t idx_mask = (1u << idx_bits) - 1;
+    P64 rec[EC];
+    uint64_t lag[EC];
+#pragma unroll
+    for (int r = 0; r < EC; ++r) {
+        const int i = tid * EC + r;
+        rec[r] = p64_from(i < C ? (uint64_t)i : ~0ull);
+        lag[r] = (i < C && i < P) ? (key[i] ^ kLagKeyFlip) : 0;
+    }
+    for (int64_t q = 0; q < rounds; ++q) {
+        if (q > 0) {
+            // sort the n bins: inside every wavefront first, then merges across wavefronts
+            dpp_fence<EC>(rec);
+            bitonic_sort_tile_p64<64, EC>(rec);
+            for (int K = 2 * kSpan; K <= n; K <<= 1) {
+                cross_wave_step<EC>(rec, s_bin, tid, K - 1, K >> 1);                     // mirror: i <-> i ^ (K-1)
+                for (int j = K >> 2; j >= kSpan; j >>= 1) cross_wave_step<EC>(rec, s_bin, tid, j, j);
+                dpp_fence<EC>(rec);
+                clean_p64<64, EC, kSpan / 2, false>(rec);                                 // i <-> i ^ j, j < span
+            }
+        }
+        // position i of the sorted bins takes partition q*C + i; the next round's lags are fetched now
+        uint64_t next_lag[EC];
+#pragma unroll
+        for (int r = 0; r < EC; ++r) {
+            const int i = tid * EC + r;
+            const int64_t s = (q + 1) * C + i;
+            next_lag[r] = (i < C && s < P) ? (key[s] ^ kLagKeyFlip) : 0;
+        }
+#pragma unroll
+        for (int r = 0; r < EC; ++r) {
+            const int i = tid * EC + r;
+            const int64_t s = q * C + i;
+            if (i < C && s < P) {
+                const uint64_t nb = p64_value(rec[r]) + (lag[r] << idx_bits);          // Main.java:265
+                rec[r] = p64_from(nb);
+                a.out_rank[a.p0 + s] = a.cons_rank[a.c0 + ((uint32_t)nb & idx_mask)];
+            }
+            lag[r] = next_lag[r];
+        }
+    }
+    if (a.out_total) {
+#pragma unroll
+        for (int r = 0; r < EC; ++r) {
+            const uint64_t v = p64_value(rec[r]);
+            if (v != ~0ull) a.out_total[a.c0 + ((uint32_t)v & idx_mask)] = (int64_t)(v >> idx_bits);
+        }
+    }
+}
+
 // ---- kernel 3: round-structured greedy, one workgroup -----------------------------------------------
 // n = EC * blockDim.x consumer slots (power of two >= C); slot i = tid*EC + r.
 template <int EC>
@@ -410,6 +495,19 @@ __global__ __launch_bounds__(1024) void greedy_rounds_kernel(LargeArgs a, SortBu
     const int64_t P = a.n_part;
     const int C = (int)a.n_cons;
 
+    const int64_t rounds = (P + C - 1) / C;
+    {
+        // Packed bins (total << idx_bits) | index when nothing can overflow: the keys are sorted, so the
+        // first one carries the largest lag and the last one the smallest.
+        const int64_t lmax = (int64_t)(key[0] ^ kLagKeyFlip), lmin = (int64_t)(key[P - 1] ^ kLagKeyFlip);
+        const int idx_bits = 31 - __builtin_clz(n);                                  // n is a power of two
+        const int lag_bits = lmax > 0 ? 64 - __builtin_clzll((unsigned long long)lmax) : 0;
+        const int round_bits = 64 - __builtin_clzll((unsigned long long)rounds);
+        if (lmin >= 0 && lag_bits + round_bits + idx_bits <= 62) {
+            greedy_rounds_packed<EC>(a, key, P, C, rounds, idx_bits, reinterpret_cast<uint64_t*>(smem));
+            return;
+        }
+    }
     Rec rec[EC];
 #pragma unroll
     for (int r = 0; r < EC; ++r) {
@@ -417,7 +515,6 @@ __global__ __launch_bounds__(1024) void greedy_rounds_kernel(LargeArgs a, SortBu
         if (i < C) { rec[r].hi = (uint32_t)(kTotalBias >> 32); rec[r].lo = 0; rec[r].tb = (uint32_t)i; }
         else rec[r].hi = rec[r].lo = rec[r].tb = 0xFFFFFFFFu;
     }
-    const int64_t rounds = (P + C - 1) / C;
     for (int64_t q = 0; q < rounds; ++q) {
         if (q > 0) {
             // bitonic sort of the n bins, ascending by (biased total, index)

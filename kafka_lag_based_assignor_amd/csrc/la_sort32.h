@@ -80,6 +80,7 @@ __device__ __forceinline__ void cmpx32_same_mirror(uint32_t& x) {
         else if constexpr (M == 8) LA32_SAME_PADS("row_half_mirror");
         else LA32_SAME_PADS("row_mirror");
     } else {
+        asm volatile("s_nop 1" : "+v"(x));        // compiler code reads x through DPP next (see la_sort64.h)
         const uint32_t o = shfl_mirror<M>(x);
         const bool keep_min = (KeepMin<M / 2>::value >> __lane_id()) & 1;
         const uint32_t lo = o < x ? o : x, hi = o < x ? x : o;
@@ -116,6 +117,7 @@ __device__ __forceinline__ void cmpx32_cross_mirror(uint32_t& r, uint32_t& q) {
         else if constexpr (M == 8) LA32_CROSS_PADS("row_half_mirror");
         else LA32_CROSS_PADS("row_mirror");
     } else {
+        asm volatile("s_nop 1" : "+v"(r), "+v"(q));
         const uint32_t oq = shfl_mirror<M>(q), orr = shfl_mirror<M>(r);
         const bool keep_min = (keep >> __lane_id()) & 1;
         const uint32_t rl = oq < r ? oq : r, rh = oq < r ? r : oq;

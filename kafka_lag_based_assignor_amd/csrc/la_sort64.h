@@ -25,6 +25,8 @@
 //     order does (see the notes at bitonic_sort_tile_p64), and blocks that may directly follow a write
 //     of their DPP source take PAD = 1 (s_nop 0) or 2 (s_nop 1).
 //   * VCC: v_sub_co -> v_subb_co is a carry chain (no wait); SALU write of VCC -> VALU read needs none.
+//   * s_xor_b64 writes SCC: every statement that contains one lists "scc" as clobbered (the compiler keeps
+//     s_cmp / s_cselect pairs live across asm statements otherwise -- found the hard way).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -64,7 +66,7 @@ struct KeepMin {
                  "v_cndmask_b32_dpp %1, %1, %1, vcc " CTRL LA_DPP_TAIL                       \
                  : "+v"(r.lo), "+v"(r.hi), "=&v"(t)                                         \
                  : "s"(keep)                                                               \
-                 : "vcc")
+                 : "vcc", "scc")
 
 #define LA_SAME_PADS(CTRL)                                  \
     do {                                                    \
@@ -86,7 +88,7 @@ struct KeepMin {
                  "v_cndmask_b32_dpp %1, %3, %1, vcc quad_perm:[3,2,1,0]" LA_DPP_TAIL             \
                  : "+v"(r.lo), "+v"(r.hi), "=&v"(t), "=&v"(u), "=&v"(w)                          \
                  : "s"(keep)                                                                   \
-                 : "vcc")
+                 : "vcc", "scc")
 
 // lane ^ 16 / lane ^ 32: v_permlane*_swap gives both lanes of a pair (A, B) = (lower's, upper's)
 // record; each keeps A or B.  keep-min lanes keep A iff A < B.
@@ -104,7 +106,7 @@ struct KeepMin {
                  "v_cndmask_b32 %1, %1, %3, vcc"             \
                  : "+v"(r.lo), "+v"(r.hi), "=&v"(t), "=&v"(u), "=&v"(w) \
                  : "s"(keep)                                 \
-                 : "vcc")
+                 : "vcc", "scc")
 
 // rec <- min or max of (rec, record of lane ^ J), min where bit J of the lane id is clear
 template <int J, int PAD>
@@ -142,7 +144,10 @@ __device__ __forceinline__ void cmpx_same_mirror(P64& r) {
         else LA_SAME_PADS("row_mirror");
     } else {
         // lane ^ 31 = row_mirror then lane ^ 16; lane ^ 63 additionally lane ^ 32.  Rare (once per sort):
-        // move first, then a plain (non-DPP) select.
+        // move first, then a plain (non-DPP) select.  The move is compiler code whose first instruction
+        // reads r through DPP: r may have been written by the previous block's last instruction, and the
+        // compiler pads only one wait state after an asm statement.
+        asm volatile("s_nop 1" : "+v"(r.lo), "+v"(r.hi));
         P64 o;
         o.lo = shfl_mirror<M>(r.lo);
         o.hi = shfl_mirror<M>(r.hi);
@@ -155,7 +160,7 @@ __device__ __forceinline__ void cmpx_same_mirror(P64& r) {
                      "v_cndmask_b32 %1, %4, %1, vcc"
                      : "+v"(r.lo), "+v"(r.hi), "=&v"(t)
                      : "v"(o.lo), "v"(o.hi), "s"(keep)
-                     : "vcc");
+                     : "vcc", "scc");
     }
 }
 
@@ -174,7 +179,7 @@ __device__ __forceinline__ void cmpx_same_mirror(P64& r) {
                  "v_cndmask_b32_dpp %1, %6, %1, vcc " CTRL LA_DPP_TAIL                        \
                  : "+v"(q.lo), "+v"(q.hi), "=&v"(t), "=&v"(n.lo), "=&v"(n.hi)                       \
                  : "v"(r.lo), "v"(r.hi), "s"(keep)                                          \
-                 : "vcc")
+                 : "vcc", "scc")
 
 #define LA_CROSS_PADS(CTRL)                                   \
     do {                                                      \
@@ -193,7 +198,7 @@ __device__ __forceinline__ void select_minmax(P64& r, const P64& o, uint64_t kee
                  "v_cndmask_b32 %1, %4, %1, vcc"
                  : "+v"(r.lo), "+v"(r.hi), "=&v"(t)
                  : "v"(o.lo), "v"(o.hi), "s"(keep)
-                 : "vcc");
+                 : "vcc", "scc");
 }
 
 template <int M, int PAD>
@@ -209,6 +214,7 @@ __device__ __forceinline__ void cmpx_cross_mirror(P64& r, P64& q) {
         else LA_CROSS_PADS("row_mirror");
         r = n;
     } else {
+        asm volatile("s_nop 1" : "+v"(r.lo), "+v"(r.hi), "+v"(q.lo), "+v"(q.hi));   // as in cmpx_same_mirror
         P64 oq, orr;
         oq.lo = shfl_mirror<M>(q.lo); oq.hi = shfl_mirror<M>(q.hi);
         orr.lo = shfl_mirror<M>(r.lo); orr.hi = shfl_mirror<M>(r.hi);
@@ -229,7 +235,7 @@ __device__ __forceinline__ void cmpx_regs_p64(P64& a, P64& b) {
                  "v_cndmask_b32 %1, %1, %6, vcc"
                  : "+v"(b.lo), "+v"(b.hi), "=&v"(t), "=&v"(n.lo), "=&v"(n.hi)
                  : "v"(a.lo), "v"(a.hi)
-                 : "vcc");
+                 : "vcc", "scc");
     a = n;
 }
 
