@@ -18,7 +18,7 @@ from collections import defaultdict
 
 
 def short(name):
-    name = re.sub(r"^void ", "", name)
+    name = re.sub(r"^void ", "", name).replace("(anonymous namespace)::", "")
     return re.sub(r"\(.*$", "", name)
 
 

@@ -10,7 +10,7 @@ idx = [i for i, r in enumerate(rows) if "build_keys" in r["Kernel_Name"]][-1]
 prev_end = None
 tot = {}
 for r in rows[idx:]:
-    n = r["Kernel_Name"].split("::")[-1].split("(")[0]
+    n = r["Kernel_Name"].replace("void ", "").replace("la::", "").replace("(anonymous namespace)::", "").split("(")[0]
     s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
     gap = (s - prev_end) / 1e3 if prev_end else 0
     print("%-24s %8.1f us  gap %5.1f" % (n, (e - s) / 1e3, gap))
