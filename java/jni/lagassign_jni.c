@@ -41,6 +41,16 @@ Java_com_github_grantneale_kafka_gpu_LagAssignNative_assignBatch(
                            (int64_t *)ADDR(env, out_total_lag));
 }
 
+JNIEXPORT jint JNICALL
+Java_com_github_grantneale_kafka_gpu_LagAssignNative_groupByMember(
+    JNIEnv *env, jclass cls, jlong ctx, jint n_topics, jobject part_off, jobject out_partition,
+    jobject out_member_rank, jint n_members, jobject member_off, jobject grouped_topic, jobject grouped_partition) {
+    return la_group_by_member((la_ctx *)(intptr_t)ctx, n_topics, (const int64_t *)ADDR(env, part_off),
+                              (const int32_t *)ADDR(env, out_partition), (const int32_t *)ADDR(env, out_member_rank),
+                              n_members, (int64_t *)ADDR(env, member_off), (int32_t *)ADDR(env, grouped_topic),
+                              (int32_t *)ADDR(env, grouped_partition));
+}
+
 JNIEXPORT jstring JNICALL
 Java_com_github_grantneale_kafka_gpu_LagAssignNative_lastError(JNIEnv *env, jclass cls, jlong ctx) {
     return (*env)->NewStringUTF(env, la_last_error((const la_ctx *)(intptr_t)ctx));

@@ -167,18 +167,27 @@ public class GpuLagBasedPartitionAssignor implements ConsumerPartitionAssignor, 
             throw new IllegalStateException("liblagassign error " + rc + ": " + LagAssignNative.lastError(nativeCtx));
         }
 
-        // rebuild member -> list, topic by topic in container order, inside a topic in device order
-        Map<String, List<TopicPartition>> lists = new HashMap<>();
-        for (String member : memberTopics.keySet()) {
-            lists.put(member, new ArrayList<>());
+        // member -> list: the device groups the entries by member (stable, so every list keeps the
+        // reference's order: topic by topic in container order, inside a topic in assignment order,
+        // Main.java:171-174 and :264); the host only wraps its own slice per member
+        int nMembers = byRank.length;
+        LongBuffer memberOff = longs(nMembers + 1);
+        IntBuffer groupedTopic = ints(n);
+        IntBuffer groupedPartition = ints(n);
+        rc = LagAssignNative.groupByMember(nativeCtx, nTopics, bytes(partOff), bytes(outPartition),
+            bytes(outMemberRank), nMembers, bytes(memberOff), bytes(groupedTopic), bytes(groupedPartition));
+        if (rc != 0) {
+            throw new IllegalStateException("liblagassign error " + rc + ": " + LagAssignNative.lastError(nativeCtx));
         }
-        for (int t = 0; t < nTopics; t++) {
-            for (long i = partOff.get(t); i < partOff.get(t + 1); i++) {
-                int rank = outMemberRank.get((int) i);
-                if (rank >= 0) {
-                    lists.get(byRank[rank]).add(new TopicPartition(topicOrder.get(t), outPartition.get((int) i)));
-                }
+        Map<String, List<TopicPartition>> lists = new HashMap<>();
+        for (int r = 0; r < nMembers; r++) {
+            int from = (int) memberOff.get(r);
+            int to = (int) memberOff.get(r + 1);
+            List<TopicPartition> list = new ArrayList<>(to - from);
+            for (int j = from; j < to; j++) {
+                list.add(new TopicPartition(topicOrder.get(groupedTopic.get(j)), groupedPartition.get(j)));
             }
+            lists.put(byRank[r], list);
         }
         Map<String, Assignment> out = new HashMap<>();
         for (Map.Entry<String, List<TopicPartition>> e : lists.entrySet()) {

@@ -38,6 +38,15 @@ final class LagAssignNative {
                                   ByteBuffer consOff, ByteBuffer consRank, ByteBuffer outPartition,
                                   ByteBuffer outMemberRank, ByteBuffer outTotalLag);
 
+    /**
+     * la_group_by_member: every member's list in the reference's order, as slices.
+     * memberOff: int64[M+1]; groupedTopic/groupedPartition: int32[N].  Member r owns
+     * [memberOff[r], memberOff[r+1]); positions before memberOff[0] belong to topics without consumers.
+     */
+    static native int groupByMember(long ctx, int nTopics, ByteBuffer partOff, ByteBuffer outPartition,
+                                    ByteBuffer outMemberRank, int nMembers, ByteBuffer memberOff,
+                                    ByteBuffer groupedTopic, ByteBuffer groupedPartition);
+
     /** la_last_error */
     static native String lastError(long ctx);
 }

@@ -148,20 +148,31 @@ Assignment run_native(const Plan& plan, const std::vector<const TopicData*>& dat
         check(ctx, rc);
     }
 
+    // Every member's list, in the reference's order (topic by topic as consumersPerTopic iterates, inside a
+    // topic in assignment order, Main.java:171-174 and :264): grouped on the device, wrapped here.
+    const int32_t n_members = (int32_t)plan.members.size();
+    std::vector<int64_t> member_off((size_t)n_members + 1, 0);
+    std::vector<int32_t> grouped_topic(n), grouped_pid(n);
+    if (!plan.topics.empty()) {
+        std::lock_guard<std::mutex> lock(g_ctx_mutex);
+        la_ctx* ctx = shared_ctx_locked();
+        check(ctx, la_group_by_member(ctx, (int32_t)plan.topics.size(), f.part_off.data(), out_pid.data(),
+                                      out_rank.data(), n_members, member_off.data(), grouped_topic.data(),
+                                      grouped_pid.data()));
+    }
+    // partition id -> the element's own topic string (normally the map key), per topic
+    std::vector<std::unordered_map<int32_t, const std::string*>> topic_of(plan.topics.size());
+    for (size_t t = 0; t < plan.topics.size(); ++t)
+        if (const TopicData* d = data[t])
+            for (size_t i = 0; i < d->partition.size(); ++i) topic_of[t].emplace(d->partition[i], &d->element_topic[i]);
     Assignment assignment;
-    for (const std::string& m : plan.members) assignment[m];            // a list for EVERY member, :171-174
-    for (size_t t = 0; t < plan.topics.size(); ++t) {
-        const TopicData* d = data[t];
-        // partition id -> the element's own topic string (normally the map key)
-        std::unordered_map<int32_t, const std::string*> topic_of;
-        if (d)
-            for (size_t i = 0; i < d->partition.size(); ++i) topic_of.emplace(d->partition[i], &d->element_topic[i]);
-        for (int64_t i = f.part_off[t]; i < f.part_off[t + 1]; ++i) {
-            if (out_rank[i] < 0) continue;
-            const std::string& member = plan.members[plan.member_of_rank[out_rank[i]]];
-            assignment[member].push_back(TopicPartition{*topic_of.at(out_pid[i]), out_pid[i]});   // :264
-        }
-        if (totals_out) {
+    for (int32_t r = 0; r < n_members; ++r) {
+        auto& list = assignment[plan.members[plan.member_of_rank[r]]];     // a list for EVERY member, :171-174
+        for (int64_t j = member_off[r]; j < member_off[r + 1]; ++j)
+            list.push_back(TopicPartition{*topic_of[grouped_topic[j]].at(grouped_pid[j]), grouped_pid[j]});   // :264
+    }
+    if (totals_out) {
+        for (size_t t = 0; t < plan.topics.size(); ++t) {
             auto& per = (*totals_out)[plan.topics[t]];
             for (int64_t c = f.cons_off[t]; c < f.cons_off[t + 1]; ++c)
                 per[plan.members[plan.member_of_rank[f.cons_rank[c]]]] = out_total[c];
