@@ -96,31 +96,47 @@ struct Raw {
     I32x2 id[(E + 1) / 2];      // partition ids
 };
 
-struct TopicDesc {
-    int64_t p0, c0;
+// IDX = uint32_t when every element index and byte offset of the batch fits 32 bits (the launcher
+// checks): clamps become one v_min_u32 and addresses SGPR base + 32-bit VGPR offset instead of 64-bit
+// VALU arithmetic.  int64_t otherwise.
+template <typename IDX>
+struct TopicDescT {
+    IDX p0, c0;
     int P, C;
 };
+using TopicDesc = TopicDescT<int64_t>;
 
 // element index of a lane's v-th pair, clamped so that a 2-element load stays inside [0, n_total)
-template <int L, int E>
-__device__ __forceinline__ int64_t clamped_index(const TileArgs& a, const TopicDesc& d, int v, int gl) {
-    const int64_t g = d.p0 + load_index<L, E>(v, gl);
-    const int64_t hi = a.n_total - (E >= 2 ? 2 : 1);
+// element `idx` of `base`, read as V (a 1- or 2-element vector of T).  With 32-bit indexing the byte offset is
+// formed in 32 bits, which lets the load use the SGPR-base + VGPR-offset form (no 64-bit VALU address math).
+template <typename V, typename T, typename IDX>
+__device__ __forceinline__ V load_at(const T* base, IDX idx) {
+    if constexpr (sizeof(IDX) == 4)
+        return *reinterpret_cast<const V*>(reinterpret_cast<const char*>(base) + (uint32_t)(idx * (uint32_t)sizeof(T)));
+    else
+        return *reinterpret_cast<const V*>(base + idx);
+}
+
+template <int L, int E, typename D>
+__device__ __forceinline__ auto clamped_index(const TileArgs& a, const D& d, int v, int gl) {
+    using IDX = decltype(d.p0);
+    const IDX g = d.p0 + (IDX)load_index<L, E>(v, gl);
+    const IDX hi = (IDX)(a.n_total - (E >= 2 ? 2 : 1));
     return g < hi ? g : hi;
 }
 
 // stage 1: everything that does not depend on data.  Committed offsets first: stage 2 needs only them.
-template <int L, int E>
-__device__ __forceinline__ void issue_loads(const TileArgs& a, const TopicDesc& d, int gl, Raw<E>& raw) {
+template <int L, int E, typename D>
+__device__ __forceinline__ void issue_loads(const TileArgs& a, const D& d, int gl, Raw<E>& raw) {
     if constexpr (kAblate == 2) return;
     constexpr int NP = (E + 1) / 2;
     const int64_t* src_en = a.lag ? a.lag : a.end;
     if (!a.lag) {
 #pragma unroll
         for (int k = 0; k < NP; ++k) {
-            const int64_t g = clamped_index<L, E>(a, d, 2 * k, gl);
-            if constexpr (E >= 2) raw.cm[k] = *reinterpret_cast<const I64x2*>(a.committed + g);
-            else { raw.cm[k].x = a.committed[g]; raw.cm[k].y = 0; }
+            const auto g = clamped_index<L, E>(a, d, 2 * k, gl);
+            if constexpr (E >= 2) raw.cm[k] = load_at<I64x2>(a.committed, g);
+            else { raw.cm[k].x = load_at<int64_t>(a.committed, g); raw.cm[k].y = 0; }
         }
     } else {
 #pragma unroll
@@ -128,13 +144,13 @@ __device__ __forceinline__ void issue_loads(const TileArgs& a, const TopicDesc& 
     }
 #pragma unroll
     for (int k = 0; k < NP; ++k) {
-        const int64_t g = clamped_index<L, E>(a, d, 2 * k, gl);
+        const auto g = clamped_index<L, E>(a, d, 2 * k, gl);
         if constexpr (E >= 2) {
-            raw.en[k] = *reinterpret_cast<const I64x2*>(src_en + g);
-            raw.id[k] = *reinterpret_cast<const I32x2*>(a.pid + g);
+            raw.en[k] = load_at<I64x2>(src_en, g);
+            raw.id[k] = load_at<I32x2>(a.pid, g);
         } else {
-            raw.en[k].x = src_en[g]; raw.en[k].y = 0;
-            raw.id[k].x = a.pid[g]; raw.id[k].y = 0;
+            raw.en[k].x = load_at<int64_t>(src_en, g); raw.en[k].y = 0;
+            raw.id[k].x = load_at<int32_t>(a.pid, g); raw.id[k].y = 0;
         }
     }
 }
@@ -149,14 +165,14 @@ __device__ __forceinline__ bool second_stage_needed(const TileArgs& a) {
     return !a.lag && !a.reset_latest && a.begin;                        // wave-uniform
 }
 
-template <int L, int E>
-__device__ __forceinline__ void issue_begin_loads(const TileArgs& a, const TopicDesc& d, int gl, Raw<E>& raw) {
+template <int L, int E, typename D>
+__device__ __forceinline__ void issue_begin_loads(const TileArgs& a, const D& d, int gl, Raw<E>& raw) {
     if constexpr (kAblate == 2) return;
     constexpr int NP = (E + 1) / 2;
     if (!second_stage_needed<L, E>(a)) return;
 #pragma unroll
     for (int k = 0; k < NP; ++k) {
-        const int64_t g = clamped_index<L, E>(a, d, 2 * k, gl);
+        const auto g = clamped_index<L, E>(a, d, 2 * k, gl);
         const int64_t* sx = raw.cm[k].x < 0 ? a.begin : a.committed;
         raw.cm[k].x = sx[g];
         if constexpr (E >= 2) {
@@ -167,8 +183,8 @@ __device__ __forceinline__ void issue_begin_loads(const TileArgs& a, const Topic
 }
 
 // computePartitionLag (Main.java:376-404) on what the two stages fetched
-template <int L, int E>
-__device__ __forceinline__ void finish_lags(const TileArgs& a, const TopicDesc& d, int gl, const Raw<E>& raw,
+template <int L, int E, typename D>
+__device__ __forceinline__ void finish_lags(const TileArgs& a, const D& d, int gl, const Raw<E>& raw,
                                             int64_t (&lag)[E], int32_t (&pid)[E]) {
     const bool latest = a.reset_latest != 0;
     if constexpr (kAblate == 2) {
@@ -194,7 +210,7 @@ __device__ __forceinline__ void finish_lags(const TileArgs& a, const TopicDesc& 
         const int e = load_index<L, E>(2 * k, gl);
         // a pair clamped back by one element holds this lane's first element in .y (only the very last
         // element of the batch can be in that position)
-        const bool shifted = (E >= 2) && (d.p0 + e == a.n_total - 1);
+        const bool shifted = (E >= 2) && (d.p0 + (decltype(d.p0))e == (decltype(d.p0))(a.n_total - 1));
         const int64_t en_x = shifted ? raw.en[k].y : raw.en[k].x;
         const int64_t cm_x = shifted ? raw.cm[k].y : raw.cm[k].x;
         pid[2 * k] = shifted ? raw.id[k].y : raw.id[k].x;
@@ -302,9 +318,9 @@ __device__ __forceinline__ void sort_into_slice(uint64_t* slice, int gl, P64 (&r
 }
 
 // ---- 3..5: greedy rounds over the sorted slice, outputs ------------------------------------------------------
-template <int L, int E>
-__device__ __forceinline__ void assign_packed(const TileArgs& a, uint64_t* slice, int32_t* rank_tab, int64_t p0,
-                                              int64_t c0, int P, int C, int gl, int sh, uint64_t lag_max,
+template <int L, int E, typename IDX>
+__device__ __forceinline__ void assign_packed(const TileArgs& a, uint64_t* slice, int32_t* rank_tab, IDX p0,
+                                              IDX c0, int P, int C, int gl, int sh, uint64_t lag_max,
                                               int32_t my_rank) {
     const uint32_t pid_mask = (uint32_t)((1ull << sh) - 1);
 
@@ -483,12 +499,12 @@ __device__ __forceinline__ DescWords fetch_desc(const TileArgs& a, int64_t t, in
     return w;
 }
 
-template <int L, int E>
-__device__ __forceinline__ TopicDesc make_desc(const TileArgs& a, const DescWords& w, int gl) {
+template <int L, int E, typename IDX = int64_t>
+__device__ __forceinline__ TopicDescT<IDX> make_desc(const TileArgs& a, const DescWords& w, int gl) {
     using Cfg = TileCfg<L, E>;
-    TopicDesc d;
-    d.p0 = w.p0;
-    d.c0 = w.c0;
+    TopicDescT<IDX> d;
+    d.p0 = (IDX)w.p0;
+    d.c0 = (IDX)w.c0;
     const int64_t Pl = w.p1 - w.p0, Cl = w.c1 - w.c0;
     const bool bad = Pl > Cfg::kCap || Cl > L || Pl < 0 || Cl < 0;
     if (w.exists && bad && gl == 0) atomicOr(a.status, kStatusShape);    // hint was wrong; leave outputs alone
@@ -497,16 +513,16 @@ __device__ __forceinline__ TopicDesc make_desc(const TileArgs& a, const DescWord
     return d;
 }
 
-template <int L, int E>
-__device__ __forceinline__ TopicDesc load_desc(const TileArgs& a, int64_t t, int64_t n_tiles, int grp, int gl) {
-    return make_desc<L, E>(a, fetch_desc<L, E>(a, t, n_tiles, grp), gl);
+template <int L, int E, typename IDX = int64_t>
+__device__ __forceinline__ TopicDescT<IDX> load_desc(const TileArgs& a, int64_t t, int64_t n_tiles, int grp, int gl) {
+    return make_desc<L, E, IDX>(a, fetch_desc<L, E>(a, t, n_tiles, grp), gl);
 }
 
 // ---- kernel 1: packed records -------------------------------------------------------------------------
 // One tile per wavefront.  Loads (all issued back to back) -> lags -> format decision -> 32-bit key sort ->
 // greedy rounds -> stores.  A tile whose records do not fit the packed format is appended to the deferred
 // list and left to kernel 2.
-template <int L, int E>
+template <int L, int E, typename IDX>
 __global__ __launch_bounds__(256) void wave_tile_packed_kernel(TileArgs a) {
     using Cfg = TileCfg<L, E>;
     __shared__ uint64_t lds[Cfg::kTopicsPerBlock * Cfg::kSlots];
@@ -526,14 +542,14 @@ __global__ __launch_bounds__(256) void wave_tile_packed_kernel(TileArgs a) {
     const int64_t tile = (int64_t)blockIdx.x * Cfg::kWavesPerBlock + wave;
     if (tile >= n_tiles) return;
     {
-        const TopicDesc cur = load_desc<L, E>(a, tile, n_tiles, grp, gl);
+        const TopicDescT<IDX> cur = load_desc<L, E, IDX>(a, tile, n_tiles, grp, gl);
         Raw<E> raw;
         issue_loads<L, E>(a, cur, gl, raw);
         // consumer ranks of the topic, used only at the very end: fetched with everything else
         int32_t my_rank = 0;
         if constexpr (kAblate != 2) {
-            const int64_t kc = cur.c0 + gl < a.k_total ? cur.c0 + gl : (a.k_total > 0 ? a.k_total - 1 : 0);
-            if (a.k_total > 0) my_rank = a.cons_rank[kc];
+            const IDX want = cur.c0 + (IDX)gl, last = (IDX)(a.k_total > 0 ? a.k_total - 1 : 0);
+            if (a.k_total > 0) my_rank = load_at<int32_t>(a.cons_rank, want < last ? want : last);
         }
         issue_begin_loads<L, E>(a, cur, gl, raw);
 
@@ -626,7 +642,7 @@ static hipError_t launch_one(const TileArgs& a, int mode, hipStream_t stream) {
     static int res_packed = 0, res_wide = 0, res_argmin = 0;       // per instantiation; one device family
     hipError_t e;
     if (res_packed == 0) {
-        if ((e = resident_blocks(wave_tile_packed_kernel<L, E>, Cfg::kThreads, &res_packed)) != hipSuccess) return e;
+        if ((e = resident_blocks(wave_tile_packed_kernel<L, E, uint32_t>, Cfg::kThreads, &res_packed)) != hipSuccess) return e;
         if ((e = resident_blocks(wave_tile_wide_kernel<L, E, false>, Cfg::kThreads, &res_wide)) != hipSuccess) return e;
         if ((e = resident_blocks(wave_tile_wide_kernel<L, E, true>, Cfg::kThreads, &res_argmin)) != hipSuccess) return e;
 #ifdef LA_LAB
@@ -641,7 +657,11 @@ static hipError_t launch_one(const TileArgs& a, int mode, hipStream_t stream) {
         hipLaunchKernelGGL((wave_tile_wide_kernel<L, E, false>), grid(res_wide), b, 0, stream, a, 0);
     } else {
         if (!a.defer_count || !a.defer_count_next || !a.defer_list) return hipErrorInvalidValue;
-        hipLaunchKernelGGL((wave_tile_packed_kernel<L, E>), dim3((unsigned)blocks), b, 0, stream, a);
+        // 32-bit indexing when every byte offset (8-byte arrays) fits 32 bits
+        if (a.n_total < ((int64_t)1 << 29) && a.k_total < ((int64_t)1 << 30))
+            hipLaunchKernelGGL((wave_tile_packed_kernel<L, E, uint32_t>), dim3((unsigned)blocks), b, 0, stream, a);
+        else
+            hipLaunchKernelGGL((wave_tile_packed_kernel<L, E, int64_t>), dim3((unsigned)blocks), b, 0, stream, a);
         // usually nothing was deferred: every wavefront reads the count and leaves
 #ifdef LA_LAB
         if (getenv("LA_NO_WIDE")) return hipGetLastError();

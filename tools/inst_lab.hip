@@ -44,7 +44,7 @@ __global__ __launch_bounds__(256) void k(uint64_t* out, int iters) {
                                "s_xor_b64 vcc, vcc, %5\n\t"
                                "v_cndmask_b32_dpp %3, %3, %3, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
                                "v_cndmask_b32_dpp %4, %4, %4, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t")
-                         : "+v"(a), "+v"(b), "=&v"(t), "+v"(c), "+v"(d) : "s"(keep) : "vcc");
+                         : "+v"(a), "+v"(b), "=&v"(t), "+v"(c), "+v"(d) : "s"(keep) : "vcc", "scc");
         } else if constexpr (KIND == 6) {   // v_sub_co_u32 / v_subb_co_u32 chain pairs, non-dpp
             asm volatile(REP16("v_sub_co_u32 %2, vcc, %0, %1\n\tv_subb_co_u32 %2, vcc, %1, %0, vcc\n\t"
                                "v_sub_co_u32 %3, vcc, %1, %0\n\tv_subb_co_u32 %3, vcc, %0, %1, vcc\n\t")
@@ -79,7 +79,7 @@ __global__ __launch_bounds__(256) void k(uint64_t* out, int iters) {
         } else if constexpr (KIND == 15) {  // s_xor writes sgpr mask then cndmask e64 reads (SALU->VALU)
             asm volatile(REP16("s_xor_b64 %4, %4, %5\n\tv_cndmask_b32_e64 %0, %0, %1, %4\n\tv_cndmask_b32_e64 %1, %1, %0, %4\n\t"
                                "s_xor_b64 %4, %4, %5\n\tv_cndmask_b32_e64 %2, %2, %3, %4\n\tv_cndmask_b32_e64 %3, %3, %2, %4\n\t")
-                         : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+s"(m0) : "s"(keep));
+                         : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+s"(m0) : "s"(keep) : "scc");
         } else if constexpr (KIND == 16) {  // v_min_u32 / v_max_u32 with dpp
             asm volatile(REP16("v_min_u32_dpp %4, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
                                "v_max_u32_dpp %5, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
@@ -89,6 +89,24 @@ __global__ __launch_bounds__(256) void k(uint64_t* out, int iters) {
         } else if constexpr (KIND == 17) {  // exec-masked v_swap_b32
             asm volatile(REP16("v_swap_b32 %0, %1\n\tv_swap_b32 %2, %3\n\tv_swap_b32 %0, %1\n\tv_swap_b32 %2, %3\n\t")
                          : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+        } else if constexpr (KIND == 18) {  // 32-bit lane cmpx: min_dpp, max_dpp, cndmask e64 (2 independent keys)
+            asm volatile(REP16("v_min_u32_dpp %4, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                               "v_max_u32_dpp %5, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                               "v_cndmask_b32_e64 %0, %5, %4, %6\n\t"
+                               "v_min_u32_dpp %4, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                               "v_max_u32_dpp %5, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                               "v_cndmask_b32_e64 %1, %5, %4, %6\n\t")
+                         : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "=&v"(t), "=&v"(u) : "s"(keep));
+        } else if constexpr (KIND == 19) {  // 64-bit lane cmpx without dpp selects: 2 mov_dpp, sub, subb (e64 sgpr), xor, 2 cndmask e64
+            asm volatile(REP16("v_mov_b32_dpp %4, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                               "v_mov_b32_dpp %5, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                               "v_sub_co_u32_e64 %6, %7, %4, %0\n\t"
+                               "v_subb_co_u32_e64 %6, %7, %5, %1, %7\n\t"
+                               "s_xor_b64 %7, %7, %8\n\t"
+                               "s_nop 0\n\t"
+                               "v_cndmask_b32_e64 %0, %4, %0, %7\n\t"
+                               "v_cndmask_b32_e64 %1, %5, %1, %7\n\t")
+                         : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "=&v"(t), "=&v"(u), "=&v"(w), "=&s"(m0) : "s"(keep) : "scc");
         } else if constexpr (KIND == 10) {  // row_mirror dpp mov
             asm volatile(REP16("v_mov_b32_dpp %0, %1 row_mirror row_mask:0xf bank_mask:0xf\n\t"
                                "v_mov_b32_dpp %2, %3 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
@@ -137,7 +155,9 @@ int main() {
     run<4>("v_cmp_lt_u64", 64, d_out);
     run<6>("v_sub_co/v_subb_co", 64, d_out);
     run<7>("v_permlane16_swap", 64, d_out);
-    run<5>("fused cmpx block (4 VALU + s_xor)", 16 * 8, d_out);
+    run<5>("64-bit fused cmpx (4 VALU: sub_dpp subb_dpp cnd_dpp x2)", 16 * 8, d_out);
+    run<19>("64-bit cmpx e64 form (6 VALU)", 16 * 6, d_out);
+    run<18>("32-bit cmpx (3 VALU: min_dpp max_dpp cnd_e64)", 16 * 6, d_out);
     run<11>("v_cndmask e32 vcc (s_mov vcc once)", 64, d_out);
     run<12>("v_cndmask e64 explicit vcc", 64, d_out);
     run<13>("v_cmp vcc + 2 cndmask e32", 16 * 6, d_out);
