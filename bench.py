@@ -250,6 +250,22 @@ def main():
                        np.array_equal(e_tot, g_tot[done * C:t1 * C]))
             done = t1
         parity = {"checked_topics": done, "bit_exact": ok}
+        # the same batch through the host-buffer entry point (la_assign_batch: H2D of the five input arrays,
+        # kernels, D2H of the results); reported beside the bench value, never as it
+        host_leg = None
+        try:
+            ctx.assign_batch(h["part_off"], h["pid"], None if latest else h["begin"], h["end"], h["committed"],
+                             N.LA_RESET_LATEST if latest else N.LA_RESET_EARLIEST, h["cons_off"], h["cons_rank"])
+            c0 = time.perf_counter()
+            hp, hm, ht = ctx.assign_batch(h["part_off"], h["pid"], None if latest else h["begin"], h["end"],
+                                          h["committed"], N.LA_RESET_LATEST if latest else N.LA_RESET_EARLIEST,
+                                          h["cons_off"], h["cons_rank"])
+            dt = time.perf_counter() - c0
+            host_leg = {"ms": round(dt * 1e3, 2), "value": round(n_part / dt, 1), "unit": "partition-assignments/sec",
+                        "what": "one la_assign_batch call on pageable host buffers, PCIe copies included",
+                        "bit_exact_vs_device_path": bool(np.array_equal(hp, g_pid) and np.array_equal(hm, g_rank))}
+        except Exception as exc:  # noqa: BLE001 -- a reported extra, not part of the contract
+            host_leg = {"error": str(exc)}
         cpu = {"value": round(done * P / spent, 1), "unit": "partition-assignments/sec", "cores": 1,
                "kind": "port",
                "sample": "first %d of %d topics of the same batch, C oracle (oracle/lag_oracle.c, literal "
@@ -279,6 +295,7 @@ def main():
         "roofline": roofline,
         "cpu_baseline": cpu,
         "parity": parity,
+        "host_boundary": host_leg if (not args.no_cpu_baseline and world == 1) else None,
     }
     print(json.dumps(line))
     if world > 1:

@@ -435,3 +435,37 @@ def test_group_by_member_many_members(ctx):
     np.testing.assert_array_equal(off, e_off)
     np.testing.assert_array_equal(g_t, e_t)
     np.testing.assert_array_equal(g_p, e_p)
+
+
+# ---- randomized sweep: shapes x distributions x entry points ----------------------------------------------
+@pytest.mark.parametrize("seed", range(24))
+def test_fuzz_tile_batches(ctx, seed):
+    rng = np.random.default_rng(1000 + seed)
+    max_p = int(rng.choice([1, 2, 7, 8, 9, 31, 64, 65, 100, 128, 255, 256, 257, 511, 512, 1000, 1024]))
+    max_c = int(rng.choice([1, 2, 3, 7, 8, 9, 16, 17, 31, 32, 33, 63, 64]))
+    t = int(rng.integers(1, 400))
+    dist = str(rng.choice(["mixed", "zero", "ties", "small", "u40", "u63", "full"]))
+    w = synth.ragged(seed * 7919 + 13, t, max_p, max_c, dist=dist, negative=bool(rng.integers(0, 2)))
+    if rng.integers(0, 2):
+        _check_lags(ctx, w, "fuzz %d" % seed)
+    mode = N.LA_RESET_LATEST if rng.integers(0, 2) else N.LA_RESET_EARLIEST
+    _check_offsets(ctx, w, mode, "fuzz %d" % seed)
+    lag = oracle.compute_lags(w.begin, w.end, w.committed, mode == N.LA_RESET_LATEST)
+    exp = oracle.assign_flat(w.part_off, w.partition_id, lag, w.cons_off, w.cons_rank)
+    got = _run_device(ctx, w, N.LA_ALGO_AUTO, use_lag=False, latest=(mode == N.LA_RESET_LATEST))
+    for g, e in zip(got, exp):
+        np.testing.assert_array_equal(g, e)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_fuzz_large_topics(ctx, seed):
+    rng = np.random.default_rng(5000 + seed)
+    p = int(rng.choice([1025, 1500, 4096, 4097, 9000, 20000, 66000]))
+    c = int(rng.choice([1, 2, 63, 64, 65, 100, 127, 128, 129, 500, 1024, 1025, 3000]))
+    kind = str(rng.choice(["u40", "ties", "zero", "u63", "full"]))
+    po, pid, lag, co, ranks = _single_topic(seed + 77, p, c, kind, shuffled=bool(rng.integers(0, 2)),
+                                            negative=(kind == "full"))
+    exp = oracle.assign_flat(po, pid, lag, co, ranks)
+    got = ctx.assign_batch_lags(po, pid, lag, co, ranks)
+    for g, e, what in zip(got, exp, ("partition order", "member", "totals")):
+        np.testing.assert_array_equal(g, e, err_msg="%s p=%d c=%d %s" % (what, p, c, kind))
