@@ -74,6 +74,10 @@ class LagBasedPartitionAssignor:
     def set_warn(self, fn: Callable[[str], None]) -> None:
         self._impl.set_warn(fn)
 
+    def set_debug(self, fn: Callable[[str], None]) -> None:
+        """LOGGER.debug of Main.java:279-306: one "Assignment for <topic>:\\n<summary>" message per topic."""
+        self._impl.set_debug(fn)
+
     # -- the seams the reference's tests use ------------------------------------------------
     @staticmethod
     def assign_lags(partition_lag_per_topic: Mapping[str, Iterable[TopicPartitionLag]],

@@ -3,6 +3,7 @@
 #include "lag_based_partition_assignor.hpp"
 
 #include <algorithm>
+#include <functional>
 #include <mutex>
 #include <numeric>
 #include <unordered_map>
@@ -44,6 +45,7 @@ struct Plan {
     std::vector<int> member_of_rank;
     std::vector<std::string> topics;               // consumersPerTopic.entrySet() order
     std::vector<std::vector<int32_t>> topic_ranks; // per topic: sorted unique subscriber ranks
+    std::vector<std::vector<int>> topic_members;   // per topic: subscriber member indices in consumers-list order
     bool order_exact = true;
 };
 
@@ -70,6 +72,7 @@ Plan make_plan(const GroupSubscription& subscriptions) {
     std::unordered_map<std::string, int> topic_index;
     std::vector<std::string> names;
     std::vector<std::vector<int32_t>> ranks;
+    std::vector<std::vector<int>> members_of;
     for (size_t m = 0; m < p.members.size(); ++m) {
         for (const std::string& topic : *member_topics[m]) {
             auto it = topic_index.find(topic);
@@ -79,11 +82,13 @@ Plan make_plan(const GroupSubscription& subscriptions) {
                 topic_index.emplace(topic, ti);
                 names.push_back(topic);
                 ranks.emplace_back();
+                members_of.emplace_back();
                 order.compute_if_absent_new(ti, java_string_hash(topic));
             } else {
                 ti = it->second;
             }
             ranks[ti].push_back(p.rank_of_member[m]);          // duplicates allowed here ...
+            members_of[ti].push_back((int)m);
         }
     }
     for (int ti : order.order()) {
@@ -92,6 +97,7 @@ Plan make_plan(const GroupSubscription& subscriptions) {
         r.erase(std::unique(r.begin(), r.end()), r.end());     // ... the keyed bins de-dup, Main.java:216-225
         p.topics.push_back(names[ti]);
         p.topic_ranks.push_back(std::move(r));
+        p.topic_members.push_back(members_of[ti]);
     }
     p.order_exact = order.order_exact();
     return p;
@@ -112,7 +118,8 @@ struct Flat {
 };
 
 Assignment run_native(const Plan& plan, const std::vector<const TopicData*>& data, bool offsets_mode,
-                      int32_t reset_mode, std::map<std::string, std::map<std::string, int64_t>>* totals_out) {
+                      int32_t reset_mode, std::map<std::string, std::map<std::string, int64_t>>* totals_out,
+                      const std::function<void(const std::string&)>* debug = nullptr) {
     Flat f;
     for (size_t t = 0; t < plan.topics.size(); ++t) {
         const TopicData* d = data[t];
@@ -170,6 +177,33 @@ Assignment run_native(const Plan& plan, const std::vector<const TopicData*>& dat
         auto& list = assignment[plan.members[plan.member_of_rank[r]]];     // a list for EVERY member, :171-174
         for (int64_t j = member_off[r]; j < member_off[r + 1]; ++j)
             list.push_back(TopicPartition{*topic_of[grouped_topic[j]].at(grouped_pid[j]), grouped_pid[j]});   // :264
+    }
+    if (debug && *debug) {
+        // Main.java:279-306.  consumerTotalLags is a HashMap filled with put() in consumers-list order (:216-225).
+        for (size_t t = 0; t < plan.topics.size(); ++t) {
+            JavaHashMapOrder order;
+            std::vector<int> uniq;
+            for (int m : plan.topic_members[t])
+                if (std::find(uniq.begin(), uniq.end(), m) == uniq.end()) {
+                    order.put_new((int)uniq.size(), java_string_hash(plan.members[m]));
+                    uniq.push_back(m);
+                }
+            std::string summary;
+            for (int u : order.order()) {
+                const int m = uniq[u];
+                const int32_t r = plan.rank_of_member[m];
+                int64_t total = 0;
+                for (int64_t c = f.cons_off[t]; c < f.cons_off[t + 1]; ++c)
+                    if (f.cons_rank[c] == r) total = out_total[c];
+                summary += "\t" + plan.members[m] + " (total_lag=" + std::to_string(total) + ")\n";
+                for (int64_t j = member_off[r]; j < member_off[r + 1]; ++j) {
+                    if ((size_t)grouped_topic[j] > t) break;               // the map as it stood after this topic
+                    summary += "\t\t" + *topic_of[grouped_topic[j]].at(grouped_pid[j]) + "-" +
+                               std::to_string(grouped_pid[j]) + "\n";    // TopicPartition.toString()
+                }
+            }
+            (*debug)("Assignment for " + plan.topics[t] + ":\n" + summary);
+        }
     }
     if (totals_out) {
         for (size_t t = 0; t < plan.topics.size(); ++t) {
@@ -313,7 +347,7 @@ Assignment LagBasedPartitionAssignor::assign(const Cluster& metadata, const Grou
         data.push_back(it == by_topic.end() ? nullptr : &it->second);
     }
     last_totals_.clear();
-    return run_native(plan, data, true, reset, &last_totals_);                   // wrap: :152-156
+    return run_native(plan, data, true, reset, &last_totals_, &debug);           // wrap: :152-156
 }
 
 }  // namespace kafka_lag

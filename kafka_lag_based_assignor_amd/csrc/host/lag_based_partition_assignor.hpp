@@ -105,6 +105,12 @@ class LagBasedPartitionAssignor {
     // Hook for log lines the reference emits through slf4j (warn on missing metadata, :359).
     std::function<void(const std::string&)> warn = [](const std::string&) {};
 
+    // LOGGER.debug of Main.java:279-306, one message per topic ("Assignment for <topic>:\n<summary>"), in the
+    // reference's format and order: consumers in consumerTotalLags' HashMap order, each followed by every
+    // partition that consumer holds SO FAR (the reference prints the cumulative assignment map, :296).
+    // Unset (the default) = isDebugEnabled() false: nothing is formatted.
+    std::function<void(const std::string&)> debug;
+
  private:
     std::map<std::string, std::string> consumer_group_props_;
     std::map<std::string, std::string> metadata_consumer_props_;

@@ -96,6 +96,7 @@ PYBIND11_MODULE(_host, m) {
         .def("metadata_consumer_props", &LagBasedPartitionAssignor::metadataConsumerProps)
         .def("last_topic_totals", &LagBasedPartitionAssignor::lastTopicTotals)
         .def("set_warn", [](LagBasedPartitionAssignor& self, std::function<void(const std::string&)> f) { self.warn = std::move(f); })
+        .def("set_debug", [](LagBasedPartitionAssignor& self, std::function<void(const std::string&)> f) { self.debug = std::move(f); })
         .def("assign",
              [](LagBasedPartitionAssignor& self, const Cluster& metadata, const GroupSubscription& subs, py::object offsets) {
                  PyOffsetSource src(std::move(offsets));

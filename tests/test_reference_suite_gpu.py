@@ -153,3 +153,40 @@ def test_plugin_level_assign_with_offsets(mode):
     for t in ("orders", "payments"):
         assigned = {m: sum(l for (tt, p, l) in lags[t] if (tt, p) in got[m]) for m in totals[t]}
         assert totals[t] == assigned
+
+
+def test_debug_summary_matches_reference_format():
+    """LOGGER.debug of Main.java:279-306: one message per topic, consumers in consumerTotalLags' HashMap
+    order, each followed by every partition it holds so far (cumulative map, Main.java:296)."""
+    from oracle.java_collections import JavaHashMap
+    metadata = {"topic1": [0, 1, 2, 3], "topic2": [0, 1]}
+    lag = {("topic1", 0): 100000, ("topic1", 1): 100000, ("topic1", 2): 500, ("topic1", 3): 1,
+           ("topic2", 0): 900000, ("topic2", 1): 100000}
+    begin = {k: 0 for k in lag}
+    end = dict(lag)
+    com = {k: 0 for k in lag}
+    subs = {"consumer-1": ["topic1", "topic2"], "consumer-2": ["topic1"]}
+    a = LagBasedPartitionAssignor()
+    a.configure({"group.id": "g", "auto.offset.reset": "earliest"})
+    messages = []
+    a.set_debug(messages.append)
+    got = a.assign(metadata, subs, FakeOffsets(begin, end, com))
+    assert got == {"consumer-1": [("topic1", 0), ("topic1", 2), ("topic2", 0), ("topic2", 1)],
+                   "consumer-2": [("topic1", 1), ("topic1", 3)]}                     # Test.java:112-125
+    assert len(messages) == 2 and messages[0].startswith("Assignment for topic1:\n")
+    # expected text from the container model: per topic, a HashMap of its consumers filled by put()
+    cumulative = {"consumer-1": [], "consumer-2": []}
+    totals = a.last_topic_totals()
+    for msg, topic in zip(messages, ["topic1", "topic2"]):
+        for m in cumulative:
+            cumulative[m] += [tp for tp in got[m] if tp[0] == topic]
+        hm = JavaHashMap()
+        for m in [m for m, ts in subs.items() if topic in ts]:
+            hm.put(m, 0)
+        exp = "Assignment for %s:\n" % topic
+        for m in hm.keys():
+            exp += "\t%s (total_lag=%d)\n" % (m, totals[topic][m])
+            for (t, p) in cumulative[m]:
+                exp += "\t\t%s-%d\n" % (t, p)
+        assert msg == exp
+    assert "\tconsumer-1 (total_lag=100500)\n\t\ttopic1-0\n\t\ttopic1-2\n" in messages[0]
