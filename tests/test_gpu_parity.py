@@ -469,3 +469,25 @@ def test_fuzz_large_topics(ctx, seed):
     got = ctx.assign_batch_lags(po, pid, lag, co, ranks)
     for g, e, what in zip(got, exp, ("partition order", "member", "totals")):
         np.testing.assert_array_equal(g, e, err_msg="%s p=%d c=%d %s" % (what, p, c, kind))
+
+
+# ---- committed fixtures: the HIP path against tests/golden/oracle_frozen.json -------------------------------
+def test_hip_path_matches_frozen_digests(ctx):
+    import importlib.util
+    import json
+    import os
+    gdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    spec = importlib.util.spec_from_file_location("make_golden", os.path.join(gdir, "make_golden.py"))
+    mg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mg)
+    frozen = json.load(open(os.path.join(gdir, "oracle_frozen.json")))
+    for name, scale, mode in mg.CASES:
+        w = synth.config(name, scale)
+        if mode == "lags":
+            p, m, t = ctx.assign_batch_lags(w.part_off, w.partition_id, w.lag, w.cons_off, w.cons_rank)
+        else:
+            latest = mode == "latest"
+            p, m, t = ctx.assign_batch(w.part_off, w.partition_id, None if latest else w.begin, w.end, w.committed,
+                                       N.LA_RESET_LATEST if latest else N.LA_RESET_EARLIEST, w.cons_off, w.cons_rank)
+        got = mg.digest(p.astype(np.int32), m.astype(np.int32), t.astype(np.int64))
+        assert got == frozen[mg.case_key(name, scale, mode)]["sha256"], "%s %s" % (name, mode)
