@@ -46,6 +46,8 @@ def parse_args():
     ap.add_argument("--topics", type=int, default=100000)
     ap.add_argument("--partitions", type=int, default=256)
     ap.add_argument("--consumers", type=int, default=32)
+    ap.add_argument("--dist", choices=["zipf", "uniform40"], default="zipf",
+                    help="lag distribution: Zipf(1.1) shuffled per topic (cfg3 / target) or uniform on [0, 2^40) (cfg4)")
     ap.add_argument("--reset-mode", choices=["latest", "earliest"], default="earliest",
                     help="earliest reads all four marshalled arrays (the 36 B/partition of SURVEY 8d)")
     ap.add_argument("--algo", choices=["auto", "wide", "argmin"], default="auto")
@@ -154,7 +156,7 @@ def main():
 
     T, P, C = args.topics, args.partitions, args.consumers
     n_part = T * P
-    w = make_device_workload(torch, dev, T, P, C, seed=0x5EED + rank)
+    w = make_device_workload(torch, dev, T, P, C, seed=0x5EED + rank, dist=args.dist)
     outs = alloc_outputs(torch, dev, T, P, C)
     out_pid, out_rank, out_total = outs["pid"], outs["rank"], outs["total"]
     if args.gather and world > 1:
@@ -287,9 +289,9 @@ def main():
         "vs_baseline": None,
         "dtype": "int64",
         "data": "synthetic",
-        "config": {"workload": "%d topics x %d partitions x %d consumers per GPU, Zipf(1.1) lags, "
+        "config": {"workload": "%d topics x %d partitions x %d consumers per GPU, %s lags, "
                                "shuffled partition ids, 1%% no committed offset, auto.offset.reset=%s"
-                               % (T, P, C, args.reset_mode),
+                               % (T, P, C, "Zipf(1.1)" if args.dist == "zipf" else "uniform [0, 2^40)", args.reset_mode),
                    "topics_per_gpu": T, "partitions_per_topic": P, "consumers_per_topic": C,
                    "gather": bool(args.gather and world > 1), "algo": args.algo},
         "roofline": roofline,

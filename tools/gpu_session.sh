@@ -14,7 +14,7 @@ fi
 timeout 300 python bench.py --steps 100 --warmup 20 > $O/bench.json 2> $O/bench.err; tail -2 $O/bench.json
 timeout 300 python bench.py --steps 100 --warmup 20 --reset-mode latest --no-cpu-baseline > $O/bench_latest.json 2>> $O/bench.err
 timeout 300 python bench.py --steps 100 --warmup 20 --algo wide --no-cpu-baseline > $O/bench_wide.json 2>> $O/bench.err
-timeout 300 python bench.py --steps 100 --warmup 20 --topics 100000 --partitions 64 --consumers 8 --no-cpu-baseline > $O/bench_cfg4.json 2>> $O/bench.err
+timeout 300 python bench.py --steps 100 --warmup 20 --topics 100000 --partitions 64 --consumers 8 --dist uniform40 --no-cpu-baseline > $O/bench_cfg4.json 2>> $O/bench.err
 cat $O/bench_latest.json $O/bench_wide.json $O/bench_cfg4.json | cut -c1-400
 cd /tmp
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python $R/bench.py --steps 100 --warmup 20 --no-cpu-baseline > $O/stats.log 2>&1
