@@ -41,7 +41,7 @@ def main():
               open(os.path.join(dst, name + "_pmc_summary.json"), "w"), indent=1, sort_keys=True)
     # traffic.json: the packed tile kernel on the bench's default workload (+ the empty wide kernel)
     entries = []
-    pk = next((v for k, v in ours.items() if "wave_tile_packed_kernel<32, 8>" in k), None)
+    pk = next((v for k, v in ours.items() if "wave_tile_packed_kernel<32, 8" in k), None)
     wk = next((v for k, v in ours.items() if "wave_tile_wide_kernel<32, 8, false>" in k), None)
     if pk and "fetch_bytes_calibrated" in pk and "write_bytes_calibrated" in pk:
         hbm = pk["fetch_bytes_calibrated"] + pk["write_bytes_calibrated"]
