@@ -85,6 +85,7 @@ __device__ __forceinline__ void cmpx32_same_mirror(uint32_t& x) {
         const bool keep_min = (KeepMin<M / 2>::value >> __lane_id()) & 1;
         const uint32_t lo = o < x ? o : x, hi = o < x ? x : o;
         x = keep_min ? lo : hi;
+        asm volatile("s_nop 1" : "+v"(x));        // ... and the next block reads x through DPP
     }
 }
 
@@ -124,6 +125,7 @@ __device__ __forceinline__ void cmpx32_cross_mirror(uint32_t& r, uint32_t& q) {
         const uint32_t ql = orr < q ? orr : q, qh = orr < q ? q : orr;
         r = keep_min ? rl : rh;
         q = keep_min ? ql : qh;
+        asm volatile("s_nop 1" : "+v"(r), "+v"(q));   // the next block may read either through DPP
     }
 }
 
