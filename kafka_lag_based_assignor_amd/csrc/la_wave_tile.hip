@@ -521,8 +521,10 @@ __device__ __forceinline__ TopicDescT<IDX> load_desc(const TileArgs& a, int64_t 
 // ---- kernel 1: packed records -------------------------------------------------------------------------
 // One tile per wavefront.  Loads (all issued back to back) -> lags -> format decision -> 32-bit key sort ->
 // greedy rounds -> stores.  A tile whose records do not fit the packed format is appended to the deferred
-// list and left to kernel 2.
-template <int L, int E, typename IDX>
+// list and left to kernel 2 -- except in the INLINE_WIDE build, used when the whole batch is one round of
+// resident workgroups: there occupancy does not matter, the wide code sits in the same kernel and the second
+// launch (the larger part of a small batch's latency) disappears.
+template <int L, int E, typename IDX, bool INLINE_WIDE>
 __global__ __launch_bounds__(256) void wave_tile_packed_kernel(TileArgs a) {
     using Cfg = TileCfg<L, E>;
     __shared__ uint64_t lds[Cfg::kTopicsPerBlock * Cfg::kSlots];
@@ -557,9 +559,9 @@ __global__ __launch_bounds__(256) void wave_tile_packed_kernel(TileArgs a) {
         int sh, lbw;
         bool fits;
         uint64_t lag_max;
+        int64_t lag[E];
+        int32_t pid[E];
         {
-            int64_t lag[E];
-            int32_t pid[E];
             finish_lags<L, E>(a, cur, gl, raw, lag, pid);
             // can this wavefront's records be packed into 64 bits?  (empty slots hold lag 0, id 0)
             uint32_t id_or = 0;
@@ -581,6 +583,8 @@ __global__ __launch_bounds__(256) void wave_tile_packed_kernel(TileArgs a) {
         if (fits) {
             sort_into_slice<L, E>(slice, gl, rec, lbw, sh);
             assign_packed<L, E>(a, slice, rank_tab, cur.p0, cur.c0, cur.P, cur.C, gl, sh, lag_max, my_rank);
+        } else if constexpr (INLINE_WIDE) {
+            assign_wide<L, E, false>(a, slice, (int64_t)cur.p0, (int64_t)cur.c0, cur.P, cur.C, gl, lag, pid);
         } else if (lane == 0) {
             a.defer_list[atomicAdd(a.defer_count, 1)] = (int32_t)tile;
         }
@@ -639,14 +643,14 @@ static hipError_t launch_one(const TileArgs& a, int mode, hipStream_t stream) {
     using Cfg = TileCfg<L, E>;
     const int64_t blocks = (a.n_topics + Cfg::kTopicsPerBlock - 1) / Cfg::kTopicsPerBlock;
     if (blocks <= 0) return hipSuccess;
-    static int res_packed = 0, res_wide = 0, res_argmin = 0;       // per instantiation; one device family
+    static int res_inline = 0, res_wide = 0, res_argmin = 0;       // per instantiation; one device family
     hipError_t e;
-    if (res_packed == 0) {
-        if ((e = resident_blocks(wave_tile_packed_kernel<L, E, uint32_t>, Cfg::kThreads, &res_packed)) != hipSuccess) return e;
+    if (res_inline == 0) {
+        if ((e = resident_blocks(wave_tile_packed_kernel<L, E, uint32_t, true>, Cfg::kThreads, &res_inline)) != hipSuccess) return e;
         if ((e = resident_blocks(wave_tile_wide_kernel<L, E, false>, Cfg::kThreads, &res_wide)) != hipSuccess) return e;
         if ((e = resident_blocks(wave_tile_wide_kernel<L, E, true>, Cfg::kThreads, &res_argmin)) != hipSuccess) return e;
 #ifdef LA_LAB
-        printf("resident blocks: packed %d wide %d argmin %d (needed %lld)\n", res_packed, res_wide, res_argmin, (long long)blocks);
+        printf("resident blocks: inline %d wide %d argmin %d (needed %lld)\n", res_inline, res_wide, res_argmin, (long long)blocks);
 #endif
     }
     const dim3 b(Cfg::kThreads);
@@ -658,10 +662,16 @@ static hipError_t launch_one(const TileArgs& a, int mode, hipStream_t stream) {
     } else {
         if (!a.defer_count || !a.defer_count_next || !a.defer_list) return hipErrorInvalidValue;
         // 32-bit indexing when every byte offset (8-byte arrays) fits 32 bits
-        if (a.n_total < ((int64_t)1 << 29) && a.k_total < ((int64_t)1 << 30))
-            hipLaunchKernelGGL((wave_tile_packed_kernel<L, E, uint32_t>), dim3((unsigned)blocks), b, 0, stream, a);
+        const bool idx32 = a.n_total < ((int64_t)1 << 29) && a.k_total < ((int64_t)1 << 30);
+        if (idx32 && blocks <= res_inline) {
+            // the whole batch is resident at once: one kernel with the wide code inline, no second launch
+            hipLaunchKernelGGL((wave_tile_packed_kernel<L, E, uint32_t, true>), dim3((unsigned)blocks), b, 0, stream, a);
+            return hipGetLastError();
+        }
+        if (idx32)
+            hipLaunchKernelGGL((wave_tile_packed_kernel<L, E, uint32_t, false>), dim3((unsigned)blocks), b, 0, stream, a);
         else
-            hipLaunchKernelGGL((wave_tile_packed_kernel<L, E, int64_t>), dim3((unsigned)blocks), b, 0, stream, a);
+            hipLaunchKernelGGL((wave_tile_packed_kernel<L, E, int64_t, false>), dim3((unsigned)blocks), b, 0, stream, a);
         // usually nothing was deferred: every wavefront reads the count and leaves
 #ifdef LA_LAB
         if (getenv("LA_NO_WIDE")) return hipGetLastError();

@@ -491,3 +491,29 @@ def test_hip_path_matches_frozen_digests(ctx):
                                        N.LA_RESET_LATEST if latest else N.LA_RESET_EARLIEST, w.cons_off, w.cons_rank)
         got = mg.digest(p.astype(np.int32), m.astype(np.int32), t.astype(np.int64))
         assert got == frozen[mg.case_key(name, scale, mode)]["sha256"], "%s %s" % (name, mode)
+
+
+def test_deferred_wide_tiles_in_a_batch_larger_than_the_resident_grid(ctx):
+    # Small batches run one kernel with the wide-record code inline; beyond one round of resident workgroups
+    # the packed kernel defers tiles it cannot pack to a list that the wide kernel walks.  100 000 tiny topics
+    # (8 per wavefront) with a sprinkling of negative / huge lags exercise that list.
+    rng = np.random.default_rng(21)
+    t = 100000
+    ps = rng.integers(0, 9, t)
+    cs = rng.integers(0, 9, t)
+    part_off = np.concatenate([[0], np.cumsum(ps)]).astype(np.int64)
+    cons_off = np.concatenate([[0], np.cumsum(cs)]).astype(np.int64)
+    n = int(part_off[-1])
+    pid = np.concatenate([rng.permutation(int(p)) for p in ps]).astype(np.int32)
+    lag = rng.integers(0, 1 << 30, n).astype(np.int64)
+    wide = rng.integers(0, n, 400)
+    lag[wide[:200]] = -rng.integers(1, 1 << 40, 200)                 # negative lags: cannot be packed
+    lag[wide[200:]] = rng.integers(1 << 60, (1 << 63) - 1, 200)      # totals would overflow the packed bins
+    ranks = np.concatenate([np.sort(rng.choice(64, int(c), replace=False)) for c in cs]).astype(np.int32)
+    zeros = np.zeros(n, dtype=np.int64)
+    w = synth.Workload("defer", t, part_off, pid, zeros, lag.copy(), zeros, lag, cons_off, ranks, 8, 8)
+    exp = oracle.assign_flat(w.part_off, w.partition_id, w.lag, w.cons_off, w.cons_rank)
+    for rep in range(2):                                             # twice: the counter pair alternates
+        got = _run_device(ctx, w, N.LA_ALGO_AUTO, use_lag=True)
+        for g, e, what in zip(got, exp, ("partition order", "member", "totals")):
+            np.testing.assert_array_equal(g, e, err_msg="%s rep %d" % (what, rep))
