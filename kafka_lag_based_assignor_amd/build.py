@@ -21,7 +21,8 @@ CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(HERE, "liblagassign.so")
 HOST = os.path.join(HERE, "_host" + (sysconfig.get_config_var("EXT_SUFFIX") or ".so"))
-SOURCES = ["la_api.hip", "la_lag.hip", "la_wave_tile.hip", "la_large.hip"]
+SOURCES = ["la_api.hip", "la_lag.hip", "la_wave_tile.hip", "la_wave_tile_l8.hip", "la_wave_tile_l16.hip",
+           "la_wave_tile_l32.hip", "la_wave_tile_l64.hip", "la_large.hip"]
 HOST_SOURCES = ["host/lag_based_partition_assignor.cpp", "host/pybind_host.cpp"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden",
          "-Wall", "-Wextra", "-Wno-unused-parameter"]
@@ -69,7 +70,7 @@ def build(force: bool = False, verbose: bool = False, host: bool = True) -> str:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
 
-    with ThreadPoolExecutor(max_workers=min(4, max(1, len(jobs)))) as ex:
+    with ThreadPoolExecutor(max_workers=min(os.cpu_count() or 4, 8, max(1, len(jobs)))) as ex:
         list(ex.map(run, jobs))
     if force or jobs or _stale(LIB, objs):
         run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs])

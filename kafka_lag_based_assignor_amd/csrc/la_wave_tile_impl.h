@@ -1,0 +1,698 @@
+// la_wave_tile_impl.h -- fused lag + sort + greedy for topics that fit one sub-wave tile (device code and
+// the per-tile-shape launchers; included by the la_wave_tile_l*.hip translation units, one per group width,
+// so they compile in parallel).
+//
+// Replaces, per topic, computePartitionLag (Main.java:376-404) + the sort
+// (Main.java:228-235) + the greedy select/update loop (Main.java:237-266).
+//
+// Mapping.  A *group* of L lanes (L = 8/16/32/64) owns one topic; a 64-lane wavefront
+// carries 64/L topics, a 256-thread workgroup 4x that.  Each lane holds E partition
+// records in registers (L*E >= partitions of the topic, L >= consumers of the topic).
+//
+//   1. load      committed / end / partition id, 16 B per lane per array, unconditional and clamped, all
+//                issued back to back; `begin` only where there is no committed offset; lag in registers.
+//   2. format    per wavefront: packed 64-bit records if ids and lags are narrow enough (kernel 1), else
+//                the tile is deferred to the wide-record kernel (kernel 2).
+//   3. sort      32-bit keys (top bits of the record, id as tie-break) through a bitonic network of DPP
+//                min/max; records fetched from the LDS slice by the key's index and CHECKED to be strictly
+//                ascending; the full 64-bit network only if the check fails.  No HBM.
+//   4. greedy    ROUND-STRUCTURED: the count is the comparator's first key (Main.java:246-250),
+//                so assignment proceeds in rounds of C partitions; in a round the k-th
+//                partition goes to the k-th consumer in (total lag, memberId) order as of
+//                the round start.  One round = one L-lane bitonic sort of the consumer
+//                bins (one bin per lane, in registers) + one add.  ceil(P/C) dependent
+//                steps instead of P.  LA_ALGO_ARGMIN keeps the literal per-partition
+//                wavefront argmin for cross-checking.
+//   5. store     partition ids in assignment order + chosen member rank, 16 B per lane.  [8 B/partition]
+//
+// Record formats:
+//
+//   packed   one 64-bit word per record.  With sh = bits of the wavefront's largest partition id and
+//            lbw = bits of its largest lag:   rec = ((2^lbw - 1 - lag) << sh) | id     ascending == (lag desc, id asc)
+//            and consumer bins  bin = (total << 6) | index.  Taken when no id or lag is negative and
+//            lbw <= min(63-sh, 57-log2(L*E)); then no total can reach 2^57, nothing wraps, and the
+//            packed order is exactly the reference's.
+//   wide     (key64, tie-break32) records, biased so that unsigned order == Java's signed
+//            order; totals wrap like Java's long.  Any int64 lag, any int32 id.
+//            LA_ALGO_ROUNDS_WIDE forces it (tests run both on the same inputs).
+//
+// HBM traffic is at most the algorithmic 36 B/partition (+ ~2% descriptors): every input byte is read at
+// most once (`begin` usually not at all), every output byte written once, nothing spills in between.
+#pragma once
+#include "la_kernels.h"
+#include "la_device.h"
+#include "la_sort64.h"
+#include "la_sort32.h"
+#ifdef LA_LAB
+#include <cstdio>
+#include <cstdlib>
+#endif
+
+namespace la {
+
+enum : int { kModeAuto = 0, kModeWide = 1, kModeArgmin = 2 };
+
+// Ablation hooks for tools/tile_lab.hip (phase timing on the GPU); always 0 in the library.
+//   1: no sort, no greedy (memory only)   2: no global loads / stores (compute only)
+//   3: sort but no greedy                 4: greedy but no sort
+#ifndef LA_ABLATE
+#define LA_ABLATE 0
+#endif
+constexpr int kAblate = LA_ABLATE;
+
+template <int L, int E>
+struct TileCfg {
+    static constexpr int kGroupsPerWave = kWave / L;
+    static constexpr int kWavesPerBlock = 4;
+    static constexpr int kThreads = kWave * kWavesPerBlock;
+    static constexpr int kTopicsPerBlock = kGroupsPerWave * kWavesPerBlock;
+    static constexpr int kCap = L * E;                          // partitions per tile
+    // 8-byte slots, one pad slot per 8: lane stride of E slots becomes bank-conflict-free
+    static constexpr int kSlots = kCap + (kCap >> 3) + 1;
+    static constexpr int kLog2Cap = (kCap <= 1) ? 0 : (31 - __builtin_clz(kCap - 1)) + 1;
+};
+
+__device__ __forceinline__ int slot_of(int s) { return s + (s >> 3); }
+
+// 16-byte / 8-byte loads from arrays that are only element-aligned (a topic may start anywhere)
+struct __attribute__((aligned(8))) I64x2 { int64_t x, y; };
+struct __attribute__((aligned(4))) I32x2 { int32_t x, y; };
+
+// position of the v-th record a lane loads: pairs of neighbours, so int64 arrays move 16 B per lane
+template <int L, int E>
+__device__ __forceinline__ int load_index(int v, int gl) {
+    if constexpr (E >= 2) return (v >> 1) * (2 * L) + 2 * gl + (v & 1);
+    else return gl;
+}
+
+// ---- 1. load + lag ------------------------------------------------------------------------------
+// The loads of a tile are split from their use so the kernel can keep the NEXT tile's loads in flight
+// while it sorts the current one (software pipeline, see the kernel).  Raw holds what is in flight.
+//
+// Every load is unconditional: lanes beyond their topic's partitions (and groups beyond the last topic)
+// read a CLAMPED in-bounds element and ignore it.  Branches around loads make hipcc wait for each load
+// before issuing the next (one HBM round trip per branch); straight-line loads all go out back to back.
+template <int E>
+struct Raw {
+    I64x2 en[(E + 1) / 2];      // end offsets (or precomputed lags)
+    I64x2 cm[(E + 1) / 2];      // committed offsets; after stage 2 (earliest mode): the offset to subtract
+    I32x2 id[(E + 1) / 2];      // partition ids
+};
+
+// IDX = uint32_t when every element index and byte offset of the batch fits 32 bits (the launcher
+// checks): clamps become one v_min_u32 and addresses SGPR base + 32-bit VGPR offset instead of 64-bit
+// VALU arithmetic.  int64_t otherwise.
+template <typename IDX>
+struct TopicDescT {
+    IDX p0, c0;
+    int P, C;
+};
+using TopicDesc = TopicDescT<int64_t>;
+
+// element index of a lane's v-th pair, clamped so that a 2-element load stays inside [0, n_total)
+// element `idx` of `base`, read as V (a 1- or 2-element vector of T).  With 32-bit indexing the byte offset is
+// formed in 32 bits, which lets the load use the SGPR-base + VGPR-offset form (no 64-bit VALU address math).
+template <typename V, typename T, typename IDX>
+__device__ __forceinline__ V load_at(const T* base, IDX idx) {
+    if constexpr (sizeof(IDX) == 4)
+        return *reinterpret_cast<const V*>(reinterpret_cast<const char*>(base) + (uint32_t)(idx * (uint32_t)sizeof(T)));
+    else
+        return *reinterpret_cast<const V*>(base + idx);
+}
+
+template <int L, int E, typename D>
+__device__ __forceinline__ auto clamped_index(const TileArgs& a, const D& d, int v, int gl) {
+    using IDX = decltype(d.p0);
+    const IDX g = d.p0 + (IDX)load_index<L, E>(v, gl);
+    const IDX hi = (IDX)(a.n_total - (E >= 2 ? 2 : 1));
+    return g < hi ? g : hi;
+}
+
+// stage 1: everything that does not depend on data.  Committed offsets first: stage 2 needs only them.
+template <int L, int E, typename D>
+__device__ __forceinline__ void issue_loads(const TileArgs& a, const D& d, int gl, Raw<E>& raw) {
+    if constexpr (kAblate == 2) return;
+    constexpr int NP = (E + 1) / 2;
+    const int64_t* src_en = a.lag ? a.lag : a.end;
+    if (!a.lag) {
+#pragma unroll
+        for (int k = 0; k < NP; ++k) {
+            const auto g = clamped_index<L, E>(a, d, 2 * k, gl);
+            if constexpr (E >= 2) raw.cm[k] = load_at<I64x2>(a.committed, g);
+            else { raw.cm[k].x = load_at<int64_t>(a.committed, g); raw.cm[k].y = 0; }
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < NP; ++k) raw.cm[k].x = raw.cm[k].y = 0;
+    }
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+        const auto g = clamped_index<L, E>(a, d, 2 * k, gl);
+        if constexpr (E >= 2) {
+            raw.en[k] = load_at<I64x2>(src_en, g);
+            raw.id[k] = load_at<I32x2>(a.pid, g);
+        } else {
+            raw.en[k].x = load_at<int64_t>(src_en, g); raw.en[k].y = 0;
+            raw.id[k].x = load_at<int32_t>(a.pid, g); raw.id[k].y = 0;
+        }
+    }
+}
+
+// stage 2: the beginning offset is needed only where there is no committed offset and auto.offset.reset is
+// not "latest" (Main.java:384-396).  Lanes that need it read `begin`; every other lane re-reads its own
+// `committed` element (a cache hit, no HBM traffic), so the loads stay unconditional and batched, and the
+// result lands in the committed offset's own registers: afterwards cm is the "next offset" of
+// Main.java:386-396 itself.  A topic whose partitions all have committed offsets never touches `begin`.
+template <int L, int E>
+__device__ __forceinline__ bool second_stage_needed(const TileArgs& a) {
+    return !a.lag && !a.reset_latest && a.begin;                        // wave-uniform
+}
+
+template <int L, int E, typename D>
+__device__ __forceinline__ void issue_begin_loads(const TileArgs& a, const D& d, int gl, Raw<E>& raw) {
+    if constexpr (kAblate == 2) return;
+    constexpr int NP = (E + 1) / 2;
+    if (!second_stage_needed<L, E>(a)) return;
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+        const auto g = clamped_index<L, E>(a, d, 2 * k, gl);
+        const int64_t* sx = raw.cm[k].x < 0 ? a.begin : a.committed;
+        raw.cm[k].x = sx[g];
+        if constexpr (E >= 2) {
+            const int64_t* sy = raw.cm[k].y < 0 ? a.begin : a.committed;
+            raw.cm[k].y = sy[g + 1];
+        }
+    }
+}
+
+// computePartitionLag (Main.java:376-404) on what the two stages fetched
+template <int L, int E, typename D>
+__device__ __forceinline__ void finish_lags(const TileArgs& a, const D& d, int gl, const Raw<E>& raw,
+                                            int64_t (&lag)[E], int32_t (&pid)[E]) {
+    const bool latest = a.reset_latest != 0;
+    if constexpr (kAblate == 2) {
+#pragma unroll
+        for (int v = 0; v < E; ++v) {
+            const uint32_t h = ((uint32_t)d.p0 + (uint32_t)(v * L + gl)) * 2654435761u;
+            lag[v] = (int64_t)(h >> 2) + a.reset_latest;
+            pid[v] = (int32_t)((v * L + gl) * 77 + 13) & (L * E - 1);
+        }
+        return;
+    }
+    constexpr int NP = (E + 1) / 2;
+    // after stage 2 the cm registers hold the offset to subtract; otherwise "none" (< 0) means `end`
+    // (latest) or 0 (earliest without a begin array)
+    const bool cm_is_next = second_stage_needed<L, E>(a);
+    auto lag_of = [&](int64_t en, int64_t cm) -> int64_t {
+        if (a.lag) return en;
+        if (cm_is_next) { const int64_t dlt = (int64_t)((uint64_t)en - (uint64_t)cm); return dlt > 0 ? dlt : 0; }
+        return partition_lag(0, en, cm, latest);
+    };
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+        const int e = load_index<L, E>(2 * k, gl);
+        // a pair clamped back by one element holds this lane's first element in .y (only the very last
+        // element of the batch can be in that position)
+        const bool shifted = (E >= 2) && (d.p0 + (decltype(d.p0))e == (decltype(d.p0))(a.n_total - 1));
+        const int64_t en_x = shifted ? raw.en[k].y : raw.en[k].x;
+        const int64_t cm_x = shifted ? raw.cm[k].y : raw.cm[k].x;
+        pid[2 * k] = shifted ? raw.id[k].y : raw.id[k].x;
+        lag[2 * k] = lag_of(en_x, cm_x);
+        if constexpr (E >= 2) {
+            pid[2 * k + 1] = raw.id[k].y;
+            lag[2 * k + 1] = lag_of(raw.en[k].y, raw.cm[k].y);
+        }
+    }
+    // slots past the topic's partitions: lag 0, id 0 (they must not influence the format decision)
+#pragma unroll
+    for (int v = 0; v < E; ++v) {
+        const bool valid = load_index<L, E>(v, gl) < d.P;
+        lag[v] = valid ? lag[v] : 0;
+        pid[v] = valid ? pid[v] : 0;
+    }
+}
+
+// ---- packed path ------------------------------------------------------------------------------------
+// records of the packed format:  ((2^lbw - 1 - lag) << sh) | id,  empty slots all ones (sort last)
+template <int L, int E>
+__device__ __forceinline__ void pack_records(int P, int gl, const int64_t (&lag)[E], const int32_t (&pid)[E], int sh,
+                                             uint64_t lag_max, P64 (&rec)[E]) {
+#pragma unroll
+    for (int v = 0; v < E; ++v) {
+        const int e = load_index<L, E>(v, gl);
+        rec[v] = p64_from((e < P) ? (((lag_max - (uint64_t)lag[v]) << sh) | (uint32_t)pid[v]) : ~0ull);
+    }
+}
+
+// ---- 2. sort (lag desc, partition asc), leaving the sorted records in the LDS slice ---------------------
+// Fast form: sort 32-bit keys that are a monotone function of the record "almost always", fetch each
+// record from the slice through the index carried in the key's low bits, then CHECK that the fetched
+// records are strictly ascending.  If any neighbour pair in the wavefront is not, the wavefront re-sorts
+// the full 64-bit records (la_sort64.h).  Two key layouts (wave-uniform choice):
+//   ids dense (every id < tile capacity):  key = (lag part, low bits dropped to fit) << sh | id, record stored
+//        at slot `id`.  Equal lags -- the common tie, e.g. many partitions with lag 0 -- are ordered by id
+//        inside the key itself, exactly as Main.java:231-234 orders them.
+//   otherwise:  key = (top bits of the record) << idx_bits | slot, record stored at its load slot.
+// Dropped low bits (and duplicate ids, which would collide in a slot) can only make the check fail, never
+// pass wrongly: the check is on the full records.
+template <int L, int E>
+__device__ __forceinline__ void sort_into_slice(uint64_t* slice, int gl, P64 (&rec)[E], int lbw, int sh) {
+    using Cfg = TileCfg<L, E>;
+    if constexpr (kAblate == 1 || kAblate == 4) {
+#pragma unroll
+        for (int r = 0; r < E; ++r) slice[slot_of(gl * E + r)] = p64_value(rec[r]);
+        return;
+    }
+    const bool by_id = sh <= Cfg::kLog2Cap;                               // wave-uniform
+    const int idx_bits = by_id ? sh : Cfg::kLog2Cap;
+    const uint32_t idx_mask = (1u << idx_bits) - 1;
+    const int top_bits = by_id ? lbw : lbw + sh;                          // bits above the index field's source
+    const int keep = 31 - idx_bits;                                       // key < 2^31: all-ones stays largest
+    const int drop = (by_id ? sh : 0) + (top_bits > keep ? top_bits - keep : 0);
+    uint32_t key[E];
+    if (by_id && drop == sh) {
+        // nothing dropped: the key IS the record (it is shorter than 31 bits); no fetch, no check
+#pragma unroll
+        for (int v = 0; v < E; ++v) key[v] = rec[v].hi == 0xFFFFFFFFu ? 0xFFFFFFFFu : rec[v].lo;
+        bitonic_sort_tile_u32<L, E>(key);
+#pragma unroll
+        for (int r = 0; r < E; ++r)
+            slice[slot_of(gl * E + r)] = key[r] == 0xFFFFFFFFu ? ~0ull : (uint64_t)key[r];
+        return;
+    }
+#pragma unroll
+    for (int v = 0; v < E; ++v) {
+        const uint64_t r = p64_value(rec[v]);
+        const bool valid = r != ~0ull;
+        const uint32_t idx = by_id ? ((uint32_t)r & idx_mask) : (uint32_t)load_index<L, E>(v, gl);
+        if (valid) slice[slot_of((int)idx)] = r;
+        key[v] = valid ? (((uint32_t)(r >> drop) << idx_bits) | idx) : 0xFFFFFFFFu;
+    }
+    wave_lds_fence();
+    bitonic_sort_tile_u32<L, E>(key);
+
+    P64 got[E];
+#pragma unroll
+    for (int r = 0; r < E; ++r) {
+        const uint64_t x = slice[slot_of((int)(key[r] & idx_mask))];
+        got[r] = p64_from(key[r] == 0xFFFFFFFFu ? ~0ull : x);
+    }
+    // strictly ascending?  position s = gl*E + r; all-ones records (empty slots) are all at the end
+    bool bad = false;
+#pragma unroll
+    for (int r = 0; r + 1 < E; ++r) {
+        const uint64_t x = p64_value(got[r]), y = p64_value(got[r + 1]);
+        bad |= (x >= y) && (y != ~0ull);
+    }
+    {
+        const uint64_t x = p64_value(got[E - 1]);
+        const uint64_t y = ((uint64_t)(uint32_t)__shfl_down((int)got[0].hi, 1) << 32) | (uint32_t)__shfl_down((int)got[0].lo, 1);
+        bad |= (gl != L - 1) && (x >= y) && (y != ~0ull);
+    }
+    wave_lds_fence();
+    if (__builtin_amdgcn_ballot_w64(bad) != 0) {
+        bitonic_sort_tile_p64<L, E>(rec);                                 // full records, full network
+#pragma unroll
+        for (int r = 0; r < E; ++r) slice[slot_of(gl * E + r)] = p64_value(rec[r]);
+    } else {
+#pragma unroll
+        for (int r = 0; r < E; ++r) slice[slot_of(gl * E + r)] = p64_value(got[r]);
+    }
+}
+
+// ---- 3..5: greedy rounds over the sorted slice, outputs ------------------------------------------------------
+template <int L, int E, typename IDX>
+__device__ __forceinline__ void assign_packed(const TileArgs& a, uint64_t* slice, int32_t* rank_tab, IDX p0,
+                                              IDX c0, int P, int C, int gl, int sh, uint64_t lag_max,
+                                              int32_t my_rank) {
+    const uint32_t pid_mask = (uint32_t)((1ull << sh) - 1);
+
+    if (gl < C) rank_tab[gl] = my_rank;
+    wave_lds_fence();
+
+    // ---- 4. greedy rounds: bin = (total << 6) | index in the rank-sorted consumer list ----------------
+    P64 bin = p64_from((gl < C) ? (uint64_t)gl : ~0ull);
+    const int rounds = (C > 0) ? (P + C - 1) / C : 0;
+    int max_rounds = __builtin_amdgcn_readfirstlane(wave_max_i32(rounds));
+    if constexpr (kAblate == 1 || kAblate == 3) max_rounds = 0;
+    for (int q = 0; q < max_rounds; ++q) {
+        // round 0 starts sorted: all totals 0, indices ascending
+        if (q > 0) bitonic_sort_lanes_p64<L>(bin);
+        const int s = q * C + gl;
+        if (gl < C && s < P) {
+            const uint64_t r = slice[slot_of(s)];
+            const uint64_t nb = p64_value(bin) + ((lag_max - (r >> sh)) << 6);                  // Main.java:265
+            bin = p64_from(nb);
+            slice[slot_of(s)] = ((uint64_t)(bin.lo & 63u) << 32) | ((uint32_t)r & pid_mask);
+        }
+    }
+    wave_lds_fence();
+
+    // ---- 5. outputs ------------------------------------------------------------------------------------
+    if (a.out_total && gl < C) a.out_total[c0 + (bin.lo & 63u)] = (int64_t)(p64_value(bin) >> 6);
+    if constexpr (E >= 4) {
+        // four consecutive positions per lane: 16-byte stores
+#pragma unroll
+        for (int k = 0; k < E / 4; ++k) {
+            const int s0 = k * 4 * L + 4 * gl;
+            int32_t op[4], om[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const uint64_t w = slice[slot_of(s0 + i)];
+                op[i] = (int32_t)((uint32_t)w & pid_mask);
+                om[i] = (C > 0) ? rank_tab[(uint32_t)(w >> 32) & 63u] : -1;
+            }
+            if (kAblate == 2 && (op[0] ^ om[1] ^ op[2] ^ om[3]) != 0x7FFFFFF1) continue;
+            if (s0 + 3 < P) {
+                struct __attribute__((aligned(4))) I32x4 { int32_t x, y, z, w; };
+                I32x4 vp; vp.x = op[0]; vp.y = op[1]; vp.z = op[2]; vp.w = op[3];
+                I32x4 vm; vm.x = om[0]; vm.y = om[1]; vm.z = om[2]; vm.w = om[3];
+                *reinterpret_cast<I32x4*>(a.out_pid + p0 + s0) = vp;
+                *reinterpret_cast<I32x4*>(a.out_rank + p0 + s0) = vm;
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (s0 + i < P) { a.out_pid[p0 + s0 + i] = op[i]; a.out_rank[p0 + s0 + i] = om[i]; }
+            }
+        }
+    } else {
+#pragma unroll
+        for (int v = 0; v < E; ++v) {
+            const int s = v * L + gl;
+            if (s < P) {
+                const uint64_t w = slice[slot_of(s)];
+                a.out_pid[p0 + s] = (int32_t)((uint32_t)w & pid_mask);
+                a.out_rank[p0 + s] = (C > 0) ? rank_tab[(uint32_t)(w >> 32) & 63u] : -1;
+            }
+        }
+    }
+}
+
+// ---- wide path (any int64 lag, any int32 id; also hosts the literal argmin form) ---------------------
+template <int L, int E, bool ARGMIN>
+__device__ __forceinline__ void assign_wide(const TileArgs& a, uint64_t* slice, int64_t p0, int64_t c0, int P, int C,
+                                            int gl, const int64_t (&lag)[E], const int32_t (&pid)[E]) {
+    Rec rec[E];
+#pragma unroll
+    for (int v = 0; v < E; ++v) {
+        const int e = load_index<L, E>(v, gl);
+        rec[v].hi = rec[v].lo = rec[v].tb = 0xFFFFFFFFu;             // sentinel: sorts last
+        if (e < P) {
+            const uint64_t key = (uint64_t)lag[v] ^ kLagKeyFlip;
+            rec[v].hi = (uint32_t)(key >> 32);
+            rec[v].lo = (uint32_t)key;
+            rec[v].tb = (uint32_t)pid[v] ^ kPidBias;
+        }
+    }
+
+    bitonic_sort_tile<L, E>(rec, gl);
+
+    // sorted position s = gl*E + r.  ids out (striped through LDS), lags into LDS
+#pragma unroll
+    for (int r = 0; r < E; ++r) slice[slot_of(gl * E + r)] = rec[r].tb ^ kPidBias;
+    wave_lds_fence();
+#pragma unroll
+    for (int v = 0; v < E; ++v) {
+        const int s = v * L + gl;
+        if (s < P) a.out_pid[p0 + s] = (int32_t)(uint32_t)slice[slot_of(s)];
+    }
+    wave_lds_fence();
+#pragma unroll
+    for (int r = 0; r < E; ++r) {
+        const uint64_t key = ((uint64_t)rec[r].hi << 32) | rec[r].lo;
+        slice[slot_of(gl * E + r)] = key ^ kLagKeyFlip;              // the lag itself
+    }
+    wave_lds_fence();
+
+    // bin of consumer `gl` (position in the rank-sorted list): biased total + index
+    Rec bin;
+    uint64_t total = kTotalBias;                                       // biased 0
+    bin.tb = (gl < C) ? (uint32_t)gl : 0xFFFFFFFFu;
+    if constexpr (!ARGMIN) {
+        const int rounds = (C > 0) ? (P + C - 1) / C : 0;
+        const int max_rounds = __builtin_amdgcn_readfirstlane(wave_max_i32(rounds));
+        bin.hi = (gl < C) ? (uint32_t)(total >> 32) : 0xFFFFFFFFu;
+        bin.lo = (gl < C) ? (uint32_t)total : 0xFFFFFFFFu;
+        for (int q = 0; q < max_rounds; ++q) {
+            if (q > 0) bitonic_sort_lanes(bin, gl, a.lc);
+            const int s = q * C + gl;
+            if (gl < C && s < P) {
+                const uint64_t lg = slice[slot_of(s)];
+                uint64_t t = (((uint64_t)bin.hi << 32) | bin.lo) + lg;       // Main.java:265
+                bin.hi = (uint32_t)(t >> 32);
+                bin.lo = (uint32_t)t;
+                slice[slot_of(s)] = bin.tb;                                // chosen consumer
+            }
+        }
+        total = ((uint64_t)bin.hi << 32) | bin.lo;
+    } else {
+        // literal form: P dependent wavefront argmins over (count, total, index)
+        const int maxP = __builtin_amdgcn_readfirstlane(wave_max_i32(C > 0 ? P : 0));
+        uint32_t count = (gl < C) ? 0u : 0xFFFFFFFFu;
+        for (int s = 0; s < maxP; ++s) {
+            uint32_t bc = count, bh = (uint32_t)(total >> 32), bl = (uint32_t)total, bi = bin.tb;
+            for (int j = 1; j < L; j <<= 1) {                  // butterfly argmin inside the group
+                Rec o; o.hi = bh; o.lo = bl; o.tb = bi;
+                o = shfl_xor_dyn(o, j);
+                Rec m; m.hi = bh; m.lo = bl; m.tb = bi;
+                const uint32_t oc = (uint32_t)__shfl_xor((int)bc, j);
+                const bool take = (oc < bc) | ((oc == bc) & rec_less(o, m));
+                bc = take ? oc : bc; bh = take ? o.hi : bh; bl = take ? o.lo : bl; bi = take ? o.tb : bi;
+            }
+            if (s < P && C > 0 && bi == (uint32_t)gl) {
+                total += slice[slot_of(s)];
+                count += 1;
+                slice[slot_of(s)] = (uint64_t)gl;
+            }
+        }
+    }
+    wave_lds_fence();
+
+    if (a.out_total && bin.tb < (uint32_t)C)
+        a.out_total[c0 + bin.tb] = (int64_t)(total ^ kTotalBias);
+#pragma unroll
+    for (int v = 0; v < E; ++v) {
+        const int s = v * L + gl;
+        if (s < P) {
+            int32_t m = -1;
+            if (C > 0) m = a.cons_rank[c0 + (uint32_t)slice[slot_of(s)]];
+            a.out_rank[p0 + s] = m;
+        }
+    }
+}
+
+// Tile -> topic descriptor of this lane's group.
+// Tile -> topic descriptor of this lane's group.  Unconditional loads (clamped topic index); the words are
+// fetched one step (fetch_desc) and interpreted another (make_desc), so a prefetched descriptor is not
+// waited for where it is issued.
+struct DescWords {
+    int64_t p0, p1, c0, c1;
+    bool exists;
+};
+
+template <int L, int E>
+__device__ __forceinline__ DescWords fetch_desc(const TileArgs& a, int64_t t, int64_t n_tiles, int grp) {
+    using Cfg = TileCfg<L, E>;
+    const int64_t topic = t * Cfg::kGroupsPerWave + grp;
+    DescWords w;
+    w.exists = t < n_tiles && topic < a.n_topics;
+    const int64_t tc = w.exists ? topic : a.n_topics - 1;
+    w.p0 = a.part_off[tc]; w.p1 = a.part_off[tc + 1];
+    w.c0 = a.cons_off[tc]; w.c1 = a.cons_off[tc + 1];
+    return w;
+}
+
+template <int L, int E, typename IDX = int64_t>
+__device__ __forceinline__ TopicDescT<IDX> make_desc(const TileArgs& a, const DescWords& w, int gl) {
+    using Cfg = TileCfg<L, E>;
+    TopicDescT<IDX> d;
+    d.p0 = (IDX)w.p0;
+    d.c0 = (IDX)w.c0;
+    const int64_t Pl = w.p1 - w.p0, Cl = w.c1 - w.c0;
+    const bool bad = Pl > Cfg::kCap || Cl > L || Pl < 0 || Cl < 0;
+    if (w.exists && bad && gl == 0) atomicOr(a.status, kStatusShape);    // hint was wrong; leave outputs alone
+    d.P = (w.exists && !bad) ? (int)Pl : 0;
+    d.C = (w.exists && !bad) ? (int)Cl : 0;
+    return d;
+}
+
+template <int L, int E, typename IDX = int64_t>
+__device__ __forceinline__ TopicDescT<IDX> load_desc(const TileArgs& a, int64_t t, int64_t n_tiles, int grp, int gl) {
+    return make_desc<L, E, IDX>(a, fetch_desc<L, E>(a, t, n_tiles, grp), gl);
+}
+
+// ---- kernel 1: packed records -------------------------------------------------------------------------
+// One tile per wavefront.  Loads (all issued back to back) -> lags -> format decision -> 32-bit key sort ->
+// greedy rounds -> stores.  A tile whose records do not fit the packed format is appended to the deferred
+// list and left to kernel 2 -- except in the INLINE_WIDE build, used when the whole batch is one round of
+// resident workgroups: there occupancy does not matter, the wide code sits in the same kernel and the second
+// launch (the larger part of a small batch's latency) disappears.
+template <int L, int E, typename IDX, bool INLINE_WIDE>
+__global__ __launch_bounds__(256) void wave_tile_packed_kernel(TileArgs a) {
+    using Cfg = TileCfg<L, E>;
+    __shared__ uint64_t lds[Cfg::kTopicsPerBlock * Cfg::kSlots];
+    __shared__ int32_t rank_lds[Cfg::kTopicsPerBlock * L];
+
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = threadIdx.x >> 6;
+    const int gl = lane & (L - 1);            // lane within group
+    const int grp = lane / L;                 // group within wave
+    uint64_t* slice = lds + (wave * Cfg::kGroupsPerWave + grp) * Cfg::kSlots;
+    int32_t* rank_tab = rank_lds + (wave * Cfg::kGroupsPerWave + grp) * L;
+
+    const int64_t n_tiles = (a.n_topics + Cfg::kGroupsPerWave - 1) / Cfg::kGroupsPerWave;
+    // one tile per wavefront: the grid covers all tiles (a resident-sized grid looping over tiles, with or
+    // without the next tile's loads prefetched into registers, measured 10-25 % slower: more live
+    // registers, fewer wavefronts per SIMD)
+    const int64_t tile = (int64_t)blockIdx.x * Cfg::kWavesPerBlock + wave;
+    if (tile >= n_tiles) return;
+    {
+        const TopicDescT<IDX> cur = load_desc<L, E, IDX>(a, tile, n_tiles, grp, gl);
+        Raw<E> raw;
+        issue_loads<L, E>(a, cur, gl, raw);
+        // consumer ranks of the topic, used only at the very end: fetched with everything else
+        int32_t my_rank = 0;
+        if constexpr (kAblate != 2) {
+            const IDX want = cur.c0 + (IDX)gl, last = (IDX)(a.k_total > 0 ? a.k_total - 1 : 0);
+            if (a.k_total > 0) my_rank = load_at<int32_t>(a.cons_rank, want < last ? want : last);
+        }
+        issue_begin_loads<L, E>(a, cur, gl, raw);
+
+        P64 rec[E];
+        int sh, lbw;
+        bool fits;
+        uint64_t lag_max;
+        int64_t lag[E];
+        int32_t pid[E];
+        {
+            finish_lags<L, E>(a, cur, gl, raw, lag, pid);
+            // can this wavefront's records be packed into 64 bits?  (empty slots hold lag 0, id 0)
+            uint32_t id_or = 0;
+            uint64_t lag_or = 0;
+#pragma unroll
+            for (int v = 0; v < E; ++v) { id_or |= (uint32_t)pid[v]; lag_or |= (uint64_t)lag[v]; }
+            id_or = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave_or_u32(id_or));
+            sh = 32 - __builtin_clz(id_or | 1u);                             // 1..32 (32: a negative id)
+            // bits of the wavefront's largest lag (64: a negative lag)
+            const uint32_t hi = (uint32_t)(lag_or >> 32), lo = (uint32_t)lag_or;
+            const int my_bits = hi ? 64 - __builtin_clz(hi) : (lo ? 32 - __builtin_clz(lo) : 0);
+            lbw = __builtin_amdgcn_readfirstlane(wave_max_i32(my_bits));
+            int lim = 63 - sh;
+            if (lim > 57 - Cfg::kLog2Cap) lim = 57 - Cfg::kLog2Cap;
+            fits = sh < 32 && lbw <= lim;                                    // wave-uniform
+            lag_max = lbw >= 64 ? ~0ull : (((uint64_t)1 << lbw) - 1);
+            if (fits) pack_records<L, E>(cur.P, gl, lag, pid, sh, lag_max, rec);
+        }
+        if (fits) {
+            sort_into_slice<L, E>(slice, gl, rec, lbw, sh);
+            assign_packed<L, E>(a, slice, rank_tab, cur.p0, cur.c0, cur.P, cur.C, gl, sh, lag_max, my_rank);
+        } else if constexpr (INLINE_WIDE) {
+            assign_wide<L, E, false>(a, slice, (int64_t)cur.p0, (int64_t)cur.c0, cur.P, cur.C, gl, lag, pid);
+        } else if (lane == 0) {
+            a.defer_list[atomicAdd(a.defer_count, 1)] = (int32_t)tile;
+        }
+    }
+}
+
+// ---- kernel 2: wide records (and the literal argmin form) ------------------------------------------------------
+// Tiles come from the deferred list of kernel 1 (LA_ALGO_AUTO) or are all tiles (forced wide / argmin).
+template <int L, int E, bool ARGMIN>
+__global__ __launch_bounds__(256) void wave_tile_wide_kernel(TileArgs a, int from_list) {
+    using Cfg = TileCfg<L, E>;
+    __shared__ uint64_t lds[Cfg::kTopicsPerBlock * Cfg::kSlots];
+
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = threadIdx.x >> 6;
+    const int gl = lane & (L - 1);
+    const int grp = lane / L;
+    uint64_t* slice = lds + (wave * Cfg::kGroupsPerWave + grp) * Cfg::kSlots;
+
+    const int64_t n_tiles = (a.n_topics + Cfg::kGroupsPerWave - 1) / Cfg::kGroupsPerWave;
+    const int64_t n_waves = (int64_t)gridDim.x * Cfg::kWavesPerBlock;
+    const int64_t count = from_list ? (int64_t)*a.defer_count : n_tiles;
+    // the other counter of the pair is the next launch's: it is idle now (stream order), reset it here
+    if (from_list && blockIdx.x == 0 && threadIdx.x == 0) *a.defer_count_next = 0;
+    for (int64_t i = (int64_t)blockIdx.x * Cfg::kWavesPerBlock + wave; i < count; i += n_waves) {
+        const int64_t tile = from_list ? (int64_t)a.defer_list[i] : i;
+        const TopicDesc d = load_desc<L, E>(a, tile, n_tiles, grp, gl);
+        Raw<E> raw;
+        issue_loads<L, E>(a, d, gl, raw);
+        issue_begin_loads<L, E>(a, d, gl, raw);
+        int64_t lag[E];
+        int32_t pid[E];
+        finish_lags<L, E>(a, d, gl, raw, lag, pid);
+        assign_wide<L, E, ARGMIN>(a, slice, d.p0, d.c0, d.P, d.C, gl, lag, pid);
+        wave_lds_fence();
+    }
+}
+
+// Grid = what is resident: CUs x (workgroups per CU the kernel's registers / LDS admit), at most one
+// workgroup per four tiles.  Nothing depends on co-residency (no inter-workgroup communication); a
+// smaller or larger grid only changes speed.
+template <typename K>
+static hipError_t resident_blocks(K kernel, int threads, int* out) {
+    int dev = 0, cus = 0, per_cu = 0;
+    hipError_t e;
+    if ((e = hipGetDevice(&dev)) != hipSuccess) return e;
+    if ((e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev)) != hipSuccess) return e;
+    if ((e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, threads, 0)) != hipSuccess) return e;
+    if (per_cu < 1) per_cu = 1;
+    *out = cus * per_cu;
+    return hipSuccess;
+}
+
+template <int L, int E>
+static hipError_t launch_one(const TileArgs& a, int mode, hipStream_t stream) {
+    using Cfg = TileCfg<L, E>;
+    const int64_t blocks = (a.n_topics + Cfg::kTopicsPerBlock - 1) / Cfg::kTopicsPerBlock;
+    if (blocks <= 0) return hipSuccess;
+    static int res_inline = 0, res_wide = 0, res_argmin = 0;       // per instantiation; one device family
+    hipError_t e;
+    if (res_inline == 0) {
+        if ((e = resident_blocks(wave_tile_packed_kernel<L, E, uint32_t, true>, Cfg::kThreads, &res_inline)) != hipSuccess) return e;
+        if ((e = resident_blocks(wave_tile_wide_kernel<L, E, false>, Cfg::kThreads, &res_wide)) != hipSuccess) return e;
+        if ((e = resident_blocks(wave_tile_wide_kernel<L, E, true>, Cfg::kThreads, &res_argmin)) != hipSuccess) return e;
+#ifdef LA_LAB
+        printf("resident blocks: inline %d wide %d argmin %d (needed %lld)\n", res_inline, res_wide, res_argmin, (long long)blocks);
+#endif
+    }
+    const dim3 b(Cfg::kThreads);
+    auto grid = [&](int resident) { return dim3((unsigned)(blocks < resident ? blocks : resident)); };
+    if (mode == kModeArgmin) {
+        hipLaunchKernelGGL((wave_tile_wide_kernel<L, E, true>), grid(res_argmin), b, 0, stream, a, 0);
+    } else if (mode == kModeWide) {
+        hipLaunchKernelGGL((wave_tile_wide_kernel<L, E, false>), grid(res_wide), b, 0, stream, a, 0);
+    } else {
+        if (!a.defer_count || !a.defer_count_next || !a.defer_list) return hipErrorInvalidValue;
+        // 32-bit indexing when every byte offset (8-byte arrays) fits 32 bits
+        const bool idx32 = a.n_total < ((int64_t)1 << 29) && a.k_total < ((int64_t)1 << 30);
+        if (idx32 && blocks <= res_inline) {
+            // the whole batch is resident at once: one kernel with the wide code inline, no second launch
+            hipLaunchKernelGGL((wave_tile_packed_kernel<L, E, uint32_t, true>), dim3((unsigned)blocks), b, 0, stream, a);
+            return hipGetLastError();
+        }
+        if (idx32)
+            hipLaunchKernelGGL((wave_tile_packed_kernel<L, E, uint32_t, false>), dim3((unsigned)blocks), b, 0, stream, a);
+        else
+            hipLaunchKernelGGL((wave_tile_packed_kernel<L, E, int64_t, false>), dim3((unsigned)blocks), b, 0, stream, a);
+        // usually nothing was deferred: every wavefront reads the count and leaves
+#ifdef LA_LAB
+        if (getenv("LA_NO_WIDE")) return hipGetLastError();
+#endif
+        hipLaunchKernelGGL((wave_tile_wide_kernel<L, E, false>), grid(res_wide), b, 0, stream, a, 1);
+    }
+    return hipGetLastError();
+}
+
+template <int L>
+static inline hipError_t launch_l(int e, const TileArgs& a, int mode, hipStream_t stream) {
+    switch (e) {
+        case 1: return launch_one<L, 1>(a, mode, stream);
+        case 2: return launch_one<L, 2>(a, mode, stream);
+        case 4: return launch_one<L, 4>(a, mode, stream);
+        case 8: return launch_one<L, 8>(a, mode, stream);
+        default: return launch_one<L, 16>(a, mode, stream);
+    }
+}
+
+}  // namespace la

@@ -1,0 +1,6 @@
+// la_wave_tile_l16.hip -- the wave-tile kernels for groups of 16 lanes (all E, all modes).
+#include "la_wave_tile_impl.h"
+
+namespace la {
+hipError_t wave_tile_launch_l16(int e, const TileArgs& a, int mode, hipStream_t stream) { return launch_l<16>(e, a, mode, stream); }
+}  // namespace la

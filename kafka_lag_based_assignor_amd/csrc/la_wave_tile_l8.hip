@@ -1,0 +1,6 @@
+// la_wave_tile_l8.hip -- the wave-tile kernels for groups of 8 lanes (all E, all modes).
+#include "la_wave_tile_impl.h"
+
+namespace la {
+hipError_t wave_tile_launch_l8(int e, const TileArgs& a, int mode, hipStream_t stream) { return launch_l<8>(e, a, mode, stream); }
+}  // namespace la

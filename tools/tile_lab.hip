@@ -5,6 +5,10 @@
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
+#include "../kafka_lag_based_assignor_amd/csrc/la_wave_tile_l8.hip"
+#include "../kafka_lag_based_assignor_amd/csrc/la_wave_tile_l16.hip"
+#include "../kafka_lag_based_assignor_amd/csrc/la_wave_tile_l32.hip"
+#include "../kafka_lag_based_assignor_amd/csrc/la_wave_tile_l64.hip"
 #include "../kafka_lag_based_assignor_amd/csrc/la_wave_tile.hip"
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
