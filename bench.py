@@ -228,6 +228,15 @@ def main():
     if tr:
         roofline["traffic_source"] = tr.get("source")
 
+    # ---- quality metric of BASELINE.json: max/min per-consumer total lag per topic (min clamped to 1) ----
+    lag_ratio = None
+    if C > 0 and T * C == out_total.numel():
+        tot = out_total.reshape(T, C).to(torch.float64)
+        ratio = tot.max(dim=1).values / tot.min(dim=1).values.clamp(min=1.0)
+        lag_ratio = {"mean": round(float(ratio.mean()), 4), "p99": round(float(torch.quantile(ratio[:1000000], 0.99)), 4),
+                     "max": round(float(ratio.max()), 4),
+                     "what": "max/min per-consumer assigned lag per topic of the last step's assignment (README.md:54-69 quotes 1.10 for its example)"}
+
     # ---- parity spot check + cpu_baseline (oracle; test infrastructure, timed on host cores) ----
     cpu = None
     parity = None
@@ -295,6 +304,7 @@ def main():
                    "topics_per_gpu": T, "partitions_per_topic": P, "consumers_per_topic": C,
                    "gather": bool(args.gather and world > 1), "algo": args.algo},
         "roofline": roofline,
+        "lag_ratio": lag_ratio,
         "cpu_baseline": cpu,
         "parity": parity,
         "host_boundary": host_leg if (not args.no_cpu_baseline and world == 1) else None,
