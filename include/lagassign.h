@@ -78,6 +78,11 @@ extern "C" {
 #define LA_ALGO_ROUNDS_WIDE 3 /* rounds, but never the packed 64-bit record format (tile path);
                               * results are identical, this exists so tests can run both  */
 
+/* la_device_batch.flags -- test hooks; results are identical with or without them */
+#define LA_FLAG_INDEX64      1  /* 64-bit element indexing even when 32-bit offsets would do   */
+#define LA_FLAG_DEFER_WIDE   2  /* never the single-launch form for small batches: tiles that  *
+                                 * cannot use packed records go through the deferred-tile list */
+
 typedef struct la_ctx la_ctx;
 
 /* Creates a context on HIP device `device_id` (streams, scratch, kernels). */
@@ -126,7 +131,7 @@ typedef struct la_device_batch {
     int32_t n_topics;
     int32_t reset_mode;
     int32_t algo;                    /* LA_ALGO_*                                        */
-    int32_t reserved;
+    int32_t flags;                   /* LA_FLAG_*; 0 in normal use                       */
     int64_t n_partitions;            /* N                                                */
     int64_t n_consumers;             /* K                                                */
     /* Shape hint: upper bounds over the batch.  A topic that exceeds them is reported

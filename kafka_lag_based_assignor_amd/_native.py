@@ -18,6 +18,7 @@ LA_OK = 0
 LA_EINVAL, LA_ENOMEM, LA_EHIP, LA_ENODEV, LA_ESHAPE = -1, -2, -3, -4, -5
 LA_RESET_LATEST, LA_RESET_EARLIEST = 0, 1
 LA_ALGO_AUTO, LA_ALGO_ROUNDS, LA_ALGO_ARGMIN, LA_ALGO_ROUNDS_WIDE = 0, 1, 2, 3
+LA_FLAG_INDEX64, LA_FLAG_DEFER_WIDE = 1, 2
 
 EXPORTED_SYMBOLS = (
     "la_create", "la_destroy", "la_last_error", "la_version", "la_compute_lag",
@@ -39,7 +40,7 @@ class DeviceBatch(ctypes.Structure):
     """struct la_device_batch"""
     _fields_ = [
         ("n_topics", ctypes.c_int32), ("reset_mode", ctypes.c_int32),
-        ("algo", ctypes.c_int32), ("reserved", ctypes.c_int32),
+        ("algo", ctypes.c_int32), ("flags", ctypes.c_int32),
         ("n_partitions", ctypes.c_int64), ("n_consumers", ctypes.c_int64),
         ("max_partitions_per_topic", ctypes.c_int64), ("max_consumers_per_topic", ctypes.c_int64),
         ("d_part_off", ctypes.c_void_p), ("d_partition_id", ctypes.c_void_p),

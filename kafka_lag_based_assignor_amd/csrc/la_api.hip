@@ -133,6 +133,7 @@ int enqueue_batch(la_ctx* ctx, const la_device_batch* b, hipStream_t stream) {
     a.status = ctx->d_status;
     a.reset_latest = (b->reset_mode == LA_RESET_LATEST) ? 1 : 0;
     a.n_total = b->n_partitions;
+    a.flags = b->flags;
     a.k_total = b->n_consumers;
     if (int rc = reserve(ctx, ctx->defer, la::wave_tile_defer_bytes(b->n_topics))) return rc;
     a.defer_list = (int32_t*)ctx->defer.p;

@@ -32,6 +32,7 @@ struct TileArgs {
     uint32_t* status;
     int32_t reset_latest;
     int32_t lc;                 // pow2ceil(max consumers per topic), set by the launcher
+    int32_t flags;              // LA_FLAG_* of the batch (test hooks)
     // tiles the packed kernel leaves to the wide kernel (LA_ALGO_AUTO): a counter pair that alternates
     // per launch (the wide kernel zeroes the other one), and the list of tile ids
     int32_t* defer_count;

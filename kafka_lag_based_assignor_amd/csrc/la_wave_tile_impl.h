@@ -665,8 +665,8 @@ static hipError_t launch_one(const TileArgs& a, int mode, hipStream_t stream) {
     } else {
         if (!a.defer_count || !a.defer_count_next || !a.defer_list) return hipErrorInvalidValue;
         // 32-bit indexing when every byte offset (8-byte arrays) fits 32 bits
-        const bool idx32 = a.n_total < ((int64_t)1 << 29) && a.k_total < ((int64_t)1 << 30);
-        if (idx32 && blocks <= res_inline) {
+        const bool idx32 = a.n_total < ((int64_t)1 << 29) && a.k_total < ((int64_t)1 << 30) && !(a.flags & 1);
+        if (idx32 && blocks <= res_inline && !(a.flags & 2)) {
             // the whole batch is resident at once: one kernel with the wide code inline, no second launch
             hipLaunchKernelGGL((wave_tile_packed_kernel<L, E, uint32_t, true>), dim3((unsigned)blocks), b, 0, stream, a);
             return hipGetLastError();

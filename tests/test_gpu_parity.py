@@ -327,7 +327,7 @@ def test_cfg5_scaled(ctx):
 
 
 # ---- device-resident entry point; round form == literal wavefront argmin ------------------------------
-def _run_device(ctx, w, algo, use_lag=False, latest=True):
+def _run_device(ctx, w, algo, use_lag=False, latest=True, flags=0):
     import ctypes
     import torch
     dev = torch.device("cuda", 0)
@@ -340,6 +340,7 @@ def _run_device(ctx, w, algo, use_lag=False, latest=True):
     b.n_topics = w.n_topics
     b.reset_mode = N.LA_RESET_LATEST if latest else N.LA_RESET_EARLIEST
     b.algo = algo
+    b.flags = flags
     b.n_partitions = w.n_partitions
     b.n_consumers = w.cons_rank.size
     b.max_partitions_per_topic = w.max_partitions
@@ -517,3 +518,21 @@ def test_deferred_wide_tiles_in_a_batch_larger_than_the_resident_grid(ctx):
         got = _run_device(ctx, w, N.LA_ALGO_AUTO, use_lag=True)
         for g, e, what in zip(got, exp, ("partition order", "member", "totals")):
             np.testing.assert_array_equal(g, e, err_msg="%s rep %d" % (what, rep))
+
+
+@pytest.mark.parametrize("flags", [N.LA_FLAG_INDEX64, N.LA_FLAG_DEFER_WIDE, N.LA_FLAG_INDEX64 | N.LA_FLAG_DEFER_WIDE])
+@pytest.mark.parametrize("max_p,max_c", [(8, 8), (100, 16), (256, 32), (1024, 64)])
+def test_kernel_variants_selected_by_size_agree(ctx, flags, max_p, max_c):
+    # 64-bit indexing is otherwise only taken beyond 2^29 partitions, the deferred-tile list only beyond one
+    # round of resident workgroups: force both on small mixed batches (packed and wide tiles in one launch)
+    w = synth.ragged(max_p * 3 + max_c + flags, 300, max_p, max_c, negative=True)
+    for latest in (True, False):
+        lag = oracle.compute_lags(w.begin, w.end, w.committed, latest)
+        exp = oracle.assign_flat(w.part_off, w.partition_id, lag, w.cons_off, w.cons_rank)
+        got = _run_device(ctx, w, N.LA_ALGO_AUTO, use_lag=False, latest=latest, flags=flags)
+        for g, e in zip(got, exp):
+            np.testing.assert_array_equal(g, e)
+    exp = oracle.assign_flat(w.part_off, w.partition_id, w.lag, w.cons_off, w.cons_rank)
+    got = _run_device(ctx, w, N.LA_ALGO_AUTO, use_lag=True, flags=flags)
+    for g, e in zip(got, exp):
+        np.testing.assert_array_equal(g, e)
