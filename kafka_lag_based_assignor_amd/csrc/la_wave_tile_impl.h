@@ -337,7 +337,22 @@ __device__ __forceinline__ void assign_packed(const TileArgs& a, uint64_t* slice
     if constexpr (kAblate == 1 || kAblate == 3) max_rounds = 0;
     for (int q = 0; q < max_rounds; ++q) {
         // round 0 starts sorted: all totals 0, indices ascending
-        if (q > 0) bitonic_sort_lanes_p64<L>(bin);
+        if (q == 1) {
+            // After round 0 consumer k holds the k-th largest lag: if those lags are STRICTLY descending over
+            // a full group, ascending (total, index) order is simply the reverse -- one mirror instead of a
+            // sort.  Equal lags (index order must win) or a partly filled group take the sort.
+            const uint64_t mine = p64_value(bin);
+            const uint64_t prev = ((uint64_t)(uint32_t)__shfl_up((int)bin.hi, 1) << 32) | (uint32_t)__shfl_up((int)bin.lo, 1);
+            const bool bad = (C != L) || (gl > 0 && !((prev >> 6) > (mine >> 6)));
+            if (__builtin_amdgcn_ballot_w64(bad) == 0) {
+                bin.lo = shfl_mirror<L>(bin.lo);
+                bin.hi = shfl_mirror<L>(bin.hi);
+            } else {
+                bitonic_sort_lanes_p64<L>(bin);
+            }
+        } else if (q > 1) {
+            bitonic_sort_lanes_p64<L>(bin);
+        }
         const int s = q * C + gl;
         if (gl < C && s < P) {
             const uint64_t r = slice[slot_of(s)];
