@@ -38,6 +38,7 @@ DEFK(15, "v_pk_min_u16 %0, %0, %4", "v_pk_max_u16 %1, %1, %5", "v_pk_min_u16 %2,
 DEFK(16, "v_lshl_add_u32 %0, %0, 3, %4", "v_lshl_or_b32 %1, %1, 3, %5", "v_add3_u32 %2, %2, %6, %7", "v_and_or_b32 %3, %3, %7, %4")
 DEFK(17, "v_perm_b32 %0, %0, %4, %5", "v_alignbit_b32 %1, %1, %5, 8", "v_perm_b32 %2, %2, %6, %7", "v_alignbit_b32 %3, %3, %7, 8")
 
+DEFK(21, "v_min_f64 %[ab], %[ab], %[cd]", "v_max_f64 %[cd], %[cd], %[ab]", "v_min_f64 %[ab], %[ab], %[cd]", "v_max_f64 %[cd], %[cd], %[ab]")
 DEFK(19, "s_xor_b64 %8, %8, %9", "v_add_u32 %0, %0, %4", "s_xor_b64 %9, %9, %8", "v_add_u32 %1, %1, %5")
 DEFK(20, "v_readlane_b32 s20, %0, 3", "v_add_u32 %0, %0, %4", "v_readlane_b32 s21, %1, 5", "v_add_u32 %1, %1, %5")
 
