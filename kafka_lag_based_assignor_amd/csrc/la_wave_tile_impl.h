@@ -335,6 +335,7 @@ __device__ __forceinline__ void assign_packed(const TileArgs& a, uint64_t* slice
     const int rounds = (C > 0) ? (P + C - 1) / C : 0;
     int max_rounds = __builtin_amdgcn_readfirstlane(wave_max_i32(rounds));
     if constexpr (kAblate == 1 || kAblate == 3) max_rounds = 0;
+    if constexpr (kAblate >= 10) max_rounds = max_rounds < kAblate - 10 ? max_rounds : kAblate - 10;   // lab: cap the rounds
     for (int q = 0; q < max_rounds; ++q) {
         // round 0 starts sorted: all totals 0, indices ascending
         if (q == 1) {
