@@ -54,7 +54,7 @@ enum : int { kModeAuto = 0, kModeWide = 1, kModeArgmin = 2 };
 
 // Ablation hooks for tools/tile_lab.hip (phase timing on the GPU); always 0 in the library.
 //   1: no sort, no greedy (memory only)   2: no global loads / stores (compute only)
-//   3: sort but no greedy                 4: greedy but no sort
+//   3: sort but no greedy                 4: greedy but no sort       10+n: at most n greedy rounds
 #ifndef LA_ABLATE
 #define LA_ABLATE 0
 #endif
@@ -86,8 +86,7 @@ __device__ __forceinline__ int load_index(int v, int gl) {
 }
 
 // ---- 1. load + lag ------------------------------------------------------------------------------
-// The loads of a tile are split from their use so the kernel can keep the NEXT tile's loads in flight
-// while it sorts the current one (software pipeline, see the kernel).  Raw holds what is in flight.
+// The loads of a tile are issued first, all of them, and used later; Raw holds what is in flight.
 //
 // Every load is unconditional: lanes beyond their topic's partitions (and groups beyond the last topic)
 // read a CLAMPED in-bounds element and ignore it.  Branches around loads make hipcc wait for each load
@@ -109,7 +108,6 @@ struct TopicDescT {
 };
 using TopicDesc = TopicDescT<int64_t>;
 
-// element index of a lane's v-th pair, clamped so that a 2-element load stays inside [0, n_total)
 // element `idx` of `base`, read as V (a 1- or 2-element vector of T).  With 32-bit indexing the byte offset is
 // formed in 32 bits, which lets the load use the SGPR-base + VGPR-offset form (no 64-bit VALU address math).
 template <typename V, typename T, typename IDX>
@@ -120,6 +118,7 @@ __device__ __forceinline__ V load_at(const T* base, IDX idx) {
         return *reinterpret_cast<const V*>(base + idx);
 }
 
+// element index of a lane's v-th pair, clamped so that a 2-element load stays inside [0, n_total)
 template <int L, int E, typename D>
 __device__ __forceinline__ auto clamped_index(const TileArgs& a, const D& d, int v, int gl) {
     using IDX = decltype(d.p0);
