@@ -149,7 +149,10 @@ def main():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # LA_BENCH_FORCE_DIST=1 runs the RCCL legs (init, barrier, max-reduce) at world size 1 too, so that the N>1
+    # code path can be exercised under torchrun on a one-GPU box
+    use_dist = world > 1 or os.environ.get("LA_BENCH_FORCE_DIST") == "1"
+    if use_dist:
         dist.init_process_group("nccl", device_id=dev)
     if args.gpus != world and rank == 0:
         print("warning: --gpus %d but WORLD_SIZE=%d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
@@ -159,7 +162,7 @@ def main():
     w = make_device_workload(torch, dev, T, P, C, seed=0x5EED + rank, dist=args.dist)
     outs = alloc_outputs(torch, dev, T, P, C)
     out_pid, out_rank, out_total = outs["pid"], outs["rank"], outs["total"]
-    if args.gather and world > 1:
+    if args.gather and use_dist:
         gathered_pid = torch.empty(world * n_part, device=dev, dtype=torch.int32)
         gathered_rank = torch.empty(world * n_part, device=dev, dtype=torch.int32)
 
@@ -171,13 +174,13 @@ def main():
 
     def step():
         ctx.assign_batch_device(b, stream)
-        if args.gather and world > 1:
+        if args.gather and use_dist:
             dist.all_gather_into_tensor(gathered_pid, out_pid)
             dist.all_gather_into_tensor(gathered_rank, out_rank)
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -201,12 +204,12 @@ def main():
     kern_ms = float(np.mean([a.elapsed_time(z) for a, z in ev]))
 
     t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
 
     if rank != 0:
-        if world > 1:
+        if use_dist:
             dist.destroy_process_group()
         return
 
@@ -310,7 +313,7 @@ def main():
         "host_boundary": host_leg if (not args.no_cpu_baseline and world == 1) else None,
     }
     print(json.dumps(line))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
     if parity is not None and not parity["bit_exact"]:
         sys.exit(2)
