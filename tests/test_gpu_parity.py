@@ -326,6 +326,82 @@ def test_cfg5_scaled(ctx):
     _check_offsets(ctx, w, N.LA_RESET_EARLIEST, "cfg5/16")
 
 
+# ---- BASELINE.json's configurations at FULL size ---------------------------------------------------------
+def _round_form(part_off, pid, lag, cons_off, ranks):
+    """Independent checker built on the round property (SURVEY.md section 8a note 5): sort by (lag desc, id asc);
+    in each round of C positions the k-th partition goes to the k-th consumer by (total, rank) at round start."""
+    exp_p = np.empty_like(pid)
+    exp_m = np.empty_like(pid)
+    exp_t = np.zeros(ranks.size, dtype=np.int64)
+    for t in range(part_off.size - 1):
+        a, z = int(part_off[t]), int(part_off[t + 1])
+        ca, cz = int(cons_off[t]), int(cons_off[t + 1])
+        order = np.lexsort((pid[a:z], ~lag[a:z]))              # ~x = -x-1: descending lag without overflow
+        sp, sl = pid[a:z][order], lag[a:z][order]
+        exp_p[a:z] = sp
+        c = cz - ca
+        if c == 0:
+            exp_m[a:z] = -1
+            continue
+        tot = np.zeros(c, dtype=np.int64)
+        r = ranks[ca:cz]
+        for lo in range(0, z - a, c):
+            k = min(c, z - a - lo)
+            who = np.lexsort((r, tot))[:k]
+            exp_m[a + lo:a + lo + k] = r[who]
+            with np.errstate(over="ignore"):
+                tot[who] += sl[lo:lo + k]
+        exp_t[ca:cz] = tot
+    return exp_p, exp_m, exp_t
+
+
+def test_cfg4_full_size(ctx):
+    w = synth.config("cfg4")                       # 100 000 topics x 64 partitions x 8 consumers
+    _check_offsets(ctx, w, N.LA_RESET_LATEST, "cfg4 latest")
+    _check_offsets(ctx, w, N.LA_RESET_EARLIEST, "cfg4 earliest")
+
+
+def test_target_full_size(ctx):
+    w = synth.config("target")                     # 100 000 topics x 256 partitions x 32 consumers, 25.6 M partitions
+    lag = oracle.compute_lags(w.begin, w.end, w.committed, False)
+    exp_p, exp_m, exp_t = oracle.assign_flat(w.part_off, w.partition_id, lag, w.cons_off, w.cons_rank)
+    got_p, got_m, got_t = ctx.assign_batch(w.part_off, w.partition_id, w.begin, w.end, w.committed,
+                                           N.LA_RESET_EARLIEST, w.cons_off, w.cons_rank)
+    assert np.array_equal(got_p, exp_p) and np.array_equal(got_m, exp_m) and np.array_equal(got_t, exp_t)
+    # the quality metric of BASELINE.json follows from the totals, so it is the oracle's exactly
+    np.testing.assert_array_equal(synth.lag_ratio(got_t, w.cons_off), synth.lag_ratio(exp_t, w.cons_off))
+    # size-independent properties: a permutation per topic, sorted by (lag desc, id asc), every round a
+    # permutation of the consumers, totals = sums of what each consumer received
+    t, p, c = w.n_topics, 256, 32
+    assert np.array_equal(np.sort(got_p.reshape(t, p), axis=1), np.tile(np.arange(p, dtype=np.int32), (t, 1)))
+    lag_by_id = np.empty_like(lag).reshape(t, p)
+    np.put_along_axis(lag_by_id, w.partition_id.reshape(t, p).astype(np.int64), lag.reshape(t, p), axis=1)
+    sl = np.take_along_axis(lag_by_id, got_p.reshape(t, p).astype(np.int64), axis=1)
+    assert (sl[:, 1:] <= sl[:, :-1]).all()
+    tie = sl[:, 1:] == sl[:, :-1]
+    gp = got_p.reshape(t, p)
+    assert (gp[:, 1:][tie] > gp[:, :-1][tie]).all()
+    assert np.array_equal(np.sort(got_m.reshape(t, p // c, c), axis=2),
+                          np.broadcast_to(np.arange(c, dtype=np.int32), (t, p // c, c)))
+    sums = np.zeros((t, c), dtype=np.int64)
+    np.add.at(sums, (np.repeat(np.arange(t), p), got_m.astype(np.int64)), sl.reshape(-1))
+    assert np.array_equal(sums.reshape(-1), got_t)
+
+
+def test_cfg5_full_size(ctx):
+    w = synth.config("cfg5")                       # 1 topic, 1 048 576 partitions, 8 192 consumers, 128 rounds
+    lag = oracle.compute_lags(w.begin, w.end, w.committed, False)
+    got = ctx.assign_batch(w.part_off, w.partition_id, w.begin, w.end, w.committed, N.LA_RESET_EARLIEST,
+                           w.cons_off, w.cons_rank)
+    for g, e, what in zip(got, _round_form(w.part_off, w.partition_id, lag, w.cons_off, w.cons_rank),
+                          ("partition order", "member", "totals")):
+        np.testing.assert_array_equal(g, e, err_msg="round form: " + what)
+    # the literal per-step Collections.min of the oracle: 8.6e9 comparator steps, about 15 s of one host core
+    for g, e, what in zip(got, oracle.assign_flat(w.part_off, w.partition_id, lag, w.cons_off, w.cons_rank),
+                          ("partition order", "member", "totals")):
+        np.testing.assert_array_equal(g, e, err_msg="oracle: " + what)
+
+
 # ---- device-resident entry point; round form == literal wavefront argmin ------------------------------
 def _run_device(ctx, w, algo, use_lag=False, latest=True, flags=0):
     import ctypes
