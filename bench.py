@@ -268,15 +268,21 @@ def main():
         # kernels, D2H of the results); reported beside the bench value, never as it
         host_leg = None
         try:
-            ctx.assign_batch(h["part_off"], h["pid"], None if latest else h["begin"], h["end"], h["committed"],
-                             N.LA_RESET_LATEST if latest else N.LA_RESET_EARLIEST, h["cons_off"], h["cons_rank"])
+            # result buffers are the caller's and reused across calls (a Java host's direct ByteBuffers): the first
+            # call touches them, the second is timed
+            reuse = ctx.assign_batch(h["part_off"], h["pid"], None if latest else h["begin"], h["end"], h["committed"],
+                                     N.LA_RESET_LATEST if latest else N.LA_RESET_EARLIEST, h["cons_off"], h["cons_rank"])
+            for o in reuse:
+                o.fill(0)
             c0 = time.perf_counter()
             hp, hm, ht = ctx.assign_batch(h["part_off"], h["pid"], None if latest else h["begin"], h["end"],
                                           h["committed"], N.LA_RESET_LATEST if latest else N.LA_RESET_EARLIEST,
-                                          h["cons_off"], h["cons_rank"])
+                                          h["cons_off"], h["cons_rank"], out=reuse)
             dt = time.perf_counter() - c0
             host_leg = {"ms": round(dt * 1e3, 2), "value": round(n_part / dt, 1), "unit": "partition-assignments/sec",
-                        "what": "one la_assign_batch call on pageable host buffers, PCIe copies included",
+                        "what": "one la_assign_batch call on pageable host buffers (results into reused, already "
+                                "touched buffers), PCIe copies included",
+                        "pcie_gbs": round((n_part * (bpp) + out_total.numel() * 8) / dt / 1e9, 1),
                         "bit_exact_vs_device_path": bool(np.array_equal(hp, g_pid) and np.array_equal(hm, g_rank))}
         except Exception as exc:  # noqa: BLE001 -- a reported extra, not part of the contract
             host_leg = {"error": str(exc)}
