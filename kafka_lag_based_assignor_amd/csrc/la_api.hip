@@ -41,6 +41,15 @@ struct la_ctx {
     // counters (d_status + 16 / + 17 words) the next launch uses
     DevBuf defer;
     unsigned launches = 0;
+    // block path: topic lists per size class.  Built on the host into a small ring of pinned slots (a slot
+    // is reused only after the copy that read it has completed) and copied to block_list.
+    DevBuf block_list;
+    struct Stage {
+        int32_t* p = nullptr;
+        size_t cap = 0;          // in int32 entries
+        hipEvent_t done = nullptr;
+    } stage[4];
+    unsigned stage_next = 0;
 };
 
 namespace {
@@ -133,7 +142,7 @@ int enqueue_batch(la_ctx* ctx, const la_device_batch* b, hipStream_t stream) {
     a.status = ctx->d_status;
     a.reset_latest = (b->reset_mode == LA_RESET_LATEST) ? 1 : 0;
     a.n_total = b->n_partitions;
-    a.flags = b->flags;
+    a.flags = b->flags & (LA_FLAG_INDEX64 | LA_FLAG_DEFER_WIDE);
     a.k_total = b->n_consumers;
     if (int rc = reserve(ctx, ctx->defer, la::wave_tile_defer_bytes(b->n_topics))) return rc;
     a.defer_list = (int32_t*)ctx->defer.p;
@@ -160,33 +169,85 @@ int enqueue_batch(la_ctx* ctx, const la_device_batch* b, hipStream_t stream) {
         return LA_OK;
     }
 
-    // Mixed or large shapes: walk the topics on the host.  Runs of tile-sized topics go to
-    // the wave-tile kernel in one launch each; every larger topic takes the large path.
+    // Mixed shapes: classify the topics on the host.  Tile-sized topics: ONE wave-tile launch over the whole
+    // batch that skips the others.  Up to 8 192 partitions x 2 048 consumers: the block path, one workgroup
+    // per topic, one launch per size class.  Beyond: the large path, topic by topic.
     if (!b->h_part_off || !b->h_cons_off)
         return fail(ctx, LA_EINVAL,
                     "shape hint exceeds one wave tile (%lld partitions / %lld consumers per topic): "
                     "h_part_off and h_cons_off are required",
                     (long long)la::kTileMaxPartitions, (long long)la::kTileMaxConsumers);
     const int64_t T = b->n_topics;
-    int64_t t = 0;
-    while (t < T) {
-        auto psize = [&](int64_t i) { return b->h_part_off[i + 1] - b->h_part_off[i]; };
-        auto csize = [&](int64_t i) { return b->h_cons_off[i + 1] - b->h_cons_off[i]; };
-        if (la::wave_tile_fits(psize(t), csize(t))) {
-            int64_t u = t, mp = 0, mc = 0;
-            while (u < T && la::wave_tile_fits(psize(u), csize(u))) {
-                if (psize(u) > mp) mp = psize(u);
-                if (csize(u) > mc) mc = csize(u);
-                ++u;
-            }
-            la::TileArgs run = a;
-            run.n_topics = u - t;
-            run.part_off = b->d_part_off + t;
-            run.cons_off = b->d_cons_off + t;
-            next_counters(run);
-            LA_HIP(ctx, la::wave_tile_launch(run, mp, mc, tile_mode, stream));
-            t = u;
-        } else {
+    auto psize = [&](int64_t i) { return b->h_part_off[i + 1] - b->h_part_off[i]; };
+    auto csize = [&](int64_t i) { return b->h_cons_off[i + 1] - b->h_cons_off[i]; };
+    int64_t tile_mp = 0, tile_mc = 0, n_tile = 0, n_block[la::kBlockClasses] = {0, 0, 0};
+    const bool use_block = !argmin && b->algo != LA_ALGO_ROUNDS_WIDE && T <= 0x7FFFFFFF;
+    for (int64_t t = 0; t < T; ++t) {
+        const int64_t p = psize(t), c = csize(t);
+        if (p < 0 || c < 0) return fail(ctx, LA_EINVAL, "offsets of topic %lld decrease", (long long)t);
+        if (la::wave_tile_fits(p, c)) {
+            ++n_tile;
+            if (p > tile_mp) tile_mp = p;
+            if (c > tile_mc) tile_mc = c;
+        } else if (use_block && la::block_fits(p, c)) {
+            ++n_block[la::block_class(p, c)];
+        }
+    }
+    if (n_tile > 0) {
+        la::TileArgs run = a;
+        run.flags |= la::kTileSkipOversize;
+        next_counters(run);
+        LA_HIP(ctx, la::wave_tile_launch(run, tile_mp, tile_mc, tile_mode, stream));
+    }
+    const int64_t n_block_all = n_block[0] + n_block[1] + n_block[2];
+    if (n_block_all > 0) {
+        // the lists, class by class, into a pinned slot -> device
+        la_ctx::Stage& sg = ctx->stage[ctx->stage_next++ & 3u];
+        if (sg.done) LA_HIP(ctx, hipEventSynchronize(sg.done));
+        else LA_HIP(ctx, hipEventCreateWithFlags(&sg.done, hipEventDisableTiming));
+        if (sg.cap < (size_t)n_block_all) {
+            if (sg.p) { LA_HIP(ctx, hipHostFree(sg.p)); sg.p = nullptr; sg.cap = 0; }
+            const size_t want = (size_t)n_block_all + (size_t)n_block_all / 2 + 64;
+            LA_HIP(ctx, hipHostMalloc((void**)&sg.p, want * sizeof(int32_t), hipHostMallocDefault));
+            sg.cap = want;
+        }
+        int64_t at[la::kBlockClasses] = {0, n_block[0], n_block[0] + n_block[1]};
+        for (int64_t t = 0; t < T; ++t) {
+            const int64_t p = psize(t), c = csize(t);
+            if (!la::wave_tile_fits(p, c) && la::block_fits(p, c)) sg.p[at[la::block_class(p, c)]++] = (int32_t)t;
+        }
+        // a batch enqueued earlier on another stream may still read the device list: one list per call
+        // would need a ring on the device too; calls of one context are documented as stream-ordered
+        if (int rc = reserve(ctx, ctx->block_list, (size_t)n_block_all * sizeof(int32_t))) return rc;
+        LA_HIP(ctx, hipMemcpyAsync(ctx->block_list.p, sg.p, (size_t)n_block_all * sizeof(int32_t),
+                                   hipMemcpyHostToDevice, stream));
+        LA_HIP(ctx, hipEventRecord(sg.done, stream));
+        la::BlockArgs g{};
+        g.part_off = b->d_part_off;
+        g.cons_off = b->d_cons_off;
+        g.pid = b->d_partition_id;
+        g.begin = b->d_begin_off;
+        g.end = b->d_end_off;
+        g.committed = b->d_committed_off;
+        g.lag = b->d_lag;
+        g.cons_rank = b->d_cons_rank;
+        g.out_pid = b->d_out_partition;
+        g.out_rank = b->d_out_member_rank;
+        g.out_total = b->d_out_total_lag;
+        g.status = ctx->d_status;
+        g.reset_latest = a.reset_latest;
+        int64_t first = 0;
+        for (int cls = 0; cls < la::kBlockClasses; ++cls) {
+            g.list = (const int32_t*)ctx->block_list.p + first;
+            g.n_list = (int32_t)n_block[cls];
+            LA_HIP(ctx, la::block_launch(g, cls, stream));
+            first += n_block[cls];
+        }
+    }
+    for (int64_t t = 0; t < T; ++t) {
+        if (la::wave_tile_fits(psize(t), csize(t))) continue;
+        if (use_block && la::block_fits(psize(t), csize(t))) continue;
+        {
             if (csize(t) > la::kLargeMaxConsumers)
                 return fail(ctx, LA_ESHAPE, "topic %lld has %lld consumers; at most %lld are supported",
                             (long long)t, (long long)csize(t), (long long)la::kLargeMaxConsumers);
@@ -213,7 +274,6 @@ int enqueue_batch(la_ctx* ctx, const la_device_batch* b, hipStream_t stream) {
             if (e != hipSuccess)
                 return fail(ctx, e == hipErrorOutOfMemory ? LA_ENOMEM : LA_EHIP, "large topic %lld: %s",
                             (long long)t, hipGetErrorString(e));
-            ++t;
         }
     }
     return LA_OK;
@@ -353,8 +413,13 @@ LA_API void la_destroy(la_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     for (DevBuf* b : {&ctx->part_off, &ctx->pid, &ctx->begin, &ctx->end, &ctx->committed, &ctx->cons_off,
-                      &ctx->cons_rank, &ctx->out_pid, &ctx->out_rank, &ctx->out_total, &ctx->defer})
+                      &ctx->cons_rank, &ctx->out_pid, &ctx->out_rank, &ctx->out_total, &ctx->defer,
+                      &ctx->block_list})
         release(*b);
+    for (la_ctx::Stage& sg : ctx->stage) {
+        if (sg.done) { (void)hipEventSynchronize(sg.done); (void)hipEventDestroy(sg.done); }
+        if (sg.p) (void)hipHostFree(sg.p);
+    }
     la::large_scratch_release(ctx->large);
     if (ctx->d_status) (void)hipFree(ctx->d_status);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);

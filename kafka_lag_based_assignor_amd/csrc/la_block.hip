@@ -1,0 +1,255 @@
+// la_block.hip -- the block path: one workgroup per topic, for topics beyond a wave tile (more than 1 024
+// partitions or more than 64 consumers) up to kBlockMaxPartitions x kBlockMaxConsumers.  All such topics of a
+// batch run side by side (one launch per size class), where the large path (la_large.hip) would take them
+// one after another through a dozen device-wide kernels each.
+//
+// Per topic, everything stays in the workgroup's LDS:
+//   1. records  key = (uint64)lag ^ 0x7FFF...F, id = partition ^ 0x8000'0000      (computePartitionLag,
+//      Main.java:376-404, fused into the load)
+//   2. bitonic sort ascending by (key, id) == lag descending, partition ascending   (Main.java:228-235)
+//   3. greedy in rounds of C partitions: bins (total + 2^63, position in the rank-sorted consumer list) are
+//      sorted ascending and the k-th partition of the round goes to the k-th bin     (Main.java:237-266; the
+//      comparator's first key, the assigned count, is what makes rounds -- SURVEY.md section 8a note 5)
+//
+// The network is the direction-free bitonic form (first step of a merge is the mirror i <-> i ^ (K-1), the
+// rest i <-> i ^ j, the lower slot always keeps the smaller record).  Two properties make it shape-generic:
+//   * slots >= the live count behave as +inf that never moves (a compare-exchange never lowers the larger
+//     record), so they are neither stored nor visited: no padding, any P and C;
+//   * a step whose pairs stay inside 128-slot spans is executed by the span's owner wavefront, so runs of
+//     such steps need only a wavefront-level fence; the workgroup barrier is paid by the few wider steps.
+// With at most 256 consumers the greedy runs in ONE wavefront with the bins in registers (greedy_one_wave).
+#include "la_device.h"
+#include "la_kernels.h"
+
+namespace la {
+
+namespace {
+
+constexpr int kSpan = 128;      // slots a wavefront owns: 64 pairs
+
+// n: power of two >= live.  cmpx(i, p) with i < p leaves the smaller record at i.
+// entry_fence_only: the data was last written by the span owners (so an in-span first step needs no barrier).
+template <typename F>
+__device__ __forceinline__ void lds_bitonic_sort(int n, int live, int tid, int nt, bool entry_fence_only, F cmpx) {
+    bool prev_cross = !entry_fence_only;
+    const int half = n >> 1;
+    for (int K = 2; K <= n; K <<= 1) {
+        for (int j = K >> 1; j >= 1; j >>= 1) {
+            const bool mirror = (j == (K >> 1));
+            const bool cross = 2 * j > kSpan;
+            if (prev_cross || cross) __syncthreads(); else wave_lds_fence();
+            const int flip = mirror ? (K - 1) : j;
+            for (int idx = tid; idx < half; idx += nt) {
+                const int off = idx & (j - 1);
+                const int i = ((idx - off) << 1) | off;
+                const int p = i ^ flip;
+                if (p < live) cmpx(i, p);
+            }
+            prev_cross = cross;
+        }
+    }
+}
+
+__device__ __forceinline__ int pow2ceil_dev(int x) {
+    return x <= 1 ? 1 : 1 << (32 - __builtin_clz((unsigned)(x - 1)));
+}
+
+// Greedy rounds for up to 256 consumers: one wavefront, bins in registers (EC per lane, slot = lane*EC + r),
+// sorted by the DPP / permlane networks of la_device.h -- no LDS traffic and no barrier between rounds.
+// Slots >= C hold an all-ones sentinel (a real bin's index is < C, so it never equals it).  L = lanes in use
+// (EC == 1: the network is unrolled for that width).
+template <int EC, int L>
+__device__ __forceinline__ void greedy_one_wave(const BlockArgs& a, const uint64_t* s_key, const int32_t* s_rank,
+                                                int64_t p0, int64_t c0, int P, int C, int lane) {
+    Rec bin[EC];
+#pragma unroll
+    for (int r = 0; r < EC; ++r) {
+        const int e = lane * EC + r;
+        if (e < C) { bin[r].hi = (uint32_t)(kTotalBias >> 32); bin[r].lo = 0; bin[r].tb = (uint32_t)e; }
+        else bin[r].hi = bin[r].lo = bin[r].tb = 0xFFFFFFFFu;
+    }
+    const int rounds = (P + C - 1) / C;
+    uint64_t lag[EC];                                    // this round's lags, read before the bins are sorted
+#pragma unroll
+    for (int r = 0; r < EC; ++r) {
+        const int e = lane * EC + r;
+        lag[r] = (e < C && e < P) ? (s_key[e] ^ kLagKeyFlip) : 0;
+    }
+    for (int q = 0; q < rounds; ++q) {
+        uint64_t next[EC];
+#pragma unroll
+        for (int r = 0; r < EC; ++r) {
+            const int e = lane * EC + r;
+            const int s = (q + 1) * C + e;
+            next[r] = (e < C && s < P) ? (s_key[s] ^ kLagKeyFlip) : 0;
+        }
+        if (q > 0) {
+            bitonic_sort_tile<L, EC>(bin, lane & (L - 1));      // lanes >= L sort sentinels among themselves
+        }
+#pragma unroll
+        for (int r = 0; r < EC; ++r) {
+            const int e = lane * EC + r;
+            const int s = q * C + e;
+            if (e < C && s < P) {
+                const uint64_t t = (((uint64_t)bin[r].hi << 32) | bin[r].lo) + lag[r];   // Main.java:265
+                bin[r].hi = (uint32_t)(t >> 32);
+                bin[r].lo = (uint32_t)t;
+                a.out_rank[p0 + s] = s_rank[bin[r].tb];
+            }
+            lag[r] = next[r];
+        }
+    }
+    if (a.out_total) {
+#pragma unroll
+        for (int r = 0; r < EC; ++r)
+            if (bin[r].tb < (uint32_t)C)
+                a.out_total[c0 + bin[r].tb] = (int64_t)((((uint64_t)bin[r].hi << 32) | bin[r].lo) ^ kTotalBias);
+    }
+}
+
+__global__ __launch_bounds__(1024) void block_topic_kernel(BlockArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint64_t smem64[];
+    uint64_t* s_key = smem64;                                         // [np_cap] sorted partition keys
+    uint64_t* s_tot = s_key + a.np_cap;                               // [nc_cap] biased bin totals
+    uint32_t* s_id = reinterpret_cast<uint32_t*>(s_tot + a.nc_cap);   // [np_cap] biased partition ids
+    uint32_t* s_idx = s_id + a.np_cap;                                // [nc_cap] bin -> consumer position
+    int32_t* s_rank = reinterpret_cast<int32_t*>(s_idx + a.nc_cap);   // [nc_cap] consumer position -> member rank
+
+    const int tid = threadIdx.x, nt = blockDim.x;
+    const int64_t topic = a.list[blockIdx.x];
+    const int64_t p0 = a.part_off[topic], c0 = a.cons_off[topic];
+    const int64_t Pl = a.part_off[topic + 1] - p0, Cl = a.cons_off[topic + 1] - c0;
+    if (Pl < 0 || Cl < 0 || Pl > a.np_cap || Cl > a.nc_cap) {           // the host's lists disagree with the
+        if (tid == 0) atomicOr(a.status, kStatusShape);                 // device's offsets: leave outputs alone
+        return;
+    }
+    const int P = (int)Pl, C = (int)Cl;
+    const bool latest = a.reset_latest != 0;
+
+    // ---- records --------------------------------------------------------------------------------------
+    for (int i = tid; i < P; i += nt) {
+        const int64_t g = p0 + i;
+        int64_t lag;
+        if (a.lag) {
+            lag = a.lag[g];
+        } else {
+            const int64_t cm = a.committed[g];
+            const int64_t bg = (cm < 0 && !latest && a.begin) ? a.begin[g] : 0;
+            lag = partition_lag(bg, a.end[g], cm, latest);
+        }
+        s_key[i] = (uint64_t)lag ^ kLagKeyFlip;
+        s_id[i] = (uint32_t)a.pid[g] ^ kPidBias;
+    }
+    for (int i = tid; i < C; i += nt) {
+        s_tot[i] = kTotalBias;                                          // total 0
+        s_idx[i] = (uint32_t)i;
+        s_rank[i] = a.cons_rank[c0 + i];
+    }
+
+    // ---- sort by (lag desc, partition asc) ------------------------------------------------------------
+    lds_bitonic_sort(pow2ceil_dev(P), P, tid, nt, false, [&](int i, int p) {
+        const uint64_t ka = s_key[i], kb = s_key[p];
+        const uint32_t ia = s_id[i], ib = s_id[p];
+        if ((kb < ka) | ((kb == ka) & (ib < ia))) {
+            s_key[i] = kb; s_key[p] = ka;
+            s_id[i] = ib; s_id[p] = ia;
+        }
+    });
+    __syncthreads();
+    for (int s = tid; s < P; s += nt) {
+        a.out_pid[p0 + s] = (int32_t)(s_id[s] ^ kPidBias);
+        if (C == 0) a.out_rank[p0 + s] = -1;                            // Main.java:211-214: nobody to assign to
+    }
+    if (C == 0) return;
+
+    // ---- greedy rounds --------------------------------------------------------------------------------
+    // Slots 2*idx and 2*idx+1 are updated by the thread that owns pair idx in the network's in-span steps,
+    // so the update and the next round's sort are separated by a wavefront fence only.
+    const int n_c = pow2ceil_dev(C);
+    if (n_c <= 4 * kWave) {
+        if (tid < kWave) {
+            switch (n_c) {                               // a fully unrolled network per width
+                case 1: greedy_one_wave<1, 1>(a, s_key, s_rank, p0, c0, P, C, tid); break;
+                case 2: greedy_one_wave<1, 2>(a, s_key, s_rank, p0, c0, P, C, tid); break;
+                case 4: greedy_one_wave<1, 4>(a, s_key, s_rank, p0, c0, P, C, tid); break;
+                case 8: greedy_one_wave<1, 8>(a, s_key, s_rank, p0, c0, P, C, tid); break;
+                case 16: greedy_one_wave<1, 16>(a, s_key, s_rank, p0, c0, P, C, tid); break;
+                case 32: greedy_one_wave<1, 32>(a, s_key, s_rank, p0, c0, P, C, tid); break;
+                case 64: greedy_one_wave<1, 64>(a, s_key, s_rank, p0, c0, P, C, tid); break;
+                case 128: greedy_one_wave<2, 64>(a, s_key, s_rank, p0, c0, P, C, tid); break;
+                default: greedy_one_wave<4, 64>(a, s_key, s_rank, p0, c0, P, C, tid); break;
+            }
+        }
+        return;
+    }
+    // more bins than one wavefront holds comfortably: bins in LDS, same network as the partition sort
+    const int upd = n_c >> 1;
+    const int rounds = (P + C - 1) / C;
+    for (int q = 0; q < rounds; ++q) {
+        if (q > 0) {
+            lds_bitonic_sort(n_c, C, tid, nt, true, [&](int i, int p) {
+                const uint64_t ta = s_tot[i], tb = s_tot[p];
+                const uint32_t ia = s_idx[i], ib = s_idx[p];
+                if ((tb < ta) | ((tb == ta) & (ib < ia))) {             // Main.java:253-259
+                    s_tot[i] = tb; s_tot[p] = ta;
+                    s_idx[i] = ib; s_idx[p] = ia;
+                }
+            });
+            wave_lds_fence();
+        }
+        const int base = q * C;
+        for (int idx = tid; idx < upd; idx += nt) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int e = 2 * idx + h;
+                const int s = base + e;
+                if (e < C && s < P) {
+                    s_tot[e] += s_key[s] ^ kLagKeyFlip;                 // Main.java:265, wrapping like a long
+                    a.out_rank[p0 + s] = s_rank[s_idx[e]];
+                }
+            }
+        }
+    }
+    if (a.out_total) {
+        wave_lds_fence();
+        for (int idx = tid; idx < upd; idx += nt) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int e = 2 * idx + h;
+                if (e < C) a.out_total[c0 + s_idx[e]] = (int64_t)(s_tot[e] ^ kTotalBias);
+            }
+        }
+    }
+}
+
+}  // namespace
+
+bool block_fits(int64_t p, int64_t c) { return p <= kBlockMaxPartitions && c <= kBlockMaxConsumers; }
+
+int block_class(int64_t p, int64_t c) {
+    if (p <= 2048 && c <= 256) return 0;
+    if (p <= 4096 && c <= 1024) return 1;
+    return 2;
+}
+
+hipError_t block_launch(BlockArgs a, int cls, hipStream_t stream) {
+    static const int kThreads[kBlockClasses] = {256, 512, 1024};
+    static const int kNp[kBlockClasses] = {2048, 4096, (int)kBlockMaxPartitions};
+    static const int kNc[kBlockClasses] = {256, 1024, (int)kBlockMaxConsumers};
+    if (a.n_list <= 0) return hipSuccess;
+    if (cls < 0 || cls >= kBlockClasses) return hipErrorInvalidValue;
+    a.np_cap = kNp[cls];
+    a.nc_cap = kNc[cls];
+    const size_t lds = (size_t)12 * a.np_cap + (size_t)16 * a.nc_cap;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)block_topic_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           160 * 1024);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(block_topic_kernel, dim3((unsigned)a.n_list), dim3(kThreads[cls]), lds, stream, a);
+    return hipGetLastError();
+}
+
+}  // namespace la

@@ -9,6 +9,8 @@ namespace la {
 constexpr uint32_t kStatusShape = 1u;      // a topic exceeded the shape hint
 constexpr uint32_t kStatusUnsorted = 2u;   // a topic's cons_rank segment is not strictly ascending
 
+constexpr int32_t kTileSkipOversize = 4;  // TileArgs::flags: topics beyond the tile belong to another path, no error
+
 constexpr int64_t kTileMaxPartitions = 1024;   // 64 lanes x 16 records
 constexpr int64_t kTileMaxConsumers = 64;      // one consumer bin per lane
 constexpr int64_t kLargeMaxConsumers = 8192;   // large path: 8 bins per thread x 1024 threads
@@ -32,7 +34,7 @@ struct TileArgs {
     uint32_t* status;
     int32_t reset_latest;
     int32_t lc;                 // pow2ceil(max consumers per topic), set by the launcher
-    int32_t flags;              // LA_FLAG_* of the batch (test hooks)
+    int32_t flags;              // LA_FLAG_* of the batch (test hooks) | kTileSkipOversize
     // tiles the packed kernel leaves to the wide kernel (LA_ALGO_AUTO): a counter pair that alternates
     // per launch (the wide kernel zeroes the other one), and the list of tile ids
     int32_t* defer_count;
@@ -55,6 +57,34 @@ hipError_t lag_launch(int64_t n, const int64_t* begin, const int64_t* end, const
 // Checks that every topic's cons_rank segment is strictly ascending; sets kStatusUnsorted.
 hipError_t check_consumers_launch(int64_t n_topics, const int64_t* cons_off, const int32_t* cons_rank,
                                   uint32_t* status, hipStream_t stream);
+
+// ---- block path (la_block.hip): one workgroup per topic, everything in LDS --------------------
+constexpr int64_t kBlockMaxPartitions = 8192;
+constexpr int64_t kBlockMaxConsumers = 2048;
+constexpr int kBlockClasses = 3;               // LDS / workgroup size classes, see block_class()
+
+struct BlockArgs {
+    const int64_t* part_off;    // the batch's offsets (device)
+    const int64_t* cons_off;
+    const int32_t* list;        // topic indices this launch handles (device)
+    int32_t n_list;
+    const int32_t* pid;
+    const int64_t* begin;
+    const int64_t* end;
+    const int64_t* committed;
+    const int64_t* lag;
+    const int32_t* cons_rank;
+    int32_t* out_pid;
+    int32_t* out_rank;
+    int64_t* out_total;
+    uint32_t* status;
+    int32_t reset_latest;
+    int32_t np_cap, nc_cap;     // LDS capacity in records / bins, set by the launcher
+};
+
+bool block_fits(int64_t partitions, int64_t consumers);
+int block_class(int64_t partitions, int64_t consumers);
+hipError_t block_launch(BlockArgs a, int cls, hipStream_t stream);
 
 // ---- large-topic path (device-wide radix sort + one-workgroup greedy) ---------------------
 struct LargeScratch {

@@ -525,7 +525,8 @@ __device__ __forceinline__ TopicDescT<IDX> make_desc(const TileArgs& a, const De
     d.c0 = (IDX)w.c0;
     const int64_t Pl = w.p1 - w.p0, Cl = w.c1 - w.c0;
     const bool bad = Pl > Cfg::kCap || Cl > L || Pl < 0 || Cl < 0;
-    if (w.exists && bad && gl == 0) atomicOr(a.status, kStatusShape);    // hint was wrong; leave outputs alone
+    // hint was wrong: leave outputs alone (kTileSkipOversize: the topic belongs to the block / large path)
+    if (w.exists && bad && gl == 0 && !(a.flags & kTileSkipOversize)) atomicOr(a.status, kStatusShape);
     d.P = (w.exists && !bad) ? (int)Pl : 0;
     d.C = (w.exists && !bad) ? (int)Cl : 0;
     return d;

@@ -548,6 +548,61 @@ def test_fuzz_large_topics(ctx, seed):
         np.testing.assert_array_equal(g, e, err_msg="%s p=%d c=%d %s" % (what, p, c, kind))
 
 
+# ---- block path: one workgroup per topic, 1 024 < P <= 8 192 or 64 < C <= 2 048 ------------------------------
+@pytest.mark.parametrize("p,c,kind", [
+    (1025, 1, "u40"), (8192, 2048, "u40"), (100, 65, "ties"), (1, 65, "u40"), (0, 100, "zero"), (5000, 0, "u40"),
+    (8192, 3, "full"), (4097, 1025, "zero"), (2048, 256, "u63"), (2049, 257, "full"), (200, 100, "u40"),
+    (127, 128, "ties"), (129, 128, "u40"), (3000, 129, "ties"), (8191, 2047, "u63"), (64, 2048, "u40"),
+])
+def test_block_single_topic(ctx, p, c, kind):
+    po, pid, lag, co, ranks = _single_topic(31 * p + c, p, c, kind, negative=(kind == "full"))
+    exp = oracle.assign_flat(po, pid, lag, co, ranks)
+    got = ctx.assign_batch_lags(po, pid, lag, co, ranks)
+    for g, e, what in zip(got, exp, ("partition order", "member", "totals")):
+        np.testing.assert_array_equal(g, e, err_msg=what)
+
+
+@pytest.mark.parametrize("seed,max_p,max_c", [(1, 3000, 300), (2, 9000, 70), (3, 1500, 2500), (4, 600, 100),
+                                              (5, 8192, 2048)])
+def test_block_batches_mixed_with_tile_and_large_topics(ctx, seed, max_p, max_c):
+    # ragged batches whose topics fall in all three classes (wave tile, block, large), offsets entry point in
+    # both reset modes and the lag entry point with negative lags
+    w = synth.ragged(9000 + seed, 120 if max_p < 5000 else 40, max_p, max_c, negative=True)
+    for mode in (N.LA_RESET_LATEST, N.LA_RESET_EARLIEST):
+        _check_offsets(ctx, w, mode, "ragged block batch %d" % seed)
+    _check_lags(ctx, w, "ragged block batch %d, lags" % seed)
+
+
+def test_block_many_topics_same_shape(ctx):
+    # more topics than resident workgroups: 1 500 topics x 300 partitions x 100 consumers
+    rng = np.random.default_rng(77)
+    t, p, c = 1500, 300, 100
+    part_off = np.arange(t + 1, dtype=np.int64) * p
+    cons_off = np.arange(t + 1, dtype=np.int64) * c
+    pid = np.concatenate([rng.permutation(p) for _ in range(t)]).astype(np.int32)
+    lag = rng.integers(0, 1 << 34, t * p).astype(np.int64)
+    ranks = np.tile(np.arange(c, dtype=np.int32), t)
+    exp = oracle.assign_flat(part_off, pid, lag, cons_off, ranks)
+    for rep in range(2):                                  # twice: the host's list slots rotate
+        got = ctx.assign_batch_lags(part_off, pid, lag, cons_off, ranks)
+        for g, e, what in zip(got, exp, ("partition order", "member", "totals")):
+            np.testing.assert_array_equal(g, e, err_msg=what)
+
+
+@pytest.mark.parametrize("seed", range(10))
+def test_fuzz_block_topics(ctx, seed):
+    rng = np.random.default_rng(7000 + seed)
+    p = int(rng.choice([0, 1, 63, 64, 65, 127, 128, 129, 1000, 1024, 1025, 2047, 2048, 2049, 4096, 4097, 8191, 8192]))
+    c = int(rng.choice([1, 2, 63, 64, 65, 127, 128, 129, 255, 256, 257, 1023, 1024, 1025, 2047, 2048]))
+    kind = str(rng.choice(["u40", "ties", "zero", "u63", "full"]))
+    po, pid, lag, co, ranks = _single_topic(seed + 177, p, c, kind, shuffled=bool(rng.integers(0, 2)),
+                                            negative=(kind == "full"))
+    exp = oracle.assign_flat(po, pid, lag, co, ranks)
+    got = ctx.assign_batch_lags(po, pid, lag, co, ranks)
+    for g, e, what in zip(got, exp, ("partition order", "member", "totals")):
+        np.testing.assert_array_equal(g, e, err_msg="%s p=%d c=%d %s" % (what, p, c, kind))
+
+
 # ---- committed fixtures: the HIP path against tests/golden/oracle_frozen.json -------------------------------
 def test_hip_path_matches_frozen_digests(ctx):
     import importlib.util
