@@ -224,7 +224,9 @@ def main():
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "traffic": tr["hbm_bytes_per_launch"] if tr else None,
                 "kernel": ("wave_tile_packed_kernel (+ the wide-record kernel over its deferred-tile list, empty here)"
-                           if (P <= 1024 and C <= 64) else "large-topic path (all kernels)"),
+                           if (P <= 1024 and C <= 64) else
+                           "block_topic_kernel (one workgroup per topic; + the list copy)"
+                           if (P <= 8192 and C <= 2048) else "large-topic path (all kernels)"),
                 "kernel_ms": round(kern_ms, 4),
                 "algorithmic_bytes_per_partition": bpp,
                 "algorithmic_bytes_per_launch": bpp * n_part}

@@ -180,7 +180,7 @@ int enqueue_batch(la_ctx* ctx, const la_device_batch* b, hipStream_t stream) {
     const int64_t T = b->n_topics;
     auto psize = [&](int64_t i) { return b->h_part_off[i + 1] - b->h_part_off[i]; };
     auto csize = [&](int64_t i) { return b->h_cons_off[i + 1] - b->h_cons_off[i]; };
-    int64_t tile_mp = 0, tile_mc = 0, n_tile = 0, n_block[la::kBlockClasses] = {0, 0, 0};
+    int64_t tile_mp = 0, tile_mc = 0, n_tile = 0, n_block[la::kBlockClasses] = {};
     const bool use_block = !argmin && b->algo != LA_ALGO_ROUNDS_WIDE && T <= 0x7FFFFFFF;
     for (int64_t t = 0; t < T; ++t) {
         const int64_t p = psize(t), c = csize(t);
@@ -199,7 +199,8 @@ int enqueue_batch(la_ctx* ctx, const la_device_batch* b, hipStream_t stream) {
         next_counters(run);
         LA_HIP(ctx, la::wave_tile_launch(run, tile_mp, tile_mc, tile_mode, stream));
     }
-    const int64_t n_block_all = n_block[0] + n_block[1] + n_block[2];
+    int64_t n_block_all = 0;
+    for (int cls = 0; cls < la::kBlockClasses; ++cls) n_block_all += n_block[cls];
     if (n_block_all > 0) {
         // the lists, class by class, into a pinned slot -> device
         la_ctx::Stage& sg = ctx->stage[ctx->stage_next++ & 3u];
@@ -211,7 +212,8 @@ int enqueue_batch(la_ctx* ctx, const la_device_batch* b, hipStream_t stream) {
             LA_HIP(ctx, hipHostMalloc((void**)&sg.p, want * sizeof(int32_t), hipHostMallocDefault));
             sg.cap = want;
         }
-        int64_t at[la::kBlockClasses] = {0, n_block[0], n_block[0] + n_block[1]};
+        int64_t at[la::kBlockClasses] = {};
+        for (int cls = 1; cls < la::kBlockClasses; ++cls) at[cls] = at[cls - 1] + n_block[cls - 1];
         for (int64_t t = 0; t < T; ++t) {
             const int64_t p = psize(t), c = csize(t);
             if (!la::wave_tile_fits(p, c) && la::block_fits(p, c)) sg.p[at[la::block_class(p, c)]++] = (int32_t)t;

@@ -54,6 +54,79 @@ __device__ __forceinline__ int pow2ceil_dev(int x) {
     return x <= 1 ? 1 : 1 << (32 - __builtin_clz((unsigned)(x - 1)));
 }
 
+// ---- partition sort: kE records per thread in registers, slot = tid*kE + r --------------------------------
+// Classic bitonic network over n_eff = pow2ceil(P) slots (slots >= P hold an all-ones sentinel; a record equal
+// to it carries the same bits, so which of the two lands where does not matter).  Distances below kE stay in
+// registers, distances inside a wavefront go through DPP / permlane moves, only distances >= 64*kE cross
+// wavefronts through LDS (10 of the 91 steps at 8 192 slots).  Wavefronts wholly beyond n_eff only keep the
+// barriers company.
+constexpr int kE = 8;
+
+template <int JL>
+__device__ __forceinline__ void sort_lane_step(Rec (&rec)[kE], int tid, int k) {
+    if (JL * kE < k) {
+        const bool keep_min = (((tid & JL) == 0) == ((tid & (k / kE)) == 0));
+#pragma unroll
+        for (int r = 0; r < kE; ++r) cmpx_lanes<JL>(rec[r], keep_min);
+    }
+}
+
+template <int J>
+__device__ __forceinline__ void sort_reg_step(Rec (&rec)[kE], int tid, int k) {
+    if (J < k) {
+#pragma unroll
+        for (int r = 0; r < kE; ++r) {
+            if ((r & J) == 0) {
+                const bool asc = k < kE ? ((r & k) == 0) : ((tid & (k / kE)) == 0);
+                cmpx_regs(rec[r], rec[r | J], asc);
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ void block_sort_regs(Rec (&rec)[kE], int n_eff, int tid, int nt, uint64_t* s_key,
+                                                uint32_t* s_id) {
+    const bool active = (tid & ~(kWave - 1)) * kE < n_eff;               // wavefront-uniform
+    for (int k = 2; k <= n_eff; k <<= 1) {
+        for (int j = k >> 1; j >= kWave * kE; j >>= 1) {                  // across wavefronts: LDS, r-major slots
+            if (active) {
+#pragma unroll
+                for (int r = 0; r < kE; ++r) {
+                    s_key[r * nt + tid] = ((uint64_t)rec[r].hi << 32) | rec[r].lo;
+                    s_id[r * nt + tid] = rec[r].tb;
+                }
+            }
+            __syncthreads();
+            if (active) {
+                const int pt = tid ^ (j / kE);
+                const bool keep_min = (((tid & (j / kE)) == 0) == ((tid & (k / kE)) == 0));
+#pragma unroll
+                for (int r = 0; r < kE; ++r) {
+                    const uint64_t ok = s_key[r * nt + pt];
+                    Rec o;
+                    o.hi = (uint32_t)(ok >> 32); o.lo = (uint32_t)ok; o.tb = s_id[r * nt + pt];
+                    const bool take = (rec_less(o, rec[r]) == keep_min);
+                    rec[r].hi = take ? o.hi : rec[r].hi;
+                    rec[r].lo = take ? o.lo : rec[r].lo;
+                    rec[r].tb = take ? o.tb : rec[r].tb;
+                }
+            }
+            __syncthreads();
+        }
+        if (active) {
+            sort_lane_step<32>(rec, tid, k);
+            sort_lane_step<16>(rec, tid, k);
+            sort_lane_step<8>(rec, tid, k);
+            sort_lane_step<4>(rec, tid, k);
+            sort_lane_step<2>(rec, tid, k);
+            sort_lane_step<1>(rec, tid, k);
+            sort_reg_step<4>(rec, tid, k);
+            sort_reg_step<2>(rec, tid, k);
+            sort_reg_step<1>(rec, tid, k);
+        }
+    }
+}
+
 // Greedy rounds for up to 256 consumers: one wavefront, bins in registers (EC per lane, slot = lane*EC + r),
 // sorted by the DPP / permlane networks of la_device.h -- no LDS traffic and no barrier between rounds.
 // Slots >= C hold an all-ones sentinel (a real bin's index is < C, so it never equals it).  L = lanes in use
@@ -126,35 +199,47 @@ __global__ __launch_bounds__(1024) void block_topic_kernel(BlockArgs a) {
     const int P = (int)Pl, C = (int)Cl;
     const bool latest = a.reset_latest != 0;
 
-    // ---- records --------------------------------------------------------------------------------------
-    for (int i = tid; i < P; i += nt) {
-        const int64_t g = p0 + i;
-        int64_t lag;
-        if (a.lag) {
-            lag = a.lag[g];
-        } else {
-            const int64_t cm = a.committed[g];
-            const int64_t bg = (cm < 0 && !latest && a.begin) ? a.begin[g] : 0;
-            lag = partition_lag(bg, a.end[g], cm, latest);
+    // ---- records: coalesced loads straight into the sort's registers (the sort does not care where a record
+    // starts), lag fused in --------------------------------------------------------------------------------
+    const int n_eff = pow2ceil_dev(P);
+    const int nt_eff = n_eff > kE ? n_eff / kE : 1;                     // threads holding slots < n_eff
+    Rec rec[kE];
+#pragma unroll
+    for (int r = 0; r < kE; ++r) {
+        const int src = r * nt_eff + tid;
+        rec[r].hi = rec[r].lo = rec[r].tb = 0xFFFFFFFFu;
+        if (tid < nt_eff && src < P) {
+            const int64_t g = p0 + src;
+            int64_t lag;
+            if (a.lag) {
+                lag = a.lag[g];
+            } else {
+                const int64_t cm = a.committed[g];
+                const int64_t bg = (cm < 0 && !latest && a.begin) ? a.begin[g] : 0;
+                lag = partition_lag(bg, a.end[g], cm, latest);
+            }
+            const uint64_t key = (uint64_t)lag ^ kLagKeyFlip;
+            rec[r].hi = (uint32_t)(key >> 32);
+            rec[r].lo = (uint32_t)key;
+            rec[r].tb = (uint32_t)a.pid[g] ^ kPidBias;
         }
-        s_key[i] = (uint64_t)lag ^ kLagKeyFlip;
-        s_id[i] = (uint32_t)a.pid[g] ^ kPidBias;
+    }
+
+    // ---- sort by (lag desc, partition asc), then lay the sorted records out in LDS by position -----------
+    block_sort_regs(rec, n_eff, tid, nt, s_key, s_id);
+#pragma unroll
+    for (int r = 0; r < kE; ++r) {
+        const int i = tid * kE + r;
+        if (i < P) {
+            s_key[i] = ((uint64_t)rec[r].hi << 32) | rec[r].lo;
+            s_id[i] = rec[r].tb;
+        }
     }
     for (int i = tid; i < C; i += nt) {
         s_tot[i] = kTotalBias;                                          // total 0
         s_idx[i] = (uint32_t)i;
         s_rank[i] = a.cons_rank[c0 + i];
     }
-
-    // ---- sort by (lag desc, partition asc) ------------------------------------------------------------
-    lds_bitonic_sort(pow2ceil_dev(P), P, tid, nt, false, [&](int i, int p) {
-        const uint64_t ka = s_key[i], kb = s_key[p];
-        const uint32_t ia = s_id[i], ib = s_id[p];
-        if ((kb < ka) | ((kb == ka) & (ib < ia))) {
-            s_key[i] = kb; s_key[p] = ka;
-            s_id[i] = ib; s_id[p] = ia;
-        }
-    });
     __syncthreads();
     for (int s = tid; s < P; s += nt) {
         a.out_pid[p0 + s] = (int32_t)(s_id[s] ^ kPidBias);
@@ -227,15 +312,17 @@ __global__ __launch_bounds__(1024) void block_topic_kernel(BlockArgs a) {
 bool block_fits(int64_t p, int64_t c) { return p <= kBlockMaxPartitions && c <= kBlockMaxConsumers; }
 
 int block_class(int64_t p, int64_t c) {
-    if (p <= 2048 && c <= 256) return 0;
-    if (p <= 4096 && c <= 1024) return 1;
-    return 2;
+    if (p <= 512 && c <= 256) return 0;
+    if (p <= 2048 && c <= 256) return 1;
+    if (p <= 4096 && c <= 1024) return 2;
+    return 3;
 }
 
 hipError_t block_launch(BlockArgs a, int cls, hipStream_t stream) {
-    static const int kThreads[kBlockClasses] = {256, 512, 1024};
-    static const int kNp[kBlockClasses] = {2048, 4096, (int)kBlockMaxPartitions};
-    static const int kNc[kBlockClasses] = {256, 1024, (int)kBlockMaxConsumers};
+    // workgroup size = np_cap / kE; the small classes leave room for many workgroups per CU
+    static const int kThreads[kBlockClasses] = {64, 256, 512, 1024};
+    static const int kNp[kBlockClasses] = {512, 2048, 4096, (int)kBlockMaxPartitions};
+    static const int kNc[kBlockClasses] = {256, 256, 1024, (int)kBlockMaxConsumers};
     if (a.n_list <= 0) return hipSuccess;
     if (cls < 0 || cls >= kBlockClasses) return hipErrorInvalidValue;
     a.np_cap = kNp[cls];

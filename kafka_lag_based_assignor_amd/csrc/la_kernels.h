@@ -61,7 +61,7 @@ hipError_t check_consumers_launch(int64_t n_topics, const int64_t* cons_off, con
 // ---- block path (la_block.hip): one workgroup per topic, everything in LDS --------------------
 constexpr int64_t kBlockMaxPartitions = 8192;
 constexpr int64_t kBlockMaxConsumers = 2048;
-constexpr int kBlockClasses = 3;               // LDS / workgroup size classes, see block_class()
+constexpr int kBlockClasses = 4;               // LDS / workgroup size classes, see block_class()
 
 struct BlockArgs {
     const int64_t* part_off;    // the batch's offsets (device)
