@@ -82,6 +82,12 @@ extern "C" {
 #define LA_FLAG_INDEX64      1  /* 64-bit element indexing even when 32-bit offsets would do   */
 #define LA_FLAG_DEFER_WIDE   2  /* never the single-launch form for small batches: tiles that  *
                                  * cannot use packed records go through the deferred-tile list */
+#define LA_FLAG_RAGGED       4  /* topic shapes vary a lot: with h_part_off / h_cons_off given, let the  *
+                                 * library group tile-sized topics by shape (one launch per class over  *
+                                 * a topic list) instead of running all of them at the largest shape.   *
+                                 * la_assign_batch decides this itself from the offsets.                */
+#define LA_FLAG_SHAPE_CLASSES 8 /* with LA_FLAG_RAGGED: always one launch per non-empty shape class,     *
+                                 * whatever the cost estimate says (test hook)                          */
 
 typedef struct la_ctx la_ctx;
 
@@ -151,8 +157,13 @@ typedef struct la_device_batch {
     int32_t *d_out_member_rank;      /* [N]                                              */
     int64_t *d_out_total_lag;        /* [K] or NULL                                      */
     /* host copies of the two offset arrays; required only when the shape hint exceeds
-     * what one wavefront tile holds (1024 partitions or 64 consumers per topic), where
-     * topics are dispatched one by one.  NULL otherwise. */
+     * what one wavefront tile holds (1024 partitions or 64 consumers per topic): the
+     * library then looks at every topic's size on the host (a few ns per topic) and
+     * sends it down the wave-tile path, the block path (one workgroup per topic, up to
+     * 8192 partitions x 2048 consumers, all such topics side by side) or the large path
+     * (device-wide sort, one topic after another).  Also read when LA_FLAG_RAGGED is set.
+     * NULL otherwise.  Calls on one context are expected to be stream-ordered: the
+     * per-call topic lists live in context-owned device memory. */
     const int64_t *h_part_off;
     const int64_t *h_cons_off;
 } la_device_batch;

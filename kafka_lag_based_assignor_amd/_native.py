@@ -18,7 +18,7 @@ LA_OK = 0
 LA_EINVAL, LA_ENOMEM, LA_EHIP, LA_ENODEV, LA_ESHAPE = -1, -2, -3, -4, -5
 LA_RESET_LATEST, LA_RESET_EARLIEST = 0, 1
 LA_ALGO_AUTO, LA_ALGO_ROUNDS, LA_ALGO_ARGMIN, LA_ALGO_ROUNDS_WIDE = 0, 1, 2, 3
-LA_FLAG_INDEX64, LA_FLAG_DEFER_WIDE = 1, 2
+LA_FLAG_INDEX64, LA_FLAG_DEFER_WIDE, LA_FLAG_RAGGED, LA_FLAG_SHAPE_CLASSES = 1, 2, 4, 8
 
 EXPORTED_SYMBOLS = (
     "la_create", "la_destroy", "la_last_error", "la_version", "la_compute_lag",

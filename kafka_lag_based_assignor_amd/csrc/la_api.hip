@@ -50,6 +50,7 @@ struct la_ctx {
         hipEvent_t done = nullptr;
     } stage[4];
     unsigned stage_next = 0;
+    std::vector<uint8_t> topic_class;   // host scratch of the dispatcher: path / class of every topic
 };
 
 namespace {
@@ -143,6 +144,7 @@ int enqueue_batch(la_ctx* ctx, const la_device_batch* b, hipStream_t stream) {
     a.reset_latest = (b->reset_mode == LA_RESET_LATEST) ? 1 : 0;
     a.n_total = b->n_partitions;
     a.flags = b->flags & (LA_FLAG_INDEX64 | LA_FLAG_DEFER_WIDE);
+    a.topic_list = nullptr;
     a.k_total = b->n_consumers;
     if (int rc = reserve(ctx, ctx->defer, la::wave_tile_defer_bytes(b->n_topics))) return rc;
     a.defer_list = (int32_t*)ctx->defer.p;
@@ -163,16 +165,22 @@ int enqueue_batch(la_ctx* ctx, const la_device_batch* b, hipStream_t stream) {
             LA_HIP(ctx, hipMemsetAsync(b->d_out_total_lag, 0, (size_t)b->n_consumers * sizeof(int64_t), stream));
         return LA_OK;
     }
-    if (la::wave_tile_fits(b->max_partitions_per_topic, b->max_consumers_per_topic)) {
+    const bool have_host = b->h_part_off && b->h_cons_off;
+    const bool fits_hint = la::wave_tile_fits(b->max_partitions_per_topic, b->max_consumers_per_topic);
+    if (fits_hint && !(have_host && (b->flags & LA_FLAG_RAGGED) && tile_mode == 0)) {
         next_counters(a);
         LA_HIP(ctx, la::wave_tile_launch(a, b->max_partitions_per_topic, b->max_consumers_per_topic, tile_mode, stream));
         return LA_OK;
     }
 
-    // Mixed shapes: classify the topics on the host.  Tile-sized topics: ONE wave-tile launch over the whole
-    // batch that skips the others.  Up to 8 192 partitions x 2 048 consumers: the block path, one workgroup
-    // per topic, one launch per size class.  Beyond: the large path, topic by topic.
-    if (!b->h_part_off || !b->h_cons_off)
+    // Mixed or ragged shapes: classify the topics on the host.
+    //   * tile-sized topics: one wave-tile launch over the whole batch that skips the others -- or, when the
+    //     shapes are ragged enough to pay for it, one launch per shape class over a topic list, so that a few
+    //     wide topics do not make every topic pay for the widest tile;
+    //   * up to 8 192 partitions x 2 048 consumers: the block path, one workgroup per topic, one launch per
+    //     size class;
+    //   * beyond: the large path, topic by topic.
+    if (!have_host)
         return fail(ctx, LA_EINVAL,
                     "shape hint exceeds one wave tile (%lld partitions / %lld consumers per topic): "
                     "h_part_off and h_cons_off are required",
@@ -180,50 +188,129 @@ int enqueue_batch(la_ctx* ctx, const la_device_batch* b, hipStream_t stream) {
     const int64_t T = b->n_topics;
     auto psize = [&](int64_t i) { return b->h_part_off[i + 1] - b->h_part_off[i]; };
     auto csize = [&](int64_t i) { return b->h_cons_off[i + 1] - b->h_cons_off[i]; };
-    int64_t tile_mp = 0, tile_mc = 0, n_tile = 0, n_block[la::kBlockClasses] = {};
+    constexpr int kTileClasses = 3;
+    static const int64_t kClsP[kTileClasses] = {64, 256, la::kTileMaxPartitions};
+    static const int64_t kClsC[kTileClasses] = {8, 32, la::kTileMaxConsumers};
+    struct { int64_t n = 0, mp = 0, mc = 0; } tcls[kTileClasses];
+    int64_t n_block[la::kBlockClasses] = {};
     const bool use_block = !argmin && b->algo != LA_ALGO_ROUNDS_WIDE && T <= 0x7FFFFFFF;
-    for (int64_t t = 0; t < T; ++t) {
-        const int64_t p = psize(t), c = csize(t);
-        if (p < 0 || c < 0) return fail(ctx, LA_EINVAL, "offsets of topic %lld decrease", (long long)t);
-        if (la::wave_tile_fits(p, c)) {
-            ++n_tile;
-            if (p > tile_mp) tile_mp = p;
-            if (c > tile_mc) tile_mc = c;
-        } else if (use_block && la::block_fits(p, c)) {
-            ++n_block[la::block_class(p, c)];
+    // one pass over the offsets: a class code per topic (0..2 tile classes, 3..6 block classes, 7 large)
+    constexpr uint8_t kLargeCode = kTileClasses + la::kBlockClasses;
+    ctx->topic_class.resize((size_t)T);
+    uint8_t* code = ctx->topic_class.data();
+    {
+        int64_t cnt[kLargeCode + 1] = {};
+        int64_t mp[kTileClasses] = {}, mc[kTileClasses] = {};
+        bool decreasing = false;
+        const int64_t* po = b->h_part_off;
+        const int64_t* co = b->h_cons_off;
+        for (int64_t t = 0; t < T; ++t) {
+            const int64_t p = po[t + 1] - po[t], c = co[t + 1] - co[t];
+            decreasing |= (p < 0) | (c < 0);
+            uint8_t k;
+            if (p <= kClsP[0] && c <= kClsC[0]) k = 0;
+            else if (p <= kClsP[1] && c <= kClsC[1]) k = 1;
+            else if (p <= kClsP[2] && c <= kClsC[2]) k = 2;
+            else if (use_block && la::block_fits(p, c)) k = (uint8_t)(kTileClasses + la::block_class(p, c));
+            else k = kLargeCode;
+            code[t] = k;
+            ++cnt[k];
+            if (k < kTileClasses) {
+                if (p > mp[k]) mp[k] = p;
+                if (c > mc[k]) mc[k] = c;
+            }
         }
+        if (decreasing) return fail(ctx, LA_EINVAL, "part_off / cons_off decrease");
+        for (int k = 0; k < kTileClasses; ++k) { tcls[k].n = cnt[k]; tcls[k].mp = mp[k]; tcls[k].mc = mc[k]; }
+        for (int k = 0; k < la::kBlockClasses; ++k) n_block[k] = cnt[kTileClasses + k];
     }
-    if (n_tile > 0) {
-        la::TileArgs run = a;
-        run.flags |= la::kTileSkipOversize;
-        next_counters(run);
-        LA_HIP(ctx, la::wave_tile_launch(run, tile_mp, tile_mc, tile_mode, stream));
+    // tile plan: sort slots a launch spends = topics x lanes x records per lane of its tile shape
+    auto work = [&](int64_t n, int64_t mp, int64_t mc) {
+        int L = 0, E = 0;
+        la::wave_tile_pick(mp, mc, &L, &E);
+        return (double)n * L * E;
+    };
+    int64_t n_tile = 0, all_mp = 0, all_mc = 0;
+    for (const auto& k : tcls) {
+        n_tile += k.n;
+        if (k.mp > all_mp) all_mp = k.mp;
+        if (k.mc > all_mc) all_mc = k.mc;
     }
+    int merged[kTileClasses] = {0, 1, 2};                               // class -> the class it is launched with
+    bool classed = false;
+    const bool force_classes = (b->flags & LA_FLAG_SHAPE_CLASSES) != 0;
+    if (tile_mode == 0 && (n_tile >= 4096 || force_classes) && T <= 0x7FFFFFFF) {
+        for (int k = 0; k + 1 < kTileClasses; ++k) {                    // a launch is not worth a handful of topics
+            if (tcls[k].n > 0 && tcls[k].n < 1024 && !force_classes) {
+                tcls[k + 1].n += tcls[k].n;
+                if (tcls[k].mp > tcls[k + 1].mp) tcls[k + 1].mp = tcls[k].mp;
+                if (tcls[k].mc > tcls[k + 1].mc) tcls[k + 1].mc = tcls[k].mc;
+                tcls[k].n = 0;
+                for (int q = 0; q <= k; ++q) if (merged[q] == k) merged[q] = k + 1;
+            }
+        }
+        double split = 0;
+        int launches = 0;
+        for (const auto& k : tcls) if (k.n > 0) { split += work(k.n, k.mp, k.mc); ++launches; }
+        // worth it when the sort slots saved (~12 ps each on the device) outweigh the second host pass over
+        // the topics (~2 ns each) and the extra launches
+        classed = launches >= 2 && (force_classes || work(n_tile, all_mp, all_mc) - split > 170.0 * (double)T + 8e6);
+    }
+
     int64_t n_block_all = 0;
     for (int cls = 0; cls < la::kBlockClasses; ++cls) n_block_all += n_block[cls];
-    if (n_block_all > 0) {
-        // the lists, class by class, into a pinned slot -> device
+    const int64_t n_lists = n_block_all + (classed ? n_tile : 0);
+    const int32_t* d_lists = nullptr;
+    int64_t tile_at[kTileClasses] = {};
+    if (n_lists > 0) {
+        // the lists (block classes, then tile classes) into a pinned slot -> device
         la_ctx::Stage& sg = ctx->stage[ctx->stage_next++ & 3u];
         if (sg.done) LA_HIP(ctx, hipEventSynchronize(sg.done));
         else LA_HIP(ctx, hipEventCreateWithFlags(&sg.done, hipEventDisableTiming));
-        if (sg.cap < (size_t)n_block_all) {
+        if (sg.cap < (size_t)n_lists) {
             if (sg.p) { LA_HIP(ctx, hipHostFree(sg.p)); sg.p = nullptr; sg.cap = 0; }
-            const size_t want = (size_t)n_block_all + (size_t)n_block_all / 2 + 64;
+            const size_t want = (size_t)n_lists + (size_t)n_lists / 2 + 64;
             LA_HIP(ctx, hipHostMalloc((void**)&sg.p, want * sizeof(int32_t), hipHostMallocDefault));
             sg.cap = want;
         }
         int64_t at[la::kBlockClasses] = {};
         for (int cls = 1; cls < la::kBlockClasses; ++cls) at[cls] = at[cls - 1] + n_block[cls - 1];
+        int64_t fill[kTileClasses] = {};
+        tile_at[0] = n_block_all;
+        for (int k = 1; k < kTileClasses; ++k) tile_at[k] = tile_at[k - 1] + tcls[k - 1].n;
+        for (int k = 0; k < kTileClasses; ++k) fill[k] = tile_at[k];
         for (int64_t t = 0; t < T; ++t) {
-            const int64_t p = psize(t), c = csize(t);
-            if (!la::wave_tile_fits(p, c) && la::block_fits(p, c)) sg.p[at[la::block_class(p, c)]++] = (int32_t)t;
+            const uint8_t k = code[t];
+            if (k < kTileClasses) {
+                if (classed) sg.p[fill[merged[k]]++] = (int32_t)t;
+            } else if (k < kLargeCode) {
+                sg.p[at[k - kTileClasses]++] = (int32_t)t;
+            }
         }
-        // a batch enqueued earlier on another stream may still read the device list: one list per call
-        // would need a ring on the device too; calls of one context are documented as stream-ordered
-        if (int rc = reserve(ctx, ctx->block_list, (size_t)n_block_all * sizeof(int32_t))) return rc;
-        LA_HIP(ctx, hipMemcpyAsync(ctx->block_list.p, sg.p, (size_t)n_block_all * sizeof(int32_t),
+        // calls of one context are stream-ordered (lagassign.h), so the device copy of the lists is free again
+        // by the time this copy runs
+        if (int rc = reserve(ctx, ctx->block_list, (size_t)n_lists * sizeof(int32_t))) return rc;
+        LA_HIP(ctx, hipMemcpyAsync(ctx->block_list.p, sg.p, (size_t)n_lists * sizeof(int32_t),
                                    hipMemcpyHostToDevice, stream));
         LA_HIP(ctx, hipEventRecord(sg.done, stream));
+        d_lists = (const int32_t*)ctx->block_list.p;
+    }
+    if (classed) {
+        for (int k = 0; k < kTileClasses; ++k) {
+            if (tcls[k].n == 0) continue;
+            la::TileArgs run = a;
+            run.n_topics = tcls[k].n;
+            run.topic_list = d_lists + tile_at[k];
+            next_counters(run);
+            LA_HIP(ctx, la::wave_tile_launch(run, tcls[k].mp, tcls[k].mc, tile_mode, stream));
+        }
+    } else if (n_tile > 0) {
+        la::TileArgs run = a;
+        run.flags |= la::kTileSkipOversize;
+        next_counters(run);
+        LA_HIP(ctx, la::wave_tile_launch(run, all_mp, all_mc, tile_mode, stream));
+    }
+    if (n_block_all > 0) {
         la::BlockArgs g{};
         g.part_off = b->d_part_off;
         g.cons_off = b->d_cons_off;
@@ -240,15 +327,14 @@ int enqueue_batch(la_ctx* ctx, const la_device_batch* b, hipStream_t stream) {
         g.reset_latest = a.reset_latest;
         int64_t first = 0;
         for (int cls = 0; cls < la::kBlockClasses; ++cls) {
-            g.list = (const int32_t*)ctx->block_list.p + first;
+            g.list = d_lists + first;
             g.n_list = (int32_t)n_block[cls];
             LA_HIP(ctx, la::block_launch(g, cls, stream));
             first += n_block[cls];
         }
     }
     for (int64_t t = 0; t < T; ++t) {
-        if (la::wave_tile_fits(psize(t), csize(t))) continue;
-        if (use_block && la::block_fits(psize(t), csize(t))) continue;
+        if (code[t] != kLargeCode) continue;
         {
             if (csize(t) > la::kLargeMaxConsumers)
                 return fail(ctx, LA_ESHAPE, "topic %lld has %lld consumers; at most %lld are supported",
@@ -359,6 +445,7 @@ int assign_host(la_ctx* ctx, int32_t T, const int64_t* part_off, const int32_t* 
     b.d_out_total_lag = out_total ? (int64_t*)ctx->out_total.p : nullptr;
     b.h_part_off = part_off;
     b.h_cons_off = cons_off;
+    b.flags = LA_FLAG_RAGGED;            // the offsets are on the host anyway: let the dispatcher look at the shapes
     if ((rc = enqueue_batch(ctx, &b, st))) return rc;
 
     if (s.n) {

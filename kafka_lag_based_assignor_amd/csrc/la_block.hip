@@ -309,15 +309,6 @@ __global__ __launch_bounds__(1024) void block_topic_kernel(BlockArgs a) {
 
 }  // namespace
 
-bool block_fits(int64_t p, int64_t c) { return p <= kBlockMaxPartitions && c <= kBlockMaxConsumers; }
-
-int block_class(int64_t p, int64_t c) {
-    if (p <= 512 && c <= 256) return 0;
-    if (p <= 2048 && c <= 256) return 1;
-    if (p <= 4096 && c <= 1024) return 2;
-    return 3;
-}
-
 hipError_t block_launch(BlockArgs a, int cls, hipStream_t stream) {
     // workgroup size = np_cap / kE; the small classes leave room for many workgroups per CU
     static const int kThreads[kBlockClasses] = {64, 256, 512, 1024};

@@ -37,6 +37,8 @@ struct TileArgs {
     int32_t flags;              // LA_FLAG_* of the batch (test hooks) | kTileSkipOversize
     // tiles the packed kernel leaves to the wide kernel (LA_ALGO_AUTO): a counter pair that alternates
     // per launch (the wide kernel zeroes the other one), and the list of tile ids
+    // non-null: slot s of the launch is topic topic_list[s] (shape classes of a ragged batch); null: topic s
+    const int32_t* topic_list;
     int32_t* defer_count;
     int32_t* defer_count_next;
     int32_t* defer_list;
@@ -45,7 +47,9 @@ struct TileArgs {
 // bytes of defer_list a launch over n_topics topics may need (one tile holds >= 1 topic)
 inline size_t wave_tile_defer_bytes(int64_t n_topics) { return (size_t)(n_topics > 0 ? n_topics : 1) * sizeof(int32_t); }
 
-bool wave_tile_fits(int64_t max_p, int64_t max_c);
+inline bool wave_tile_fits(int64_t max_p, int64_t max_c) {
+    return max_p <= kTileMaxPartitions && max_c <= kTileMaxConsumers;
+}
 void wave_tile_pick(int64_t max_p, int64_t max_c, int* L, int* E);
 // mode: 0 = rounds, record format picked per wavefront; 1 = rounds, wide records forced; 2 = literal argmin
 hipError_t wave_tile_launch(TileArgs a, int64_t max_p, int64_t max_c, int mode, hipStream_t stream);
@@ -82,8 +86,13 @@ struct BlockArgs {
     int32_t np_cap, nc_cap;     // LDS capacity in records / bins, set by the launcher
 };
 
-bool block_fits(int64_t partitions, int64_t consumers);
-int block_class(int64_t partitions, int64_t consumers);
+inline bool block_fits(int64_t p, int64_t c) { return p <= kBlockMaxPartitions && c <= kBlockMaxConsumers; }
+inline int block_class(int64_t p, int64_t c) {
+    if (p <= 512 && c <= 256) return 0;
+    if (p <= 2048 && c <= 256) return 1;
+    if (p <= 4096 && c <= 1024) return 2;
+    return 3;
+}
 hipError_t block_launch(BlockArgs a, int cls, hipStream_t stream);
 
 // ---- large-topic path (device-wide radix sort + one-workgroup greedy) ---------------------

@@ -16,10 +16,6 @@ static int pow2ceil(int64_t x) {
     return p;
 }
 
-bool wave_tile_fits(int64_t max_p, int64_t max_c) {
-    return max_p <= kTileMaxPartitions && max_c <= kTileMaxConsumers;
-}
-
 // Picks the tile: the narrowest group that holds the consumers (more topics per wave, more
 // of the sort in registers), at most 16 records per lane.
 void wave_tile_pick(int64_t max_p, int64_t max_c, int* L, int* E) {

@@ -511,7 +511,8 @@ __device__ __forceinline__ DescWords fetch_desc(const TileArgs& a, int64_t t, in
     const int64_t topic = t * Cfg::kGroupsPerWave + grp;
     DescWords w;
     w.exists = t < n_tiles && topic < a.n_topics;
-    const int64_t tc = w.exists ? topic : a.n_topics - 1;
+    int64_t tc = w.exists ? topic : a.n_topics - 1;
+    if (a.topic_list) tc = a.topic_list[tc];                           // uniform branch: null for plain batches
     w.p0 = a.part_off[tc]; w.p1 = a.part_off[tc + 1];
     w.c0 = a.cons_off[tc]; w.c1 = a.cons_off[tc + 1];
     return w;

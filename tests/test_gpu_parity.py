@@ -603,6 +603,60 @@ def test_fuzz_block_topics(ctx, seed):
         np.testing.assert_array_equal(g, e, err_msg="%s p=%d c=%d %s" % (what, p, c, kind))
 
 
+# ---- ragged batches: tile-sized topics grouped by shape class (one launch per class over a topic list) ------
+def _ragged_skewed(seed, t, big_every):
+    """Mostly tiny topics, every `big_every`-th one near the tile limit: the shape mix that makes classes pay."""
+    rng = np.random.default_rng(seed)
+    ps = rng.integers(0, 40, t)
+    cs = rng.integers(0, 7, t)
+    mid = rng.random(t) < 0.2
+    ps[mid] = rng.integers(65, 256, int(mid.sum()))
+    cs[mid] = rng.integers(1, 33, int(mid.sum()))
+    ps[::big_every] = rng.integers(600, 1025, ps[::big_every].size)
+    cs[::big_every] = rng.integers(1, 65, cs[::big_every].size)
+    part_off = np.concatenate([[0], np.cumsum(ps)]).astype(np.int64)
+    cons_off = np.concatenate([[0], np.cumsum(cs)]).astype(np.int64)
+    n = int(part_off[-1])
+    pid = np.concatenate([rng.permutation(int(p)) for p in ps]).astype(np.int32)
+    lag = rng.integers(0, 1 << 36, n).astype(np.int64)
+    lag[rng.integers(0, n, 50)] = -5                                  # a few tiles take the wide-record kernel
+    ranks = np.concatenate([np.sort(rng.choice(200, int(c), replace=False)) for c in cs]).astype(np.int32)
+    zeros = np.zeros(n, dtype=np.int64)
+    return synth.Workload("skewed", t, part_off, pid, zeros, lag.copy(), zeros, lag, cons_off, ranks,
+                          int(ps.max()), int(cs.max()))
+
+
+@pytest.mark.parametrize("t,big_every", [(6000, 3), (20000, 4), (5000, 1000), (300, 2)])
+def test_ragged_tile_batch_by_shape_class(ctx, t, big_every):
+    w = _ragged_skewed(t + big_every, t, big_every)
+    exp = oracle.assign_flat(w.part_off, w.partition_id, w.lag, w.cons_off, w.cons_rank)
+    got = ctx.assign_batch_lags(w.part_off, w.partition_id, w.lag, w.cons_off, w.cons_rank)   # host entry: classes itself
+    for g, e, what in zip(got, exp, ("partition order", "member", "totals")):
+        np.testing.assert_array_equal(g, e, err_msg=what)
+    forced = N.LA_FLAG_RAGGED | N.LA_FLAG_SHAPE_CLASSES
+    for flags in (0, N.LA_FLAG_RAGGED, forced, forced | N.LA_FLAG_INDEX64 | N.LA_FLAG_DEFER_WIDE):
+        got = _run_device(ctx, w, N.LA_ALGO_AUTO, use_lag=True, flags=flags)
+        for g, e, what in zip(got, exp, ("partition order", "member", "totals")):
+            np.testing.assert_array_equal(g, e, err_msg="%s flags=%d" % (what, flags))
+
+
+def test_ragged_batch_all_three_paths(ctx):
+    # shape classes for the tile-sized majority + block topics + one large topic in the same call
+    w = _ragged_skewed(5, 8000, 5)
+    rng = np.random.default_rng(6)
+    extra_p = [3000, 150, 20000]
+    extra_c = [40, 300, 10]
+    part_off = np.concatenate([w.part_off, w.part_off[-1] + np.cumsum(extra_p)]).astype(np.int64)
+    cons_off = np.concatenate([w.cons_off, w.cons_off[-1] + np.cumsum(extra_c)]).astype(np.int64)
+    pid = np.concatenate([w.partition_id] + [rng.permutation(p).astype(np.int32) for p in extra_p])
+    lag = np.concatenate([w.lag, rng.integers(0, 1 << 30, sum(extra_p)).astype(np.int64)])
+    ranks = np.concatenate([w.cons_rank] + [np.arange(c, dtype=np.int32) for c in extra_c])
+    exp = oracle.assign_flat(part_off, pid, lag, cons_off, ranks)
+    got = ctx.assign_batch_lags(part_off, pid, lag, cons_off, ranks)
+    for g, e, what in zip(got, exp, ("partition order", "member", "totals")):
+        np.testing.assert_array_equal(g, e, err_msg=what)
+
+
 # ---- committed fixtures: the HIP path against tests/golden/oracle_frozen.json -------------------------------
 def test_hip_path_matches_frozen_digests(ctx):
     import importlib.util
