@@ -59,11 +59,14 @@ enum : int { kModeAuto = 0, kModeWide = 1, kModeArgmin = 2 };
 #define LA_ABLATE 0
 #endif
 constexpr int kAblate = LA_ABLATE;
+#ifndef LA_WPB
+#define LA_WPB 4          // wavefronts per workgroup (1, 2 and 8 measured: see DESIGN.md)
+#endif
 
 template <int L, int E>
 struct TileCfg {
     static constexpr int kGroupsPerWave = kWave / L;
-    static constexpr int kWavesPerBlock = 4;
+    static constexpr int kWavesPerBlock = LA_WPB;
     static constexpr int kThreads = kWave * kWavesPerBlock;
     static constexpr int kTopicsPerBlock = kGroupsPerWave * kWavesPerBlock;
     static constexpr int kCap = L * E;                          // partitions per tile

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Long randomized parity sweep on the GPU (developer tool; the committed tests run a short version).
-    python tools/stress_gpu.py [n_tile_seeds] [n_large_seeds]
+    python tools/stress_gpu.py [n_tile_seeds] [n_large_seeds] [n_block_seeds]
 """
 import os, sys
 import numpy as np
@@ -14,6 +14,7 @@ from kafka_lag_based_assignor_amd import _native as N
 def main():
     nt = int(sys.argv[1]) if len(sys.argv) > 1 else 300
     nl = int(sys.argv[2]) if len(sys.argv) > 2 else 100
+    nb = int(sys.argv[3]) if len(sys.argv) > 3 else 300
     ctx = N.Context(0)
     bad = 0
     for seed in range(100, 100 + nt):
@@ -26,7 +27,20 @@ def main():
             tgp.test_fuzz_large_topics(ctx, seed)
         except AssertionError as e:
             bad += 1; print("LARGE seed", seed, "FAILED:", str(e)[:200])
-    print("stress done: %d tile + %d large seeds, %d failures" % (nt, nl, bad))
+    for seed in range(100, 100 + nb):
+        try:
+            tgp.test_fuzz_block_topics(ctx, seed)
+        except AssertionError as e:
+            bad += 1; print("BLOCK seed", seed, "FAILED:", str(e)[:200])
+    for seed in range(100, 100 + nb // 10):
+        rng = np.random.default_rng(seed)
+        try:
+            tgp.test_block_batches_mixed_with_tile_and_large_topics(ctx, seed, int(rng.choice([600, 1500, 3000, 9000])),
+                                                                    int(rng.choice([70, 100, 300, 2500])))
+            tgp.test_ragged_tile_batch_by_shape_class(ctx, int(rng.integers(300, 9000)), int(rng.choice([2, 3, 50])))
+        except AssertionError as e:
+            bad += 1; print("MIXED seed", seed, "FAILED:", str(e)[:200])
+    print("stress done: %d tile + %d large + %d block seeds, %d failures" % (nt, nl, nb, bad))
     ctx.close()
 
 if __name__ == "__main__":
