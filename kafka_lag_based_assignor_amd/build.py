@@ -25,7 +25,7 @@ SOURCES = ["la_api.hip", "la_lag.hip", "la_wave_tile.hip", "la_wave_tile_l8.hip"
            "la_wave_tile_l32.hip", "la_wave_tile_l64.hip", "la_large.hip", "la_block.hip"]
 HOST_SOURCES = ["host/lag_based_partition_assignor.cpp", "host/pybind_host.cpp"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden",
-         "-Wall", "-Wextra", "-Wno-unused-parameter"]
+         "-Wall", "-Wextra", "-Wno-unused-parameter"] + os.environ.get("LA_EXTRA_HIPCC_FLAGS", "").split()
 
 
 def _hipcc() -> str:
