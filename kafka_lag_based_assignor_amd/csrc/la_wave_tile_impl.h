@@ -547,8 +547,13 @@ __device__ __forceinline__ TopicDescT<IDX> load_desc(const TileArgs& a, int64_t 
 // list and left to kernel 2 -- except in the INLINE_WIDE build, used when the whole batch is one round of
 // resident workgroups: there occupancy does not matter, the wide code sits in the same kernel and the second
 // launch (the larger part of a small batch's latency) disappears.
+#ifdef LA_WPE   // lab hook: pin the packed kernel's wavefronts per SIMD (5..8 measured)
+#define LA_WPE_ATTR __attribute__((amdgpu_waves_per_eu(LA_WPE, LA_WPE)))
+#else
+#define LA_WPE_ATTR
+#endif
 template <int L, int E, typename IDX, bool INLINE_WIDE>
-__global__ __launch_bounds__(256) void wave_tile_packed_kernel(TileArgs a) {
+__global__ __launch_bounds__(256) LA_WPE_ATTR void wave_tile_packed_kernel(TileArgs a) {
     using Cfg = TileCfg<L, E>;
     __shared__ uint64_t lds[Cfg::kTopicsPerBlock * Cfg::kSlots];
     __shared__ int32_t rank_lds[Cfg::kTopicsPerBlock * L];
