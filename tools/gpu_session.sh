@@ -11,13 +11,13 @@ if [ -z "$SKIP_TESTS" ]; then
   timeout 900 python -m pytest tests -m gpu -x -q > $O/pytest.log 2>&1; echo "pytest exit $?" >> $O/pytest.log
   tail -5 $O/pytest.log
 fi
-timeout 300 python bench.py --steps 100 --warmup 20 > $O/bench.json 2> $O/bench.err; tail -2 $O/bench.json
-timeout 300 python bench.py --steps 100 --warmup 20 --reset-mode latest --no-cpu-baseline > $O/bench_latest.json 2>> $O/bench.err
-timeout 300 python bench.py --steps 100 --warmup 20 --algo wide --no-cpu-baseline > $O/bench_wide.json 2>> $O/bench.err
-timeout 300 python bench.py --steps 100 --warmup 20 --topics 100000 --partitions 64 --consumers 8 --dist uniform40 --no-cpu-baseline > $O/bench_cfg4.json 2>> $O/bench.err
+timeout 300 python bench.py > $O/bench.json 2> $O/bench.err; tail -2 $O/bench.json
+timeout 300 python bench.py --reset-mode latest --no-cpu-baseline > $O/bench_latest.json 2>> $O/bench.err
+timeout 300 python bench.py --algo wide --no-cpu-baseline > $O/bench_wide.json 2>> $O/bench.err
+timeout 300 python bench.py --topics 100000 --partitions 64 --consumers 8 --dist uniform40 --no-cpu-baseline > $O/bench_cfg4.json 2>> $O/bench.err
 cat $O/bench_latest.json $O/bench_wide.json $O/bench_cfg4.json | cut -c1-400
 cd /tmp
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python $R/bench.py --steps 100 --warmup 20 --no-cpu-baseline > $O/stats.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python $R/bench.py --no-cpu-baseline > $O/stats.log 2>&1
 PROBE="python $R/tools/pmc_probe.py $PROBE_ARGS"
 timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -- $PROBE > $O/pmc_fetch.log 2>&1
 timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -- $PROBE > $O/pmc_write.log 2>&1
