@@ -32,7 +32,7 @@ __global__ void init_kernel(int64_t n, int P, int64_t* begin, int64_t* end, int6
 
 int main(int argc, char** argv) {
     const int T = argc > 1 ? atoi(argv[1]) : 100000, P = argc > 2 ? atoi(argv[2]) : 256, C = argc > 3 ? atoi(argv[3]) : 32;
-    const int reps = 30;
+    const int reps = argc > 4 ? atoi(argv[4]) : 30;
     const int64_t n = (int64_t)T * P, k = (int64_t)T * C;
     int64_t *begin, *end, *com, *part_off, *cons_off, *out_total;
     int32_t *pid, *cons_rank, *out_pid, *out_rank;
@@ -60,7 +60,7 @@ int main(int argc, char** argv) {
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     for (int mode = 0; mode < 2; ++mode) {
-        for (int w = 0; w < 3; ++w) CK(la::wave_tile_launch(a, P, C, mode, 0));
+        for (int w = 0; w < (reps > 100 ? 300 : 3); ++w) CK(la::wave_tile_launch(a, P, C, mode, 0));
         CK(hipDeviceSynchronize());
         CK(hipEventRecord(e0, 0));
         for (int r = 0; r < reps; ++r) CK(la::wave_tile_launch(a, P, C, mode, 0));
