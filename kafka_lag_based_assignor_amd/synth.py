@@ -124,6 +124,13 @@ def config(name: str, scale: float = 1.0) -> Workload:
         return make_uniform("cfg5", 5, 1, s(1048576), 8192, "pareto")
     if name == "target":
         return make_uniform("target", 6, s(100000), 256, 32, "zipf")
+    # not in BASELINE.json: shapes between a wave tile and the large path (the block path of DESIGN.md 4.2b)
+    if name == "block_a":
+        return make_uniform("block_a", 7, s(200), 2000, 100, "uniform40")
+    if name == "block_b":
+        return make_uniform("block_b", 8, s(500), 200, 100, "zipf")
+    if name == "block_c":
+        return make_uniform("block_c", 9, s(20), 8000, 700, "pareto")
     raise ValueError(name)
 
 

@@ -24,6 +24,7 @@ CASES = [  # (config name, scale, reset mode)
     ("cfg1", 1.0, "lags"), ("cfg2a", 1.0, "lags"), ("cfg2b", 1.0, "latest"), ("cfg2b", 1.0, "earliest"),
     ("cfg3", 1.0, "latest"), ("cfg3", 1.0, "earliest"), ("cfg4", 0.01, "earliest"), ("cfg5", 1.0 / 64, "earliest"),
     ("target", 0.01, "latest"), ("target", 0.01, "earliest"),
+    ("block_a", 1.0, "earliest"), ("block_b", 1.0, "latest"), ("block_c", 1.0, "earliest"),
 ]
 
 
