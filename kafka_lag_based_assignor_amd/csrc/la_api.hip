@@ -112,6 +112,197 @@ int scan_shape(la_ctx* ctx, int32_t T, const int64_t* part_off, const int64_t* c
     return LA_OK;
 }
 
+// ---- dispatcher: which path every topic of a batch takes --------------------------------------------------
+//   * tile-sized topics (<= 1 024 partitions, <= 64 consumers): one wave-tile launch over the whole batch that
+//     skips the others -- or, when the shapes are ragged enough to pay for it, one launch per shape class over a
+//     topic list, so that a few wide topics do not make every topic pay for the widest tile;
+//   * up to 8 192 partitions x 2 048 consumers: the block path, one workgroup per topic, one launch per size
+//     class over a topic list;
+//   * beyond: the large path, topic by topic.
+constexpr int kTileClasses = 3;
+constexpr int64_t kTileClsP[kTileClasses] = {64, 256, la::kTileMaxPartitions};
+constexpr int64_t kTileClsC[kTileClasses] = {8, 32, la::kTileMaxConsumers};
+constexpr uint8_t kLargeCode = kTileClasses + la::kBlockClasses;      // codes: tile classes, block classes, large
+
+struct BatchPlan {
+    const uint8_t* code = nullptr;                                    // per topic
+    struct { int64_t n = 0, mp = 0, mc = 0; } tile[kTileClasses];     // after merging: what each launch holds
+    int merged[kTileClasses] = {0, 1, 2};                             // tile class -> the class it is launched with
+    bool classed = false;                                             // tile topics go by shape class (lists)
+    int64_t n_tile = 0, tile_mp = 0, tile_mc = 0;
+    int64_t n_block[la::kBlockClasses] = {};
+    int64_t n_block_all = 0, n_large = 0;
+    // offsets of the lists in the staged array: block classes first, then tile classes
+    int64_t block_at[la::kBlockClasses] = {}, tile_at[kTileClasses] = {};
+    int64_t n_lists = 0;
+};
+
+// One pass over the host offsets: a class code per topic, counts and maxima; then the tile plan.
+int plan_batch(la_ctx* ctx, const la_device_batch* b, int tile_mode, bool use_block, BatchPlan* plan) {
+    const int64_t T = b->n_topics;
+    ctx->topic_class.resize((size_t)T);
+    uint8_t* code = ctx->topic_class.data();
+    int64_t cnt[kLargeCode + 1] = {};
+    int64_t mp[kTileClasses] = {}, mc[kTileClasses] = {};
+    bool decreasing = false;
+    const int64_t* po = b->h_part_off;
+    const int64_t* co = b->h_cons_off;
+    for (int64_t t = 0; t < T; ++t) {
+        const int64_t p = po[t + 1] - po[t], c = co[t + 1] - co[t];
+        decreasing |= (p < 0) | (c < 0);
+        uint8_t k;
+        if (p <= kTileClsP[0] && c <= kTileClsC[0]) k = 0;
+        else if (p <= kTileClsP[1] && c <= kTileClsC[1]) k = 1;
+        else if (p <= kTileClsP[2] && c <= kTileClsC[2]) k = 2;
+        else if (use_block && la::block_fits(p, c)) k = (uint8_t)(kTileClasses + la::block_class(p, c));
+        else k = kLargeCode;
+        code[t] = k;
+        ++cnt[k];
+        if (k < kTileClasses) {
+            if (p > mp[k]) mp[k] = p;
+            if (c > mc[k]) mc[k] = c;
+        }
+    }
+    if (decreasing) return fail(ctx, LA_EINVAL, "part_off / cons_off decrease");
+    plan->code = code;
+    for (int k = 0; k < kTileClasses; ++k) {
+        plan->tile[k].n = cnt[k]; plan->tile[k].mp = mp[k]; plan->tile[k].mc = mc[k];
+        plan->n_tile += cnt[k];
+        if (mp[k] > plan->tile_mp) plan->tile_mp = mp[k];
+        if (mc[k] > plan->tile_mc) plan->tile_mc = mc[k];
+    }
+    for (int k = 0; k < la::kBlockClasses; ++k) {
+        plan->n_block[k] = cnt[kTileClasses + k];
+        plan->n_block_all += cnt[kTileClasses + k];
+    }
+    plan->n_large = cnt[kLargeCode];
+
+    // tile plan: the sort slots a launch spends = topics x lanes x records per lane of its tile shape
+    auto work = [](int64_t n, int64_t p, int64_t c) {
+        int L = 0, E = 0;
+        la::wave_tile_pick(p, c, &L, &E);
+        return (double)n * L * E;
+    };
+    const bool force = (b->flags & LA_FLAG_SHAPE_CLASSES) != 0;
+    if (tile_mode == 0 && (plan->n_tile >= 4096 || force)) {
+        for (int k = 0; k + 1 < kTileClasses; ++k) {                    // a launch is not worth a handful of topics
+            auto& lo = plan->tile[k];
+            auto& hi = plan->tile[k + 1];
+            if (lo.n > 0 && lo.n < 1024 && !force) {
+                hi.n += lo.n;
+                if (lo.mp > hi.mp) hi.mp = lo.mp;
+                if (lo.mc > hi.mc) hi.mc = lo.mc;
+                lo.n = 0;
+                for (int q = 0; q <= k; ++q) if (plan->merged[q] == k) plan->merged[q] = k + 1;
+            }
+        }
+        double split = 0;
+        int launches = 0;
+        for (const auto& k : plan->tile) if (k.n > 0) { split += work(k.n, k.mp, k.mc); ++launches; }
+        // worth it when the sort slots saved (~12 ps each on the device) outweigh the second host pass over
+        // the topics (~2 ns each) and the extra launches
+        plan->classed = launches >= 2 &&
+                        (force || work(plan->n_tile, plan->tile_mp, plan->tile_mc) - split > 170.0 * (double)T + 8e6);
+    }
+    for (int k = 1; k < la::kBlockClasses; ++k) plan->block_at[k] = plan->block_at[k - 1] + plan->n_block[k - 1];
+    plan->tile_at[0] = plan->n_block_all;
+    for (int k = 1; k < kTileClasses; ++k) plan->tile_at[k] = plan->tile_at[k - 1] + plan->tile[k - 1].n;
+    plan->n_lists = plan->n_block_all + (plan->classed ? plan->n_tile : 0);
+    return LA_OK;
+}
+
+// Second host pass: the topic lists, built in a pinned slot of the context's ring and copied to the device.
+int stage_topic_lists(la_ctx* ctx, const BatchPlan& plan, int64_t T, hipStream_t stream, const int32_t** d_lists) {
+    *d_lists = nullptr;
+    if (plan.n_lists == 0) return LA_OK;
+    la_ctx::Stage& sg = ctx->stage[ctx->stage_next++ & 3u];
+    if (sg.done) LA_HIP(ctx, hipEventSynchronize(sg.done));          // the copy that last read this slot
+    else LA_HIP(ctx, hipEventCreateWithFlags(&sg.done, hipEventDisableTiming));
+    if (sg.cap < (size_t)plan.n_lists) {
+        if (sg.p) { LA_HIP(ctx, hipHostFree(sg.p)); sg.p = nullptr; sg.cap = 0; }
+        const size_t want = (size_t)plan.n_lists + (size_t)plan.n_lists / 2 + 64;
+        LA_HIP(ctx, hipHostMalloc((void**)&sg.p, want * sizeof(int32_t), hipHostMallocDefault));
+        sg.cap = want;
+    }
+    int64_t block_fill[la::kBlockClasses], tile_fill[kTileClasses];
+    for (int k = 0; k < la::kBlockClasses; ++k) block_fill[k] = plan.block_at[k];
+    for (int k = 0; k < kTileClasses; ++k) tile_fill[k] = plan.tile_at[k];
+    for (int64_t t = 0; t < T; ++t) {
+        const uint8_t k = plan.code[t];
+        if (k < kTileClasses) {
+            if (plan.classed) sg.p[tile_fill[plan.merged[k]]++] = (int32_t)t;
+        } else if (k < kLargeCode) {
+            sg.p[block_fill[k - kTileClasses]++] = (int32_t)t;
+        }
+    }
+    // calls of one context are stream-ordered (lagassign.h), so the device copy of the lists is free again by
+    // the time this copy runs
+    if (int rc = reserve(ctx, ctx->block_list, (size_t)plan.n_lists * sizeof(int32_t))) return rc;
+    LA_HIP(ctx, hipMemcpyAsync(ctx->block_list.p, sg.p, (size_t)plan.n_lists * sizeof(int32_t), hipMemcpyHostToDevice,
+                               stream));
+    LA_HIP(ctx, hipEventRecord(sg.done, stream));
+    *d_lists = (const int32_t*)ctx->block_list.p;
+    return LA_OK;
+}
+
+int launch_block_topics(la_ctx* ctx, const la_device_batch* b, const BatchPlan& plan, const int32_t* d_lists,
+                        hipStream_t stream) {
+    la::BlockArgs g{};
+    g.part_off = b->d_part_off;
+    g.cons_off = b->d_cons_off;
+    g.pid = b->d_partition_id;
+    g.begin = b->d_begin_off;
+    g.end = b->d_end_off;
+    g.committed = b->d_committed_off;
+    g.lag = b->d_lag;
+    g.cons_rank = b->d_cons_rank;
+    g.out_pid = b->d_out_partition;
+    g.out_rank = b->d_out_member_rank;
+    g.out_total = b->d_out_total_lag;
+    g.status = ctx->d_status;
+    g.reset_latest = (b->reset_mode == LA_RESET_LATEST) ? 1 : 0;
+    for (int cls = 0; cls < la::kBlockClasses; ++cls) {
+        g.list = d_lists + plan.block_at[cls];
+        g.n_list = (int32_t)plan.n_block[cls];
+        LA_HIP(ctx, la::block_launch(g, cls, stream));
+    }
+    return LA_OK;
+}
+
+int launch_large_topics(la_ctx* ctx, const la_device_batch* b, const BatchPlan& plan, bool argmin, hipStream_t stream) {
+    for (int64_t t = 0; t < b->n_topics; ++t) {
+        if (plan.code[t] != kLargeCode) continue;
+        const int64_t p = b->h_part_off[t + 1] - b->h_part_off[t], c = b->h_cons_off[t + 1] - b->h_cons_off[t];
+        if (c > la::kLargeMaxConsumers)
+            return fail(ctx, LA_ESHAPE, "topic %lld has %lld consumers; at most %lld are supported", (long long)t,
+                        (long long)c, (long long)la::kLargeMaxConsumers);
+        if (p > 0x7FFFFFFF)
+            return fail(ctx, LA_ESHAPE, "topic %lld has %lld partitions; at most 2^31-1 are supported", (long long)t,
+                        (long long)p);
+        la::LargeArgs g{};
+        g.p0 = b->h_part_off[t];
+        g.n_part = p;
+        g.c0 = b->h_cons_off[t];
+        g.n_cons = c;
+        g.pid = b->d_partition_id;
+        g.begin = b->d_begin_off;
+        g.end = b->d_end_off;
+        g.committed = b->d_committed_off;
+        g.lag = b->d_lag;
+        g.cons_rank = b->d_cons_rank;
+        g.out_pid = b->d_out_partition;
+        g.out_rank = b->d_out_member_rank;
+        g.out_total = b->d_out_total_lag;
+        g.reset_latest = (b->reset_mode == LA_RESET_LATEST) ? 1 : 0;
+        g.status = ctx->d_status;
+        hipError_t e = la::large_topic_launch(ctx->large, g, argmin, stream);
+        if (e != hipSuccess)
+            return fail(ctx, e == hipErrorOutOfMemory ? LA_ENOMEM : LA_EHIP, "large topic %lld: %s", (long long)t,
+                        hipGetErrorString(e));
+    }
+    return LA_OK;
+}
+
 // The dispatcher shared by the host and device entry points.
 int enqueue_batch(la_ctx* ctx, const la_device_batch* b, hipStream_t stream) {
     if (b->n_topics < 0 || b->n_partitions < 0 || b->n_consumers < 0)
@@ -168,202 +359,42 @@ int enqueue_batch(la_ctx* ctx, const la_device_batch* b, hipStream_t stream) {
     const bool have_host = b->h_part_off && b->h_cons_off;
     const bool fits_hint = la::wave_tile_fits(b->max_partitions_per_topic, b->max_consumers_per_topic);
     if (fits_hint && !(have_host && (b->flags & LA_FLAG_RAGGED) && tile_mode == 0)) {
+        // the plain case: every topic fits a wave tile, one shape for all, nothing read on the host
         next_counters(a);
         LA_HIP(ctx, la::wave_tile_launch(a, b->max_partitions_per_topic, b->max_consumers_per_topic, tile_mode, stream));
         return LA_OK;
     }
-
-    // Mixed or ragged shapes: classify the topics on the host.
-    //   * tile-sized topics: one wave-tile launch over the whole batch that skips the others -- or, when the
-    //     shapes are ragged enough to pay for it, one launch per shape class over a topic list, so that a few
-    //     wide topics do not make every topic pay for the widest tile;
-    //   * up to 8 192 partitions x 2 048 consumers: the block path, one workgroup per topic, one launch per
-    //     size class;
-    //   * beyond: the large path, topic by topic.
     if (!have_host)
         return fail(ctx, LA_EINVAL,
                     "shape hint exceeds one wave tile (%lld partitions / %lld consumers per topic): "
                     "h_part_off and h_cons_off are required",
                     (long long)la::kTileMaxPartitions, (long long)la::kTileMaxConsumers);
-    const int64_t T = b->n_topics;
-    auto psize = [&](int64_t i) { return b->h_part_off[i + 1] - b->h_part_off[i]; };
-    auto csize = [&](int64_t i) { return b->h_cons_off[i + 1] - b->h_cons_off[i]; };
-    constexpr int kTileClasses = 3;
-    static const int64_t kClsP[kTileClasses] = {64, 256, la::kTileMaxPartitions};
-    static const int64_t kClsC[kTileClasses] = {8, 32, la::kTileMaxConsumers};
-    struct { int64_t n = 0, mp = 0, mc = 0; } tcls[kTileClasses];
-    int64_t n_block[la::kBlockClasses] = {};
-    const bool use_block = !argmin && b->algo != LA_ALGO_ROUNDS_WIDE && T <= 0x7FFFFFFF;
-    // one pass over the offsets: a class code per topic (0..2 tile classes, 3..6 block classes, 7 large)
-    constexpr uint8_t kLargeCode = kTileClasses + la::kBlockClasses;
-    ctx->topic_class.resize((size_t)T);
-    uint8_t* code = ctx->topic_class.data();
-    {
-        int64_t cnt[kLargeCode + 1] = {};
-        int64_t mp[kTileClasses] = {}, mc[kTileClasses] = {};
-        bool decreasing = false;
-        const int64_t* po = b->h_part_off;
-        const int64_t* co = b->h_cons_off;
-        for (int64_t t = 0; t < T; ++t) {
-            const int64_t p = po[t + 1] - po[t], c = co[t + 1] - co[t];
-            decreasing |= (p < 0) | (c < 0);
-            uint8_t k;
-            if (p <= kClsP[0] && c <= kClsC[0]) k = 0;
-            else if (p <= kClsP[1] && c <= kClsC[1]) k = 1;
-            else if (p <= kClsP[2] && c <= kClsC[2]) k = 2;
-            else if (use_block && la::block_fits(p, c)) k = (uint8_t)(kTileClasses + la::block_class(p, c));
-            else k = kLargeCode;
-            code[t] = k;
-            ++cnt[k];
-            if (k < kTileClasses) {
-                if (p > mp[k]) mp[k] = p;
-                if (c > mc[k]) mc[k] = c;
-            }
-        }
-        if (decreasing) return fail(ctx, LA_EINVAL, "part_off / cons_off decrease");
-        for (int k = 0; k < kTileClasses; ++k) { tcls[k].n = cnt[k]; tcls[k].mp = mp[k]; tcls[k].mc = mc[k]; }
-        for (int k = 0; k < la::kBlockClasses; ++k) n_block[k] = cnt[kTileClasses + k];
-    }
-    // tile plan: sort slots a launch spends = topics x lanes x records per lane of its tile shape
-    auto work = [&](int64_t n, int64_t mp, int64_t mc) {
-        int L = 0, E = 0;
-        la::wave_tile_pick(mp, mc, &L, &E);
-        return (double)n * L * E;
-    };
-    int64_t n_tile = 0, all_mp = 0, all_mc = 0;
-    for (const auto& k : tcls) {
-        n_tile += k.n;
-        if (k.mp > all_mp) all_mp = k.mp;
-        if (k.mc > all_mc) all_mc = k.mc;
-    }
-    int merged[kTileClasses] = {0, 1, 2};                               // class -> the class it is launched with
-    bool classed = false;
-    const bool force_classes = (b->flags & LA_FLAG_SHAPE_CLASSES) != 0;
-    if (tile_mode == 0 && (n_tile >= 4096 || force_classes) && T <= 0x7FFFFFFF) {
-        for (int k = 0; k + 1 < kTileClasses; ++k) {                    // a launch is not worth a handful of topics
-            if (tcls[k].n > 0 && tcls[k].n < 1024 && !force_classes) {
-                tcls[k + 1].n += tcls[k].n;
-                if (tcls[k].mp > tcls[k + 1].mp) tcls[k + 1].mp = tcls[k].mp;
-                if (tcls[k].mc > tcls[k + 1].mc) tcls[k + 1].mc = tcls[k].mc;
-                tcls[k].n = 0;
-                for (int q = 0; q <= k; ++q) if (merged[q] == k) merged[q] = k + 1;
-            }
-        }
-        double split = 0;
-        int launches = 0;
-        for (const auto& k : tcls) if (k.n > 0) { split += work(k.n, k.mp, k.mc); ++launches; }
-        // worth it when the sort slots saved (~12 ps each on the device) outweigh the second host pass over
-        // the topics (~2 ns each) and the extra launches
-        classed = launches >= 2 && (force_classes || work(n_tile, all_mp, all_mc) - split > 170.0 * (double)T + 8e6);
-    }
 
-    int64_t n_block_all = 0;
-    for (int cls = 0; cls < la::kBlockClasses; ++cls) n_block_all += n_block[cls];
-    const int64_t n_lists = n_block_all + (classed ? n_tile : 0);
+    // mixed or ragged shapes (see the dispatcher notes above)
+    const bool use_block = !argmin && b->algo != LA_ALGO_ROUNDS_WIDE;   // the test-hook algos keep to tile + large
+    BatchPlan plan;
+    if (int rc = plan_batch(ctx, b, tile_mode, use_block, &plan)) return rc;
     const int32_t* d_lists = nullptr;
-    int64_t tile_at[kTileClasses] = {};
-    if (n_lists > 0) {
-        // the lists (block classes, then tile classes) into a pinned slot -> device
-        la_ctx::Stage& sg = ctx->stage[ctx->stage_next++ & 3u];
-        if (sg.done) LA_HIP(ctx, hipEventSynchronize(sg.done));
-        else LA_HIP(ctx, hipEventCreateWithFlags(&sg.done, hipEventDisableTiming));
-        if (sg.cap < (size_t)n_lists) {
-            if (sg.p) { LA_HIP(ctx, hipHostFree(sg.p)); sg.p = nullptr; sg.cap = 0; }
-            const size_t want = (size_t)n_lists + (size_t)n_lists / 2 + 64;
-            LA_HIP(ctx, hipHostMalloc((void**)&sg.p, want * sizeof(int32_t), hipHostMallocDefault));
-            sg.cap = want;
-        }
-        int64_t at[la::kBlockClasses] = {};
-        for (int cls = 1; cls < la::kBlockClasses; ++cls) at[cls] = at[cls - 1] + n_block[cls - 1];
-        int64_t fill[kTileClasses] = {};
-        tile_at[0] = n_block_all;
-        for (int k = 1; k < kTileClasses; ++k) tile_at[k] = tile_at[k - 1] + tcls[k - 1].n;
-        for (int k = 0; k < kTileClasses; ++k) fill[k] = tile_at[k];
-        for (int64_t t = 0; t < T; ++t) {
-            const uint8_t k = code[t];
-            if (k < kTileClasses) {
-                if (classed) sg.p[fill[merged[k]]++] = (int32_t)t;
-            } else if (k < kLargeCode) {
-                sg.p[at[k - kTileClasses]++] = (int32_t)t;
-            }
-        }
-        // calls of one context are stream-ordered (lagassign.h), so the device copy of the lists is free again
-        // by the time this copy runs
-        if (int rc = reserve(ctx, ctx->block_list, (size_t)n_lists * sizeof(int32_t))) return rc;
-        LA_HIP(ctx, hipMemcpyAsync(ctx->block_list.p, sg.p, (size_t)n_lists * sizeof(int32_t),
-                                   hipMemcpyHostToDevice, stream));
-        LA_HIP(ctx, hipEventRecord(sg.done, stream));
-        d_lists = (const int32_t*)ctx->block_list.p;
-    }
-    if (classed) {
+    if (int rc = stage_topic_lists(ctx, plan, b->n_topics, stream, &d_lists)) return rc;
+    if (plan.classed) {
         for (int k = 0; k < kTileClasses; ++k) {
-            if (tcls[k].n == 0) continue;
+            if (plan.tile[k].n == 0) continue;
             la::TileArgs run = a;
-            run.n_topics = tcls[k].n;
-            run.topic_list = d_lists + tile_at[k];
+            run.n_topics = plan.tile[k].n;
+            run.topic_list = d_lists + plan.tile_at[k];
             next_counters(run);
-            LA_HIP(ctx, la::wave_tile_launch(run, tcls[k].mp, tcls[k].mc, tile_mode, stream));
+            LA_HIP(ctx, la::wave_tile_launch(run, plan.tile[k].mp, plan.tile[k].mc, tile_mode, stream));
         }
-    } else if (n_tile > 0) {
+    } else if (plan.n_tile > 0) {
         la::TileArgs run = a;
         run.flags |= la::kTileSkipOversize;
         next_counters(run);
-        LA_HIP(ctx, la::wave_tile_launch(run, all_mp, all_mc, tile_mode, stream));
+        LA_HIP(ctx, la::wave_tile_launch(run, plan.tile_mp, plan.tile_mc, tile_mode, stream));
     }
-    if (n_block_all > 0) {
-        la::BlockArgs g{};
-        g.part_off = b->d_part_off;
-        g.cons_off = b->d_cons_off;
-        g.pid = b->d_partition_id;
-        g.begin = b->d_begin_off;
-        g.end = b->d_end_off;
-        g.committed = b->d_committed_off;
-        g.lag = b->d_lag;
-        g.cons_rank = b->d_cons_rank;
-        g.out_pid = b->d_out_partition;
-        g.out_rank = b->d_out_member_rank;
-        g.out_total = b->d_out_total_lag;
-        g.status = ctx->d_status;
-        g.reset_latest = a.reset_latest;
-        int64_t first = 0;
-        for (int cls = 0; cls < la::kBlockClasses; ++cls) {
-            g.list = d_lists + first;
-            g.n_list = (int32_t)n_block[cls];
-            LA_HIP(ctx, la::block_launch(g, cls, stream));
-            first += n_block[cls];
-        }
-    }
-    for (int64_t t = 0; t < T; ++t) {
-        if (code[t] != kLargeCode) continue;
-        {
-            if (csize(t) > la::kLargeMaxConsumers)
-                return fail(ctx, LA_ESHAPE, "topic %lld has %lld consumers; at most %lld are supported",
-                            (long long)t, (long long)csize(t), (long long)la::kLargeMaxConsumers);
-            if (psize(t) > 0x7FFFFFFF)
-                return fail(ctx, LA_ESHAPE, "topic %lld has %lld partitions; at most 2^31-1 are supported",
-                            (long long)t, (long long)psize(t));
-            la::LargeArgs g{};
-            g.p0 = b->h_part_off[t];
-            g.n_part = psize(t);
-            g.c0 = b->h_cons_off[t];
-            g.n_cons = csize(t);
-            g.pid = b->d_partition_id;
-            g.begin = b->d_begin_off;
-            g.end = b->d_end_off;
-            g.committed = b->d_committed_off;
-            g.lag = b->d_lag;
-            g.cons_rank = b->d_cons_rank;
-            g.out_pid = b->d_out_partition;
-            g.out_rank = b->d_out_member_rank;
-            g.out_total = b->d_out_total_lag;
-            g.reset_latest = a.reset_latest;
-            g.status = ctx->d_status;
-            hipError_t e = la::large_topic_launch(ctx->large, g, argmin, stream);
-            if (e != hipSuccess)
-                return fail(ctx, e == hipErrorOutOfMemory ? LA_ENOMEM : LA_EHIP, "large topic %lld: %s",
-                            (long long)t, hipGetErrorString(e));
-        }
-    }
+    if (plan.n_block_all > 0)
+        if (int rc = launch_block_topics(ctx, b, plan, d_lists, stream)) return rc;
+    if (plan.n_large > 0)
+        if (int rc = launch_large_topics(ctx, b, plan, argmin, stream)) return rc;
     return LA_OK;
 }
 
