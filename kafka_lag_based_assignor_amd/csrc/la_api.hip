@@ -214,7 +214,7 @@ int plan_batch(la_ctx* ctx, const la_device_batch* b, int tile_mode, bool use_bl
 // Second host pass: the topic lists, built in a pinned slot of the context's ring and copied to the device.
 int stage_topic_lists(la_ctx* ctx, const BatchPlan& plan, int64_t T, hipStream_t stream, const int32_t** d_lists) {
     *d_lists = nullptr;
-    if (plan.n_lists == 0) return LA_OK;
+    if (plan.n_lists == 0 || (!plan.classed && plan.n_block_all <= 8)) return LA_OK;   // few block topics go inline
     la_ctx::Stage& sg = ctx->stage[ctx->stage_next++ & 3u];
     if (sg.done) LA_HIP(ctx, hipEventSynchronize(sg.done));          // the copy that last read this slot
     else LA_HIP(ctx, hipEventCreateWithFlags(&sg.done, hipEventDisableTiming));
@@ -261,6 +261,19 @@ int launch_block_topics(la_ctx* ctx, const la_device_batch* b, const BatchPlan& 
     g.out_total = b->d_out_total_lag;
     g.status = ctx->d_status;
     g.reset_latest = (b->reset_mode == LA_RESET_LATEST) ? 1 : 0;
+    if (!d_lists) {
+        // a handful of block topics: their indices travel in the kernel arguments (no copy, no event)
+        for (int cls = 0; cls < la::kBlockClasses; ++cls) {
+            if (plan.n_block[cls] == 0) continue;
+            int n = 0;
+            for (int64_t t = 0; t < b->n_topics && n < (int)plan.n_block[cls]; ++t)
+                if (plan.code[t] == kTileClasses + cls) g.inline_list[n++] = (int32_t)t;
+            g.list = nullptr;
+            g.n_list = n;
+            LA_HIP(ctx, la::block_launch(g, cls, stream));
+        }
+        return LA_OK;
+    }
     for (int cls = 0; cls < la::kBlockClasses; ++cls) {
         g.list = d_lists + plan.block_at[cls];
         g.n_list = (int32_t)plan.n_block[cls];

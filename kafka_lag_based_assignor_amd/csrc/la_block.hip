@@ -189,7 +189,7 @@ __global__ __launch_bounds__(1024) void block_topic_kernel(BlockArgs a) {
     int32_t* s_rank = reinterpret_cast<int32_t*>(s_idx + a.nc_cap);   // [nc_cap] consumer position -> member rank
 
     const int tid = threadIdx.x, nt = blockDim.x;
-    const int64_t topic = a.list[blockIdx.x];
+    const int64_t topic = a.list ? a.list[blockIdx.x] : a.inline_list[blockIdx.x & 7];
     const int64_t p0 = a.part_off[topic], c0 = a.cons_off[topic];
     const int64_t Pl = a.part_off[topic + 1] - p0, Cl = a.cons_off[topic + 1] - c0;
     if (Pl < 0 || Cl < 0 || Pl > a.np_cap || Cl > a.nc_cap) {           // the host's lists disagree with the

@@ -70,8 +70,9 @@ constexpr int kBlockClasses = 4;               // LDS / workgroup size classes, 
 struct BlockArgs {
     const int64_t* part_off;    // the batch's offsets (device)
     const int64_t* cons_off;
-    const int32_t* list;        // topic indices this launch handles (device)
+    const int32_t* list;        // topic indices this launch handles (device); null: inline_list
     int32_t n_list;
+    int32_t inline_list[8];     // a handful of topics travel in the kernel arguments: no list copy
     const int32_t* pid;
     const int64_t* begin;
     const int64_t* end;
