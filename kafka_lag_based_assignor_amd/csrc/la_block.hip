@@ -20,6 +20,7 @@
 // With at most 256 consumers the greedy runs in ONE wavefront with the bins in registers (greedy_one_wave).
 #include "la_device.h"
 #include "la_kernels.h"
+#include "la_sort64.h"
 
 namespace la {
 
@@ -180,6 +181,57 @@ __device__ __forceinline__ void greedy_one_wave(const BlockArgs& a, const uint64
     }
 }
 
+// The same with packed bins (total << idx_bits) | index -- one 64-bit word, sorted by the instruction-level
+// networks of la_sort64.h (4 VALU per compare-exchange step instead of ~14 for the 96-bit records).  Usable when
+// no lag is negative and no total can reach 2^62; the caller checks that on the sorted keys.
+template <int EC, int L>
+__device__ __forceinline__ void greedy_one_wave_packed(const BlockArgs& a, const uint64_t* s_key, const int32_t* s_rank,
+                                                       int64_t p0, int64_t c0, int P, int C, int idx_bits, int lane) {
+    const uint32_t idx_mask = (1u << idx_bits) - 1;
+    P64 bin[EC];
+    uint64_t lag[EC];
+#pragma unroll
+    for (int r = 0; r < EC; ++r) {
+        const int e = lane * EC + r;
+        bin[r] = p64_from(e < C ? (uint64_t)e : ~0ull);
+        lag[r] = (e < C && e < P) ? (s_key[e] ^ kLagKeyFlip) : 0;
+    }
+    const int rounds = (P + C - 1) / C;
+    for (int q = 0; q < rounds; ++q) {
+        uint64_t next[EC];
+#pragma unroll
+        for (int r = 0; r < EC; ++r) {
+            const int e = lane * EC + r;
+            const int s = (q + 1) * C + e;
+            next[r] = (e < C && s < P) ? (s_key[s] ^ kLagKeyFlip) : 0;
+        }
+        if (q > 0) {
+            // the networks read these registers through DPP: 2 wait states after their last compiler-generated write
+#pragma unroll
+            for (int r = 0; r < EC; ++r) asm volatile("s_nop 1" : "+v"(bin[r].lo), "+v"(bin[r].hi));
+            bitonic_sort_tile_p64<L, EC>(bin);
+        }
+#pragma unroll
+        for (int r = 0; r < EC; ++r) {
+            const int e = lane * EC + r;
+            const int s = q * C + e;
+            if (e < C && s < P) {
+                const uint64_t nb = p64_value(bin[r]) + (lag[r] << idx_bits);              // Main.java:265
+                bin[r] = p64_from(nb);
+                a.out_rank[p0 + s] = s_rank[(uint32_t)nb & idx_mask];
+            }
+            lag[r] = next[r];
+        }
+    }
+    if (a.out_total) {
+#pragma unroll
+        for (int r = 0; r < EC; ++r) {
+            const uint64_t v = p64_value(bin[r]);
+            if (v != ~0ull) a.out_total[c0 + ((uint32_t)v & idx_mask)] = (int64_t)(v >> idx_bits);
+        }
+    }
+}
+
 __global__ __launch_bounds__(1024) void block_topic_kernel(BlockArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint64_t smem64[];
     uint64_t* s_key = smem64;                                         // [np_cap] sorted partition keys
@@ -253,17 +305,29 @@ __global__ __launch_bounds__(1024) void block_topic_kernel(BlockArgs a) {
     const int n_c = pow2ceil_dev(C);
     if (n_c <= 4 * kWave) {
         if (tid < kWave) {
+            // packed bins when nothing can overflow: the keys are sorted, the first carries the largest lag and
+            // the last the smallest
+            const int64_t lmax = P > 0 ? (int64_t)(s_key[0] ^ kLagKeyFlip) : 0;
+            const int64_t lmin = P > 0 ? (int64_t)(s_key[P - 1] ^ kLagKeyFlip) : 0;
+            const int idx_bits = 31 - __builtin_clz((unsigned)n_c);
+            const int lag_bits = lmax > 0 ? 64 - __builtin_clzll((unsigned long long)lmax) : 0;
+            const int round_bits = 32 - __builtin_clz((unsigned)((P + C - 1) / C) | 1u);
+            const bool packed = lmin >= 0 && lag_bits + round_bits + idx_bits <= 62;
+#define LA_ONE_WAVE(EC, L)                                                                              \
+    if (packed) greedy_one_wave_packed<EC, L>(a, s_key, s_rank, p0, c0, P, C, idx_bits, tid);           \
+    else greedy_one_wave<EC, L>(a, s_key, s_rank, p0, c0, P, C, tid)
             switch (n_c) {                               // a fully unrolled network per width
-                case 1: greedy_one_wave<1, 1>(a, s_key, s_rank, p0, c0, P, C, tid); break;
-                case 2: greedy_one_wave<1, 2>(a, s_key, s_rank, p0, c0, P, C, tid); break;
-                case 4: greedy_one_wave<1, 4>(a, s_key, s_rank, p0, c0, P, C, tid); break;
-                case 8: greedy_one_wave<1, 8>(a, s_key, s_rank, p0, c0, P, C, tid); break;
-                case 16: greedy_one_wave<1, 16>(a, s_key, s_rank, p0, c0, P, C, tid); break;
-                case 32: greedy_one_wave<1, 32>(a, s_key, s_rank, p0, c0, P, C, tid); break;
-                case 64: greedy_one_wave<1, 64>(a, s_key, s_rank, p0, c0, P, C, tid); break;
-                case 128: greedy_one_wave<2, 64>(a, s_key, s_rank, p0, c0, P, C, tid); break;
-                default: greedy_one_wave<4, 64>(a, s_key, s_rank, p0, c0, P, C, tid); break;
+                case 1: LA_ONE_WAVE(1, 1); break;
+                case 2: LA_ONE_WAVE(1, 2); break;
+                case 4: LA_ONE_WAVE(1, 4); break;
+                case 8: LA_ONE_WAVE(1, 8); break;
+                case 16: LA_ONE_WAVE(1, 16); break;
+                case 32: LA_ONE_WAVE(1, 32); break;
+                case 64: LA_ONE_WAVE(1, 64); break;
+                case 128: LA_ONE_WAVE(2, 64); break;
+                default: LA_ONE_WAVE(4, 64); break;
             }
+#undef LA_ONE_WAVE
         }
         return;
     }
