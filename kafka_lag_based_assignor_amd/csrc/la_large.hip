@@ -409,15 +409,19 @@ __device__ __forceinline__ void dpp_fence(P64 (&rec)[EC]) {
     for (int r = 0; r < EC; ++r) asm volatile("s_nop 1" : "+v"(rec[r].lo), "+v"(rec[r].hi));
 }
 
+// LDS layout is register-major (slot r of thread t at r * blockDim + t): consecutive lanes touch consecutive
+// 8-byte words, where element order (t * EC + r) would put a 64-byte stride between lanes (16-way conflicts).
 template <int EC>
 __device__ __forceinline__ void cross_wave_step(P64 (&rec)[EC], uint64_t* s_bin, int tid, int mask, int min_bit) {
+    const int nt = blockDim.x;
 #pragma unroll
-    for (int r = 0; r < EC; ++r) s_bin[tid * EC + r] = p64_value(rec[r]);
+    for (int r = 0; r < EC; ++r) s_bin[r * nt + tid] = p64_value(rec[r]);
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < EC; ++r) {
         const int i = tid * EC + r;
-        const uint64_t o = s_bin[i ^ mask], x = p64_value(rec[r]);
+        const int pi = i ^ mask;                                     // partner element: thread pi / EC, register pi % EC
+        const uint64_t o = s_bin[(pi % EC) * nt + pi / EC], x = p64_value(rec[r]);
         const bool keep_min = (i & min_bit) == 0;
         const uint64_t lo = o < x ? o : x, hi = o < x ? x : o;
         rec[r] = p64_from(keep_min ? lo : hi);
