@@ -1,0 +1,49 @@
+"""Time batches of block-path topics (device entry, inputs resident): ms per call and assignments/s."""
+import sys, time, ctypes
+import numpy as np
+import torch
+sys.path.insert(0, ".")
+from kafka_lag_based_assignor_amd import _native as N
+
+dev = torch.device("cuda", 0)
+ctx = N.Context(0)
+rng = np.random.default_rng(1)
+
+def run(t, p, c, algo=N.LA_ALGO_AUTO, reps=5, lag_bits=34):
+    n, k = t * p, t * c
+    part_off = np.arange(t + 1, dtype=np.int64) * p
+    cons_off = np.arange(t + 1, dtype=np.int64) * c
+    pid = torch.argsort(torch.rand(t, p, device=dev), dim=1).to(torch.int32).reshape(-1).contiguous()
+    lag = torch.randint(0, 1 << lag_bits, (n,), device=dev, dtype=torch.int64)
+    ranks = torch.arange(c, device=dev, dtype=torch.int32).repeat(t).contiguous()
+    d_po, d_co = torch.from_numpy(part_off).to(dev), torch.from_numpy(cons_off).to(dev)
+    out_pid = torch.empty(n, device=dev, dtype=torch.int32); out_rank = torch.empty(n, device=dev, dtype=torch.int32)
+    out_total = torch.empty(max(k, 1), device=dev, dtype=torch.int64)
+    b = N.DeviceBatch()
+    b.n_topics, b.reset_mode, b.algo, b.flags = t, N.LA_RESET_LATEST, algo, 0
+    b.n_partitions, b.n_consumers = n, k
+    b.max_partitions_per_topic, b.max_consumers_per_topic = p, c
+    b.d_part_off, b.d_partition_id = d_po.data_ptr(), pid.data_ptr()
+    b.d_begin_off = b.d_end_off = b.d_committed_off = None
+    b.d_lag = lag.data_ptr()
+    b.d_cons_off, b.d_cons_rank = d_co.data_ptr(), ranks.data_ptr()
+    b.d_out_partition, b.d_out_member_rank, b.d_out_total_lag = out_pid.data_ptr(), out_rank.data_ptr(), out_total.data_ptr()
+    b.h_part_off = part_off.ctypes.data_as(ctypes.POINTER(ctypes.c_int64))
+    b.h_cons_off = cons_off.ctypes.data_as(ctypes.POINTER(ctypes.c_int64))
+    st = torch.cuda.current_stream().cuda_stream
+    ctx.assign_batch_device(b, st); ctx.sync(st)
+    best = 1e9
+    for _ in range(reps):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        ctx.assign_batch_device(b, st); ctx.sync(st)
+        best = min(best, time.perf_counter() - t0)
+    return best
+
+for (t, p, c) in [(1000, 2000, 100), (5000, 200, 100), (200, 8000, 16), (2000, 1000, 500), (64, 8192, 2048),
+                  (1, 2000, 100), (1, 8192, 2048), (20000, 100, 65), (300, 5000, 3), (1, 100, 65), (1, 1025, 8), (20000, 300, 10)]:
+    ms = run(t, p, c) * 1e3
+    print("T=%6d P=%5d C=%5d : %8.3f ms  %.3e assignments/s" % (t, p, c, ms, t * p / ms * 1e3), flush=True)
+print("-- P=8000 sweep over C")
+for c in (2000, 300, 100, 64, 16, 4):
+    ms = run(200, 8000, c) * 1e3
+    print("T=200 P=8000 C=%5d : %8.3f ms (%d rounds)" % (c, ms, -(-8000 // c)), flush=True)

@@ -1,0 +1,43 @@
+"""Time la_assign_batch on host buffers (target batch): python wrapper vs pre-touched outputs."""
+import sys, time, ctypes
+import numpy as np
+sys.path.insert(0, ".")
+from kafka_lag_based_assignor_amd import _native as N
+from kafka_lag_based_assignor_amd import synth
+
+w = synth.config("target")
+ctx = N.Context(0)
+lib = ctx._lib
+def p64(a): return None if a is None else a.ctypes.data_as(ctypes.POINTER(ctypes.c_int64))
+def p32(a): return a.ctypes.data_as(ctypes.POINTER(ctypes.c_int32))
+for rep in range(3):
+    t = time.perf_counter()
+    r = ctx.assign_batch(w.part_off, w.partition_id, w.begin, w.end, w.committed, N.LA_RESET_EARLIEST, w.cons_off, w.cons_rank)
+    print("wrapper, fresh outputs: %.1f ms" % ((time.perf_counter() - t) * 1e3))
+op = np.zeros(w.n_partitions, np.int32); om = np.zeros(w.n_partitions, np.int32); ot = np.zeros(w.cons_rank.size, np.int64)
+for rep in range(4):
+    t = time.perf_counter()
+    rc = lib.la_assign_batch(ctx._h, w.n_topics, p64(w.part_off), p32(w.partition_id), p64(w.begin), p64(w.end), p64(w.committed),
+                             N.LA_RESET_EARLIEST, p64(w.cons_off), p32(w.cons_rank), p32(op), p32(om), p64(ot))
+    dt = time.perf_counter() - t
+    print("C call, touched outputs: rc=%d %.1f ms  (%.2e assignments/s)" % (rc, dt * 1e3, w.n_partitions / dt))
+print("same result:", np.array_equal(op, r[0]), np.array_equal(om, r[1]), np.array_equal(ot, r[2]))
+if hasattr(lib, "la_host_alloc"):
+    lib.la_host_alloc.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_void_p)]
+    def pinned(a):
+        ptr = ctypes.c_void_p()
+        assert lib.la_host_alloc(ctx._h, a.nbytes, ctypes.byref(ptr)) == 0
+        buf = (ctypes.c_char * a.nbytes).from_address(ptr.value)
+        out = np.frombuffer(buf, dtype=a.dtype)
+        out[:] = a
+        return out
+    P = {k: pinned(getattr(w, k)) for k in ("part_off", "partition_id", "begin", "end", "committed", "cons_off", "cons_rank")}
+    pop, pom, pot = pinned(op * 0), pinned(om * 0), pinned(ot * 0)
+    for rep in range(4):
+        t = time.perf_counter()
+        rc = lib.la_assign_batch(ctx._h, w.n_topics, p64(P["part_off"]), p32(P["partition_id"]), p64(P["begin"]), p64(P["end"]),
+                                 p64(P["committed"]), N.LA_RESET_EARLIEST, p64(P["cons_off"]), p32(P["cons_rank"]),
+                                 p32(pop), p32(pom), p64(pot))
+        dt = time.perf_counter() - t
+        print("C call, pinned buffers: rc=%d %.1f ms  (%.2e assignments/s)" % (rc, dt * 1e3, w.n_partitions / dt))
+    print("same result:", np.array_equal(pop, r[0]), np.array_equal(pom, r[1]), np.array_equal(pot, r[2]))
