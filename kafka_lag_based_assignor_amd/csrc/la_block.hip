@@ -1,5 +1,5 @@
 // la_block.hip -- the block path: one workgroup per topic, for topics beyond a wave tile (more than 1 024
-// partitions or more than 64 consumers) up to kBlockMaxPartitions x kBlockMaxConsumers.  All such topics of a
+// partitions or more than 64 consumers) up to 8 192 x 2 048 (16 384 partitions with up to 1 024 consumers).  All such topics of a
 // batch run side by side (one launch per size class), where the large path (la_large.hip) would take them
 // one after another through a dozen device-wide kernels each.
 //
@@ -55,75 +55,85 @@ __device__ __forceinline__ int pow2ceil_dev(int x) {
     return x <= 1 ? 1 : 1 << (32 - __builtin_clz((unsigned)(x - 1)));
 }
 
-// ---- partition sort: kE records per thread in registers, slot = tid*kE + r --------------------------------
+// ---- partition sort: E records per thread in registers (8, or 16 in the largest class), slot = tid*E + r --------
 // Classic bitonic network over n_eff = pow2ceil(P) slots (slots >= P hold an all-ones sentinel; a record equal
-// to it carries the same bits, so which of the two lands where does not matter).  Distances below kE stay in
-// registers, distances inside a wavefront go through DPP / permlane moves, only distances >= 64*kE cross
+// to it carries the same bits, so which of the two lands where does not matter).  Distances below E stay in
+// registers, distances inside a wavefront go through DPP / permlane moves, only distances >= 64*E cross
 // wavefronts through LDS (10 of the 91 steps at 8 192 slots).  Wavefronts wholly beyond n_eff only keep the
 // barriers company.
-constexpr int kE = 8;
+constexpr int kXchg = 8;              // records per thread that cross wavefronts in one LDS exchange
 
-template <int JL>
-__device__ __forceinline__ void sort_lane_step(Rec (&rec)[kE], int tid, int k) {
-    if (JL * kE < k) {
-        const bool keep_min = (((tid & JL) == 0) == ((tid & (k / kE)) == 0));
+template <int JL, int E>
+__device__ __forceinline__ void sort_lane_step(Rec (&rec)[E], int tid, int k) {
+    if (JL * E < k) {
+        const bool keep_min = (((tid & JL) == 0) == ((tid & (k / E)) == 0));
 #pragma unroll
-        for (int r = 0; r < kE; ++r) cmpx_lanes<JL>(rec[r], keep_min);
+        for (int r = 0; r < E; ++r) cmpx_lanes<JL>(rec[r], keep_min);
     }
 }
 
-template <int J>
-__device__ __forceinline__ void sort_reg_step(Rec (&rec)[kE], int tid, int k) {
-    if (J < k) {
+template <int J, int E>
+__device__ __forceinline__ void sort_reg_step(Rec (&rec)[E], int tid, int k) {
+    if constexpr (J >= 1 && J < E) {
+        if (J < k) {
 #pragma unroll
-        for (int r = 0; r < kE; ++r) {
-            if ((r & J) == 0) {
-                const bool asc = k < kE ? ((r & k) == 0) : ((tid & (k / kE)) == 0);
-                cmpx_regs(rec[r], rec[r | J], asc);
+            for (int r = 0; r < E; ++r) {
+                if ((r & J) == 0) {
+                    const bool asc = k < E ? ((r & k) == 0) : ((tid & (k / E)) == 0);
+                    cmpx_regs(rec[r], rec[r | J], asc);
+                }
             }
         }
     }
 }
 
-__device__ __forceinline__ void block_sort_regs(Rec (&rec)[kE], int n_eff, int tid, int nt, uint64_t* s_key,
-                                                uint32_t* s_id) {
-    const bool active = (tid & ~(kWave - 1)) * kE < n_eff;               // wavefront-uniform
+// x_key / x_id: exchange area of kXchg * blockDim slots (register-major: slot r of thread t at r * blockDim + t,
+// so consecutive lanes touch consecutive words); with 16 records per thread the exchange runs in two halves.
+template <int E>
+__device__ __forceinline__ void block_sort_regs(Rec (&rec)[E], int n_eff, int tid, int nt, uint64_t* x_key,
+                                                uint32_t* x_id) {
+    const bool active = (tid & ~(kWave - 1)) * E < n_eff;                // wavefront-uniform
     for (int k = 2; k <= n_eff; k <<= 1) {
-        for (int j = k >> 1; j >= kWave * kE; j >>= 1) {                  // across wavefronts: LDS, r-major slots
-            if (active) {
+        for (int j = k >> 1; j >= kWave * E; j >>= 1) {                   // across wavefronts: LDS
+            const int pt = tid ^ (j / E);
+            const bool keep_min = (((tid & (j / E)) == 0) == ((tid & (k / E)) == 0));
 #pragma unroll
-                for (int r = 0; r < kE; ++r) {
-                    s_key[r * nt + tid] = ((uint64_t)rec[r].hi << 32) | rec[r].lo;
-                    s_id[r * nt + tid] = rec[r].tb;
-                }
-            }
-            __syncthreads();
-            if (active) {
-                const int pt = tid ^ (j / kE);
-                const bool keep_min = (((tid & (j / kE)) == 0) == ((tid & (k / kE)) == 0));
+            for (int h = 0; h < E; h += kXchg) {
+                if (active) {
 #pragma unroll
-                for (int r = 0; r < kE; ++r) {
-                    const uint64_t ok = s_key[r * nt + pt];
-                    Rec o;
-                    o.hi = (uint32_t)(ok >> 32); o.lo = (uint32_t)ok; o.tb = s_id[r * nt + pt];
-                    const bool take = (rec_less(o, rec[r]) == keep_min);
-                    rec[r].hi = take ? o.hi : rec[r].hi;
-                    rec[r].lo = take ? o.lo : rec[r].lo;
-                    rec[r].tb = take ? o.tb : rec[r].tb;
+                    for (int r = 0; r < kXchg; ++r) {
+                        x_key[r * nt + tid] = ((uint64_t)rec[h + r].hi << 32) | rec[h + r].lo;
+                        x_id[r * nt + tid] = rec[h + r].tb;
+                    }
                 }
+                __syncthreads();
+                if (active) {
+#pragma unroll
+                    for (int r = 0; r < kXchg; ++r) {
+                        const uint64_t ok = x_key[r * nt + pt];
+                        Rec o;
+                        o.hi = (uint32_t)(ok >> 32); o.lo = (uint32_t)ok; o.tb = x_id[r * nt + pt];
+                        Rec& mine = rec[h + r];
+                        const bool take = (rec_less(o, mine) == keep_min);
+                        mine.hi = take ? o.hi : mine.hi;
+                        mine.lo = take ? o.lo : mine.lo;
+                        mine.tb = take ? o.tb : mine.tb;
+                    }
+                }
+                __syncthreads();
             }
-            __syncthreads();
         }
         if (active) {
-            sort_lane_step<32>(rec, tid, k);
-            sort_lane_step<16>(rec, tid, k);
-            sort_lane_step<8>(rec, tid, k);
-            sort_lane_step<4>(rec, tid, k);
-            sort_lane_step<2>(rec, tid, k);
-            sort_lane_step<1>(rec, tid, k);
-            sort_reg_step<4>(rec, tid, k);
-            sort_reg_step<2>(rec, tid, k);
-            sort_reg_step<1>(rec, tid, k);
+            sort_lane_step<32, E>(rec, tid, k);
+            sort_lane_step<16, E>(rec, tid, k);
+            sort_lane_step<8, E>(rec, tid, k);
+            sort_lane_step<4, E>(rec, tid, k);
+            sort_lane_step<2, E>(rec, tid, k);
+            sort_lane_step<1, E>(rec, tid, k);
+            sort_reg_step<8, E>(rec, tid, k);
+            sort_reg_step<4, E>(rec, tid, k);
+            sort_reg_step<2, E>(rec, tid, k);
+            sort_reg_step<1, E>(rec, tid, k);
         }
     }
 }
@@ -232,12 +242,17 @@ __device__ __forceinline__ void greedy_one_wave_packed(const BlockArgs& a, const
     }
 }
 
+// LDS: [region A][bins].  Region A is the sort's exchange area (kXchg * blockDim keys + ids) and, once the sort is
+// done, the sorted keys by position (E * blockDim words); the ids leave through the registers.
+template <int E>
 __global__ __launch_bounds__(1024) void block_topic_kernel(BlockArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint64_t smem64[];
-    uint64_t* s_key = smem64;                                         // [np_cap] sorted partition keys
-    uint64_t* s_tot = s_key + a.np_cap;                               // [nc_cap] biased bin totals
-    uint32_t* s_id = reinterpret_cast<uint32_t*>(s_tot + a.nc_cap);   // [np_cap] biased partition ids
-    uint32_t* s_idx = s_id + a.np_cap;                                // [nc_cap] bin -> consumer position
+    const int region_a = (E * 8 > kXchg * 12 ? E * 8 : kXchg * 12) * (int)blockDim.x;   // bytes
+    uint64_t* s_key = smem64;                                         // sorted partition keys by position
+    uint64_t* x_key = smem64;                                         // exchange area of the sort
+    uint32_t* x_id = reinterpret_cast<uint32_t*>(x_key + kXchg * blockDim.x);
+    uint64_t* s_tot = smem64 + region_a / 8;                          // [nc_cap] biased bin totals
+    uint32_t* s_idx = reinterpret_cast<uint32_t*>(s_tot + a.nc_cap);  // [nc_cap] bin -> consumer position
     int32_t* s_rank = reinterpret_cast<int32_t*>(s_idx + a.nc_cap);   // [nc_cap] consumer position -> member rank
 
     const int tid = threadIdx.x, nt = blockDim.x;
@@ -254,10 +269,10 @@ __global__ __launch_bounds__(1024) void block_topic_kernel(BlockArgs a) {
     // ---- records: coalesced loads straight into the sort's registers (the sort does not care where a record
     // starts), lag fused in --------------------------------------------------------------------------------
     const int n_eff = pow2ceil_dev(P);
-    const int nt_eff = n_eff > kE ? n_eff / kE : 1;                     // threads holding slots < n_eff
-    Rec rec[kE];
+    const int nt_eff = n_eff > E ? n_eff / E : 1;                       // threads holding slots < n_eff
+    Rec rec[E];
 #pragma unroll
-    for (int r = 0; r < kE; ++r) {
+    for (int r = 0; r < E; ++r) {
         const int src = r * nt_eff + tid;
         rec[r].hi = rec[r].lo = rec[r].tb = 0xFFFFFFFFu;
         if (tid < nt_eff && src < P) {
@@ -277,14 +292,15 @@ __global__ __launch_bounds__(1024) void block_topic_kernel(BlockArgs a) {
         }
     }
 
-    // ---- sort by (lag desc, partition asc), then lay the sorted records out in LDS by position -----------
-    block_sort_regs(rec, n_eff, tid, nt, s_key, s_id);
+    // ---- sort by (lag desc, partition asc); the ids leave from the registers, the keys go to LDS by position --
+    block_sort_regs<E>(rec, n_eff, tid, nt, x_key, x_id);
 #pragma unroll
-    for (int r = 0; r < kE; ++r) {
-        const int i = tid * kE + r;
+    for (int r = 0; r < E; ++r) {
+        const int i = tid * E + r;
         if (i < P) {
             s_key[i] = ((uint64_t)rec[r].hi << 32) | rec[r].lo;
-            s_id[i] = rec[r].tb;
+            a.out_pid[p0 + i] = (int32_t)(rec[r].tb ^ kPidBias);
+            if (C == 0) a.out_rank[p0 + i] = -1;                        // Main.java:211-214: nobody to assign to
         }
     }
     for (int i = tid; i < C; i += nt) {
@@ -293,10 +309,6 @@ __global__ __launch_bounds__(1024) void block_topic_kernel(BlockArgs a) {
         s_rank[i] = a.cons_rank[c0 + i];
     }
     __syncthreads();
-    for (int s = tid; s < P; s += nt) {
-        a.out_pid[p0 + s] = (int32_t)(s_id[s] ^ kPidBias);
-        if (C == 0) a.out_rank[p0 + s] = -1;                            // Main.java:211-214: nobody to assign to
-    }
     if (C == 0) return;
 
     // ---- greedy rounds --------------------------------------------------------------------------------
@@ -374,23 +386,28 @@ __global__ __launch_bounds__(1024) void block_topic_kernel(BlockArgs a) {
 }  // namespace
 
 hipError_t block_launch(BlockArgs a, int cls, hipStream_t stream) {
-    // workgroup size = np_cap / kE; the small classes leave room for many workgroups per CU
-    static const int kThreads[kBlockClasses] = {64, 256, 512, 1024};
-    static const int kNp[kBlockClasses] = {512, 2048, 4096, (int)kBlockMaxPartitions};
-    static const int kNc[kBlockClasses] = {256, 256, 1024, (int)kBlockMaxConsumers};
+    // workgroup size = np_cap / records per thread; the small classes leave room for many workgroups per CU
+    static const int kThreads[kBlockClasses] = {64, 256, 512, 1024, 1024};
+    static const int kRecs[kBlockClasses] = {8, 8, 8, 8, 16};
+    static const int kNc[kBlockClasses] = {256, 256, 1024, (int)kBlockMaxConsumers, 1024};
     if (a.n_list <= 0) return hipSuccess;
     if (cls < 0 || cls >= kBlockClasses) return hipErrorInvalidValue;
-    a.np_cap = kNp[cls];
+    const int nt = kThreads[cls], e = kRecs[cls];
+    a.np_cap = nt * e;
     a.nc_cap = kNc[cls];
-    const size_t lds = (size_t)12 * a.np_cap + (size_t)16 * a.nc_cap;
+    const size_t region_a = (size_t)(e * 8 > kXchg * 12 ? e * 8 : kXchg * 12) * nt;
+    const size_t lds = region_a + (size_t)16 * a.nc_cap;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)block_topic_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           160 * 1024);
-        if (e != hipSuccess) return e;
+        hipError_t err;
+        if ((err = hipFuncSetAttribute((const void*)block_topic_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       160 * 1024)) != hipSuccess) return err;
+        if ((err = hipFuncSetAttribute((const void*)block_topic_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       160 * 1024)) != hipSuccess) return err;
         attr_set = true;
     }
-    hipLaunchKernelGGL(block_topic_kernel, dim3((unsigned)a.n_list), dim3(kThreads[cls]), lds, stream, a);
+    if (e == 8) hipLaunchKernelGGL(block_topic_kernel<8>, dim3((unsigned)a.n_list), dim3(nt), lds, stream, a);
+    else hipLaunchKernelGGL(block_topic_kernel<16>, dim3((unsigned)a.n_list), dim3(nt), lds, stream, a);
     return hipGetLastError();
 }
 

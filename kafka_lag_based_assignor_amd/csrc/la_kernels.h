@@ -63,9 +63,11 @@ hipError_t check_consumers_launch(int64_t n_topics, const int64_t* cons_off, con
                                   uint32_t* status, hipStream_t stream);
 
 // ---- block path (la_block.hip): one workgroup per topic, everything in LDS --------------------
-constexpr int64_t kBlockMaxPartitions = 8192;
+constexpr int64_t kBlockMaxPartitions = 8192;    // with up to kBlockMaxConsumers consumers
 constexpr int64_t kBlockMaxConsumers = 2048;
-constexpr int kBlockClasses = 4;               // LDS / workgroup size classes, see block_class()
+constexpr int64_t kBlockWidePartitions = 16384;  // with up to kBlockWideConsumers consumers (16 records per thread)
+constexpr int64_t kBlockWideConsumers = 1024;
+constexpr int kBlockClasses = 5;               // LDS / workgroup size classes, see block_class()
 
 struct BlockArgs {
     const int64_t* part_off;    // the batch's offsets (device)
@@ -87,12 +89,15 @@ struct BlockArgs {
     int32_t np_cap, nc_cap;     // LDS capacity in records / bins, set by the launcher
 };
 
-inline bool block_fits(int64_t p, int64_t c) { return p <= kBlockMaxPartitions && c <= kBlockMaxConsumers; }
+inline bool block_fits(int64_t p, int64_t c) {
+    return (p <= kBlockMaxPartitions && c <= kBlockMaxConsumers) || (p <= kBlockWidePartitions && c <= kBlockWideConsumers);
+}
 inline int block_class(int64_t p, int64_t c) {
     if (p <= 512 && c <= 256) return 0;
     if (p <= 2048 && c <= 256) return 1;
     if (p <= 4096 && c <= 1024) return 2;
-    return 3;
+    if (p <= kBlockMaxPartitions) return 3;
+    return 4;
 }
 hipError_t block_launch(BlockArgs a, int cls, hipStream_t stream);
 

@@ -553,6 +553,9 @@ def test_fuzz_large_topics(ctx, seed):
     (1025, 1, "u40"), (8192, 2048, "u40"), (100, 65, "ties"), (1, 65, "u40"), (0, 100, "zero"), (5000, 0, "u40"),
     (8192, 3, "full"), (4097, 1025, "zero"), (2048, 256, "u63"), (2049, 257, "full"), (200, 100, "u40"),
     (127, 128, "ties"), (129, 128, "u40"), (3000, 129, "ties"), (8191, 2047, "u63"), (64, 2048, "u40"),
+    # the 16-records-per-thread class (8 192 < P <= 16 384, C <= 1 024) and its borders with the large path
+    (8193, 1, "u40"), (16384, 1024, "u40"), (16384, 1024, "full"), (10000, 128, "ties"), (12000, 300, "u63"),
+    (16385, 7, "u40"), (9000, 1025, "ties"), (16000, 3, "zero"),
 ])
 def test_block_single_topic(ctx, p, c, kind):
     po, pid, lag, co, ranks = _single_topic(31 * p + c, p, c, kind, negative=(kind == "full"))
@@ -592,7 +595,8 @@ def test_block_many_topics_same_shape(ctx):
 @pytest.mark.parametrize("seed", range(10))
 def test_fuzz_block_topics(ctx, seed):
     rng = np.random.default_rng(7000 + seed)
-    p = int(rng.choice([0, 1, 63, 64, 65, 127, 128, 129, 1000, 1024, 1025, 2047, 2048, 2049, 4096, 4097, 8191, 8192]))
+    p = int(rng.choice([0, 1, 63, 64, 65, 127, 128, 129, 1000, 1024, 1025, 2047, 2048, 2049, 4096, 4097, 8191, 8192, 8193,
+                        12000, 16383, 16384]))
     c = int(rng.choice([1, 2, 63, 64, 65, 127, 128, 129, 255, 256, 257, 1023, 1024, 1025, 2047, 2048]))
     kind = str(rng.choice(["u40", "ties", "zero", "u63", "full"]))
     po, pid, lag, co, ranks = _single_topic(seed + 177, p, c, kind, shuffled=bool(rng.integers(0, 2)),
