@@ -138,6 +138,49 @@ __device__ __forceinline__ void block_sort_regs(Rec (&rec)[E], int n_eff, int ti
     }
 }
 
+// ---- the same sort on packed records ((lag_max - lag) << sh) | id -- one 64-bit word, ascending == (lag desc,
+// id asc) -- through the instruction-level networks of la_sort64.h: 4 VALU per compare-exchange step instead of
+// ~14.  Direction-free form (every block comes out ascending), so stopping at n_eff slots works here too.  The
+// workgroup decides per topic whether its records fit (no negative lag or id, lag bits + id bits <= 63).
+template <int E>
+__device__ __forceinline__ void block_sort_packed(P64 (&rec)[E], int n_eff, int tid, int nt, uint64_t* x_key) {
+    constexpr int kSpanSlots = kWave * E;                                // slots of one wavefront
+    const bool active = (tid & ~(kWave - 1)) * E < n_eff;                // wavefront-uniform
+    if (active) {
+#pragma unroll
+        for (int r = 0; r < E; ++r) asm volatile("s_nop 1" : "+v"(rec[r].lo), "+v"(rec[r].hi));
+        bitonic_sort_tile_p64<kWave, E>(rec);
+    }
+    for (int K = 2 * kSpanSlots; K <= n_eff; K <<= 1) {
+        for (int j = K >> 1; j >= kSpanSlots; j >>= 1) {
+            // first step of a merge: i <-> i ^ (K-1) (mirror); the rest: i <-> i ^ j; the lower slot keeps the min
+            const int mask = (j == (K >> 1)) ? (K - 1) : j;
+            if (active) {
+#pragma unroll
+                for (int r = 0; r < E; ++r) x_key[r * nt + tid] = p64_value(rec[r]);
+            }
+            __syncthreads();
+            if (active) {
+#pragma unroll
+                for (int r = 0; r < E; ++r) {
+                    const int i = tid * E + r;
+                    const int pi = i ^ mask;
+                    const uint64_t o = x_key[(pi % E) * nt + pi / E], x = p64_value(rec[r]);
+                    const bool keep_min = (i & j) == 0;
+                    const uint64_t lo = o < x ? o : x, hi = o < x ? x : o;
+                    rec[r] = p64_from(keep_min ? lo : hi);
+                }
+            }
+            __syncthreads();
+        }
+        if (active) {
+#pragma unroll
+            for (int r = 0; r < E; ++r) asm volatile("s_nop 1" : "+v"(rec[r].lo), "+v"(rec[r].hi));
+            clean_p64<kWave, E, kSpanSlots / 2, false>(rec);              // i <-> i ^ j for every j inside the wavefront
+        }
+    }
+}
+
 // Greedy rounds for up to 256 consumers: one wavefront, bins in registers (EC per lane, slot = lane*EC + r),
 // sorted by the DPP / permlane networks of la_device.h -- no LDS traffic and no barrier between rounds.
 // Slots >= C hold an all-ones sentinel (a real bin's index is < C, so it never equals it).  L = lanes in use
@@ -270,37 +313,88 @@ __global__ __launch_bounds__(1024) void block_topic_kernel(BlockArgs a) {
     // starts), lag fused in --------------------------------------------------------------------------------
     const int n_eff = pow2ceil_dev(P);
     const int nt_eff = n_eff > E ? n_eff / E : 1;                       // threads holding slots < n_eff
-    Rec rec[E];
+    int64_t lag[E];
+    int32_t pid[E];
+    uint64_t lag_or = 0;
+    uint32_t id_or = 0;
 #pragma unroll
     for (int r = 0; r < E; ++r) {
         const int src = r * nt_eff + tid;
-        rec[r].hi = rec[r].lo = rec[r].tb = 0xFFFFFFFFu;
+        lag[r] = 0;
+        pid[r] = 0;
         if (tid < nt_eff && src < P) {
             const int64_t g = p0 + src;
-            int64_t lag;
             if (a.lag) {
-                lag = a.lag[g];
+                lag[r] = a.lag[g];
             } else {
                 const int64_t cm = a.committed[g];
                 const int64_t bg = (cm < 0 && !latest && a.begin) ? a.begin[g] : 0;
-                lag = partition_lag(bg, a.end[g], cm, latest);
+                lag[r] = partition_lag(bg, a.end[g], cm, latest);
             }
-            const uint64_t key = (uint64_t)lag ^ kLagKeyFlip;
-            rec[r].hi = (uint32_t)(key >> 32);
-            rec[r].lo = (uint32_t)key;
-            rec[r].tb = (uint32_t)a.pid[g] ^ kPidBias;
+            pid[r] = a.pid[g];
+            lag_or |= (uint64_t)lag[r];
+            id_or |= (uint32_t)pid[r];
         }
     }
+    // do the topic's records fit one 64-bit word?  (workgroup-wide OR of the lags and the ids)
+    uint32_t* s_or = reinterpret_cast<uint32_t*>(s_rank + a.nc_cap);   // [3] (4 allotted) workgroup-wide ORs
+    if (tid < 3) s_or[tid] = 0;
+    __syncthreads();
+    {
+        const uint32_t a0 = wave_or_u32((uint32_t)lag_or), a1 = wave_or_u32((uint32_t)(lag_or >> 32)), a2 = wave_or_u32(id_or);
+        if ((tid & (kWave - 1)) == 0) {
+            if (a0) atomicOr(&s_or[0], a0);
+            if (a1) atomicOr(&s_or[1], a1);
+            if (a2) atomicOr(&s_or[2], a2);
+        }
+    }
+    __syncthreads();
+    const uint64_t all_lag = ((uint64_t)s_or[1] << 32) | s_or[0];
+    const uint32_t all_id = s_or[2];
+    const int lbw = all_lag ? 64 - __builtin_clzll((unsigned long long)all_lag) : 0;    // 64: a negative lag
+    const int sh = all_id ? 32 - __builtin_clz(all_id) : 0;                             // 32: a negative id
+    const bool fits = sh < 32 && lbw + sh <= 63;                                        // workgroup-uniform
 
     // ---- sort by (lag desc, partition asc); the ids leave from the registers, the keys go to LDS by position --
-    block_sort_regs<E>(rec, n_eff, tid, nt, x_key, x_id);
+    if (fits) {
+        const uint64_t lag_max = lbw ? (~0ull >> (64 - lbw)) : 0;
+        const uint32_t id_mask = sh ? (0xFFFFFFFFu >> (32 - sh)) : 0;
+        P64 rec[E];
 #pragma unroll
-    for (int r = 0; r < E; ++r) {
-        const int i = tid * E + r;
-        if (i < P) {
-            s_key[i] = ((uint64_t)rec[r].hi << 32) | rec[r].lo;
-            a.out_pid[p0 + i] = (int32_t)(rec[r].tb ^ kPidBias);
-            if (C == 0) a.out_rank[p0 + i] = -1;                        // Main.java:211-214: nobody to assign to
+        for (int r = 0; r < E; ++r) {
+            const bool valid = tid < nt_eff && r * nt_eff + tid < P;
+            rec[r] = p64_from(valid ? (((lag_max - (uint64_t)lag[r]) << sh) | (uint32_t)pid[r]) : ~0ull);
+        }
+        block_sort_packed<E>(rec, n_eff, tid, nt, x_key);
+#pragma unroll
+        for (int r = 0; r < E; ++r) {
+            const int i = tid * E + r;
+            if (i < P) {
+                const uint64_t v = p64_value(rec[r]);
+                s_key[i] = (lag_max - (v >> sh)) ^ kLagKeyFlip;
+                a.out_pid[p0 + i] = (int32_t)((uint32_t)v & id_mask);
+                if (C == 0) a.out_rank[p0 + i] = -1;                    // Main.java:211-214: nobody to assign to
+            }
+        }
+    } else {
+        Rec rec[E];
+#pragma unroll
+        for (int r = 0; r < E; ++r) {
+            const bool valid = tid < nt_eff && r * nt_eff + tid < P;
+            const uint64_t key = (uint64_t)lag[r] ^ kLagKeyFlip;
+            rec[r].hi = valid ? (uint32_t)(key >> 32) : 0xFFFFFFFFu;
+            rec[r].lo = valid ? (uint32_t)key : 0xFFFFFFFFu;
+            rec[r].tb = valid ? ((uint32_t)pid[r] ^ kPidBias) : 0xFFFFFFFFu;
+        }
+        block_sort_regs<E>(rec, n_eff, tid, nt, x_key, x_id);
+#pragma unroll
+        for (int r = 0; r < E; ++r) {
+            const int i = tid * E + r;
+            if (i < P) {
+                s_key[i] = ((uint64_t)rec[r].hi << 32) | rec[r].lo;
+                a.out_pid[p0 + i] = (int32_t)(rec[r].tb ^ kPidBias);
+                if (C == 0) a.out_rank[p0 + i] = -1;                    // Main.java:211-214: nobody to assign to
+            }
         }
     }
     for (int i = tid; i < C; i += nt) {
@@ -396,7 +490,7 @@ hipError_t block_launch(BlockArgs a, int cls, hipStream_t stream) {
     a.np_cap = nt * e;
     a.nc_cap = kNc[cls];
     const size_t region_a = (size_t)(e * 8 > kXchg * 12 ? e * 8 : kXchg * 12) * nt;
-    const size_t lds = region_a + (size_t)16 * a.nc_cap;
+    const size_t lds = region_a + (size_t)16 * a.nc_cap + 16;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t err;
