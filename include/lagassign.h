@@ -119,8 +119,8 @@ int la_assign_batch(la_ctx *ctx, int32_t n_topics,
                     int32_t reset_mode,
                     const int64_t *cons_off,       /* [T+1]                              */
                     const int32_t *cons_rank,      /* [K]  ascending within each topic   */
-                    int32_t *out_partition,        /* [N]                                */
-                    int32_t *out_member_rank,      /* [N]                                */
+                    int32_t *out_partition,        /* [N]  (both NULL: results stay on   */
+                    int32_t *out_member_rank,      /* [N]   the device, see la_group_last_by_member) */
                     int64_t *out_total_lag);       /* [K]  or NULL                       */
 
 /* Same, on precomputed lags: the static assign(Map,Map) seam the reference's own tests
@@ -192,6 +192,14 @@ void *la_stream(la_ctx *ctx);
 int la_group_by_member(la_ctx *ctx, int32_t n_topics, const int64_t *part_off,
                        const int32_t *out_partition, const int32_t *out_member_rank, int32_t n_members,
                        int64_t *member_off, int32_t *grouped_topic, int32_t *grouped_partition);
+
+/* The same for the results the last successful la_assign_batch / la_assign_batch_lags call on this context left
+ * on the device: nothing is uploaded again.  A caller that only wants the grouped form gives that call
+ * out_partition = out_member_rank = NULL (both), which also skips their download: the assignment then crosses
+ * PCIe once, as member_off + grouped_topic + grouped_partition.  LA_EINVAL when there is no such result (no
+ * assign call yet, or another host-buffer call on this context since).  grouped_topic may be NULL. */
+int la_group_last_by_member(la_ctx *ctx, int32_t n_members,
+                            int64_t *member_off, int32_t *grouped_topic, int32_t *grouped_partition);
 
 /* Same on device buffers (N = n_partitions entries); enqueues on `stream` and returns. */
 int la_group_by_member_device(la_ctx *ctx, int32_t n_topics, int64_t n_partitions,

@@ -51,6 +51,14 @@ Java_com_github_grantneale_kafka_gpu_LagAssignNative_groupByMember(
                               (int32_t *)ADDR(env, grouped_partition));
 }
 
+JNIEXPORT jint JNICALL
+Java_com_github_grantneale_kafka_gpu_LagAssignNative_groupLastByMember(
+    JNIEnv *env, jclass cls, jlong ctx, jint n_members, jobject member_off, jobject grouped_topic,
+    jobject grouped_partition) {
+    return la_group_last_by_member((la_ctx *)(intptr_t)ctx, n_members, (int64_t *)ADDR(env, member_off),
+                                   (int32_t *)ADDR(env, grouped_topic), (int32_t *)ADDR(env, grouped_partition));
+}
+
 JNIEXPORT jstring JNICALL
 Java_com_github_grantneale_kafka_gpu_LagAssignNative_lastError(JNIEnv *env, jclass cls, jlong ctx) {
     return (*env)->NewStringUTF(env, la_last_error((const la_ctx *)(intptr_t)ctx));

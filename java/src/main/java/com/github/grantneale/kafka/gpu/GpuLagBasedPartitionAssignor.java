@@ -151,8 +151,6 @@ public class GpuLagBasedPartitionAssignor implements ConsumerPartitionAssignor, 
         for (int i = 0; i < consRankList.size(); i++) {
             consRank.put(i, consRankList.get(i));
         }
-        IntBuffer outPartition = ints(n);
-        IntBuffer outMemberRank = ints(n);
 
         String resetMode = groupProps.getProperty(ConsumerConfig.AUTO_OFFSET_RESET_CONFIG, "latest");
         int reset = resetMode.equalsIgnoreCase("latest") ? LagAssignNative.RESET_LATEST
@@ -162,20 +160,20 @@ public class GpuLagBasedPartitionAssignor implements ConsumerPartitionAssignor, 
         }
         int rc = LagAssignNative.assignBatch(nativeCtx, nTopics, bytes(partOff), bytes(partitionId),
             bytes(beginOff), bytes(endOff), bytes(committedOff), reset, bytes(consOff), bytes(consRank),
-            bytes(outPartition), bytes(outMemberRank), null);
+            null, null, null);              // the ungrouped result stays on the device
         if (rc != 0) {
             throw new IllegalStateException("liblagassign error " + rc + ": " + LagAssignNative.lastError(nativeCtx));
         }
 
-        // member -> list: the device groups the entries by member (stable, so every list keeps the
+        // member -> list: the device groups the entries it still holds by member (stable, so every list keeps the
         // reference's order: topic by topic in container order, inside a topic in assignment order,
         // Main.java:171-174 and :264); the host only wraps its own slice per member
         int nMembers = byRank.length;
         LongBuffer memberOff = longs(nMembers + 1);
         IntBuffer groupedTopic = ints(n);
         IntBuffer groupedPartition = ints(n);
-        rc = LagAssignNative.groupByMember(nativeCtx, nTopics, bytes(partOff), bytes(outPartition),
-            bytes(outMemberRank), nMembers, bytes(memberOff), bytes(groupedTopic), bytes(groupedPartition));
+        rc = LagAssignNative.groupLastByMember(nativeCtx, nMembers, bytes(memberOff), bytes(groupedTopic),
+            bytes(groupedPartition));
         if (rc != 0) {
             throw new IllegalStateException("liblagassign error " + rc + ": " + LagAssignNative.lastError(nativeCtx));
         }

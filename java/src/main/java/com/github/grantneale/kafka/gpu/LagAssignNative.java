@@ -30,7 +30,8 @@ final class LagAssignNative {
     /**
      * la_assign_batch.  partOff/consOff: int64[T+1]; partitionId/consRank: int32;
      * begin/end/committed: int64[N] (begin may be null for RESET_LATEST);
-     * outPartition/outMemberRank: int32[N]; outTotalLag: int64[K] or null.
+     * outPartition/outMemberRank: int32[N], or both null (results stay on the device for groupLastByMember);
+     * outTotalLag: int64[K] or null.
      * Returns the la_* status code (0 = ok); lastError(ctx) has the text.
      */
     static native int assignBatch(long ctx, int nTopics, ByteBuffer partOff, ByteBuffer partitionId,
@@ -46,6 +47,13 @@ final class LagAssignNative {
     static native int groupByMember(long ctx, int nTopics, ByteBuffer partOff, ByteBuffer outPartition,
                                     ByteBuffer outMemberRank, int nMembers, ByteBuffer memberOff,
                                     ByteBuffer groupedTopic, ByteBuffer groupedPartition);
+
+    /**
+     * la_group_last_by_member: groupByMember on the results the last assignBatch call of this context left on the
+     * device (that call may be given outPartition = outMemberRank = null), so the assignment crosses PCIe once.
+     */
+    static native int groupLastByMember(long ctx, int nMembers, ByteBuffer memberOff, ByteBuffer groupedTopic,
+                                        ByteBuffer groupedPartition);
 
     /** la_last_error */
     static native String lastError(long ctx);

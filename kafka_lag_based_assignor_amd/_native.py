@@ -23,7 +23,7 @@ LA_FLAG_INDEX64, LA_FLAG_DEFER_WIDE, LA_FLAG_RAGGED, LA_FLAG_SHAPE_CLASSES = 1, 
 EXPORTED_SYMBOLS = (
     "la_create", "la_destroy", "la_last_error", "la_version", "la_compute_lag",
     "la_assign_batch", "la_assign_batch_lags", "la_assign_batch_device", "la_sync", "la_stream",
-    "la_group_by_member", "la_group_by_member_device",
+    "la_group_by_member", "la_group_by_member_device", "la_group_last_by_member",
 )
 
 _i64p = ctypes.POINTER(ctypes.c_int64)
@@ -99,6 +99,8 @@ def load() -> ctypes.CDLL:
     L.la_group_by_member.restype = ctypes.c_int
     L.la_group_by_member.argtypes = [ctypes.c_void_p, ctypes.c_int32, _i64p, _i32p, _i32p, ctypes.c_int32,
                                      _i64p, _i32p, _i32p]
+    L.la_group_last_by_member.restype = ctypes.c_int
+    L.la_group_last_by_member.argtypes = [ctypes.c_void_p, ctypes.c_int32, _i64p, _i32p, _i32p]
     L.la_group_by_member_device.restype = ctypes.c_int
     L.la_group_by_member_device.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_void_p,
                                             ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p,
@@ -174,7 +176,11 @@ class Context:
         partition_id, cons_rank = _a32(partition_id), _a32(cons_rank)
         end, committed = _a64(end), _a64(committed)
         begin = None if begin is None else _a64(begin)
-        if out is not None:
+        if out == "device":
+            # results stay on the device for group_last_by_member(); only the totals come back
+            out_p = out_m = None
+            out_t = np.zeros(cons_rank.size, dtype=np.int64) if want_totals else None
+        elif out is not None:
             out_p, out_m, out_t = out
             if (out_p.dtype != np.int32 or out_m.dtype != np.int32 or out_p.size != partition_id.size or
                     out_m.size != partition_id.size or not out_p.flags.c_contiguous or not out_m.flags.c_contiguous or
@@ -191,12 +197,13 @@ class Context:
                                               _p64(out_t)))
         return out_p, out_m, out_t
 
-    def assign_batch_lags(self, part_off, partition_id, lag, cons_off, cons_rank, want_totals: bool = True
-                          ) -> Tuple[np.ndarray, np.ndarray, Optional[np.ndarray]]:
+    def assign_batch_lags(self, part_off, partition_id, lag, cons_off, cons_rank, want_totals: bool = True,
+                          out=None) -> Tuple[np.ndarray, np.ndarray, Optional[np.ndarray]]:
+        """out="device": the results stay on the device for group_last_by_member()."""
         part_off, cons_off = _a64(part_off), _a64(cons_off)
         partition_id, cons_rank, lag = _a32(partition_id), _a32(cons_rank), _a64(lag)
-        out_p = np.empty(partition_id.size, dtype=np.int32)
-        out_m = np.empty(partition_id.size, dtype=np.int32)
+        out_p = None if out == "device" else np.empty(partition_id.size, dtype=np.int32)
+        out_m = None if out == "device" else np.empty(partition_id.size, dtype=np.int32)
         out_t = np.zeros(cons_rank.size, dtype=np.int64) if want_totals else None
         self._check(self._lib.la_assign_batch_lags(self._h, part_off.size - 1, _p64(part_off),
                                                    _p32(partition_id), _p64(lag), _p64(cons_off),
@@ -214,6 +221,15 @@ class Context:
         g_p = np.empty(out_partition.size, dtype=np.int32)
         self._check(self._lib.la_group_by_member(self._h, part_off.size - 1, _p64(part_off), _p32(out_partition),
                                                  _p32(out_member_rank), n_members, _p64(off), _p32(g_t), _p32(g_p)))
+        return off, g_t, g_p
+
+    def group_last_by_member(self, n_partitions: int, n_members: int) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+        """group_by_member on the results the last assign_batch / assign_batch_lags call left on the device
+        (give that call out="device" to skip the download of the ungrouped arrays)."""
+        off = np.zeros(n_members + 1, dtype=np.int64)
+        g_t = np.empty(n_partitions, dtype=np.int32)
+        g_p = np.empty(n_partitions, dtype=np.int32)
+        self._check(self._lib.la_group_last_by_member(self._h, n_members, _p64(off), _p32(g_t), _p32(g_p)))
         return off, g_t, g_p
 
     def group_by_member_device(self, n_topics: int, n_partitions: int, d_part_off: int, d_out_partition: int,

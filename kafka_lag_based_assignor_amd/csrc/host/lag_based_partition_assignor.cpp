@@ -138,34 +138,26 @@ Assignment run_native(const Plan& plan, const std::vector<const TopicData*>& dat
         f.cons_off.push_back((int64_t)f.cons_rank.size());
     }
     const size_t n = f.pid.size(), k = f.cons_rank.size();
-    std::vector<int32_t> out_pid(n), out_rank(n);
+    // The assignment stays on the device (out_partition = out_member_rank = NULL) and crosses PCIe once, already
+    // grouped: every member's list in the reference's order (topic by topic as consumersPerTopic iterates, inside a
+    // topic in assignment order, Main.java:171-174 and :264); the host only wraps it.
     std::vector<int64_t> out_total(k);
+    const int32_t n_members = (int32_t)plan.members.size();
+    std::vector<int64_t> member_off((size_t)n_members + 1, 0);
+    std::vector<int32_t> grouped_topic(n), grouped_pid(n);
     if (!plan.topics.empty()) {
-        std::lock_guard<std::mutex> lock(g_ctx_mutex);
+        std::lock_guard<std::mutex> lock(g_ctx_mutex);       // one lock over both calls: the second reads the first's results
         la_ctx* ctx = shared_ctx_locked();
         int rc;
         if (offsets_mode)
             rc = la_assign_batch(ctx, (int32_t)plan.topics.size(), f.part_off.data(), f.pid.data(), f.begin.data(),
                                  f.end.data(), f.committed.data(), reset_mode, f.cons_off.data(), f.cons_rank.data(),
-                                 out_pid.data(), out_rank.data(), out_total.data());
+                                 nullptr, nullptr, out_total.data());
         else
             rc = la_assign_batch_lags(ctx, (int32_t)plan.topics.size(), f.part_off.data(), f.pid.data(), f.lag.data(),
-                                      f.cons_off.data(), f.cons_rank.data(), out_pid.data(), out_rank.data(),
-                                      out_total.data());
+                                      f.cons_off.data(), f.cons_rank.data(), nullptr, nullptr, out_total.data());
         check(ctx, rc);
-    }
-
-    // Every member's list, in the reference's order (topic by topic as consumersPerTopic iterates, inside a
-    // topic in assignment order, Main.java:171-174 and :264): grouped on the device, wrapped here.
-    const int32_t n_members = (int32_t)plan.members.size();
-    std::vector<int64_t> member_off((size_t)n_members + 1, 0);
-    std::vector<int32_t> grouped_topic(n), grouped_pid(n);
-    if (!plan.topics.empty()) {
-        std::lock_guard<std::mutex> lock(g_ctx_mutex);
-        la_ctx* ctx = shared_ctx_locked();
-        check(ctx, la_group_by_member(ctx, (int32_t)plan.topics.size(), f.part_off.data(), out_pid.data(),
-                                      out_rank.data(), n_members, member_off.data(), grouped_topic.data(),
-                                      grouped_pid.data()));
+        check(ctx, la_group_last_by_member(ctx, n_members, member_off.data(), grouped_topic.data(), grouped_pid.data()));
     }
     // partition id -> the element's own topic string (normally the map key), per topic
     std::vector<std::unordered_map<int32_t, const std::string*>> topic_of(plan.topics.size());

@@ -51,6 +51,10 @@ struct la_ctx {
     } stage[4];
     unsigned stage_next = 0;
     std::vector<uint8_t> topic_class;   // host scratch of the dispatcher: path / class of every topic
+    // results of the last host-buffer assign call, still in part_off / out_pid / out_rank (la_group_last_by_member)
+    bool last_valid = false;
+    int32_t last_topics = 0;
+    int64_t last_n = 0;
 };
 
 namespace {
@@ -429,13 +433,15 @@ int assign_host(la_ctx* ctx, int32_t T, const int64_t* part_off, const int32_t* 
                 const int64_t* cons_off, const int32_t* cons_rank, int32_t* out_pid, int32_t* out_rank,
                 int64_t* out_total) {
     if (!ctx) return LA_EINVAL;
+    ctx->last_valid = false;
     if (T < 0) return fail(ctx, LA_EINVAL, "n_topics < 0");
     if (T == 0) return LA_OK;
     if (!part_off || !cons_off) return fail(ctx, LA_EINVAL, "null offsets");
     Shape s;
     if (int rc = scan_shape(ctx, T, part_off, cons_off, cons_rank, &s)) return rc;
-    if (s.n > 0 && (!pid || !out_pid || !out_rank || (!lag && (!end || !committed))))
-        return fail(ctx, LA_EINVAL, "null per-partition buffer");
+    if (s.n > 0 && (!pid || (!lag && (!end || !committed)))) return fail(ctx, LA_EINVAL, "null per-partition buffer");
+    if ((out_pid == nullptr) != (out_rank == nullptr))
+        return fail(ctx, LA_EINVAL, "out_partition and out_member_rank must both be given or both be NULL");
     if (s.k > 0 && !cons_rank) return fail(ctx, LA_EINVAL, "null cons_rank");
     if (!lag && reset_mode != LA_RESET_LATEST && !begin && s.n > 0)
         return fail(ctx, LA_EINVAL, "begin_off is required unless reset_mode is LA_RESET_LATEST");
@@ -492,12 +498,16 @@ int assign_host(la_ctx* ctx, int32_t T, const int64_t* part_off, const int32_t* 
     b.flags = LA_FLAG_RAGGED;            // the offsets are on the host anyway: let the dispatcher look at the shapes
     if ((rc = enqueue_batch(ctx, &b, st))) return rc;
 
-    if (s.n) {
+    if (s.n && out_pid) {
         LA_HIP(ctx, hipMemcpyAsync(out_pid, ctx->out_pid.p, nb4, hipMemcpyDeviceToHost, st));
         LA_HIP(ctx, hipMemcpyAsync(out_rank, ctx->out_rank.p, nb4, hipMemcpyDeviceToHost, st));
     }
     if (out_total && s.k) LA_HIP(ctx, hipMemcpyAsync(out_total, ctx->out_total.p, kb8, hipMemcpyDeviceToHost, st));
-    return sync_status(ctx, st);
+    if ((rc = sync_status(ctx, st))) return rc;
+    ctx->last_valid = true;
+    ctx->last_topics = T;
+    ctx->last_n = s.n;
+    return LA_OK;
 }
 
 }  // namespace
@@ -656,6 +666,7 @@ LA_API int la_group_by_member(la_ctx* ctx, int32_t n_topics, const int64_t* part
                               int32_t* grouped_topic, int32_t* grouped_partition) {
     if (!ctx) return LA_EINVAL;
     try {
+        ctx->last_valid = false;                       // this call reuses the scratch the last results live in
         if (n_topics < 0 || n_members < 0) return fail(ctx, LA_EINVAL, "negative size");
         if (!member_off || (n_topics > 0 && !part_off)) return fail(ctx, LA_EINVAL, "null buffer");
         const int64_t n = n_topics > 0 ? part_off[n_topics] : 0;
@@ -689,6 +700,41 @@ LA_API int la_group_by_member(la_ctx* ctx, int32_t n_topics, const int64_t* part
         return LA_OK;
     } catch (...) {
         return fail(ctx, LA_ENOMEM, "exception in la_group_by_member");
+    }
+}
+
+LA_API int la_group_last_by_member(la_ctx* ctx, int32_t n_members, int64_t* member_off, int32_t* grouped_topic,
+                                   int32_t* grouped_partition) {
+    if (!ctx) return LA_EINVAL;
+    try {
+        if (!ctx->last_valid)
+            return fail(ctx, LA_EINVAL, "no result of la_assign_batch / la_assign_batch_lags is held on the device");
+        if (n_members < 0) return fail(ctx, LA_EINVAL, "negative size");
+        const int64_t n = ctx->last_n;
+        if (!member_off || (n > 0 && !grouped_partition)) return fail(ctx, LA_EINVAL, "null buffer");
+        LA_HIP(ctx, hipSetDevice(ctx->device));
+        const size_t nb4 = (size_t)n * 4, mb = ((size_t)n_members + 1) * 8;
+        int rc;
+        // part_off, out_pid and out_rank hold the batch and its results; pid <- grouped_partition,
+        // cons_rank <- grouped_topic, out_total <- member_off (their old contents are no longer needed)
+        if ((rc = reserve(ctx, ctx->pid, nb4 + 16)) || (rc = reserve(ctx, ctx->cons_rank, nb4 + 16)) ||
+            (rc = reserve(ctx, ctx->out_total, mb + 16)))
+            return rc;
+        hipStream_t st = ctx->stream;
+        rc = la_group_by_member_device(ctx, ctx->last_topics, n, (const int64_t*)ctx->part_off.p,
+                                       (const int32_t*)ctx->out_pid.p, (const int32_t*)ctx->out_rank.p, n_members,
+                                       (int64_t*)ctx->out_total.p, grouped_topic ? (int32_t*)ctx->cons_rank.p : nullptr,
+                                       (int32_t*)ctx->pid.p, st);
+        if (rc) return rc;
+        LA_HIP(ctx, hipMemcpyAsync(member_off, ctx->out_total.p, mb, hipMemcpyDeviceToHost, st));
+        if (n) {
+            LA_HIP(ctx, hipMemcpyAsync(grouped_partition, ctx->pid.p, nb4, hipMemcpyDeviceToHost, st));
+            if (grouped_topic) LA_HIP(ctx, hipMemcpyAsync(grouped_topic, ctx->cons_rank.p, nb4, hipMemcpyDeviceToHost, st));
+        }
+        LA_HIP(ctx, hipStreamSynchronize(st));
+        return LA_OK;
+    } catch (...) {
+        return fail(ctx, LA_ENOMEM, "exception in la_group_last_by_member");
     }
 }
 

@@ -501,6 +501,34 @@ def test_group_by_member_reference_vector(ctx):              # Test.java:82-132:
     assert lists[1] == [(0, 1), (0, 3)]                          # consumer-2: topic1-1, topic1-3
 
 
+def test_group_last_by_member_equals_group_by_member(ctx):
+    # results kept on the device by the assign call == the same grouping of downloaded results
+    for w in (synth.ragged(31, 400, 300, 40, negative=True), synth.config("block_b", 0.1), synth.config("cfg3", 0.2)):
+        n_members = int(w.cons_rank.max()) + 1 if w.cons_rank.size else 0
+        exp_p, exp_m, exp_t = oracle.assign_flat(w.part_off, w.partition_id, w.lag, w.cons_off, w.cons_rank)
+        want = ctx.group_by_member(w.part_off, exp_p, exp_m, n_members)
+        p, m, t = ctx.assign_batch_lags(w.part_off, w.partition_id, w.lag, w.cons_off, w.cons_rank, out="device")
+        assert p is None and m is None
+        np.testing.assert_array_equal(t, exp_t)
+        got = ctx.group_last_by_member(w.n_partitions, n_members)
+        for g, e, what in zip(got, want, ("member_off", "grouped_topic", "grouped_partition")):
+            np.testing.assert_array_equal(g, e, err_msg=what)
+        got2 = ctx.group_last_by_member(w.n_partitions, n_members)           # the results are still there
+        np.testing.assert_array_equal(got2[2], want[2])
+    # a host-buffer grouping call reuses the scratch: the kept results are gone afterwards
+    ctx.group_by_member(w.part_off, exp_p, exp_m, n_members)
+    with pytest.raises(N.LagAssignError) as ei:
+        ctx.group_last_by_member(w.n_partitions, n_members)
+    assert ei.value.code == N.LA_EINVAL
+    # one output array without the other is refused
+    import ctypes
+    one = np.zeros(3, dtype=np.int32)
+    rc = ctx._lib.la_assign_batch_lags(ctx._h, 1, N._p64(np.array([0, 3], dtype=np.int64)), N._p32(np.arange(3, dtype=np.int32)),
+                                       N._p64(np.array([5, 6, 7], dtype=np.int64)), N._p64(np.array([0, 1], dtype=np.int64)),
+                                       N._p32(np.zeros(1, dtype=np.int32)), N._p32(one), None, None)
+    assert rc == N.LA_EINVAL
+
+
 def test_group_by_member_many_members(ctx):
     rng = np.random.default_rng(5)
     n, m = 200000, 70000

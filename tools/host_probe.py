@@ -41,3 +41,27 @@ if hasattr(lib, "la_host_alloc"):
         dt = time.perf_counter() - t
         print("C call, pinned buffers: rc=%d %.1f ms  (%.2e assignments/s)" % (rc, dt * 1e3, w.n_partitions / dt))
     print("same result:", np.array_equal(pop, r[0]), np.array_equal(pom, r[1]), np.array_equal(pot, r[2]))
+
+# the Java host's flow: assign, then every member's list.  (a) download the result, upload it again for the
+# grouping call; (b) keep it on the device and download only the grouped form
+M = 32
+gt, gp = np.zeros(w.n_partitions, np.int32), np.zeros(w.n_partitions, np.int32)
+off = np.zeros(M + 1, np.int64)
+lib.la_group_last_by_member.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.POINTER(ctypes.c_int64),
+                                        ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_int32)]
+for rep in range(3):
+    t = time.perf_counter()
+    rc1 = lib.la_assign_batch(ctx._h, w.n_topics, p64(w.part_off), p32(w.partition_id), p64(w.begin), p64(w.end), p64(w.committed),
+                              N.LA_RESET_EARLIEST, p64(w.cons_off), p32(w.cons_rank), p32(op), p32(om), p64(ot))
+    rc2 = lib.la_group_by_member(ctx._h, w.n_topics, p64(w.part_off), p32(op), p32(om), M, p64(off), p32(gt), p32(gp))
+    dt = time.perf_counter() - t
+    print("assign + group_by_member (two round trips): rc=%d,%d %.1f ms" % (rc1, rc2, dt * 1e3))
+ref = (off.copy(), gt.copy(), gp.copy())
+for rep in range(3):
+    t = time.perf_counter()
+    rc1 = lib.la_assign_batch(ctx._h, w.n_topics, p64(w.part_off), p32(w.partition_id), p64(w.begin), p64(w.end), p64(w.committed),
+                              N.LA_RESET_EARLIEST, p64(w.cons_off), p32(w.cons_rank), None, None, p64(ot))
+    rc2 = lib.la_group_last_by_member(ctx._h, M, p64(off), p32(gt), p32(gp))
+    dt = time.perf_counter() - t
+    print("assign (results stay) + group_last_by_member: rc=%d,%d %.1f ms  (%.2e assignments/s)" % (rc1, rc2, dt * 1e3, w.n_partitions / dt))
+print("same lists:", np.array_equal(off, ref[0]), np.array_equal(gt, ref[1]), np.array_equal(gp, ref[2]))
