@@ -1,23 +1,27 @@
 // la_block.hip -- the block path: one workgroup per topic, for topics beyond a wave tile (more than 1 024
-// partitions or more than 64 consumers) up to 8 192 x 2 048 (16 384 partitions with up to 1 024 consumers).  All such topics of a
-// batch run side by side (one launch per size class), where the large path (la_large.hip) would take them
-// one after another through a dozen device-wide kernels each.
+// partitions or more than 64 consumers) up to 8 192 partitions x 2 048 consumers, or 16 384 x 1 024.  All such
+// topics of a batch run side by side (one launch per size class over a topic list), where the large path
+// (la_large.hip) would take them one after another through a dozen device-wide kernels each.
 //
-// Per topic, everything stays in the workgroup's LDS:
-//   1. records  key = (uint64)lag ^ 0x7FFF...F, id = partition ^ 0x8000'0000      (computePartitionLag,
-//      Main.java:376-404, fused into the load)
-//   2. bitonic sort ascending by (key, id) == lag descending, partition ascending   (Main.java:228-235)
-//   3. greedy in rounds of C partitions: bins (total + 2^63, position in the rank-sorted consumer list) are
-//      sorted ascending and the k-th partition of the round goes to the k-th bin     (Main.java:237-266; the
-//      comparator's first key, the assigned count, is what makes rounds -- SURVEY.md section 8a note 5)
-//
-// The network is the direction-free bitonic form (first step of a merge is the mirror i <-> i ^ (K-1), the
-// rest i <-> i ^ j, the lower slot always keeps the smaller record).  Two properties make it shape-generic:
-//   * slots >= the live count behave as +inf that never moves (a compare-exchange never lowers the larger
-//     record), so they are neither stored nor visited: no padding, any P and C;
-//   * a step whose pairs stay inside 128-slot spans is executed by the span's owner wavefront, so runs of
-//     such steps need only a wavefront-level fence; the workgroup barrier is paid by the few wider steps.
-// With at most 256 consumers the greedy runs in ONE wavefront with the bins in registers (greedy_one_wave).
+// Per topic:
+//   1. loads, lag fused in (computePartitionLag, Main.java:376-404), straight into the sort's registers;
+//   2. bitonic sort by (lag descending, partition ascending) (Main.java:228-235): E records per thread; distances
+//      below E in registers, inside a wavefront through DPP / v_permlane*_swap, across wavefronts through LDS.
+//      Records that fit one 64-bit word -- ((lag_max - lag) << sh) | id, decided per topic by a workgroup-wide OR
+//      -- run through the instruction-level networks of la_sort64.h (block_sort_packed), the rest as (key64, id32)
+//      records (block_sort_regs);
+//   3. sorted keys to LDS by position, partition ids to out_partition from the registers;
+//   4. greedy in rounds of C partitions: the bins are sorted ascending by (total, position in the rank-sorted
+//      consumer list) and the k-th partition of the round goes to the k-th bin (Main.java:237-266; the
+//      comparator's first key, the assigned count, is what makes rounds -- SURVEY.md section 8a note 5).
+//      Up to 256 consumers: ONE wavefront, bins in registers, packed 64-bit words when no total can overflow
+//      them (greedy_one_wave_packed) else 96-bit records (greedy_one_wave).  More consumers: bins in LDS, sorted
+//      by the direction-free network (first step of a merge is the mirror i <-> i ^ (K-1), the rest i <-> i ^ j,
+//      the lower slot always keeps the smaller record), which has two useful properties:
+//        * slots >= the live count behave as +inf that never moves (a compare-exchange never lowers the larger
+//          record), so they are neither stored nor visited: no padding, any C;
+//        * a step whose pairs stay inside 128-slot spans is executed by the span's owner wavefront, so runs of
+//          such steps need only a wavefront-level fence; the workgroup barrier is paid by the few wider steps.
 #include "la_device.h"
 #include "la_kernels.h"
 #include "la_sort64.h"
