@@ -35,6 +35,27 @@ def test_device_batch_struct_matches_header_layout():
     assert ctypes.sizeof(_native.DeviceBatch) == 16 + 32 + 13 * 8
 
 
+def test_binding_constants_match_the_header():
+    import re
+    header = open(os.path.join(ROOT, "include", "lagassign.h")).read()
+    defines = {m.group(1): int(m.group(2), 0)
+               for m in re.finditer(r"^#define\s+(LA_[A-Z0-9_]+)\s+\(?(-?(?:0x[0-9a-fA-F]+|\d+))\)?", header, re.M)}
+    assert {"LA_OK", "LA_EINVAL", "LA_RESET_LATEST", "LA_ALGO_ARGMIN", "LA_FLAG_RAGGED"} <= set(defines)
+    checked = 0
+    for name, value in defines.items():
+        if hasattr(_native, name):
+            assert getattr(_native, name) == value, name
+            checked += 1
+    assert checked >= 12
+    # the device batch: field order and types as declared in the header
+    body = header[header.index("typedef struct la_device_batch {"):header.index("} la_device_batch;")]
+    fields = re.findall(r"^\s*(?:const\s+)?(int32_t|int64_t)\s*(\*?)\s*(\w+);", body, re.M)
+    declared = [(n, ("p" if star else t)) for t, star, n in fields]
+    bound = [(n, ("p" if (isinstance(t, type) and issubclass(t, (ctypes._Pointer, ctypes.c_void_p))) else
+                  {ctypes.c_int32: "int32_t", ctypes.c_int64: "int64_t"}[t])) for n, t in _native.DeviceBatch._fields_]
+    assert declared == bound
+
+
 @pytest.mark.skipif(os.path.exists("/dev/kfd"), reason="only meaningful without a GPU")
 def test_create_fails_loudly_without_gpu():
     with pytest.raises(_native.LagAssignError) as ei:
