@@ -382,11 +382,12 @@ __device__ __forceinline__ void assign_packed(const TileArgs& a, uint64_t* slice
             }
             if (kAblate == 2 && (op[0] ^ om[1] ^ op[2] ^ om[3]) != 0x7FFFFFF1) continue;
             if (s0 + 3 < P) {
-                struct __attribute__((aligned(4))) I32x4 { int32_t x, y, z, w; };
-                I32x4 vp; vp.x = op[0]; vp.y = op[1]; vp.z = op[2]; vp.w = op[3];
-                I32x4 vm; vm.x = om[0]; vm.y = om[1]; vm.z = om[2]; vm.w = om[3];
-                *reinterpret_cast<I32x4*>(a.out_pid + p0 + s0) = vp;
-                *reinterpret_cast<I32x4*>(a.out_rank + p0 + s0) = vm;
+                // element-aligned 16-byte stores, non-temporal: the results are not read again by this launch
+                // (measured: -1 % on the target batch; the same hint on the loads changes nothing)
+                typedef int I32x4 __attribute__((ext_vector_type(4), aligned(4)));
+                const I32x4 vp = {op[0], op[1], op[2], op[3]}, vm = {om[0], om[1], om[2], om[3]};
+                __builtin_nontemporal_store(vp, reinterpret_cast<I32x4*>(a.out_pid + p0 + s0));
+                __builtin_nontemporal_store(vm, reinterpret_cast<I32x4*>(a.out_rank + p0 + s0));
             } else {
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
