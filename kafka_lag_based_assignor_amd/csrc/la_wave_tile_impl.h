@@ -161,10 +161,9 @@ __device__ __forceinline__ void issue_loads(const TileArgs& a, const D& d, int g
 }
 
 // stage 2: the beginning offset is needed only where there is no committed offset and auto.offset.reset is
-// not "latest" (Main.java:384-396).  Lanes that need it read `begin`; every other lane re-reads its own
-// `committed` element (a cache hit, no HBM traffic), so the loads stay unconditional and batched, and the
-// result lands in the committed offset's own registers: afterwards cm is the "next offset" of
-// Main.java:386-396 itself.  A topic whose partitions all have committed offsets never touches `begin`.
+// not "latest" (Main.java:384-396).  Lanes that need it read `begin`; every other lane reads begin[0] (one cache
+// line for all of them, no HBM traffic to speak of) and keeps what it has, so the loads stay unconditional and
+// batched; afterwards cm is the "next offset" of Main.java:386-396 itself.
 template <int L, int E>
 __device__ __forceinline__ bool second_stage_needed(const TileArgs& a) {
     return !a.lag && !a.reset_latest && a.begin;                        // wave-uniform
@@ -178,11 +177,16 @@ __device__ __forceinline__ void issue_begin_loads(const TileArgs& a, const D& d,
 #pragma unroll
     for (int k = 0; k < NP; ++k) {
         const auto g = clamped_index<L, E>(a, d, 2 * k, gl);
-        const int64_t* sx = raw.cm[k].x < 0 ? a.begin : a.committed;
-        raw.cm[k].x = sx[g];
+        // a lane whose element has a committed offset needs nothing: all such lanes read ONE fixed word (a single
+        // cache line per wavefront instead of a second pass over their own lines through L2) and keep their value
+        using G = decltype(g);
+        const bool nx = raw.cm[k].x < 0;
+        const int64_t vx = a.begin[nx ? g : (G)0];
+        raw.cm[k].x = nx ? vx : raw.cm[k].x;
         if constexpr (E >= 2) {
-            const int64_t* sy = raw.cm[k].y < 0 ? a.begin : a.committed;
-            raw.cm[k].y = sy[g + 1];
+            const bool ny = raw.cm[k].y < 0;
+            const int64_t vy = a.begin[ny ? (G)(g + 1) : (G)0];
+            raw.cm[k].y = ny ? vy : raw.cm[k].y;
         }
     }
 }
