@@ -170,7 +170,10 @@ typedef struct la_device_batch {
 
 /* Enqueues the whole batch on `stream` and returns without waiting.  `stream` is a
  * hipStream_t used exactly as given (NULL = HIP's default stream); la_stream() gives
- * the context's own stream.  Device-detected errors surface in la_sync. */
+ * the context's own stream.  Device-detected errors surface in la_sync.
+ * A batch of tile-sized topics (shape hint within 1024 x 64, no LA_FLAG_RAGGED) is kernel
+ * launches only once the context has seen one call of that size (scratch allocated), so
+ * it may be captured in a HIP graph and replayed; eager launches cost about the same. */
 int la_assign_batch_device(la_ctx *ctx, const la_device_batch *batch, void *stream);
 
 /* Waits for `stream` and returns LA_OK or the first device-detected error. */

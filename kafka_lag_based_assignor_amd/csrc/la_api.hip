@@ -361,8 +361,20 @@ int enqueue_batch(la_ctx* ctx, const la_device_batch* b, hipStream_t stream) {
 
     // The counter pair alternates per LA_ALGO_AUTO launch: such a launch counts into one and its wide
     // kernel zeroes the other (idle by stream order), so no memset node sits between launches.
+    // Under stream capture the arguments are frozen into the graph, so the alternation cannot work on replay: a
+    // captured launch counts into a third word that a memset node clears first (its wide kernel "resets" a dummy).
+    hipStreamCaptureStatus capture = hipStreamCaptureStatusNone;
+    if (tile_mode == 0) LA_HIP(ctx, hipStreamIsCapturing(stream, &capture));
+    hipError_t counter_err = hipSuccess;
     auto next_counters = [&](la::TileArgs& t) {
         int32_t* pair = (int32_t*)(ctx->d_status + 16);
+        if (capture != hipStreamCaptureStatusNone) {
+            t.defer_count = pair + 2;
+            t.defer_count_next = pair + 3;
+            const hipError_t e = hipMemsetAsync(pair + 2, 0, sizeof(int32_t), stream);
+            if (e != hipSuccess) counter_err = e;
+            return;
+        }
         t.defer_count = pair + (ctx->launches & 1u);
         t.defer_count_next = pair + ((ctx->launches + 1u) & 1u);
         if (tile_mode == 0) ++ctx->launches;
@@ -378,6 +390,7 @@ int enqueue_batch(la_ctx* ctx, const la_device_batch* b, hipStream_t stream) {
     if (fits_hint && !(have_host && (b->flags & LA_FLAG_RAGGED) && tile_mode == 0)) {
         // the plain case: every topic fits a wave tile, one shape for all, nothing read on the host
         next_counters(a);
+        LA_HIP(ctx, counter_err);
         LA_HIP(ctx, la::wave_tile_launch(a, b->max_partitions_per_topic, b->max_consumers_per_topic, tile_mode, stream));
         return LA_OK;
     }
@@ -400,12 +413,14 @@ int enqueue_batch(la_ctx* ctx, const la_device_batch* b, hipStream_t stream) {
             run.n_topics = plan.tile[k].n;
             run.topic_list = d_lists + plan.tile_at[k];
             next_counters(run);
+            LA_HIP(ctx, counter_err);
             LA_HIP(ctx, la::wave_tile_launch(run, plan.tile[k].mp, plan.tile[k].mc, tile_mode, stream));
         }
     } else if (plan.n_tile > 0) {
         la::TileArgs run = a;
         run.flags |= la::kTileSkipOversize;
         next_counters(run);
+        LA_HIP(ctx, counter_err);
         LA_HIP(ctx, la::wave_tile_launch(run, plan.tile_mp, plan.tile_mc, tile_mode, stream));
     }
     if (plan.n_block_all > 0)

@@ -442,6 +442,62 @@ def _run_device(ctx, w, algo, use_lag=False, latest=True, flags=0):
     return out_pid.cpu().numpy(), out_rank.cpu().numpy(), out_total.cpu().numpy()
 
 
+def _deferring_workload():
+    """100 000 tiny topics (beyond one round of resident workgroups), a sprinkling of lags the packed format
+    cannot hold: the packed kernel defers those tiles to the wide kernel's list."""
+    rng = np.random.default_rng(21)
+    t = 100000
+    ps = rng.integers(0, 9, t)
+    cs = rng.integers(0, 9, t)
+    part_off = np.concatenate([[0], np.cumsum(ps)]).astype(np.int64)
+    cons_off = np.concatenate([[0], np.cumsum(cs)]).astype(np.int64)
+    n = int(part_off[-1])
+    pid = np.concatenate([rng.permutation(int(p)) for p in ps]).astype(np.int32)
+    lag = rng.integers(0, 1 << 30, n).astype(np.int64)
+    wide = rng.integers(0, n, 400)
+    lag[wide[:200]] = -rng.integers(1, 1 << 40, 200)                 # negative lags: cannot be packed
+    lag[wide[200:]] = rng.integers(1 << 60, (1 << 63) - 1, 200)      # totals would overflow the packed bins
+    ranks = np.concatenate([np.sort(rng.choice(64, int(c), replace=False)) for c in cs]).astype(np.int32)
+    zeros = np.zeros(n, dtype=np.int64)
+    return synth.Workload("defer", t, part_off, pid, zeros, lag.copy(), zeros, lag, cons_off, ranks, 8, 8)
+
+
+@pytest.mark.parametrize("which", ["one launch", "packed + wide kernels with deferred tiles"])
+def test_device_entry_is_graph_capturable(ctx, which):
+    # after one warm-up call (scratch allocated) the plain tile path is launches only: it can be captured in a
+    # HIP graph and replayed -- also when tiles are deferred (a captured launch clears its counter with a memset node)
+    import ctypes
+    import torch
+    dev = torch.device("cuda", 0)
+    w = synth.config("cfg3", 0.3) if which == "one launch" else _deferring_workload()
+    d = {k: torch.from_numpy(np.ascontiguousarray(getattr(w, k))).to(dev) for k in
+         ("part_off", "partition_id", "lag", "cons_off", "cons_rank")}
+    out_pid = torch.zeros(w.n_partitions, device=dev, dtype=torch.int32)
+    out_rank = torch.zeros(w.n_partitions, device=dev, dtype=torch.int32)
+    out_total = torch.zeros(w.cons_rank.size, device=dev, dtype=torch.int64)
+    b = N.DeviceBatch()
+    b.n_topics, b.reset_mode, b.algo, b.flags = w.n_topics, N.LA_RESET_LATEST, N.LA_ALGO_AUTO, 0
+    b.n_partitions, b.n_consumers = w.n_partitions, w.cons_rank.size
+    b.max_partitions_per_topic, b.max_consumers_per_topic = w.max_partitions, w.max_consumers
+    b.d_part_off, b.d_partition_id, b.d_lag = d["part_off"].data_ptr(), d["partition_id"].data_ptr(), d["lag"].data_ptr()
+    b.d_cons_off, b.d_cons_rank = d["cons_off"].data_ptr(), d["cons_rank"].data_ptr()
+    b.d_out_partition, b.d_out_member_rank, b.d_out_total_lag = out_pid.data_ptr(), out_rank.data_ptr(), out_total.data_ptr()
+    exp = oracle.assign_flat(w.part_off, w.partition_id, w.lag, w.cons_off, w.cons_rank)
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        ctx.assign_batch_device(b, s.cuda_stream)
+        ctx.sync(s.cuda_stream)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=s):
+        ctx.assign_batch_device(b, s.cuda_stream)
+    for rep in range(3):
+        out_pid.zero_(); out_rank.zero_(); out_total.zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        for got, e in zip((out_pid, out_rank, out_total), exp):
+            np.testing.assert_array_equal(got.cpu().numpy(), e)
+
+
 @pytest.mark.parametrize("max_p,max_c", [(64, 8), (256, 32), (700, 64)])
 def test_device_entry_rounds_equals_argmin_equals_oracle(ctx, max_p, max_c):
     w = synth.ragged(max_p + 11, 150, max_p, max_c, negative=True)
@@ -715,21 +771,7 @@ def test_deferred_wide_tiles_in_a_batch_larger_than_the_resident_grid(ctx):
     # Small batches run one kernel with the wide-record code inline; beyond one round of resident workgroups
     # the packed kernel defers tiles it cannot pack to a list that the wide kernel walks.  100 000 tiny topics
     # (8 per wavefront) with a sprinkling of negative / huge lags exercise that list.
-    rng = np.random.default_rng(21)
-    t = 100000
-    ps = rng.integers(0, 9, t)
-    cs = rng.integers(0, 9, t)
-    part_off = np.concatenate([[0], np.cumsum(ps)]).astype(np.int64)
-    cons_off = np.concatenate([[0], np.cumsum(cs)]).astype(np.int64)
-    n = int(part_off[-1])
-    pid = np.concatenate([rng.permutation(int(p)) for p in ps]).astype(np.int32)
-    lag = rng.integers(0, 1 << 30, n).astype(np.int64)
-    wide = rng.integers(0, n, 400)
-    lag[wide[:200]] = -rng.integers(1, 1 << 40, 200)                 # negative lags: cannot be packed
-    lag[wide[200:]] = rng.integers(1 << 60, (1 << 63) - 1, 200)      # totals would overflow the packed bins
-    ranks = np.concatenate([np.sort(rng.choice(64, int(c), replace=False)) for c in cs]).astype(np.int32)
-    zeros = np.zeros(n, dtype=np.int64)
-    w = synth.Workload("defer", t, part_off, pid, zeros, lag.copy(), zeros, lag, cons_off, ranks, 8, 8)
+    w = _deferring_workload()
     exp = oracle.assign_flat(w.part_off, w.partition_id, w.lag, w.cons_off, w.cons_rank)
     for rep in range(2):                                             # twice: the counter pair alternates
         got = _run_device(ctx, w, N.LA_ALGO_AUTO, use_lag=True)
