@@ -1,0 +1,80 @@
+"""Static ISA checks on the compiled kernels (no GPU needed: hipcc cross-compiles gfx950).
+
+The instruction-level sorting networks (csrc/la_sort32.h, la_sort64.h) place their own wait states around DPP /
+v_permlane*_swap reads and declare what their SALU ops clobber; the compiler does not look inside asm statements.
+Two bugs of that class were found the hard way in round 1 (a missing "scc" clobber, a DPP read one wait state
+after a compiler-generated write), both invisible to most parity tests.  This test recompiles the translation
+units that use the networks and runs tools/check_dpp_hazards.py over the ISA.
+"""
+import importlib.util
+import os
+import re
+import shutil
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "kafka_lag_based_assignor_amd", "csrc")
+UNITS = ["la_block.hip", "la_large.hip", "la_wave_tile_l32.hip", "la_wave_tile_l8.hip"]
+
+
+def _hipcc():
+    return shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+
+
+@pytest.fixture(scope="module")
+def isa(tmp_path_factory):
+    if not os.path.exists(_hipcc()):
+        pytest.skip("hipcc not available")
+    out = tmp_path_factory.mktemp("isa")
+
+    def compile_one(unit):
+        dst = os.path.join(str(out), unit.replace(".hip", ".s"))
+        subprocess.check_call([_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only",
+                               "-o", dst, os.path.join(CSRC, unit)], stderr=subprocess.DEVNULL)
+        return dst
+
+    with ThreadPoolExecutor(max_workers=4) as pool:
+        return list(pool.map(compile_one, UNITS))
+
+
+def test_no_dpp_read_within_two_wait_states_of_a_valu_write(isa, capsys):
+    spec = importlib.util.spec_from_file_location("check_dpp_hazards", os.path.join(ROOT, "tools", "check_dpp_hazards.py"))
+    chk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(chk)
+    for path in isa:
+        assert chk.check(path) == 0, path
+    out = capsys.readouterr().out
+    checked = sum(int(m) for m in re.findall(r"(\d+) DPP reads", out))
+    assert checked > 10000          # the networks really are in these units
+
+
+def test_asm_statements_with_salu_logic_declare_scc():
+    # s_and / s_or / s_xor / s_andn2 ... write SCC; an asm statement that contains one must say so, or the
+    # compiler keeps a live SCC across it (the bug: a loop condition's s_cmp result straddling a network block)
+    pat = re.compile(r"\bs_(and|or|xor|andn2|orn2|nand|nor|xnor|not|add|sub|cmp|bfe|lshl|lshr)[a-z0-9_]*\b")
+    offenders = []
+    seen = 0
+    for name in os.listdir(CSRC):
+        if not name.endswith((".h", ".hip")):
+            continue
+        src = open(os.path.join(CSRC, name)).read()
+        # macro-built asm bodies: look at every asm volatile( ... ); statement, macros expanded textually enough
+        for m in re.finditer(r"asm\s+volatile\s*\((.*?)\)\s*;", src, re.S):
+            body = m.group(1)
+            uses_macro = re.search(r"\bLA_[A-Z0-9_]*ASM\b|\bLA_[A-Z_]*PADS?\b", body)
+            text = body
+            if uses_macro:
+                # pull in the macro definitions of the same file
+                for mm in re.finditer(r"#define\s+(LA_[A-Z0-9_]+)\b(?:\([^)]*\))?((?:.*\\\n)*.*)", src):
+                    if mm.group(1) in body:
+                        text += mm.group(2)
+            if pat.search(text):
+                seen += 1
+                if '"scc"' not in body:
+                    offenders.append("%s: %s" % (name, " ".join(body.split())[:100]))
+    assert seen >= 3            # the check is looking at the right statements
+    assert not offenders, offenders
