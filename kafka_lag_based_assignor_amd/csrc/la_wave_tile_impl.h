@@ -326,6 +326,44 @@ __device__ __forceinline__ void sort_into_slice(uint64_t* slice, int gl, P64 (&r
     }
 }
 
+// ---- 4. greedy rounds: bin = (total << 6) | index in the rank-sorted consumer list ---------------------------
+// LC = lanes the bins' network spans: the group width L, or less when every topic of the wavefront has at most LC
+// consumers (a 1 000-partition topic with 3 consumers sits in a 64-lane group; its 334 rounds then sort 4 lanes,
+// 3 steps, instead of 64 lanes, 21 steps).  Lanes >= C hold the all-ones sentinel, so any LC >= C sorts the same.
+template <int L, int LC>
+__device__ __forceinline__ void greedy_rounds_tile(P64& bin, uint64_t* slice, int P, int C, int gl, int sh,
+                                                   uint64_t lag_max, uint32_t pid_mask, int max_rounds) {
+    for (int q = 0; q < max_rounds; ++q) {
+        // round 0 starts sorted: all totals 0, indices ascending
+        if (q == 1) {
+            // After round 0 consumer k holds the k-th largest lag: if those lags are STRICTLY descending over
+            // a full group, ascending (total, index) order is simply the reverse -- one mirror instead of a
+            // sort.  Equal lags (index order must win) or a partly filled group take the sort.
+            bool mirrored = false;
+            if constexpr (LC == L) {
+                const uint64_t mine = p64_value(bin);
+                const uint64_t prev = ((uint64_t)(uint32_t)__shfl_up((int)bin.hi, 1) << 32) | (uint32_t)__shfl_up((int)bin.lo, 1);
+                const bool bad = (C != L) || (gl > 0 && !((prev >> 6) > (mine >> 6)));
+                if (__builtin_amdgcn_ballot_w64(bad) == 0) {
+                    bin.lo = shfl_mirror<L>(bin.lo);
+                    bin.hi = shfl_mirror<L>(bin.hi);
+                    mirrored = true;
+                }
+            }
+            if (!mirrored) bitonic_sort_lanes_p64<LC>(bin);
+        } else if (q > 1) {
+            bitonic_sort_lanes_p64<LC>(bin);
+        }
+        const int s = q * C + gl;
+        if (gl < C && s < P) {
+            const uint64_t r = slice[slot_of(s)];
+            const uint64_t nb = p64_value(bin) + ((lag_max - (r >> sh)) << 6);                  // Main.java:265
+            bin = p64_from(nb);
+            slice[slot_of(s)] = ((uint64_t)(bin.lo & 63u) << 32) | ((uint32_t)r & pid_mask);
+        }
+    }
+}
+
 // ---- 3..5: greedy rounds over the sorted slice, outputs ------------------------------------------------------
 template <int L, int E, typename IDX>
 __device__ __forceinline__ void assign_packed(const TileArgs& a, uint64_t* slice, int32_t* rank_tab, IDX p0,
@@ -336,38 +374,19 @@ __device__ __forceinline__ void assign_packed(const TileArgs& a, uint64_t* slice
     if (gl < C) rank_tab[gl] = my_rank;
     wave_lds_fence();
 
-    // ---- 4. greedy rounds: bin = (total << 6) | index in the rank-sorted consumer list ----------------
     P64 bin = p64_from((gl < C) ? (uint64_t)gl : ~0ull);
     const int rounds = (C > 0) ? (P + C - 1) / C : 0;
     int max_rounds = __builtin_amdgcn_readfirstlane(wave_max_i32(rounds));
     if constexpr (kAblate == 1 || kAblate == 3) max_rounds = 0;
     if constexpr (kAblate >= 10) max_rounds = max_rounds < kAblate - 10 ? max_rounds : kAblate - 10;   // lab: cap the rounds
-    for (int q = 0; q < max_rounds; ++q) {
-        // round 0 starts sorted: all totals 0, indices ascending
-        if (q == 1) {
-            // After round 0 consumer k holds the k-th largest lag: if those lags are STRICTLY descending over
-            // a full group, ascending (total, index) order is simply the reverse -- one mirror instead of a
-            // sort.  Equal lags (index order must win) or a partly filled group take the sort.
-            const uint64_t mine = p64_value(bin);
-            const uint64_t prev = ((uint64_t)(uint32_t)__shfl_up((int)bin.hi, 1) << 32) | (uint32_t)__shfl_up((int)bin.lo, 1);
-            const bool bad = (C != L) || (gl > 0 && !((prev >> 6) > (mine >> 6)));
-            if (__builtin_amdgcn_ballot_w64(bad) == 0) {
-                bin.lo = shfl_mirror<L>(bin.lo);
-                bin.hi = shfl_mirror<L>(bin.hi);
-            } else {
-                bitonic_sort_lanes_p64<L>(bin);
-            }
-        } else if (q > 1) {
-            bitonic_sort_lanes_p64<L>(bin);
-        }
-        const int s = q * C + gl;
-        if (gl < C && s < P) {
-            const uint64_t r = slice[slot_of(s)];
-            const uint64_t nb = p64_value(bin) + ((lag_max - (r >> sh)) << 6);                  // Main.java:265
-            bin = p64_from(nb);
-            slice[slot_of(s)] = ((uint64_t)(bin.lo & 63u) << 32) | ((uint32_t)r & pid_mask);
-        }
-    }
+    // the widest consumer list among this wavefront's topics picks the network (wavefront-uniform)
+    const int c_max = __builtin_amdgcn_readfirstlane(wave_max_i32(C));
+    bool done = false;
+    if constexpr (L > 4) if (!done && c_max <= 4) { greedy_rounds_tile<L, 4>(bin, slice, P, C, gl, sh, lag_max, pid_mask, max_rounds); done = true; }
+    if constexpr (L > 8) if (!done && c_max <= 8) { greedy_rounds_tile<L, 8>(bin, slice, P, C, gl, sh, lag_max, pid_mask, max_rounds); done = true; }
+    if constexpr (L > 16) if (!done && c_max <= 16) { greedy_rounds_tile<L, 16>(bin, slice, P, C, gl, sh, lag_max, pid_mask, max_rounds); done = true; }
+    if constexpr (L > 32) if (!done && c_max <= 32) { greedy_rounds_tile<L, 32>(bin, slice, P, C, gl, sh, lag_max, pid_mask, max_rounds); done = true; }
+    if (!done) greedy_rounds_tile<L, L>(bin, slice, P, C, gl, sh, lag_max, pid_mask, max_rounds);
     wave_lds_fence();
 
     // ---- 5. outputs ------------------------------------------------------------------------------------
