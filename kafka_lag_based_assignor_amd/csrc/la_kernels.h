@@ -33,7 +33,6 @@ struct TileArgs {
     int64_t* out_total;         // may be null
     uint32_t* status;
     int32_t reset_latest;
-    int32_t lc;                 // pow2ceil(max consumers per topic), set by the launcher
     int32_t flags;              // LA_FLAG_* of the batch (test hooks) | kTileSkipOversize
     // tiles the packed kernel leaves to the wide kernel (LA_ALGO_AUTO): a counter pair that alternates
     // per launch (the wide kernel zeroes the other one), and the list of tile ids

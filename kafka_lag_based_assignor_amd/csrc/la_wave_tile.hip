@@ -33,7 +33,6 @@ hipError_t wave_tile_launch(TileArgs a, int64_t max_p, int64_t max_c, int mode, 
     if (a.n_total <= 0) return hipSuccess;
     if (max_p > a.n_total) max_p = a.n_total;      // no topic holds more than the batch (E >= 2 needs 2 elements)
     wave_tile_pick(max_p, max_c, &L, &E);
-    a.lc = pow2ceil(max_c > 1 ? max_c : 1);
     switch (L) {
         case 8: return wave_tile_launch_l8(E, a, mode, stream);
         case 16: return wave_tile_launch_l16(E, a, mode, stream);

@@ -475,8 +475,11 @@ __device__ __forceinline__ void assign_wide(const TileArgs& a, uint64_t* slice, 
         const int max_rounds = __builtin_amdgcn_readfirstlane(wave_max_i32(rounds));
         bin.hi = (gl < C) ? (uint32_t)(total >> 32) : 0xFFFFFFFFu;
         bin.lo = (gl < C) ? (uint32_t)total : 0xFFFFFFFFu;
+        // the network spans as many lanes as the widest consumer list among this wavefront's topics needs
+        const int c_max = __builtin_amdgcn_readfirstlane(wave_max_i32(C));
+        const int lc_w = c_max <= 1 ? 1 : 1 << (32 - __builtin_clz((unsigned)(c_max - 1)));
         for (int q = 0; q < max_rounds; ++q) {
-            if (q > 0) bitonic_sort_lanes(bin, gl, a.lc);
+            if (q > 0) bitonic_sort_lanes(bin, gl, lc_w);
             const int s = q * C + gl;
             if (gl < C && s < P) {
                 const uint64_t lg = slice[slot_of(s)];
