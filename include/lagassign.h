@@ -162,7 +162,8 @@ typedef struct la_device_batch {
      * sends it down the wave-tile path, the block path (one workgroup per topic, up to
      * 8192 partitions x 2048 consumers, all such topics side by side) or the large path
      * (device-wide sort, one topic after another).  Also read when LA_FLAG_RAGGED is set.
-     * NULL otherwise.  Calls on one context are expected to be stream-ordered: the
+     * NULL otherwise -- or NULL anyway: the library then fetches the offsets itself, which
+     * makes that call wait on `stream` (not asynchronous, not capturable).  Calls on one context are expected to be stream-ordered: the
      * per-call topic lists live in context-owned device memory. */
     const int64_t *h_part_off;
     const int64_t *h_cons_off;

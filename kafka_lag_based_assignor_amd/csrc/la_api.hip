@@ -51,6 +51,7 @@ struct la_ctx {
     } stage[4];
     unsigned stage_next = 0;
     std::vector<uint8_t> topic_class;   // host scratch of the dispatcher: path / class of every topic
+    std::vector<int64_t> host_offsets;  // offsets fetched from the device when the caller gave no host copy
     // results of the last host-buffer assign call, still in part_off / out_pid / out_rank (la_group_last_by_member)
     bool last_valid = false;
     int32_t last_topics = 0;
@@ -394,11 +395,25 @@ int enqueue_batch(la_ctx* ctx, const la_device_batch* b, hipStream_t stream) {
         LA_HIP(ctx, la::wave_tile_launch(a, b->max_partitions_per_topic, b->max_consumers_per_topic, tile_mode, stream));
         return LA_OK;
     }
-    if (!have_host)
-        return fail(ctx, LA_EINVAL,
-                    "shape hint exceeds one wave tile (%lld partitions / %lld consumers per topic): "
-                    "h_part_off and h_cons_off are required",
-                    (long long)la::kTileMaxPartitions, (long long)la::kTileMaxConsumers);
+    la_device_batch with_host;
+    if (!have_host) {
+        // The shape hint exceeds one wave tile and the caller kept no host copy of the offsets: fetch them (two
+        // small copies and a wait on `stream` -- this call is then neither asynchronous nor capturable).
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        LA_HIP(ctx, hipStreamIsCapturing(stream, &cap));
+        if (cap != hipStreamCaptureStatusNone)
+            return fail(ctx, LA_EINVAL, "shape hint exceeds one wave tile: h_part_off and h_cons_off are required "
+                                        "while the stream is being captured");
+        const size_t words = (size_t)b->n_topics + 1;
+        ctx->host_offsets.resize(2 * words);
+        LA_HIP(ctx, hipMemcpyAsync(ctx->host_offsets.data(), b->d_part_off, words * 8, hipMemcpyDeviceToHost, stream));
+        LA_HIP(ctx, hipMemcpyAsync(ctx->host_offsets.data() + words, b->d_cons_off, words * 8, hipMemcpyDeviceToHost, stream));
+        LA_HIP(ctx, hipStreamSynchronize(stream));
+        with_host = *b;
+        with_host.h_part_off = ctx->host_offsets.data();
+        with_host.h_cons_off = ctx->host_offsets.data() + words;
+        b = &with_host;
+    }
 
     // mixed or ragged shapes (see the dispatcher notes above)
     const bool use_block = !argmin && b->algo != LA_ALGO_ROUNDS_WIDE;   // the test-hook algos keep to tile + large

@@ -403,7 +403,7 @@ def test_cfg5_full_size(ctx):
 
 
 # ---- device-resident entry point; round form == literal wavefront argmin ------------------------------
-def _run_device(ctx, w, algo, use_lag=False, latest=True, flags=0):
+def _run_device(ctx, w, algo, use_lag=False, latest=True, flags=0, host_offsets=True):
     import ctypes
     import torch
     dev = torch.device("cuda", 0)
@@ -434,8 +434,9 @@ def _run_device(ctx, w, algo, use_lag=False, latest=True, flags=0):
     b.d_out_total_lag = out_total.data_ptr()
     po = np.ascontiguousarray(w.part_off, dtype=np.int64)
     co = np.ascontiguousarray(w.cons_off, dtype=np.int64)
-    b.h_part_off = po.ctypes.data_as(ctypes.POINTER(ctypes.c_int64))
-    b.h_cons_off = co.ctypes.data_as(ctypes.POINTER(ctypes.c_int64))
+    if host_offsets:
+        b.h_part_off = po.ctypes.data_as(ctypes.POINTER(ctypes.c_int64))
+        b.h_cons_off = co.ctypes.data_as(ctypes.POINTER(ctypes.c_int64))
     stream = torch.cuda.current_stream().cuda_stream
     ctx.assign_batch_device(b, stream)
     ctx.sync(stream)
@@ -517,6 +518,16 @@ def test_device_entry_large_argmin(ctx):
         got = _run_device(ctx, w, algo, use_lag=True)
         for g, e in zip(got, exp):
             np.testing.assert_array_equal(g, e)
+
+
+def test_device_entry_fetches_offsets_when_no_host_copy_is_given(ctx):
+    # shapes beyond a wave tile need the topics' sizes on the host; without h_part_off / h_cons_off the library
+    # copies the offsets back itself
+    w = synth.ragged(77, 60, 3000, 200, negative=True)
+    exp = oracle.assign_flat(w.part_off, w.partition_id, w.lag, w.cons_off, w.cons_rank)
+    got = _run_device(ctx, w, N.LA_ALGO_AUTO, use_lag=True, host_offsets=False)
+    for g, e, what in zip(got, exp, ("partition order", "member", "totals")):
+        np.testing.assert_array_equal(g, e, err_msg=what)
 
 
 def test_device_entry_shape_hint_violation_is_reported(ctx):
