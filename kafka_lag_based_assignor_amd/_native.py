@@ -167,7 +167,7 @@ class Context:
         return out
 
     def assign_batch(self, part_off, partition_id, begin, end, committed, reset_mode: int,
-                     cons_off, cons_rank, want_totals: bool = True, out=None
+                     cons_off, cons_rank, want_totals: bool = True, out=None, keep_on_device: bool = False
                      ) -> Tuple[np.ndarray, np.ndarray, Optional[np.ndarray]]:
         """`out` = (out_partition int32[N], out_member_rank int32[N], out_total_lag int64[K] or None): caller-owned
         result buffers to reuse across calls (fresh numpy arrays are page-faulted in by the D2H copy, which
@@ -176,7 +176,7 @@ class Context:
         partition_id, cons_rank = _a32(partition_id), _a32(cons_rank)
         end, committed = _a64(end), _a64(committed)
         begin = None if begin is None else _a64(begin)
-        if out == "device":
+        if keep_on_device:
             # results stay on the device for group_last_by_member(); only the totals come back
             out_p = out_m = None
             out_t = np.zeros(cons_rank.size, dtype=np.int64) if want_totals else None
@@ -198,12 +198,12 @@ class Context:
         return out_p, out_m, out_t
 
     def assign_batch_lags(self, part_off, partition_id, lag, cons_off, cons_rank, want_totals: bool = True,
-                          out=None) -> Tuple[np.ndarray, np.ndarray, Optional[np.ndarray]]:
-        """out="device": the results stay on the device for group_last_by_member()."""
+                          keep_on_device: bool = False) -> Tuple[Optional[np.ndarray], Optional[np.ndarray], Optional[np.ndarray]]:
+        """keep_on_device: the results stay on the device for group_last_by_member() (None, None, totals come back)."""
         part_off, cons_off = _a64(part_off), _a64(cons_off)
         partition_id, cons_rank, lag = _a32(partition_id), _a32(cons_rank), _a64(lag)
-        out_p = None if out == "device" else np.empty(partition_id.size, dtype=np.int32)
-        out_m = None if out == "device" else np.empty(partition_id.size, dtype=np.int32)
+        out_p = None if keep_on_device else np.empty(partition_id.size, dtype=np.int32)
+        out_m = None if keep_on_device else np.empty(partition_id.size, dtype=np.int32)
         out_t = np.zeros(cons_rank.size, dtype=np.int64) if want_totals else None
         self._check(self._lib.la_assign_batch_lags(self._h, part_off.size - 1, _p64(part_off),
                                                    _p32(partition_id), _p64(lag), _p64(cons_off),
@@ -225,7 +225,7 @@ class Context:
 
     def group_last_by_member(self, n_partitions: int, n_members: int) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
         """group_by_member on the results the last assign_batch / assign_batch_lags call left on the device
-        (give that call out="device" to skip the download of the ungrouped arrays)."""
+        (give that call keep_on_device=True to skip the download of the ungrouped arrays)."""
         off = np.zeros(n_members + 1, dtype=np.int64)
         g_t = np.empty(n_partitions, dtype=np.int32)
         g_p = np.empty(n_partitions, dtype=np.int32)

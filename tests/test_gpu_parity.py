@@ -574,7 +574,7 @@ def test_group_last_by_member_equals_group_by_member(ctx):
         n_members = int(w.cons_rank.max()) + 1 if w.cons_rank.size else 0
         exp_p, exp_m, exp_t = oracle.assign_flat(w.part_off, w.partition_id, w.lag, w.cons_off, w.cons_rank)
         want = ctx.group_by_member(w.part_off, exp_p, exp_m, n_members)
-        p, m, t = ctx.assign_batch_lags(w.part_off, w.partition_id, w.lag, w.cons_off, w.cons_rank, out="device")
+        p, m, t = ctx.assign_batch_lags(w.part_off, w.partition_id, w.lag, w.cons_off, w.cons_rank, keep_on_device=True)
         assert p is None and m is None
         np.testing.assert_array_equal(t, exp_t)
         got = ctx.group_last_by_member(w.n_partitions, n_members)
