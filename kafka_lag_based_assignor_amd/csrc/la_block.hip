@@ -289,6 +289,90 @@ __device__ __forceinline__ void greedy_one_wave_packed(const BlockArgs& a, const
     }
 }
 
+// Greedy rounds for 257 .. 2 048 consumers with packed bins: the bins stay in registers, EC per thread over
+// n_c / EC threads (slot = tid*EC + r); a round's sort runs inside each wavefront through the networks of
+// la_sort64.h and across wavefronts through LDS exchanges (x: n_c words, register-major) -- the scheme of the
+// large path's one-workgroup greedy, fed from LDS.  Threads beyond the bins only keep the barriers company.
+template <int EC>
+__device__ __forceinline__ void greedy_multi_wave_packed(const BlockArgs& a, const uint64_t* s_key, const int32_t* s_rank,
+                                                         uint64_t* x, int64_t p0, int64_t c0, int P, int C, int n_c,
+                                                         int idx_bits, int tid) {
+    constexpr int kSpanSlots = kWave * EC;
+    const int ntu = n_c / EC;                                            // threads that hold bins (multiple of 64)
+    const bool active = tid < ntu;                                       // wavefront-uniform
+    const uint32_t idx_mask = (1u << idx_bits) - 1;
+    P64 bin[EC];
+    uint64_t lag[EC];
+#pragma unroll
+    for (int r = 0; r < EC; ++r) {
+        const int e = tid * EC + r;
+        bin[r] = p64_from((active && e < C) ? (uint64_t)e : ~0ull);
+        lag[r] = (active && e < C && e < P) ? (s_key[e] ^ kLagKeyFlip) : 0;
+    }
+    const int rounds = (P + C - 1) / C;
+    for (int q = 0; q < rounds; ++q) {
+        uint64_t next[EC];
+#pragma unroll
+        for (int r = 0; r < EC; ++r) {
+            const int e = tid * EC + r;
+            const int s = (q + 1) * C + e;
+            next[r] = (active && e < C && s < P) ? (s_key[s] ^ kLagKeyFlip) : 0;
+        }
+        if (q > 0) {
+            if (active) {
+#pragma unroll
+                for (int r = 0; r < EC; ++r) asm volatile("s_nop 1" : "+v"(bin[r].lo), "+v"(bin[r].hi));
+                bitonic_sort_tile_p64<kWave, EC>(bin);
+            }
+            for (int K = 2 * kSpanSlots; K <= n_c; K <<= 1) {
+                for (int j = K >> 1; j >= kSpanSlots; j >>= 1) {
+                    const int mask = (j == (K >> 1)) ? (K - 1) : j;       // mirror first, then i <-> i ^ j
+                    if (active) {
+#pragma unroll
+                        for (int r = 0; r < EC; ++r) x[r * ntu + tid] = p64_value(bin[r]);
+                    }
+                    __syncthreads();
+                    if (active) {
+#pragma unroll
+                        for (int r = 0; r < EC; ++r) {
+                            const int i = tid * EC + r;
+                            const int pi = i ^ mask;
+                            const uint64_t o = x[(pi % EC) * ntu + pi / EC], v = p64_value(bin[r]);
+                            const bool keep_min = (i & j) == 0;
+                            const uint64_t lo = o < v ? o : v, hi = o < v ? v : o;
+                            bin[r] = p64_from(keep_min ? lo : hi);
+                        }
+                    }
+                    __syncthreads();
+                }
+                if (active) {
+#pragma unroll
+                    for (int r = 0; r < EC; ++r) asm volatile("s_nop 1" : "+v"(bin[r].lo), "+v"(bin[r].hi));
+                    clean_p64<kWave, EC, kSpanSlots / 2, false>(bin);
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < EC; ++r) {
+            const int e = tid * EC + r;
+            const int s = q * C + e;
+            if (active && e < C && s < P) {
+                const uint64_t nb = p64_value(bin[r]) + (lag[r] << idx_bits);              // Main.java:265
+                bin[r] = p64_from(nb);
+                a.out_rank[p0 + s] = s_rank[(uint32_t)nb & idx_mask];
+            }
+            lag[r] = next[r];
+        }
+    }
+    if (a.out_total && active) {
+#pragma unroll
+        for (int r = 0; r < EC; ++r) {
+            const uint64_t v = p64_value(bin[r]);
+            if (v != ~0ull) a.out_total[c0 + ((uint32_t)v & idx_mask)] = (int64_t)(v >> idx_bits);
+        }
+    }
+}
+
 // LDS: [region A][bins].  Region A is the sort's exchange area (kXchg * blockDim keys + ids) and, once the sort is
 // done, the sorted keys by position (E * blockDim words); the ids leave through the registers.
 template <int E>
@@ -441,7 +525,20 @@ __global__ __launch_bounds__(1024) void block_topic_kernel(BlockArgs a) {
         }
         return;
     }
-    // more bins than one wavefront holds comfortably: bins in LDS, same network as the partition sort
+    // more bins than one wavefront holds comfortably.  Packed bins (no negative lag, no total near 2^62): registers
+    // across wavefronts.  Otherwise: bins in LDS, same network as the classic sort, 96-bit comparisons.
+    {
+        const int64_t lmax = P > 0 ? (int64_t)(s_key[0] ^ kLagKeyFlip) : 0;
+        const int64_t lmin = P > 0 ? (int64_t)(s_key[P - 1] ^ kLagKeyFlip) : 0;
+        const int idx_bits = 31 - __builtin_clz((unsigned)n_c);
+        const int lag_bits = lmax > 0 ? 64 - __builtin_clzll((unsigned long long)lmax) : 0;
+        const int round_bits = 32 - __builtin_clz((unsigned)((P + C - 1) / C) | 1u);
+        if (lmin >= 0 && lag_bits + round_bits + idx_bits <= 62) {       // workgroup-uniform
+            if (n_c <= nt) greedy_multi_wave_packed<1>(a, s_key, s_rank, s_tot, p0, c0, P, C, n_c, idx_bits, tid);
+            else greedy_multi_wave_packed<2>(a, s_key, s_rank, s_tot, p0, c0, P, C, n_c, idx_bits, tid);
+            return;
+        }
+    }
     const int upd = n_c >> 1;
     const int rounds = (P + C - 1) / C;
     for (int q = 0; q < rounds; ++q) {
