@@ -6,6 +6,7 @@ assignment) over one batch of synthetic topics that is already resident in HBM w
 timed region starts.  Default workload at N=1 is the configuration BASELINE.json quotes
 its metric on: 100 000 topics x 256 partitions x 32 consumers, Zipf(1.1) lags.
 
+    python bench.py                         # N=1, 2 000 timed steps after 200 warm-up steps (about 15 s in all)
     python bench.py --gpus 1 --steps 20 --warmup 3
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
