@@ -217,3 +217,22 @@ def test_oracle_reproduces_frozen_digests():
             f["inputs_sha256"], "generator drifted: " + name
         p, m, t = mg.run_oracle(w, mode)
         assert mg.digest(p.astype(np.int32), m.astype(np.int32), t.astype(np.int64)) == f["sha256"], name
+
+
+def test_round_form_equals_the_literal_per_step_min():
+    """SURVEY.md section 8a note 5: the comparator's first key is the assigned count, so the literal per-partition
+    Collections.min is the same as rounds of C partitions handed to the consumers in (total, rank) order as of the
+    round start.  Every device kernel relies on that; here the literal oracle and an independent numpy round form
+    are compared on random shapes, ties, zero lags, negative lags and totals that wrap."""
+    from round_form import round_form
+    from kafka_lag_based_assignor_amd import synth
+    cases = 0
+    for seed in range(60):
+        for dist in ("mixed", "ties", "zero", "u63", "full"):
+            w = synth.ragged(1000 * seed + len(dist), 12, 90, 17, dist=dist, negative=(dist in ("mixed", "full")))
+            e = oracle.assign_flat(w.part_off, w.partition_id, w.lag, w.cons_off, w.cons_rank)
+            r = round_form(w.part_off, w.partition_id, w.lag, w.cons_off, w.cons_rank)
+            for x, y, what in zip(e, r, ("partition order", "member", "totals")):
+                np.testing.assert_array_equal(x, y, err_msg="%s seed %d %s" % (what, seed, dist))
+            cases += w.n_topics
+    assert cases == 3600
