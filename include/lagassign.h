@@ -17,6 +17,8 @@
  *   la_assign_batch_lags    static assign(Map,Map) on precomputed lags      Main.java:166-188
  *   la_assign_batch_device  the same two, on buffers already resident in HBM
  *   la_group_by_member      building every member's List<TopicPartition>      Main.java:171-174, :264
+ *   la_create_multi         the per-topic loop, sharded over the GPUs of a node Main.java:177-184
+ *   la_plan_shards          (which topics of that loop each shard takes)
  *
  * Data model (SoA; TopicPartitionLag, Main.java:431-455, flattened):
  *   topic t owns partitions [part_off[t], part_off[t+1]) of the per-partition arrays and
@@ -38,8 +40,10 @@
  * Results are bit-identical to the reference for every input, including negative lags
  * and overflowing totals.
  *
- * Threading: a la_ctx is single-threaded (one per assignor instance, like the
- * reference's own non-thread-safe state, Main.java:89).  No global mutable state.
+ * Threading: a la_ctx is single-threaded for its CALLER (one per assignor instance, like
+ * the reference's own non-thread-safe state, Main.java:89); inside a host-buffer call the
+ * library runs one short-lived host thread per lane of every shard and joins them before
+ * it returns.  No global mutable state.
  * Errors: every function returns LA_OK or a negative code and never throws or aborts;
  * la_last_error() gives the text.  There is NO CPU fallback in this library: without a
  * usable gfx950 device la_create fails and the caller (the Java host) decides.
@@ -47,6 +51,7 @@
 #ifndef LAGASSIGN_H
 #define LAGASSIGN_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -91,9 +96,53 @@ extern "C" {
 
 typedef struct la_ctx la_ctx;
 
+/* la_create / la_create_multi flags */
+#define LA_CREATE_LANES_MASK   0xFu   /* low 4 bits: lanes (streams + host threads) per shard for the chunked    *
+                                       * H2D / kernels / D2H overlap of the host-buffer calls; 0 = automatic      *
+                                       * (3 for one or two shards, 2 beyond; environment LA_LANES overrides)      */
+#define LA_CREATE_SPLIT_ALWAYS 0x10u  /* test hook: shard and chunk every batch, however small (normally a batch  *
+                                       * under 65 536 partitions per extra shard stays on fewer devices and a     *
+                                       * shard under 2 chunks of 524 288 partitions is one chunk, no threads)     */
+
+/* Number of HIP devices visible to the process (>= 0), or a negative code. */
+int la_device_count(void);
+
 /* Creates a context on HIP device `device_id` (streams, scratch, kernels). */
 int la_create(la_ctx **out, int device_id, unsigned flags);
+
+/* Creates a context over several devices of one node: shard i of every host-buffer call runs on
+ * device_ids[i].  This is the multi-GPU form of the per-topic loop of assign(Map,Map) (Main.java:177-184):
+ * assignTopic touches only its own topic's bins (Main.java:216-225), so a batch is split into n_devices
+ * contiguous topic ranges balanced by partition count (la_plan_shards), every range runs the whole hot path on
+ * its device concurrently (one host thread per lane), and each shard's results are copied straight to their
+ * offset in the caller's output arrays -- that IS the reassembly of the global assignment; no device ever needs
+ * another device's topics.  n_devices = 0 (device_ids NULL) = every device of the node.  An id may appear more than
+ * once (several logical shards on one GPU; how the tests exercise the split on a one-GPU box).
+ * The device-buffer entry points (la_assign_batch_device, la_group_by_member_device, la_sync, la_stream) and
+ * la_compute_lag / la_group_by_member use the first device. */
+int la_create_multi(la_ctx **out, int n_devices, const int *device_ids, unsigned flags);
 void la_destroy(la_ctx *ctx);
+
+/* Shards of the context, and the HIP device of shard i. */
+int la_shard_count(const la_ctx *ctx);
+int la_shard_device(const la_ctx *ctx, int shard);
+
+/* The planner the library uses for shards and for the chunks inside a shard: contiguous topic ranges
+ * [bounds[r], bounds[r+1]) for r in [0, n_shards), balanced by partition count (bounds[r] = first topic boundary
+ * at or after r/n_shards of the partitions).  Every topic lands in exactly one range; ranges may be empty.
+ * bounds has n_shards + 1 entries.  Pure host code: needs no context and no device, so a multi-process
+ * launcher (one process per GPU) can shard a batch exactly as a multi-device context would. */
+int la_plan_shards(int32_t n_topics, const int64_t *part_off, int32_t n_shards, int32_t *bounds);
+
+/* The split the last la_assign_batch / la_assign_batch_lags call used: returns the number of shards S and writes
+ * min(S + 1, capacity) bounds (bounds may be NULL). */
+int la_last_shard_bounds(const la_ctx *ctx, int32_t *bounds, int32_t capacity);
+
+/* Pinned host memory for the arrays handed to the host-buffer calls (a JNI shim wraps it in a direct ByteBuffer
+ * with NewDirectByteBuffer): the copies then run as plain DMA, without the runtime staging or pinning pageable
+ * pages per call.  Optional -- every entry point takes pageable memory too.  NULL on failure. */
+void *la_host_alloc(la_ctx *ctx, size_t bytes);
+void la_host_free(la_ctx *ctx, void *p);
 /* Text of the last error on this context ("" if none).  ctx may be NULL: returns the
  * text of the last la_create failure on the calling thread. */
 const char *la_last_error(const la_ctx *ctx);

@@ -19,11 +19,14 @@ LA_EINVAL, LA_ENOMEM, LA_EHIP, LA_ENODEV, LA_ESHAPE = -1, -2, -3, -4, -5
 LA_RESET_LATEST, LA_RESET_EARLIEST = 0, 1
 LA_ALGO_AUTO, LA_ALGO_ROUNDS, LA_ALGO_ARGMIN, LA_ALGO_ROUNDS_WIDE = 0, 1, 2, 3
 LA_FLAG_INDEX64, LA_FLAG_DEFER_WIDE, LA_FLAG_RAGGED, LA_FLAG_SHAPE_CLASSES = 1, 2, 4, 8
+LA_CREATE_LANES_MASK, LA_CREATE_SPLIT_ALWAYS = 0xF, 0x10
 
 EXPORTED_SYMBOLS = (
     "la_create", "la_destroy", "la_last_error", "la_version", "la_compute_lag",
     "la_assign_batch", "la_assign_batch_lags", "la_assign_batch_device", "la_sync", "la_stream",
     "la_group_by_member", "la_group_by_member_device", "la_group_last_by_member",
+    "la_device_count", "la_create_multi", "la_shard_count", "la_shard_device", "la_plan_shards",
+    "la_last_shard_bounds", "la_host_alloc", "la_host_free",
 )
 
 _i64p = ctypes.POINTER(ctypes.c_int64)
@@ -78,6 +81,23 @@ def load() -> ctypes.CDLL:
     L.la_version.restype = ctypes.c_int
     L.la_create.restype = ctypes.c_int
     L.la_create.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, ctypes.c_uint]
+    L.la_create_multi.restype = ctypes.c_int
+    L.la_create_multi.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int, ctypes.POINTER(ctypes.c_int),
+                                  ctypes.c_uint]
+    L.la_device_count.restype = ctypes.c_int
+    L.la_device_count.argtypes = []
+    L.la_shard_count.restype = ctypes.c_int
+    L.la_shard_count.argtypes = [ctypes.c_void_p]
+    L.la_shard_device.restype = ctypes.c_int
+    L.la_shard_device.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    L.la_plan_shards.restype = ctypes.c_int
+    L.la_plan_shards.argtypes = [ctypes.c_int32, _i64p, ctypes.c_int32, _i32p]
+    L.la_last_shard_bounds.restype = ctypes.c_int
+    L.la_last_shard_bounds.argtypes = [ctypes.c_void_p, _i32p, ctypes.c_int32]
+    L.la_host_alloc.restype = ctypes.c_void_p
+    L.la_host_alloc.argtypes = [ctypes.c_void_p, ctypes.c_size_t]
+    L.la_host_free.restype = None
+    L.la_host_free.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
     L.la_destroy.restype = None
     L.la_destroy.argtypes = [ctypes.c_void_p]
     L.la_last_error.restype = ctypes.c_char_p
@@ -125,16 +145,75 @@ def _p32(a: Optional[np.ndarray]):
     return None if a is None else a.ctypes.data_as(_i32p)
 
 
-class Context:
-    """RAII wrapper of la_ctx (one per assignor instance; not thread-safe)."""
+def plan_shards(part_off, n_shards: int) -> np.ndarray:
+    """la_plan_shards: the library's own planner (pure host code, no device needed).  Returns int32
+    bounds[n_shards + 1]: shard r owns topics [bounds[r], bounds[r+1])."""
+    part_off = _a64(part_off)
+    bounds = np.zeros(n_shards + 1, dtype=np.int32)
+    rc = load().la_plan_shards(part_off.size - 1, _p64(part_off), n_shards, _p32(bounds))
+    if rc != LA_OK:
+        raise LagAssignError(rc, "la_plan_shards: bad arguments")
+    return bounds
 
-    def __init__(self, device_id: int = 0):
+
+def device_count() -> int:
+    n = load().la_device_count()
+    if n < 0:
+        raise LagAssignError(n, load().la_last_error(None).decode())
+    return n
+
+
+class Context:
+    """RAII wrapper of la_ctx (one per assignor instance; not thread-safe).
+
+    ``device_id`` may be an int (one device) or a sequence of device ids (la_create_multi: one shard per
+    entry; an id may repeat -- several logical shards on one GPU); ``devices="all"`` takes every device."""
+
+    def __init__(self, device_id=0, flags: int = 0):
         self._lib = load()
         h = ctypes.c_void_p()
-        rc = self._lib.la_create(ctypes.byref(h), device_id, 0)
+        if isinstance(device_id, str):
+            if device_id != "all":
+                raise ValueError("device_id must be an int, a sequence of ints or 'all'")
+            rc = self._lib.la_create_multi(ctypes.byref(h), 0, None, flags)
+        elif isinstance(device_id, (list, tuple)):
+            ids = (ctypes.c_int * len(device_id))(*device_id)
+            rc = self._lib.la_create_multi(ctypes.byref(h), len(device_id), ids, flags)
+        else:
+            rc = self._lib.la_create(ctypes.byref(h), int(device_id), flags)
         if rc != LA_OK:
             raise LagAssignError(rc, self._lib.la_last_error(None).decode())
         self._h = h
+
+    @property
+    def shard_count(self) -> int:
+        return int(self._lib.la_shard_count(self._h))
+
+    def shard_device(self, i: int) -> int:
+        return int(self._lib.la_shard_device(self._h, i))
+
+    def last_shard_bounds(self) -> np.ndarray:
+        """Topic ranges the last host-buffer assign call gave to its shards (int32 [S + 1])."""
+        buf = np.zeros(65, dtype=np.int32)
+        s = int(self._lib.la_last_shard_bounds(self._h, _p32(buf), buf.size))
+        return buf[: s + 1].copy()
+
+    def host_alloc(self, shape, dtype) -> np.ndarray:
+        """A numpy array over pinned host memory from la_host_alloc (freed when the array is collected)."""
+        dtype = np.dtype(dtype)
+        n = int(np.prod(shape))
+        p = self._lib.la_host_alloc(self._h, max(1, n * dtype.itemsize))
+        if not p:
+            raise LagAssignError(LA_ENOMEM, self._lib.la_last_error(self._h).decode())
+        lib = self._lib
+
+        class _Owner:
+            def __del__(self_inner):
+                lib.la_host_free(None, ctypes.c_void_p(p))
+
+        buf = (ctypes.c_char * max(1, n * dtype.itemsize)).from_address(p)
+        buf._owner = _Owner()
+        return np.frombuffer(buf, dtype=dtype, count=n).reshape(shape)
 
     def close(self) -> None:
         if getattr(self, "_h", None):

@@ -6,11 +6,15 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+#include <atomic>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "la_kernels.h"
@@ -20,6 +24,9 @@
 namespace {
 
 thread_local std::string g_create_error;
+// Worker threads of a host-buffer call report into their own slot (the first failing worker's text becomes the
+// context's last error once they have joined); everything else writes the context's string directly.
+thread_local std::string* t_err_sink = nullptr;
 
 struct DevBuf {
     void* p = nullptr;
@@ -28,15 +35,14 @@ struct DevBuf {
 
 }  // namespace
 
-struct la_ctx {
-    int device = 0;
+// Everything ONE in-flight batch needs besides the bulk arrays: a stream, the device status word + deferred-tile
+// counters, and the per-call scratch of the three kernel paths.  A shard owns several lanes so that chunks of one
+// host-buffer call can be in flight side by side (H2D of one chunk under the kernels / D2H of another); the device
+// entry points use lane 0 with the caller's stream.
+struct Lane {
     hipStream_t stream = nullptr;
-    uint32_t* d_status = nullptr;
-    std::string err;
-    // grow-only device scratch for the host-buffer entry points
-    DevBuf part_off, pid, begin, end, committed, cons_off, cons_rank, out_pid, out_rank, out_total;
-    // scratch of the large-topic path
-    la::LargeScratch large;
+    uint32_t* d_status = nullptr;        // 256 B: word 0 = status bits, words 16..19 = deferred-tile counters
+    uint32_t* h_status = nullptr;        // pinned word the status is copied to (one stream sync per call)
     // tile path: list of tiles the packed kernel leaves to the wide kernel, and which of the two
     // counters (d_status + 16 / + 17 words) the next launch uses
     DevBuf defer;
@@ -50,12 +56,38 @@ struct la_ctx {
         hipEvent_t done = nullptr;
     } stage[4];
     unsigned stage_next = 0;
-    std::vector<uint8_t> topic_class;   // host scratch of the dispatcher: path / class of every topic
-    std::vector<int64_t> host_offsets;  // offsets fetched from the device when the caller gave no host copy
+    la::LargeScratch large;              // scratch of the large-topic path and of la_group_by_member
+    std::vector<uint8_t> topic_class;    // host scratch of the dispatcher: path / class of every topic
+    std::vector<int64_t> host_offsets;   // offsets fetched from the device when the caller gave no host copy
+};
+
+struct HostBuf {                         // pinned, grow-only
+    void* p = nullptr;
+    size_t cap = 0;
+};
+
+// One shard = one device (or, for tests, one of several logical shards mapped to the same device): the bulk
+// device arrays of the host-buffer entry points, and its lanes.
+struct Shard {
+    int device = 0;
+    DevBuf part_off, pid, begin, end, committed, cons_off, cons_rank, out_pid, out_rank, out_total;
+    std::vector<Lane> lanes;
+    hipEvent_t ready = nullptr;          // the shard's offsets are on the device (lane 0's stream)
+    std::vector<int64_t> local_part_off, local_cons_off;   // offsets rebased to the shard's first topic (shards > 0)
+    HostBuf g_off, g_topic, g_part;      // multi-shard la_group_last_by_member: this shard's CSR before the merge
     // results of the last host-buffer assign call, still in part_off / out_pid / out_rank (la_group_last_by_member)
+    int32_t last_t0 = 0, last_topics = 0;
+    int64_t last_p0 = 0, last_n = 0;
+};
+
+struct la_ctx {
+    std::vector<Shard> shards;
+    std::string err;
+    bool split_always = false;           // LA_CREATE_SPLIT_ALWAYS: shard and chunk even tiny batches (tests)
+    int64_t chunk_partitions = 0;        // LA_CHUNK_PARTITIONS override (0: automatic)
     bool last_valid = false;
-    int32_t last_topics = 0;
-    int64_t last_n = 0;
+    int last_shards = 0;                 // shards the last call used
+    int32_t last_bounds[65] = {};        // their topic ranges
 };
 
 namespace {
@@ -66,7 +98,9 @@ int fail(la_ctx* ctx, int code, const char* fmt, ...) {
     va_start(ap, fmt);
     vsnprintf(buf, sizeof buf, fmt, ap);
     va_end(ap);
-    if (ctx) ctx->err = buf; else g_create_error = buf;
+    if (t_err_sink) *t_err_sink = buf;
+    else if (ctx) ctx->err = buf;
+    else g_create_error = buf;
     return code;
 }
 
@@ -143,10 +177,10 @@ struct BatchPlan {
 };
 
 // One pass over the host offsets: a class code per topic, counts and maxima; then the tile plan.
-int plan_batch(la_ctx* ctx, const la_device_batch* b, int tile_mode, bool use_block, BatchPlan* plan) {
+int plan_batch(la_ctx* ctx, Lane& ln, const la_device_batch* b, int tile_mode, bool use_block, BatchPlan* plan) {
     const int64_t T = b->n_topics;
-    ctx->topic_class.resize((size_t)T);
-    uint8_t* code = ctx->topic_class.data();
+    ln.topic_class.resize((size_t)T);
+    uint8_t* code = ln.topic_class.data();
     int64_t cnt[kLargeCode + 1] = {};
     int64_t mp[kTileClasses] = {}, mc[kTileClasses] = {};
     bool decreasing = false;
@@ -217,10 +251,10 @@ int plan_batch(la_ctx* ctx, const la_device_batch* b, int tile_mode, bool use_bl
 }
 
 // Second host pass: the topic lists, built in a pinned slot of the context's ring and copied to the device.
-int stage_topic_lists(la_ctx* ctx, const BatchPlan& plan, int64_t T, hipStream_t stream, const int32_t** d_lists) {
+int stage_topic_lists(la_ctx* ctx, Lane& ln, const BatchPlan& plan, int64_t T, hipStream_t stream, const int32_t** d_lists) {
     *d_lists = nullptr;
     if (plan.n_lists == 0 || (!plan.classed && plan.n_block_all <= 8)) return LA_OK;   // few block topics go inline
-    la_ctx::Stage& sg = ctx->stage[ctx->stage_next++ & 3u];
+    Lane::Stage& sg = ln.stage[ln.stage_next++ & 3u];
     if (sg.done) LA_HIP(ctx, hipEventSynchronize(sg.done));          // the copy that last read this slot
     else LA_HIP(ctx, hipEventCreateWithFlags(&sg.done, hipEventDisableTiming));
     if (sg.cap < (size_t)plan.n_lists) {
@@ -242,15 +276,15 @@ int stage_topic_lists(la_ctx* ctx, const BatchPlan& plan, int64_t T, hipStream_t
     }
     // calls of one context are stream-ordered (lagassign.h), so the device copy of the lists is free again by
     // the time this copy runs
-    if (int rc = reserve(ctx, ctx->block_list, (size_t)plan.n_lists * sizeof(int32_t))) return rc;
-    LA_HIP(ctx, hipMemcpyAsync(ctx->block_list.p, sg.p, (size_t)plan.n_lists * sizeof(int32_t), hipMemcpyHostToDevice,
+    if (int rc = reserve(ctx, ln.block_list, (size_t)plan.n_lists * sizeof(int32_t))) return rc;
+    LA_HIP(ctx, hipMemcpyAsync(ln.block_list.p, sg.p, (size_t)plan.n_lists * sizeof(int32_t), hipMemcpyHostToDevice,
                                stream));
     LA_HIP(ctx, hipEventRecord(sg.done, stream));
-    *d_lists = (const int32_t*)ctx->block_list.p;
+    *d_lists = (const int32_t*)ln.block_list.p;
     return LA_OK;
 }
 
-int launch_block_topics(la_ctx* ctx, const la_device_batch* b, const BatchPlan& plan, const int32_t* d_lists,
+int launch_block_topics(la_ctx* ctx, Lane& ln, const la_device_batch* b, const BatchPlan& plan, const int32_t* d_lists,
                         hipStream_t stream) {
     la::BlockArgs g{};
     g.part_off = b->d_part_off;
@@ -264,7 +298,7 @@ int launch_block_topics(la_ctx* ctx, const la_device_batch* b, const BatchPlan& 
     g.out_pid = b->d_out_partition;
     g.out_rank = b->d_out_member_rank;
     g.out_total = b->d_out_total_lag;
-    g.status = ctx->d_status;
+    g.status = ln.d_status;
     g.reset_latest = (b->reset_mode == LA_RESET_LATEST) ? 1 : 0;
     if (!d_lists) {
         // a handful of block topics: their indices travel in the kernel arguments (no copy, no event)
@@ -287,7 +321,7 @@ int launch_block_topics(la_ctx* ctx, const la_device_batch* b, const BatchPlan& 
     return LA_OK;
 }
 
-int launch_large_topics(la_ctx* ctx, const la_device_batch* b, const BatchPlan& plan, bool argmin, hipStream_t stream) {
+int launch_large_topics(la_ctx* ctx, Lane& ln, const la_device_batch* b, const BatchPlan& plan, bool argmin, hipStream_t stream) {
     for (int64_t t = 0; t < b->n_topics; ++t) {
         if (plan.code[t] != kLargeCode) continue;
         const int64_t p = b->h_part_off[t + 1] - b->h_part_off[t], c = b->h_cons_off[t + 1] - b->h_cons_off[t];
@@ -312,8 +346,8 @@ int launch_large_topics(la_ctx* ctx, const la_device_batch* b, const BatchPlan& 
         g.out_rank = b->d_out_member_rank;
         g.out_total = b->d_out_total_lag;
         g.reset_latest = (b->reset_mode == LA_RESET_LATEST) ? 1 : 0;
-        g.status = ctx->d_status;
-        hipError_t e = la::large_topic_launch(ctx->large, g, argmin, stream);
+        g.status = ln.d_status;
+        hipError_t e = la::large_topic_launch(ln.large, g, argmin, stream);
         if (e != hipSuccess)
             return fail(ctx, e == hipErrorOutOfMemory ? LA_ENOMEM : LA_EHIP, "large topic %lld: %s", (long long)t,
                         hipGetErrorString(e));
@@ -322,7 +356,7 @@ int launch_large_topics(la_ctx* ctx, const la_device_batch* b, const BatchPlan& 
 }
 
 // The dispatcher shared by the host and device entry points.
-int enqueue_batch(la_ctx* ctx, const la_device_batch* b, hipStream_t stream) {
+int enqueue_batch(la_ctx* ctx, Lane& ln, const la_device_batch* b, hipStream_t stream) {
     if (b->n_topics < 0 || b->n_partitions < 0 || b->n_consumers < 0)
         return fail(ctx, LA_EINVAL, "negative size");
     if (b->n_topics == 0) return LA_OK;
@@ -349,14 +383,14 @@ int enqueue_batch(la_ctx* ctx, const la_device_batch* b, hipStream_t stream) {
     a.out_pid = b->d_out_partition;
     a.out_rank = b->d_out_member_rank;
     a.out_total = b->d_out_total_lag;
-    a.status = ctx->d_status;
+    a.status = ln.d_status;
     a.reset_latest = (b->reset_mode == LA_RESET_LATEST) ? 1 : 0;
     a.n_total = b->n_partitions;
     a.flags = b->flags & (LA_FLAG_INDEX64 | LA_FLAG_DEFER_WIDE);
     a.topic_list = nullptr;
     a.k_total = b->n_consumers;
-    if (int rc = reserve(ctx, ctx->defer, la::wave_tile_defer_bytes(b->n_topics))) return rc;
-    a.defer_list = (int32_t*)ctx->defer.p;
+    if (int rc = reserve(ctx, ln.defer, la::wave_tile_defer_bytes(b->n_topics))) return rc;
+    a.defer_list = (int32_t*)ln.defer.p;
     const bool argmin = (b->algo == LA_ALGO_ARGMIN);
     const int tile_mode = argmin ? 2 : (b->algo == LA_ALGO_ROUNDS_WIDE ? 1 : 0);
 
@@ -368,7 +402,7 @@ int enqueue_batch(la_ctx* ctx, const la_device_batch* b, hipStream_t stream) {
     if (tile_mode == 0) LA_HIP(ctx, hipStreamIsCapturing(stream, &capture));
     hipError_t counter_err = hipSuccess;
     auto next_counters = [&](la::TileArgs& t) {
-        int32_t* pair = (int32_t*)(ctx->d_status + 16);
+        int32_t* pair = (int32_t*)(ln.d_status + 16);
         if (capture != hipStreamCaptureStatusNone) {
             t.defer_count = pair + 2;
             t.defer_count_next = pair + 3;
@@ -376,9 +410,9 @@ int enqueue_batch(la_ctx* ctx, const la_device_batch* b, hipStream_t stream) {
             if (e != hipSuccess) counter_err = e;
             return;
         }
-        t.defer_count = pair + (ctx->launches & 1u);
-        t.defer_count_next = pair + ((ctx->launches + 1u) & 1u);
-        if (tile_mode == 0) ++ctx->launches;
+        t.defer_count = pair + (ln.launches & 1u);
+        t.defer_count_next = pair + ((ln.launches + 1u) & 1u);
+        if (tile_mode == 0) ++ln.launches;
     };
     if (b->n_partitions == 0) {
         // nothing to assign; consumers of partition-less topics still report a total of 0
@@ -405,22 +439,22 @@ int enqueue_batch(la_ctx* ctx, const la_device_batch* b, hipStream_t stream) {
             return fail(ctx, LA_EINVAL, "shape hint exceeds one wave tile: h_part_off and h_cons_off are required "
                                         "while the stream is being captured");
         const size_t words = (size_t)b->n_topics + 1;
-        ctx->host_offsets.resize(2 * words);
-        LA_HIP(ctx, hipMemcpyAsync(ctx->host_offsets.data(), b->d_part_off, words * 8, hipMemcpyDeviceToHost, stream));
-        LA_HIP(ctx, hipMemcpyAsync(ctx->host_offsets.data() + words, b->d_cons_off, words * 8, hipMemcpyDeviceToHost, stream));
+        ln.host_offsets.resize(2 * words);
+        LA_HIP(ctx, hipMemcpyAsync(ln.host_offsets.data(), b->d_part_off, words * 8, hipMemcpyDeviceToHost, stream));
+        LA_HIP(ctx, hipMemcpyAsync(ln.host_offsets.data() + words, b->d_cons_off, words * 8, hipMemcpyDeviceToHost, stream));
         LA_HIP(ctx, hipStreamSynchronize(stream));
         with_host = *b;
-        with_host.h_part_off = ctx->host_offsets.data();
-        with_host.h_cons_off = ctx->host_offsets.data() + words;
+        with_host.h_part_off = ln.host_offsets.data();
+        with_host.h_cons_off = ln.host_offsets.data() + words;
         b = &with_host;
     }
 
     // mixed or ragged shapes (see the dispatcher notes above)
     const bool use_block = !argmin && b->algo != LA_ALGO_ROUNDS_WIDE;   // the test-hook algos keep to tile + large
     BatchPlan plan;
-    if (int rc = plan_batch(ctx, b, tile_mode, use_block, &plan)) return rc;
+    if (int rc = plan_batch(ctx, ln, b, tile_mode, use_block, &plan)) return rc;
     const int32_t* d_lists = nullptr;
-    if (int rc = stage_topic_lists(ctx, plan, b->n_topics, stream, &d_lists)) return rc;
+    if (int rc = stage_topic_lists(ctx, ln, plan, b->n_topics, stream, &d_lists)) return rc;
     if (plan.classed) {
         for (int k = 0; k < kTileClasses; ++k) {
             if (plan.tile[k].n == 0) continue;
@@ -439,22 +473,243 @@ int enqueue_batch(la_ctx* ctx, const la_device_batch* b, hipStream_t stream) {
         LA_HIP(ctx, la::wave_tile_launch(run, plan.tile_mp, plan.tile_mc, tile_mode, stream));
     }
     if (plan.n_block_all > 0)
-        if (int rc = launch_block_topics(ctx, b, plan, d_lists, stream)) return rc;
+        if (int rc = launch_block_topics(ctx, ln, b, plan, d_lists, stream)) return rc;
     if (plan.n_large > 0)
-        if (int rc = launch_large_topics(ctx, b, plan, argmin, stream)) return rc;
+        if (int rc = launch_large_topics(ctx, ln, b, plan, argmin, stream)) return rc;
     return LA_OK;
 }
 
-int sync_status(la_ctx* ctx, hipStream_t stream) {
+// Waits for `stream` and reports what the kernels flagged on this lane (one copy + one sync).
+int sync_status(la_ctx* ctx, Lane& ln, hipStream_t stream) {
+    LA_HIP(ctx, hipMemcpyAsync(ln.h_status, ln.d_status, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
     LA_HIP(ctx, hipStreamSynchronize(stream));
-    uint32_t st = 0;
-    LA_HIP(ctx, hipMemcpy(&st, ctx->d_status, sizeof st, hipMemcpyDeviceToHost));
+    const uint32_t st = *(volatile uint32_t*)ln.h_status;
     if (st) {
-        LA_HIP(ctx, hipMemset(ctx->d_status, 0, sizeof st));
+        LA_HIP(ctx, hipMemsetAsync(ln.d_status, 0, sizeof st, stream));
+        LA_HIP(ctx, hipStreamSynchronize(stream));
         if (st & la::kStatusUnsorted)
             return fail(ctx, LA_EINVAL, "a topic's cons_rank segment is not strictly ascending");
         return fail(ctx, LA_ESHAPE, "a topic exceeds the batch's shape hint");
     }
+    return LA_OK;
+}
+
+// ---- planner: contiguous topic ranges balanced by partition count -----------------------------------------
+// The shard axis is the per-topic loop of assign(Map,Map) (Main.java:177-184): assignTopic touches only its own
+// topic's bins, so any split at topic boundaries is valid; the kernels' cost is per partition, so the split
+// balances partitions.  bounds[r] = first topic boundary at or after r/parts of the partitions.  Every topic
+// lands in exactly one range; ranges may be empty.  Used for shards (devices) and for the chunks of one shard.
+void plan_ranges(const int64_t* po, int32_t t_begin, int32_t t_end, int parts, int32_t* bounds) {
+    const int64_t base = po[t_begin], total = po[t_end] - base;
+    bounds[0] = t_begin;
+    for (int r = 1; r < parts; ++r) {
+        const int64_t target = base + (total / parts) * r + (total % parts) * r / parts;
+        const int64_t* lo = std::lower_bound(po + bounds[r - 1], po + t_end + 1, target);
+        int64_t t = lo - po;
+        if (t > t_end) t = t_end;
+        bounds[r] = (int32_t)t;
+    }
+    bounds[parts] = t_end;
+}
+
+constexpr int kMaxShards = 64;
+constexpr int64_t kMinShardPartitions = 1 << 16;   // below this a second device costs more than it saves
+constexpr int64_t kMinChunkPartitions = 1 << 19;   // a chunk's copies must be long enough to hide a kernel
+constexpr int kMaxChunks = 64;
+
+// One host-buffer assign call (all pointers are the caller's host arrays).
+struct HostCall {
+    int32_t T = 0;
+    const int64_t* part_off = nullptr;
+    const int32_t* pid = nullptr;
+    const int64_t *begin = nullptr, *end = nullptr, *committed = nullptr, *lag = nullptr;
+    int32_t reset_mode = 0;
+    const int64_t* cons_off = nullptr;
+    const int32_t* cons_rank = nullptr;
+    int32_t *out_pid = nullptr, *out_rank = nullptr;
+    int64_t* out_total = nullptr;
+    bool use_begin = false;
+    Shape shape;
+};
+
+struct ShardPlan {
+    int32_t t0 = 0, t1 = 0;                 // the shard's topics in the caller's numbering
+    int64_t P0 = 0, K0 = 0, n = 0, k = 0;   // its partitions / consumer entries: first position, count
+    const int64_t *lpo = nullptr, *lco = nullptr;   // offsets rebased to the shard (host)
+    std::vector<int32_t> chunk;             // chunk boundaries, shard-local topic indices
+    std::atomic<int> next{0};
+};
+
+// Buffers + offsets of one shard, on the calling thread, before its lanes start.
+int prepare_shard(la_ctx* ctx, const HostCall& c, Shard& sh, ShardPlan& sp) {
+    LA_HIP(ctx, hipSetDevice(sh.device));
+    const int32_t Ts = sp.t1 - sp.t0;
+    if (sp.P0 == 0 && sp.K0 == 0) {
+        sp.lpo = c.part_off + sp.t0;
+        sp.lco = c.cons_off + sp.t0;
+    } else {
+        sh.local_part_off.resize((size_t)Ts + 1);
+        sh.local_cons_off.resize((size_t)Ts + 1);
+        for (int32_t t = 0; t <= Ts; ++t) {
+            sh.local_part_off[t] = c.part_off[sp.t0 + t] - sp.P0;
+            sh.local_cons_off[t] = c.cons_off[sp.t0 + t] - sp.K0;
+        }
+        sp.lpo = sh.local_part_off.data();
+        sp.lco = sh.local_cons_off.data();
+    }
+    const size_t nb8 = (size_t)sp.n * 8, nb4 = (size_t)sp.n * 4, kb8 = (size_t)sp.k * 8, kb4 = (size_t)sp.k * 4;
+    const size_t tb = (size_t)(Ts + 1) * 8;
+    int rc;
+    if ((rc = reserve(ctx, sh.part_off, tb)) || (rc = reserve(ctx, sh.cons_off, tb)) ||
+        (rc = reserve(ctx, sh.pid, nb4 + 16)) || (rc = reserve(ctx, sh.end, nb8 + 16)) ||
+        (rc = reserve(ctx, sh.committed, c.lag ? 16 : nb8 + 16)) ||
+        (rc = reserve(ctx, sh.begin, c.use_begin ? nb8 + 16 : 16)) ||
+        (rc = reserve(ctx, sh.cons_rank, kb4 + 16)) || (rc = reserve(ctx, sh.out_pid, nb4 + 16)) ||
+        (rc = reserve(ctx, sh.out_rank, nb4 + 16)) || (rc = reserve(ctx, sh.out_total, kb8 + 16)))
+        return rc;
+    hipStream_t st = sh.lanes[0].stream;
+    LA_HIP(ctx, hipMemcpyAsync(sh.part_off.p, sp.lpo, tb, hipMemcpyHostToDevice, st));
+    LA_HIP(ctx, hipMemcpyAsync(sh.cons_off.p, sp.lco, tb, hipMemcpyHostToDevice, st));
+    LA_HIP(ctx, hipEventRecord(sh.ready, st));
+
+    // chunks: enough of them that the copies of one overlap the kernels and the opposite copies of another
+    int n_chunks = 1;
+    if (ctx->split_always) {
+        n_chunks = Ts < 3 ? (Ts > 0 ? Ts : 1) : 3;
+    } else if ((int)sh.lanes.size() > 1) {
+        int64_t target = ctx->chunk_partitions > 0 ? ctx->chunk_partitions : sp.n / 16;
+        if (ctx->chunk_partitions <= 0 && target < kMinChunkPartitions) target = kMinChunkPartitions;
+        const int64_t want = (sp.n + target - 1) / target;
+        n_chunks = (int)(want < 1 ? 1 : (want > kMaxChunks ? kMaxChunks : want));
+        if (n_chunks > Ts) n_chunks = Ts > 0 ? Ts : 1;
+    }
+    sp.chunk.resize((size_t)n_chunks + 1);
+    plan_ranges(sp.lpo, 0, Ts, n_chunks, sp.chunk.data());
+    sp.next.store(0);
+    return LA_OK;
+}
+
+// One lane of one shard: takes the shard's chunks in order until none is left.  Per chunk: H2D of its slices,
+// the kernels over its topics, D2H of its results -- all on the lane's stream; the lanes of a shard overlap
+// each other (the copies of a pageable buffer block their host thread, which is why lanes are threads).
+int run_lane(la_ctx* ctx, const HostCall& c, Shard& sh, ShardPlan& sp, int lane_idx, std::atomic<bool>& stop) {
+    LA_HIP(ctx, hipSetDevice(sh.device));
+    Lane& ln = sh.lanes[(size_t)lane_idx];
+    hipStream_t st = ln.stream;
+    if (lane_idx > 0) LA_HIP(ctx, hipStreamWaitEvent(st, sh.ready, 0));
+    const int n_chunks = (int)sp.chunk.size() - 1;
+    auto run_chunk = [&](int ci) -> int {
+        const int32_t a = sp.chunk[(size_t)ci], z = sp.chunk[(size_t)ci + 1];
+        const int64_t p0 = sp.lpo[a], p1 = sp.lpo[z], k0 = sp.lco[a], k1 = sp.lco[z];
+        const int64_t gp = sp.P0 + p0, gk = sp.K0 + k0;              // the chunk in the caller's arrays
+        const size_t np = (size_t)(p1 - p0), nk = (size_t)(k1 - k0);
+        if (np) {
+            LA_HIP(ctx, hipMemcpyAsync((int32_t*)sh.pid.p + p0, c.pid + gp, np * 4, hipMemcpyHostToDevice, st));
+            if (c.lag) {
+                LA_HIP(ctx, hipMemcpyAsync((int64_t*)sh.end.p + p0, c.lag + gp, np * 8, hipMemcpyHostToDevice, st));
+            } else {
+                LA_HIP(ctx, hipMemcpyAsync((int64_t*)sh.end.p + p0, c.end + gp, np * 8, hipMemcpyHostToDevice, st));
+                LA_HIP(ctx, hipMemcpyAsync((int64_t*)sh.committed.p + p0, c.committed + gp, np * 8,
+                                           hipMemcpyHostToDevice, st));
+                if (c.use_begin)
+                    LA_HIP(ctx, hipMemcpyAsync((int64_t*)sh.begin.p + p0, c.begin + gp, np * 8, hipMemcpyHostToDevice, st));
+            }
+        }
+        if (nk) {
+            LA_HIP(ctx, hipMemcpyAsync((int32_t*)sh.cons_rank.p + k0, c.cons_rank + gk, nk * 4, hipMemcpyHostToDevice, st));
+            // the ascending-rank contract of cons_rank is checked on the device (one pass over K entries there
+            // instead of ~1 ns per entry of host time), reported by sync_status as LA_EINVAL
+            LA_HIP(ctx, la::check_consumers_launch(z - a, (const int64_t*)sh.cons_off.p + a,
+                                                   (const int32_t*)sh.cons_rank.p, ln.d_status, st));
+        }
+        // The chunk is a topic sub-range of the shard's batch: same arrays, offsets advanced to its first topic.
+        // n_partitions / n_consumers stay the shard's totals -- they bound the kernels' clamped loads, which may
+        // touch (and ignore) elements of neighbouring chunks.
+        la_device_batch b{};
+        b.n_topics = z - a;
+        b.reset_mode = c.reset_mode == LA_RESET_LATEST ? LA_RESET_LATEST : LA_RESET_EARLIEST;
+        b.algo = LA_ALGO_AUTO;
+        b.n_partitions = sp.n;
+        b.n_consumers = sp.k;
+        b.max_partitions_per_topic = c.shape.max_p;
+        b.max_consumers_per_topic = c.shape.max_c;
+        b.d_part_off = (const int64_t*)sh.part_off.p + a;
+        b.d_partition_id = (const int32_t*)sh.pid.p;
+        b.d_begin_off = c.use_begin ? (const int64_t*)sh.begin.p : nullptr;
+        b.d_end_off = (const int64_t*)sh.end.p;
+        b.d_committed_off = (const int64_t*)sh.committed.p;
+        b.d_lag = c.lag ? (const int64_t*)sh.end.p : nullptr;
+        b.d_cons_off = (const int64_t*)sh.cons_off.p + a;
+        b.d_cons_rank = (const int32_t*)sh.cons_rank.p;
+        b.d_out_partition = (int32_t*)sh.out_pid.p;
+        b.d_out_member_rank = (int32_t*)sh.out_rank.p;
+        b.d_out_total_lag = c.out_total ? (int64_t*)sh.out_total.p : nullptr;
+        b.h_part_off = sp.lpo + a;
+        b.h_cons_off = sp.lco + a;
+        b.flags = LA_FLAG_RAGGED;        // the offsets are on the host anyway: let the dispatcher look at the shapes
+        if (np == 0) {
+            // nothing to assign in this chunk; its consumers still report a total of 0
+            if (c.out_total && nk)
+                LA_HIP(ctx, hipMemsetAsync((int64_t*)sh.out_total.p + k0, 0, nk * 8, st));
+        } else if (int rc = enqueue_batch(ctx, ln, &b, st)) {
+            return rc;
+        }
+        if (np && c.out_pid) {
+            LA_HIP(ctx, hipMemcpyAsync(c.out_pid + gp, (const int32_t*)sh.out_pid.p + p0, np * 4, hipMemcpyDeviceToHost, st));
+            LA_HIP(ctx, hipMemcpyAsync(c.out_rank + gp, (const int32_t*)sh.out_rank.p + p0, np * 4, hipMemcpyDeviceToHost, st));
+        }
+        if (c.out_total && nk)
+            LA_HIP(ctx, hipMemcpyAsync(c.out_total + gk, (const int64_t*)sh.out_total.p + k0, nk * 8, hipMemcpyDeviceToHost, st));
+        return LA_OK;
+    };
+    int rc = LA_OK;
+    while (!stop.load(std::memory_order_relaxed)) {
+        const int ci = sp.next.fetch_add(1);
+        if (ci >= n_chunks) break;
+        if ((rc = run_chunk(ci))) break;
+    }
+    const int rs = sync_status(ctx, ln, st);     // also when stopping early: nothing of this lane stays in flight
+    return rc ? rc : rs;
+}
+
+struct WorkerResult {
+    int rc = LA_OK;
+    std::string msg;
+};
+
+// Runs fn(i) for i in [0, n): i = 0 on the calling thread, the rest on their own threads.  Each call reports
+// into its own slot; the first failure (by index) becomes the context's error.
+template <typename F>
+int run_workers(la_ctx* ctx, int n, F&& fn) {
+    std::vector<WorkerResult> res((size_t)n);
+    auto body = [&](int i) {
+        t_err_sink = &res[(size_t)i].msg;
+        try {
+            res[(size_t)i].rc = fn(i);
+        } catch (...) {
+            res[(size_t)i].rc = LA_ENOMEM;
+            res[(size_t)i].msg = "exception in a worker thread";
+        }
+        t_err_sink = nullptr;
+    };
+    std::vector<std::thread> th;
+    th.reserve((size_t)(n > 1 ? n - 1 : 0));
+    int spawn_fail = LA_OK;
+    for (int i = 1; i < n; ++i) {
+        try {
+            th.emplace_back(body, i);
+        } catch (...) {
+            body(i);                             // no thread to be had: run it here, later
+            (void)spawn_fail;
+        }
+    }
+    if (n > 0) body(0);
+    for (auto& t : th) t.join();
+    for (int i = 0; i < n; ++i)
+        if (res[(size_t)i].rc != LA_OK) {
+            ctx->err = res[(size_t)i].msg;
+            return res[(size_t)i].rc;
+        }
     return LA_OK;
 }
 
@@ -467,93 +722,133 @@ int assign_host(la_ctx* ctx, int32_t T, const int64_t* part_off, const int32_t* 
     if (T < 0) return fail(ctx, LA_EINVAL, "n_topics < 0");
     if (T == 0) return LA_OK;
     if (!part_off || !cons_off) return fail(ctx, LA_EINVAL, "null offsets");
-    Shape s;
-    // offsets are checked here; the ascending-rank contract of cons_rank is checked on the device (one pass over
-    // K entries there instead of ~1 ns per entry of host time), reported by sync_status as LA_EINVAL
-    if (int rc = scan_shape(ctx, T, part_off, cons_off, nullptr, &s)) return rc;
+    HostCall c;
+    // offsets are checked here; cons_rank's order on the device (run_lane)
+    if (int rc = scan_shape(ctx, T, part_off, cons_off, nullptr, &c.shape)) return rc;
+    const Shape& s = c.shape;
     if (s.n > 0 && (!pid || (!lag && (!end || !committed)))) return fail(ctx, LA_EINVAL, "null per-partition buffer");
     if ((out_pid == nullptr) != (out_rank == nullptr))
         return fail(ctx, LA_EINVAL, "out_partition and out_member_rank must both be given or both be NULL");
     if (s.k > 0 && !cons_rank) return fail(ctx, LA_EINVAL, "null cons_rank");
     if (!lag && reset_mode != LA_RESET_LATEST && !begin && s.n > 0)
         return fail(ctx, LA_EINVAL, "begin_off is required unless reset_mode is LA_RESET_LATEST");
-    LA_HIP(ctx, hipSetDevice(ctx->device));
+    c.T = T; c.part_off = part_off; c.pid = pid; c.begin = begin; c.end = end; c.committed = committed; c.lag = lag;
+    c.reset_mode = reset_mode; c.cons_off = cons_off; c.cons_rank = cons_rank;
+    c.out_pid = out_pid; c.out_rank = out_rank; c.out_total = out_total;
+    c.use_begin = !lag && begin && reset_mode != LA_RESET_LATEST;
 
-    const size_t nb8 = (size_t)s.n * 8, nb4 = (size_t)s.n * 4, kb8 = (size_t)s.k * 8, kb4 = (size_t)s.k * 4;
-    const size_t tb = (size_t)(T + 1) * 8;
-    const bool use_begin = !lag && begin && reset_mode != LA_RESET_LATEST;
-    int rc;
-    if ((rc = reserve(ctx, ctx->part_off, tb)) || (rc = reserve(ctx, ctx->cons_off, tb)) ||
-        (rc = reserve(ctx, ctx->pid, nb4 + 16)) || (rc = reserve(ctx, ctx->end, nb8 + 16)) ||
-        (rc = reserve(ctx, ctx->committed, lag ? 16 : nb8 + 16)) ||
-        (rc = reserve(ctx, ctx->begin, use_begin ? nb8 + 16 : 16)) ||
-        (rc = reserve(ctx, ctx->cons_rank, kb4 + 16)) || (rc = reserve(ctx, ctx->out_pid, nb4 + 16)) ||
-        (rc = reserve(ctx, ctx->out_rank, nb4 + 16)) || (rc = reserve(ctx, ctx->out_total, kb8 + 16)))
-        return rc;
-
-    hipStream_t st = ctx->stream;
-    LA_HIP(ctx, hipMemcpyAsync(ctx->part_off.p, part_off, tb, hipMemcpyHostToDevice, st));
-    LA_HIP(ctx, hipMemcpyAsync(ctx->cons_off.p, cons_off, tb, hipMemcpyHostToDevice, st));
-    if (s.n) LA_HIP(ctx, hipMemcpyAsync(ctx->pid.p, pid, nb4, hipMemcpyHostToDevice, st));
-    if (s.k) LA_HIP(ctx, hipMemcpyAsync(ctx->cons_rank.p, cons_rank, kb4, hipMemcpyHostToDevice, st));
-    if (s.n) {
-        if (lag) {
-            LA_HIP(ctx, hipMemcpyAsync(ctx->end.p, lag, nb8, hipMemcpyHostToDevice, st));
-        } else {
-            LA_HIP(ctx, hipMemcpyAsync(ctx->end.p, end, nb8, hipMemcpyHostToDevice, st));
-            LA_HIP(ctx, hipMemcpyAsync(ctx->committed.p, committed, nb8, hipMemcpyHostToDevice, st));
-            if (use_begin) LA_HIP(ctx, hipMemcpyAsync(ctx->begin.p, begin, nb8, hipMemcpyHostToDevice, st));
+    // shards: all devices for a batch worth splitting, fewer (down to one) for a small one
+    int S = (int)ctx->shards.size();
+    if (!ctx->split_always) {
+        const int64_t by_size = s.n / kMinShardPartitions;
+        if (by_size < S) S = by_size < 1 ? 1 : (int)by_size;
+    }
+    if (S > T) S = T;
+    plan_ranges(part_off, 0, T, S, ctx->last_bounds);
+    ctx->last_shards = S;
+    std::vector<ShardPlan> plans((size_t)S);
+    struct Work { int shard, lane; };
+    std::vector<Work> work;
+    for (int i = 0; i < S; ++i) {
+        ShardPlan& sp = plans[(size_t)i];
+        Shard& sh = ctx->shards[(size_t)i];
+        sp.t0 = ctx->last_bounds[i];
+        sp.t1 = ctx->last_bounds[i + 1];
+        sp.P0 = part_off[sp.t0]; sp.n = part_off[sp.t1] - sp.P0;
+        sp.K0 = cons_off[sp.t0]; sp.k = cons_off[sp.t1] - sp.K0;
+        sh.last_t0 = sp.t0; sh.last_topics = sp.t1 - sp.t0; sh.last_p0 = sp.P0; sh.last_n = sp.n;
+        if (sp.t1 == sp.t0) continue;
+        if (int rc = prepare_shard(ctx, c, sh, sp)) {
+            for (int j = 0; j <= i; ++j)                         // nothing of this call stays in flight
+                if (hipSetDevice(ctx->shards[(size_t)j].device) == hipSuccess)
+                    (void)hipStreamSynchronize(ctx->shards[(size_t)j].lanes[0].stream);
+            return rc;
         }
+        const int n_chunks = (int)sp.chunk.size() - 1;
+        const int lanes = n_chunks < (int)sh.lanes.size() ? n_chunks : (int)sh.lanes.size();
+        for (int l = 0; l < lanes; ++l) work.push_back({i, l});
     }
-
-    if (s.k) LA_HIP(ctx, la::check_consumers_launch(T, (const int64_t*)ctx->cons_off.p, (const int32_t*)ctx->cons_rank.p,
-                                                    ctx->d_status, st));
-
-    la_device_batch b{};
-    b.n_topics = T;
-    b.reset_mode = reset_mode == LA_RESET_LATEST ? LA_RESET_LATEST : LA_RESET_EARLIEST;
-    b.algo = LA_ALGO_AUTO;
-    b.n_partitions = s.n;
-    b.n_consumers = s.k;
-    b.max_partitions_per_topic = s.max_p;
-    b.max_consumers_per_topic = s.max_c;
-    b.d_part_off = (const int64_t*)ctx->part_off.p;
-    b.d_partition_id = (const int32_t*)ctx->pid.p;
-    b.d_begin_off = use_begin ? (const int64_t*)ctx->begin.p : nullptr;
-    b.d_end_off = (const int64_t*)ctx->end.p;
-    b.d_committed_off = (const int64_t*)ctx->committed.p;
-    b.d_lag = lag ? (const int64_t*)ctx->end.p : nullptr;
-    b.d_cons_off = (const int64_t*)ctx->cons_off.p;
-    b.d_cons_rank = (const int32_t*)ctx->cons_rank.p;
-    b.d_out_partition = (int32_t*)ctx->out_pid.p;
-    b.d_out_member_rank = (int32_t*)ctx->out_rank.p;
-    b.d_out_total_lag = out_total ? (int64_t*)ctx->out_total.p : nullptr;
-    b.h_part_off = part_off;
-    b.h_cons_off = cons_off;
-    b.flags = LA_FLAG_RAGGED;            // the offsets are on the host anyway: let the dispatcher look at the shapes
-    if ((rc = enqueue_batch(ctx, &b, st))) return rc;
-
-    if (s.n && out_pid) {
-        LA_HIP(ctx, hipMemcpyAsync(out_pid, ctx->out_pid.p, nb4, hipMemcpyDeviceToHost, st));
-        LA_HIP(ctx, hipMemcpyAsync(out_rank, ctx->out_rank.p, nb4, hipMemcpyDeviceToHost, st));
-    }
-    if (out_total && s.k) LA_HIP(ctx, hipMemcpyAsync(out_total, ctx->out_total.p, kb8, hipMemcpyDeviceToHost, st));
-    if ((rc = sync_status(ctx, st))) return rc;
+    std::atomic<bool> stop{false};
+    const int rc = run_workers(ctx, (int)work.size(), [&](int w) {
+        const Work& wk = work[(size_t)w];
+        const int r = run_lane(ctx, c, ctx->shards[(size_t)wk.shard], plans[(size_t)wk.shard], wk.lane, stop);
+        if (r != LA_OK) stop.store(true, std::memory_order_relaxed);
+        return r;
+    });
+    if (rc) return rc;
     ctx->last_valid = true;
-    ctx->last_topics = T;
-    ctx->last_n = s.n;
+    return LA_OK;
+}
+
+int create_lane(Lane& ln) {
+    hipError_t e;
+    if ((e = hipStreamCreateWithFlags(&ln.stream, hipStreamNonBlocking)) != hipSuccess ||
+        (e = hipMalloc((void**)&ln.d_status, 256)) != hipSuccess ||
+        (e = hipMemset(ln.d_status, 0, 256)) != hipSuccess ||
+        (e = hipHostMalloc((void**)&ln.h_status, 64, hipHostMallocDefault)) != hipSuccess)
+        return fail(nullptr, e == hipErrorOutOfMemory ? LA_ENOMEM : LA_EHIP, "context setup: %s", hipGetErrorString(e));
+    *ln.h_status = 0;
+    return LA_OK;
+}
+
+void destroy_lane(Lane& ln) {
+    if (ln.stream) (void)hipStreamSynchronize(ln.stream);
+    release(ln.defer);
+    release(ln.block_list);
+    for (Lane::Stage& sg : ln.stage) {
+        if (sg.done) { (void)hipEventSynchronize(sg.done); (void)hipEventDestroy(sg.done); }
+        if (sg.p) (void)hipHostFree(sg.p);
+    }
+    la::large_scratch_release(ln.large);
+    if (ln.d_status) (void)hipFree(ln.d_status);
+    if (ln.h_status) (void)hipHostFree(ln.h_status);
+    if (ln.stream) (void)hipStreamDestroy(ln.stream);
+}
+
+int reserve_host(la_ctx* ctx, HostBuf& b, size_t bytes) {
+    if (bytes <= b.cap) return LA_OK;
+    if (b.p) { LA_HIP(ctx, hipHostFree(b.p)); b.p = nullptr; b.cap = 0; }
+    const size_t want = bytes + bytes / 4 + 256;
+    LA_HIP(ctx, hipHostMalloc(&b.p, want, hipHostMallocPortable));
+    b.cap = want;
+    return LA_OK;
+}
+
+// grouping of one shard's last results, on its lane 0; the CSR stays in pid (grouped partition), cons_rank
+// (grouped topic, shard-local indices) and out_total (member_off) -- their old contents are no longer needed
+int group_shard_device(la_ctx* ctx, Shard& sh, int32_t n_members, bool want_topic) {
+    const int64_t n = sh.last_n;
+    const size_t nb4 = (size_t)n * 4, mb = ((size_t)n_members + 1) * 8;
+    int rc;
+    if ((rc = reserve(ctx, sh.pid, nb4 + 16)) || (rc = reserve(ctx, sh.cons_rank, nb4 + 16)) ||
+        (rc = reserve(ctx, sh.out_total, mb + 16)))
+        return rc;
+    if (n > 0x7FFFFFFF) return fail(ctx, LA_ESHAPE, "at most 2^31-1 entries per shard are supported");
+    hipError_t e = la::group_by_member_launch(sh.lanes[0].large, n, n_members, sh.last_topics,
+                                              (const int64_t*)sh.part_off.p, (const int32_t*)sh.out_pid.p,
+                                              (const int32_t*)sh.out_rank.p, (int64_t*)sh.out_total.p,
+                                              want_topic ? (int32_t*)sh.cons_rank.p : nullptr, (int32_t*)sh.pid.p,
+                                              nullptr, sh.lanes[0].stream);
+    if (e != hipSuccess)
+        return fail(ctx, e == hipErrorOutOfMemory ? LA_ENOMEM : LA_EHIP, "group_by_member: %s", hipGetErrorString(e));
     return LA_OK;
 }
 
 }  // namespace
 
 // ---- C ABI --------------------------------------------------------------------------------------
-LA_API int la_version(void) { return 100; }   // 0.1.0
+LA_API int la_version(void) { return 200; }   // 0.2.0
 
 LA_API const char* la_last_error(const la_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
 
-LA_API int la_create(la_ctx** out, int device_id, unsigned flags) {
-    (void)flags;
+LA_API int la_device_count(void) {
+    int count = 0;
+    const hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess) return fail(nullptr, LA_ENODEV, "no HIP device (%s)", hipGetErrorString(e));
+    return count;
+}
+
+LA_API int la_create_multi(la_ctx** out, int n_devices, const int* device_ids, unsigned flags) {
     if (!out) return fail(nullptr, LA_EINVAL, "out is NULL");
     *out = nullptr;
     try {
@@ -561,47 +856,116 @@ LA_API int la_create(la_ctx** out, int device_id, unsigned flags) {
         hipError_t e = hipGetDeviceCount(&count);
         if (e != hipSuccess || count <= 0)
             return fail(nullptr, LA_ENODEV, "no HIP device (%s)", e == hipSuccess ? "count = 0" : hipGetErrorString(e));
-        if (device_id < 0 || device_id >= count) return fail(nullptr, LA_ENODEV, "device %d of %d", device_id, count);
-        hipDeviceProp_t prop;
-        if ((e = hipGetDeviceProperties(&prop, device_id)) != hipSuccess)
-            return fail(nullptr, LA_EHIP, "hipGetDeviceProperties: %s", hipGetErrorString(e));
-        if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
-            return fail(nullptr, LA_ENODEV, "device %d is %s; this library is built for gfx950 only", device_id,
-                        prop.gcnArchName);
+        std::vector<int> ids;
+        if (n_devices < 0) return fail(nullptr, LA_EINVAL, "n_devices < 0");
+        if (n_devices == 0 || !device_ids) {
+            if (n_devices != 0) return fail(nullptr, LA_EINVAL, "device_ids is NULL");
+            for (int d = 0; d < count; ++d) ids.push_back(d);          // every device of the node
+        } else {
+            ids.assign(device_ids, device_ids + n_devices);
+        }
+        if ((int)ids.size() > kMaxShards) return fail(nullptr, LA_EINVAL, "at most %d shards", kMaxShards);
+        for (int d : ids) {
+            if (d < 0 || d >= count) return fail(nullptr, LA_ENODEV, "device %d of %d", d, count);
+            hipDeviceProp_t prop;
+            if ((e = hipGetDeviceProperties(&prop, d)) != hipSuccess)
+                return fail(nullptr, LA_EHIP, "hipGetDeviceProperties: %s", hipGetErrorString(e));
+            if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+                return fail(nullptr, LA_ENODEV, "device %d is %s; this library is built for gfx950 only", d,
+                            prop.gcnArchName);
+        }
+        int lanes = (int)(flags & LA_CREATE_LANES_MASK);
+        if (const char* env = getenv("LA_LANES")) lanes = atoi(env);
+        if (lanes <= 0) lanes = ids.size() <= 2 ? 3 : 2;
+        if (lanes > 8) lanes = 8;
         la_ctx* ctx = new (std::nothrow) la_ctx();
         if (!ctx) return fail(nullptr, LA_ENOMEM, "out of host memory");
-        ctx->device = device_id;
-        if ((e = hipSetDevice(device_id)) != hipSuccess ||
-            (e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess ||
-            (e = hipMalloc((void**)&ctx->d_status, 256)) != hipSuccess ||
-            (e = hipMemset(ctx->d_status, 0, 256)) != hipSuccess) {
-            int rc = fail(nullptr, LA_EHIP, "context setup: %s", hipGetErrorString(e));
-            la_destroy(ctx);
-            return rc;
+        ctx->split_always = (flags & LA_CREATE_SPLIT_ALWAYS) != 0;
+        if (const char* env = getenv("LA_CHUNK_PARTITIONS")) ctx->chunk_partitions = atoll(env);
+        ctx->shards.resize(ids.size());
+        for (size_t i = 0; i < ids.size(); ++i) {
+            Shard& sh = ctx->shards[i];
+            sh.device = ids[i];
+            sh.lanes.resize((size_t)lanes);
+            int rc = LA_OK;
+            if ((e = hipSetDevice(sh.device)) != hipSuccess ||
+                (e = hipEventCreateWithFlags(&sh.ready, hipEventDisableTiming)) != hipSuccess)
+                rc = fail(nullptr, LA_EHIP, "context setup: %s", hipGetErrorString(e));
+            for (Lane& ln : sh.lanes)
+                if (rc == LA_OK) rc = create_lane(ln);
+            if (rc != LA_OK) {
+                la_destroy(ctx);
+                return rc;
+            }
         }
         *out = ctx;
         return LA_OK;
     } catch (...) {
-        return fail(nullptr, LA_ENOMEM, "exception in la_create");
+        return fail(nullptr, LA_ENOMEM, "exception in la_create_multi");
     }
 }
 
+LA_API int la_create(la_ctx** out, int device_id, unsigned flags) { return la_create_multi(out, 1, &device_id, flags); }
+
 LA_API void la_destroy(la_ctx* ctx) {
     if (!ctx) return;
-    (void)hipSetDevice(ctx->device);
-    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
-    for (DevBuf* b : {&ctx->part_off, &ctx->pid, &ctx->begin, &ctx->end, &ctx->committed, &ctx->cons_off,
-                      &ctx->cons_rank, &ctx->out_pid, &ctx->out_rank, &ctx->out_total, &ctx->defer,
-                      &ctx->block_list})
-        release(*b);
-    for (la_ctx::Stage& sg : ctx->stage) {
-        if (sg.done) { (void)hipEventSynchronize(sg.done); (void)hipEventDestroy(sg.done); }
-        if (sg.p) (void)hipHostFree(sg.p);
+    for (Shard& sh : ctx->shards) {
+        (void)hipSetDevice(sh.device);
+        for (Lane& ln : sh.lanes) destroy_lane(ln);
+        for (DevBuf* b : {&sh.part_off, &sh.pid, &sh.begin, &sh.end, &sh.committed, &sh.cons_off, &sh.cons_rank,
+                          &sh.out_pid, &sh.out_rank, &sh.out_total})
+            release(*b);
+        for (HostBuf* h : {&sh.g_off, &sh.g_topic, &sh.g_part})
+            if (h->p) (void)hipHostFree(h->p);
+        if (sh.ready) (void)hipEventDestroy(sh.ready);
     }
-    la::large_scratch_release(ctx->large);
-    if (ctx->d_status) (void)hipFree(ctx->d_status);
-    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
+}
+
+LA_API int la_shard_count(const la_ctx* ctx) { return ctx ? (int)ctx->shards.size() : LA_EINVAL; }
+
+LA_API int la_shard_device(const la_ctx* ctx, int shard) {
+    if (!ctx || shard < 0 || shard >= (int)ctx->shards.size()) return LA_EINVAL;
+    return ctx->shards[(size_t)shard].device;
+}
+
+LA_API int la_plan_shards(int32_t n_topics, const int64_t* part_off, int32_t n_shards, int32_t* bounds) {
+    if (n_topics < 0 || n_shards < 1 || !part_off || !bounds) return LA_EINVAL;
+    for (int32_t t = 0; t < n_topics; ++t)
+        if (part_off[t + 1] < part_off[t]) return LA_EINVAL;
+    try {
+        std::vector<int32_t> tmp((size_t)n_shards + 1);
+        plan_ranges(part_off, 0, n_topics, n_shards, tmp.data());
+        memcpy(bounds, tmp.data(), tmp.size() * sizeof(int32_t));
+        return LA_OK;
+    } catch (...) {
+        return LA_ENOMEM;
+    }
+}
+
+LA_API int la_last_shard_bounds(const la_ctx* ctx, int32_t* bounds, int32_t capacity) {
+    if (!ctx) return LA_EINVAL;
+    const int S = ctx->last_shards;
+    if (bounds)
+        for (int i = 0; i <= S && i < capacity; ++i) bounds[i] = ctx->last_bounds[i];
+    return S;
+}
+
+LA_API void* la_host_alloc(la_ctx* ctx, size_t bytes) {
+    if (!ctx || ctx->shards.empty()) return nullptr;
+    void* p = nullptr;
+    if (hipSetDevice(ctx->shards[0].device) != hipSuccess) return nullptr;
+    const hipError_t e = hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocPortable);
+    if (e != hipSuccess) {
+        (void)fail(ctx, LA_ENOMEM, "hipHostMalloc(%zu): %s", bytes, hipGetErrorString(e));
+        return nullptr;
+    }
+    return p;
+}
+
+LA_API void la_host_free(la_ctx* ctx, void* p) {
+    (void)ctx;
+    if (p) (void)hipHostFree(p);
 }
 
 LA_API int la_compute_lag(la_ctx* ctx, int64_t n, const int64_t* begin_off, const int64_t* end_off,
@@ -613,19 +977,21 @@ LA_API int la_compute_lag(la_ctx* ctx, int64_t n, const int64_t* begin_off, cons
         if (!end_off || !committed_off || !out_lag) return fail(ctx, LA_EINVAL, "null buffer");
         const bool latest = reset_mode == LA_RESET_LATEST;
         if (!latest && !begin_off) return fail(ctx, LA_EINVAL, "begin_off is required unless reset_mode is LA_RESET_LATEST");
-        LA_HIP(ctx, hipSetDevice(ctx->device));
+        Shard& sh = ctx->shards[0];                    // elementwise and PCIe-bound: the first device only
+        ctx->last_valid = false;                       // reuses the scratch the last results live in
+        LA_HIP(ctx, hipSetDevice(sh.device));
         const size_t nb = (size_t)n * 8;
         int rc;
-        if ((rc = reserve(ctx, ctx->end, nb)) || (rc = reserve(ctx, ctx->committed, nb)) ||
-            (rc = reserve(ctx, ctx->begin, latest ? 16 : nb)) || (rc = reserve(ctx, ctx->out_total, nb)))
+        if ((rc = reserve(ctx, sh.end, nb)) || (rc = reserve(ctx, sh.committed, nb)) ||
+            (rc = reserve(ctx, sh.begin, latest ? 16 : nb)) || (rc = reserve(ctx, sh.out_total, nb)))
             return rc;
-        hipStream_t st = ctx->stream;
-        LA_HIP(ctx, hipMemcpyAsync(ctx->end.p, end_off, nb, hipMemcpyHostToDevice, st));
-        LA_HIP(ctx, hipMemcpyAsync(ctx->committed.p, committed_off, nb, hipMemcpyHostToDevice, st));
-        if (!latest) LA_HIP(ctx, hipMemcpyAsync(ctx->begin.p, begin_off, nb, hipMemcpyHostToDevice, st));
-        LA_HIP(ctx, la::lag_launch(n, latest ? nullptr : (const int64_t*)ctx->begin.p, (const int64_t*)ctx->end.p,
-                                   (const int64_t*)ctx->committed.p, latest, (int64_t*)ctx->out_total.p, st));
-        LA_HIP(ctx, hipMemcpyAsync(out_lag, ctx->out_total.p, nb, hipMemcpyDeviceToHost, st));
+        hipStream_t st = sh.lanes[0].stream;
+        LA_HIP(ctx, hipMemcpyAsync(sh.end.p, end_off, nb, hipMemcpyHostToDevice, st));
+        LA_HIP(ctx, hipMemcpyAsync(sh.committed.p, committed_off, nb, hipMemcpyHostToDevice, st));
+        if (!latest) LA_HIP(ctx, hipMemcpyAsync(sh.begin.p, begin_off, nb, hipMemcpyHostToDevice, st));
+        LA_HIP(ctx, la::lag_launch(n, latest ? nullptr : (const int64_t*)sh.begin.p, (const int64_t*)sh.end.p,
+                                   (const int64_t*)sh.committed.p, latest, (int64_t*)sh.out_total.p, st));
+        LA_HIP(ctx, hipMemcpyAsync(out_lag, sh.out_total.p, nb, hipMemcpyDeviceToHost, st));
         LA_HIP(ctx, hipStreamSynchronize(st));
         return LA_OK;
     } catch (...) {
@@ -663,14 +1029,15 @@ LA_API int la_assign_batch_device(la_ctx* ctx, const la_device_batch* batch, voi
     if (!ctx) return LA_EINVAL;
     try {
         if (!batch) return fail(ctx, LA_EINVAL, "batch is NULL");
-        LA_HIP(ctx, hipSetDevice(ctx->device));
-        return enqueue_batch(ctx, batch, (hipStream_t)stream);
+        Shard& sh = ctx->shards[0];                    // device buffers belong to one device: the context's first
+        LA_HIP(ctx, hipSetDevice(sh.device));
+        return enqueue_batch(ctx, sh.lanes[0], batch, (hipStream_t)stream);
     } catch (...) {
         return fail(ctx, LA_ENOMEM, "exception in la_assign_batch_device");
     }
 }
 
-LA_API void* la_stream(la_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+LA_API void* la_stream(la_ctx* ctx) { return ctx ? (void*)ctx->shards[0].lanes[0].stream : nullptr; }
 
 LA_API int la_group_by_member_device(la_ctx* ctx, int32_t n_topics, int64_t n_partitions, const int64_t* d_part_off,
                                      const int32_t* d_out_partition, const int32_t* d_out_member_rank,
@@ -684,8 +1051,9 @@ LA_API int la_group_by_member_device(la_ctx* ctx, int32_t n_topics, int64_t n_pa
                                  (d_grouped_topic && !d_part_off)))
             return fail(ctx, LA_EINVAL, "null buffer");
         if (n_partitions > 0x7FFFFFFF) return fail(ctx, LA_ESHAPE, "at most 2^31-1 entries are supported");
-        LA_HIP(ctx, hipSetDevice(ctx->device));
-        hipError_t e = la::group_by_member_launch(ctx->large, n_partitions, n_members, n_topics, d_part_off,
+        Shard& sh = ctx->shards[0];
+        LA_HIP(ctx, hipSetDevice(sh.device));
+        hipError_t e = la::group_by_member_launch(sh.lanes[0].large, n_partitions, n_members, n_topics, d_part_off,
                                                   d_out_partition, d_out_member_rank, d_member_off,
                                                   d_grouped_topic, d_grouped_partition, nullptr, (hipStream_t)stream);
         if (e != hipSuccess)
@@ -707,29 +1075,30 @@ LA_API int la_group_by_member(la_ctx* ctx, int32_t n_topics, const int64_t* part
         const int64_t n = n_topics > 0 ? part_off[n_topics] : 0;
         if (n < 0) return fail(ctx, LA_EINVAL, "part_off decreases");
         if (n > 0 && (!out_partition || !out_member_rank || !grouped_partition)) return fail(ctx, LA_EINVAL, "null buffer");
-        LA_HIP(ctx, hipSetDevice(ctx->device));
+        Shard& sh = ctx->shards[0];                    // one stable sort of the whole array: the first device
+        LA_HIP(ctx, hipSetDevice(sh.device));
         const size_t nb4 = (size_t)n * 4, tb = (size_t)(n_topics + 1) * 8, mb = ((size_t)n_members + 1) * 8;
         int rc;
         // scratch reuse: out_pid <- out_partition, out_rank <- member ranks, pid <- grouped_partition,
         // cons_rank <- grouped_topic, out_total <- member_off
-        if ((rc = reserve(ctx, ctx->part_off, tb + 16)) || (rc = reserve(ctx, ctx->out_pid, nb4 + 16)) ||
-            (rc = reserve(ctx, ctx->out_rank, nb4 + 16)) || (rc = reserve(ctx, ctx->pid, nb4 + 16)) ||
-            (rc = reserve(ctx, ctx->cons_rank, nb4 + 16)) || (rc = reserve(ctx, ctx->out_total, mb + 16)))
+        if ((rc = reserve(ctx, sh.part_off, tb + 16)) || (rc = reserve(ctx, sh.out_pid, nb4 + 16)) ||
+            (rc = reserve(ctx, sh.out_rank, nb4 + 16)) || (rc = reserve(ctx, sh.pid, nb4 + 16)) ||
+            (rc = reserve(ctx, sh.cons_rank, nb4 + 16)) || (rc = reserve(ctx, sh.out_total, mb + 16)))
             return rc;
-        hipStream_t st = ctx->stream;
-        if (n_topics > 0) LA_HIP(ctx, hipMemcpyAsync(ctx->part_off.p, part_off, tb, hipMemcpyHostToDevice, st));
+        hipStream_t st = sh.lanes[0].stream;
+        if (n_topics > 0) LA_HIP(ctx, hipMemcpyAsync(sh.part_off.p, part_off, tb, hipMemcpyHostToDevice, st));
         if (n) {
-            LA_HIP(ctx, hipMemcpyAsync(ctx->out_pid.p, out_partition, nb4, hipMemcpyHostToDevice, st));
-            LA_HIP(ctx, hipMemcpyAsync(ctx->out_rank.p, out_member_rank, nb4, hipMemcpyHostToDevice, st));
+            LA_HIP(ctx, hipMemcpyAsync(sh.out_pid.p, out_partition, nb4, hipMemcpyHostToDevice, st));
+            LA_HIP(ctx, hipMemcpyAsync(sh.out_rank.p, out_member_rank, nb4, hipMemcpyHostToDevice, st));
         }
-        rc = la_group_by_member_device(ctx, n_topics, n, (const int64_t*)ctx->part_off.p, (const int32_t*)ctx->out_pid.p,
-                                       (const int32_t*)ctx->out_rank.p, n_members, (int64_t*)ctx->out_total.p,
-                                       grouped_topic ? (int32_t*)ctx->cons_rank.p : nullptr, (int32_t*)ctx->pid.p, st);
+        rc = la_group_by_member_device(ctx, n_topics, n, (const int64_t*)sh.part_off.p, (const int32_t*)sh.out_pid.p,
+                                       (const int32_t*)sh.out_rank.p, n_members, (int64_t*)sh.out_total.p,
+                                       grouped_topic ? (int32_t*)sh.cons_rank.p : nullptr, (int32_t*)sh.pid.p, st);
         if (rc) return rc;
-        LA_HIP(ctx, hipMemcpyAsync(member_off, ctx->out_total.p, mb, hipMemcpyDeviceToHost, st));
+        LA_HIP(ctx, hipMemcpyAsync(member_off, sh.out_total.p, mb, hipMemcpyDeviceToHost, st));
         if (n) {
-            LA_HIP(ctx, hipMemcpyAsync(grouped_partition, ctx->pid.p, nb4, hipMemcpyDeviceToHost, st));
-            if (grouped_topic) LA_HIP(ctx, hipMemcpyAsync(grouped_topic, ctx->cons_rank.p, nb4, hipMemcpyDeviceToHost, st));
+            LA_HIP(ctx, hipMemcpyAsync(grouped_partition, sh.pid.p, nb4, hipMemcpyDeviceToHost, st));
+            if (grouped_topic) LA_HIP(ctx, hipMemcpyAsync(grouped_topic, sh.cons_rank.p, nb4, hipMemcpyDeviceToHost, st));
         }
         LA_HIP(ctx, hipStreamSynchronize(st));
         return LA_OK;
@@ -745,29 +1114,89 @@ LA_API int la_group_last_by_member(la_ctx* ctx, int32_t n_members, int64_t* memb
         if (!ctx->last_valid)
             return fail(ctx, LA_EINVAL, "no result of la_assign_batch / la_assign_batch_lags is held on the device");
         if (n_members < 0) return fail(ctx, LA_EINVAL, "negative size");
-        const int64_t n = ctx->last_n;
+        const int S = ctx->last_shards;
+        int64_t n = 0;
+        for (int i = 0; i < S; ++i) n += ctx->shards[(size_t)i].last_n;
         if (!member_off || (n > 0 && !grouped_partition)) return fail(ctx, LA_EINVAL, "null buffer");
-        LA_HIP(ctx, hipSetDevice(ctx->device));
-        const size_t nb4 = (size_t)n * 4, mb = ((size_t)n_members + 1) * 8;
-        int rc;
-        // part_off, out_pid and out_rank hold the batch and its results; pid <- grouped_partition,
-        // cons_rank <- grouped_topic, out_total <- member_off (their old contents are no longer needed)
-        if ((rc = reserve(ctx, ctx->pid, nb4 + 16)) || (rc = reserve(ctx, ctx->cons_rank, nb4 + 16)) ||
-            (rc = reserve(ctx, ctx->out_total, mb + 16)))
-            return rc;
-        hipStream_t st = ctx->stream;
-        rc = la_group_by_member_device(ctx, ctx->last_topics, n, (const int64_t*)ctx->part_off.p,
-                                       (const int32_t*)ctx->out_pid.p, (const int32_t*)ctx->out_rank.p, n_members,
-                                       (int64_t*)ctx->out_total.p, grouped_topic ? (int32_t*)ctx->cons_rank.p : nullptr,
-                                       (int32_t*)ctx->pid.p, st);
-        if (rc) return rc;
-        LA_HIP(ctx, hipMemcpyAsync(member_off, ctx->out_total.p, mb, hipMemcpyDeviceToHost, st));
-        if (n) {
-            LA_HIP(ctx, hipMemcpyAsync(grouped_partition, ctx->pid.p, nb4, hipMemcpyDeviceToHost, st));
-            if (grouped_topic) LA_HIP(ctx, hipMemcpyAsync(grouped_topic, ctx->cons_rank.p, nb4, hipMemcpyDeviceToHost, st));
+        const size_t mb = ((size_t)n_members + 1) * 8;
+        if (S == 1) {
+            // one shard: its CSR is the answer, straight into the caller's arrays
+            Shard& sh = ctx->shards[0];
+            LA_HIP(ctx, hipSetDevice(sh.device));
+            if (int rc = group_shard_device(ctx, sh, n_members, grouped_topic != nullptr)) return rc;
+            hipStream_t st = sh.lanes[0].stream;
+            const size_t nb4 = (size_t)n * 4;
+            LA_HIP(ctx, hipMemcpyAsync(member_off, sh.out_total.p, mb, hipMemcpyDeviceToHost, st));
+            if (n) {
+                LA_HIP(ctx, hipMemcpyAsync(grouped_partition, sh.pid.p, nb4, hipMemcpyDeviceToHost, st));
+                if (grouped_topic) LA_HIP(ctx, hipMemcpyAsync(grouped_topic, sh.cons_rank.p, nb4, hipMemcpyDeviceToHost, st));
+            }
+            LA_HIP(ctx, hipStreamSynchronize(st));
+            return LA_OK;
         }
-        LA_HIP(ctx, hipStreamSynchronize(st));
-        return LA_OK;
+        // Several shards.  A member's list is its per-topic appends in topic order (Main.java:177-184, :264), and the
+        // shards are contiguous topic ranges: the list is the concatenation, in shard order, of the shards' lists.
+        // Phase 1, per shard in parallel: group on the device, CSR into pinned staging.  Then the global offsets
+        // (a scan over members x shards on the host), then phase 2, per shard in parallel: every member's slice to
+        // its place in the caller's arrays, topic indices moved from shard-local to the caller's numbering.
+        int rc = run_workers(ctx, S, [&](int i) -> int {
+            Shard& sh = ctx->shards[(size_t)i];
+            if (sh.last_topics == 0) return LA_OK;
+            LA_HIP(ctx, hipSetDevice(sh.device));
+            const size_t nb4 = (size_t)sh.last_n * 4;
+            int r;
+            if ((r = reserve_host(ctx, sh.g_off, mb)) || (r = reserve_host(ctx, sh.g_part, nb4 + 16)) ||
+                (grouped_topic && (r = reserve_host(ctx, sh.g_topic, nb4 + 16))))
+                return r;
+            if ((r = group_shard_device(ctx, sh, n_members, grouped_topic != nullptr))) return r;
+            hipStream_t st = sh.lanes[0].stream;
+            LA_HIP(ctx, hipMemcpyAsync(sh.g_off.p, sh.out_total.p, mb, hipMemcpyDeviceToHost, st));
+            if (sh.last_n) {
+                LA_HIP(ctx, hipMemcpyAsync(sh.g_part.p, sh.pid.p, nb4, hipMemcpyDeviceToHost, st));
+                if (grouped_topic) LA_HIP(ctx, hipMemcpyAsync(sh.g_topic.p, sh.cons_rank.p, nb4, hipMemcpyDeviceToHost, st));
+            }
+            LA_HIP(ctx, hipStreamSynchronize(st));
+            return LA_OK;
+        });
+        if (rc) return rc;
+        // group g = 0 is "no consumer" (rank -1: the entries before member_off[0]), g = r + 1 is member r
+        const size_t G = (size_t)n_members + 1;
+        std::vector<int64_t> base((size_t)S * G);          // destination of shard i's slice of group g
+        {
+            int64_t run = 0;
+            for (size_t g = 0; g < G; ++g) {
+                if (g >= 1) member_off[g - 1] = run;
+                for (int i = 0; i < S; ++i) {
+                    const Shard& sh = ctx->shards[(size_t)i];
+                    base[(size_t)i * G + g] = run;
+                    if (sh.last_topics == 0) continue;
+                    const int64_t* so = (const int64_t*)sh.g_off.p;
+                    const int64_t lo = g == 0 ? 0 : so[g - 1], hi = g == G - 1 ? sh.last_n : so[g];
+                    run += hi - lo;
+                }
+            }
+            member_off[n_members] = run;
+        }
+        rc = run_workers(ctx, S, [&](int i) -> int {
+            const Shard& sh = ctx->shards[(size_t)i];
+            if (sh.last_topics == 0 || sh.last_n == 0) return LA_OK;
+            const int64_t* so = (const int64_t*)sh.g_off.p;
+            const int32_t* sp = (const int32_t*)sh.g_part.p;
+            const int32_t* stp = (const int32_t*)sh.g_topic.p;
+            for (size_t g = 0; g < G; ++g) {
+                const int64_t lo = g == 0 ? 0 : so[g - 1], hi = g == G - 1 ? sh.last_n : so[g];
+                if (hi <= lo) continue;
+                const int64_t dst = base[(size_t)i * G + g];
+                memcpy(grouped_partition + dst, sp + lo, (size_t)(hi - lo) * 4);
+                if (grouped_topic) {
+                    int32_t* gt = grouped_topic + dst;
+                    const int32_t t0 = sh.last_t0;
+                    for (int64_t j = lo; j < hi; ++j) gt[j - lo] = stp[j] + t0;
+                }
+            }
+            return LA_OK;
+        });
+        return rc;
     } catch (...) {
         return fail(ctx, LA_ENOMEM, "exception in la_group_last_by_member");
     }
@@ -776,8 +1205,9 @@ LA_API int la_group_last_by_member(la_ctx* ctx, int32_t n_members, int64_t* memb
 LA_API int la_sync(la_ctx* ctx, void* stream) {
     if (!ctx) return LA_EINVAL;
     try {
-        LA_HIP(ctx, hipSetDevice(ctx->device));
-        return sync_status(ctx, (hipStream_t)stream);
+        Shard& sh = ctx->shards[0];
+        LA_HIP(ctx, hipSetDevice(sh.device));
+        return sync_status(ctx, sh.lanes[0], (hipStream_t)stream);
     } catch (...) {
         return fail(ctx, LA_ENOMEM, "exception in la_sync");
     }

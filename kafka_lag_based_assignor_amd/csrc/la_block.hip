@@ -592,15 +592,15 @@ hipError_t block_launch(BlockArgs a, int cls, hipStream_t stream) {
     a.nc_cap = kNc[cls];
     const size_t region_a = (size_t)(e * 8 > kXchg * 12 ? e * 8 : kXchg * 12) * nt;
     const size_t lds = region_a + (size_t)16 * a.nc_cap + 16;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t err;
-        if ((err = hipFuncSetAttribute((const void*)block_topic_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       160 * 1024)) != hipSuccess) return err;
-        if ((err = hipFuncSetAttribute((const void*)block_topic_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       160 * 1024)) != hipSuccess) return err;
-        attr_set = true;
-    }
+    static PerDeviceOnce lds_opt_in;
+    hipError_t err = lds_opt_in.run([] {
+        hipError_t e2 = hipFuncSetAttribute((const void*)block_topic_kernel<8>,
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e2 != hipSuccess) return e2;
+        return hipFuncSetAttribute((const void*)block_topic_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   160 * 1024);
+    });
+    if (err != hipSuccess) return err;
     if (e == 8) hipLaunchKernelGGL(block_topic_kernel<8>, dim3((unsigned)a.n_list), dim3(nt), lds, stream, a);
     else hipLaunchKernelGGL(block_topic_kernel<16>, dim3((unsigned)a.n_list), dim3(nt), lds, stream, a);
     return hipGetLastError();

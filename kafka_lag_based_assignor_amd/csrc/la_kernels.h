@@ -3,7 +3,27 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+
 namespace la {
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) applies to the CURRENT device, and a process may hold contexts
+// on several: one bit per device id remembers where a kernel has been opted in (ids >= 32: set on every launch).
+// Calls may come from several host threads (one per shard lane), hence the atomic.
+struct PerDeviceOnce {
+    std::atomic<uint32_t> mask{0};
+    template <typename F>
+    hipError_t run(F&& set) {
+        int dev = 0;
+        hipError_t e = hipGetDevice(&dev);
+        if (e != hipSuccess) return e;
+        const uint32_t bit = (dev >= 0 && dev < 32) ? (1u << dev) : 0u;
+        if (bit && (mask.load(std::memory_order_acquire) & bit)) return hipSuccess;
+        if ((e = set()) != hipSuccess) return e;
+        if (bit) mask.fetch_or(bit, std::memory_order_release);
+        return hipSuccess;
+    }
+};
 
 // device status word bits (la_ctx::d_status)
 constexpr uint32_t kStatusShape = 1u;      // a topic exceeded the shape hint

@@ -639,13 +639,12 @@ __global__ __launch_bounds__(1024) void greedy_argmin_kernel(LargeArgs a, SortBu
 template <int EC>
 hipError_t launch_rounds(const LargeArgs& a, const SortBufs& b, int threads, hipStream_t stream) {
     const size_t lds = (size_t)3 * EC * threads * sizeof(uint32_t);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)greedy_rounds_kernel<EC>,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    static PerDeviceOnce lds_opt_in;
+    const hipError_t e = lds_opt_in.run([] {
+        return hipFuncSetAttribute((const void*)greedy_rounds_kernel<EC>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   160 * 1024);
+    });
+    if (e != hipSuccess) return e;
     hipLaunchKernelGGL((greedy_rounds_kernel<EC>), dim3(1), dim3(threads), lds, stream, a, b);
     return hipGetLastError();
 }
@@ -769,7 +768,12 @@ static void sort_run_passes(const SortBufs& b, hipStream_t stream) {
 
 hipError_t large_topic_launch(LargeScratch& scratch, const LargeArgs& a, bool argmin, hipStream_t stream) {
     const int64_t n = a.n_part;
-    if (n <= 0) return hipSuccess;
+    if (n <= 0) {
+        // no partition metadata: every subscribed consumer still reports a total of 0 (Main.java:216-225, :283-291)
+        if (a.n_cons > 0 && a.out_total)
+            return hipMemsetAsync(a.out_total + a.c0, 0, (size_t)a.n_cons * sizeof(int64_t), stream);
+        return hipSuccess;
+    }
     if (n > 0x7FFFFFFF || a.n_cons > kLargeMaxConsumers) return hipErrorInvalidValue;
     SortBufs b{};
     hipError_t e;
@@ -787,13 +791,12 @@ hipError_t large_topic_launch(LargeScratch& scratch, const LargeArgs& a, bool ar
         int threads = 64;
         while (threads < C && threads < 1024) threads <<= 1;
         const size_t lds = sizeof(uint32_t) * ((size_t)3 * C + 16 * 4);
-        static bool attr_set = false;
-        if (!attr_set) {
-            if ((e = hipFuncSetAttribute((const void*)greedy_argmin_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                         160 * 1024)) != hipSuccess)
-                return e;
-            attr_set = true;
-        }
+        static PerDeviceOnce lds_opt_in;
+        if ((e = lds_opt_in.run([] {
+                 return hipFuncSetAttribute((const void*)greedy_argmin_kernel,
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+             })) != hipSuccess)
+            return e;
         hipLaunchKernelGGL(greedy_argmin_kernel, dim3(1), dim3(threads), lds, stream, a, b);
         return hipGetLastError();
     }

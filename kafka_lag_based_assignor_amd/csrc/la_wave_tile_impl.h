@@ -597,6 +597,10 @@ __global__ __launch_bounds__(256) LA_WPE_ATTR void wave_tile_packed_kernel(TileA
     // without the next tile's loads prefetched into registers, measured 10-25 % slower: more live
     // registers, fewer wavefronts per SIMD)
     const int64_t tile = (int64_t)blockIdx.x * Cfg::kWavesPerBlock + wave;
+    // The single-launch form has no wide kernel behind it to zero the counter of the NEXT launch (the pair
+    // alternates per launch, la_api.hip): do it here, or a later deferring launch would start counting at
+    // whatever an earlier one left there and re-run a stale list.  Idle by stream order, like in the wide kernel.
+    if constexpr (INLINE_WIDE) if (blockIdx.x == 0 && threadIdx.x == 0) *a.defer_count_next = 0;
     if (tile >= n_tiles) return;
     {
         const TopicDescT<IDX> cur = load_desc<L, E, IDX>(a, tile, n_tiles, grp, gl);
@@ -698,12 +702,19 @@ static hipError_t launch_one(const TileArgs& a, int mode, hipStream_t stream) {
     using Cfg = TileCfg<L, E>;
     const int64_t blocks = (a.n_topics + Cfg::kTopicsPerBlock - 1) / Cfg::kTopicsPerBlock;
     if (blocks <= 0) return hipSuccess;
-    static int res_inline = 0, res_wide = 0, res_argmin = 0;       // per instantiation; one device family
+    // per instantiation; every device this library accepts is the same part (la_create rejects anything but gfx950),
+    // so one set of occupancy figures serves all of them.  Atomics: lanes of several shards may launch concurrently.
+    static std::atomic<int> s_inline{0}, s_wide{0}, s_argmin{0};
     hipError_t e;
+    int res_inline = s_inline.load(std::memory_order_acquire), res_wide = s_wide.load(std::memory_order_relaxed),
+        res_argmin = s_argmin.load(std::memory_order_relaxed);
     if (res_inline == 0) {
         if ((e = resident_blocks(wave_tile_packed_kernel<L, E, uint32_t, true>, Cfg::kThreads, &res_inline)) != hipSuccess) return e;
         if ((e = resident_blocks(wave_tile_wide_kernel<L, E, false>, Cfg::kThreads, &res_wide)) != hipSuccess) return e;
         if ((e = resident_blocks(wave_tile_wide_kernel<L, E, true>, Cfg::kThreads, &res_argmin)) != hipSuccess) return e;
+        s_wide.store(res_wide, std::memory_order_relaxed);
+        s_argmin.store(res_argmin, std::memory_order_relaxed);
+        s_inline.store(res_inline, std::memory_order_release);
 #ifdef LA_LAB
         printf("resident blocks: inline %d wide %d argmin %d (needed %lld)\n", res_inline, res_wide, res_argmin, (long long)blocks);
 #endif

@@ -16,23 +16,14 @@ import numpy as np
 
 def shard_bounds(part_off: np.ndarray, world_size: int) -> List[Tuple[int, int]]:
     """Contiguous topic ranges [t0, t1) per rank, balanced by partition count (the kernels'
-    cost is per partition).  Every topic lands in exactly one range; ranges may be empty."""
-    part_off = np.asarray(part_off, dtype=np.int64)
-    n_topics = part_off.size - 1
-    total = int(part_off[-1])
-    bounds = []
-    t0 = 0
-    for r in range(world_size):
-        if r == world_size - 1:
-            t1 = n_topics
-        else:
-            target = (total * (r + 1)) // world_size
-            # first topic boundary at or after the target partition count
-            t1 = int(np.searchsorted(part_off, target, side="left"))
-            t1 = min(max(t1, t0), n_topics)
-        bounds.append((t0, t1))
-        t0 = t1
-    return bounds
+    cost is per partition).  Every topic lands in exactly one range; ranges may be empty.
+
+    This IS the library's planner (``la_plan_shards`` of include/lagassign.h, pure host code): the split a
+    one-process-per-GPU launcher makes here is the split a multi-device context (``la_create_multi``) makes
+    inside ``la_assign_batch``."""
+    from . import _native
+    b = _native.plan_shards(part_off, world_size)
+    return [(int(b[r]), int(b[r + 1])) for r in range(world_size)]
 
 
 def shard_slices(part_off: np.ndarray, cons_off: np.ndarray, t0: int, t1: int):

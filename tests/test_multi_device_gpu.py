@@ -1,0 +1,237 @@
+"""Multi-device contexts (la_create_multi) and the chunked host-buffer pipeline, bit-exact against the oracle.
+
+A gpurun box has ONE MI355X, so the shard split is exercised with several logical shards mapped to device 0
+(an id may repeat in la_create_multi) and LA_CREATE_SPLIT_ALWAYS, which makes the library shard and chunk
+batches of any size: same planner, same threads, same per-shard buffers and offsets as on an 8-GPU node; only
+the device ids differ.  Everything goes through the C ABI.
+"""
+import numpy as np
+import pytest
+
+from kafka_lag_based_assignor_amd import _native as N
+from kafka_lag_based_assignor_amd import synth
+from oracle import oracle
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx4():
+    c = N.Context([0, 0, 0, 0], flags=N.LA_CREATE_SPLIT_ALWAYS)
+    yield c
+    c.close()
+
+
+@pytest.fixture(scope="module")
+def ctx1_chunked():
+    c = N.Context(0, flags=N.LA_CREATE_SPLIT_ALWAYS | 3)        # one shard, three lanes, three chunks per call
+    yield c
+    c.close()
+
+
+@pytest.fixture(scope="module")
+def ctx1():
+    c = N.Context(0)
+    yield c
+    c.close()
+
+
+def _same(got, exp, what=""):
+    for g, e, name in zip(got, exp, ("partition order", "member", "totals")):
+        np.testing.assert_array_equal(g, e, err_msg="%s %s" % (name, what))
+
+
+def _mixed_batch(seed):
+    """tile, block and large topics, topics without partitions, topics without consumers -- in one batch"""
+    rng = np.random.default_rng(seed)
+    ps = [10, 2000, 0, 300, 1500, 64, 5000, 7, 0, 20000, 130, 1, 0, 900, 12]
+    cs = [2, 5, 3, 64, 100, 0, 200, 8, 0, 10, 300, 1, 2500, 33, 0]
+    order = rng.permutation(len(ps))
+    ps = [ps[i] for i in order]
+    cs = [cs[i] for i in order]
+    part_off = np.concatenate([[0], np.cumsum(ps)]).astype(np.int64)
+    cons_off = np.concatenate([[0], np.cumsum(cs)]).astype(np.int64)
+    pid = np.concatenate([rng.permutation(p) for p in ps]).astype(np.int32)
+    lag = rng.integers(0, 1 << 30, part_off[-1]).astype(np.int64)
+    ranks = np.concatenate([np.sort(rng.choice(4000, c, replace=False)) for c in cs]).astype(np.int32)
+    return part_off, pid, lag, cons_off, ranks
+
+
+def test_create_multi_shapes(ctx4):
+    assert ctx4.shard_count == 4 and [ctx4.shard_device(i) for i in range(4)] == [0, 0, 0, 0]
+    assert N.device_count() >= 1
+    every = N.Context("all")                                   # n_devices = 0: every device of the node
+    assert every.shard_count == N.device_count()
+    every.close()
+    with pytest.raises(N.LagAssignError) as ei:
+        N.Context([0, 99])
+    assert ei.value.code == N.LA_ENODEV
+
+
+def test_four_shards_cfg4_full_size(ctx4):
+    w = synth.config("cfg4")                                   # 100 000 topics x 64 partitions x 8 consumers
+    for mode in (N.LA_RESET_LATEST, N.LA_RESET_EARLIEST):
+        latest = mode == N.LA_RESET_LATEST
+        lag = oracle.compute_lags(w.begin, w.end, w.committed, latest)
+        exp = oracle.assign_flat(w.part_off, w.partition_id, lag, w.cons_off, w.cons_rank)
+        got = ctx4.assign_batch(w.part_off, w.partition_id, None if latest else w.begin, w.end, w.committed, mode,
+                                w.cons_off, w.cons_rank)
+        _same(got, exp, "cfg4 on 4 shards")
+    # the split the call used is the planner's
+    np.testing.assert_array_equal(ctx4.last_shard_bounds(), N.plan_shards(w.part_off, 4))
+    assert ctx4.last_shard_bounds().tolist() == [0, 25000, 50000, 75000, 100000]
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_four_shards_mixed_paths(ctx4, seed):
+    part_off, pid, lag, cons_off, ranks = _mixed_batch(seed)
+    exp = oracle.assign_flat(part_off, pid, lag, cons_off, ranks)
+    _same(ctx4.assign_batch_lags(part_off, pid, lag, cons_off, ranks), exp, "mixed batch, seed %d" % seed)
+
+
+def test_four_shards_ragged_all_three_paths(ctx4, ctx1_chunked):
+    from test_gpu_parity import _ragged_skewed
+    w = _ragged_skewed(5, 8000, 5)
+    rng = np.random.default_rng(6)
+    extra_p = [3000, 150, 20000]
+    extra_c = [40, 300, 10]
+    part_off = np.concatenate([w.part_off, w.part_off[-1] + np.cumsum(extra_p)]).astype(np.int64)
+    cons_off = np.concatenate([w.cons_off, w.cons_off[-1] + np.cumsum(extra_c)]).astype(np.int64)
+    pid = np.concatenate([w.partition_id] + [rng.permutation(p).astype(np.int32) for p in extra_p])
+    lag = np.concatenate([w.lag, rng.integers(0, 1 << 30, sum(extra_p)).astype(np.int64)])
+    ranks = np.concatenate([w.cons_rank] + [np.arange(c, dtype=np.int32) for c in extra_c])
+    exp = oracle.assign_flat(part_off, pid, lag, cons_off, ranks)
+    _same(ctx4.assign_batch_lags(part_off, pid, lag, cons_off, ranks), exp, "4 shards")
+    _same(ctx1_chunked.assign_batch_lags(part_off, pid, lag, cons_off, ranks), exp, "1 shard, 3 chunks")
+
+
+def test_named_configs_on_shards_and_chunks(ctx4, ctx1_chunked):
+    for name, scale in (("cfg1", 1.0), ("cfg2b", 1.0), ("cfg3", 0.2), ("cfg5", 1.0 / 64), ("block_b", 0.1)):
+        w = synth.config(name, scale)
+        lag = oracle.compute_lags(w.begin, w.end, w.committed, False)
+        exp = oracle.assign_flat(w.part_off, w.partition_id, lag, w.cons_off, w.cons_rank)
+        for c, what in ((ctx4, "4 shards"), (ctx1_chunked, "3 chunks")):
+            got = c.assign_batch(w.part_off, w.partition_id, w.begin, w.end, w.committed, N.LA_RESET_EARLIEST,
+                                 w.cons_off, w.cons_rank)
+            _same(got, exp, "%s %s" % (name, what))
+
+
+def test_fewer_topics_than_shards(ctx4):
+    # 1, 2, 3 topics on 4 shards; and the README example
+    w = synth.config("cfg1")
+    p, m, t = ctx4.assign_batch_lags(w.part_off, w.partition_id, w.lag, w.cons_off, w.cons_rank)
+    assert p.tolist() == [0, 2, 1] and m.tolist() == [0, 1, 1] and t.tolist() == [100000, 110000]
+    p, m, t = ctx4.assign_batch_lags([0, 4, 6], [0, 1, 2, 3, 0, 1], [100000, 100000, 500, 1, 900000, 100000],
+                                     [0, 2, 3], [0, 1, 0])                     # Test.java:82-132, flat form
+    assert p.tolist() == [0, 1, 2, 3, 0, 1] and m.tolist() == [0, 1, 0, 1, 0, 0] and t.tolist() == [100500, 100001, 1000000]
+
+
+def test_group_last_by_member_across_shards(ctx4, ctx1):
+    # every member's list is the concatenation, in shard order, of the shards' lists: compare with the grouping of the
+    # downloaded global arrays on one device
+    cases = [synth.ragged(31, 400, 300, 40, negative=True), synth.config("block_b", 0.1), synth.config("cfg3", 0.2)]
+    part_off, pid, lag, cons_off, ranks = _mixed_batch(2)
+    cases.append(synth.Workload("mixed", part_off.size - 1, part_off, pid, np.zeros_like(lag), lag.copy(),
+                                np.zeros_like(lag), lag, cons_off, ranks, 20000, 2500))
+    for w in cases:
+        n_members = int(w.cons_rank.max()) + 1 if w.cons_rank.size else 0
+        exp_p, exp_m, exp_t = oracle.assign_flat(w.part_off, w.partition_id, w.lag, w.cons_off, w.cons_rank)
+        want = ctx1.group_by_member(w.part_off, exp_p, exp_m, n_members)
+        p, m, t = ctx4.assign_batch_lags(w.part_off, w.partition_id, w.lag, w.cons_off, w.cons_rank, keep_on_device=True)
+        assert p is None and m is None
+        np.testing.assert_array_equal(t, exp_t)
+        assert ctx4.last_shard_bounds().size - 1 == min(4, w.part_off.size - 1)
+        got = ctx4.group_last_by_member(int(w.part_off[-1]), n_members)
+        for g, e, what in zip(got, want, ("member_off", "grouped_topic", "grouped_partition")):
+            np.testing.assert_array_equal(g, e, err_msg="%s %s" % (w.name, what))
+
+
+def test_reference_lists_across_shards(ctx4):                  # Test.java:82-132: the exact lists, 2 topics on 2 shards
+    p, m, t = ctx4.assign_batch_lags([0, 4, 6], [0, 1, 2, 3, 0, 1], [100000, 100000, 500, 1, 900000, 100000],
+                                     [0, 2, 3], [0, 1, 0], keep_on_device=True)
+    off, g_t, g_p = ctx4.group_last_by_member(6, 2)
+    lists = [[(int(a), int(b)) for a, b in zip(g_t[off[r]:off[r + 1]], g_p[off[r]:off[r + 1]])] for r in range(2)]
+    assert lists[0] == [(0, 0), (0, 2), (1, 0), (1, 1)]        # consumer-1: topic1-0, topic1-2, topic2-0, topic2-1
+    assert lists[1] == [(0, 1), (0, 3)]                        # consumer-2: topic1-1, topic1-3
+
+
+def test_errors_from_a_late_chunk_are_reported(ctx4, ctx1_chunked):
+    w = synth.ragged(7, 300, 100, 12)
+    bad = w.cons_rank.copy()
+    k = int(w.cons_off[-2])                                    # first consumer of the LAST topic
+    if w.cons_off[-1] - k >= 2:
+        bad[k], bad[k + 1] = bad[k + 1], bad[k]
+    else:
+        pytest.skip("last topic has fewer than two consumers")
+    for c in (ctx4, ctx1_chunked):
+        with pytest.raises(N.LagAssignError) as ei:
+            c.assign_batch_lags(w.part_off, w.partition_id, w.lag, w.cons_off, bad)
+        assert ei.value.code == N.LA_EINVAL
+        # the context is usable afterwards
+        exp = oracle.assign_flat(w.part_off, w.partition_id, w.lag, w.cons_off, w.cons_rank)
+        _same(c.assign_batch_lags(w.part_off, w.partition_id, w.lag, w.cons_off, w.cons_rank), exp, "after an error")
+
+
+def test_default_context_pipelines_a_large_batch(ctx1):
+    # 8 M partitions: 16 chunks over 3 lanes (H2D of one chunk under the kernels / D2H of others)
+    w = synth.config("cfg4", 1.25)
+    assert w.n_partitions == 8_000_000
+    lag = oracle.compute_lags(w.begin, w.end, w.committed, False)
+    exp = oracle.assign_flat(w.part_off, w.partition_id, lag, w.cons_off, w.cons_rank)
+    got = ctx1.assign_batch(w.part_off, w.partition_id, w.begin, w.end, w.committed, N.LA_RESET_EARLIEST,
+                            w.cons_off, w.cons_rank)
+    _same(got, exp, "pipelined")
+    assert ctx1.last_shard_bounds().tolist() == [0, w.n_topics]
+
+
+def test_pinned_host_arrays(ctx1):
+    w = synth.config("cfg3", 2.0)
+    pin = {k: ctx1.host_alloc(getattr(w, k).shape, getattr(w, k).dtype) for k in
+           ("part_off", "partition_id", "begin", "end", "committed", "cons_off", "cons_rank")}
+    for k, a in pin.items():
+        a[...] = getattr(w, k)
+    out = (ctx1.host_alloc((w.n_partitions,), np.int32), ctx1.host_alloc((w.n_partitions,), np.int32),
+           ctx1.host_alloc((w.cons_rank.size,), np.int64))
+    lag = oracle.compute_lags(w.begin, w.end, w.committed, False)
+    exp = oracle.assign_flat(w.part_off, w.partition_id, lag, w.cons_off, w.cons_rank)
+    got = ctx1.assign_batch(pin["part_off"], pin["partition_id"], pin["begin"], pin["end"], pin["committed"],
+                            N.LA_RESET_EARLIEST, pin["cons_off"], pin["cons_rank"], out=out)
+    _same(got, exp, "pinned")
+
+
+def test_large_path_topic_without_partitions_reports_zero_totals(ctx1):
+    # a topic with no partition metadata and more consumers than the block path holds
+    part_off = np.array([0, 50, 50, 80], dtype=np.int64)
+    cons_off = np.array([0, 4, 3004, 3010], dtype=np.int64)
+    rng = np.random.default_rng(9)
+    pid = np.concatenate([rng.permutation(50), rng.permutation(30)]).astype(np.int32)
+    lag = rng.integers(0, 1 << 20, 80).astype(np.int64)
+    ranks = np.concatenate([np.arange(4), np.arange(3000), np.arange(6)]).astype(np.int32)
+    exp = oracle.assign_flat(part_off, pid, lag, cons_off, ranks)
+    assert not exp[2][4:3004].any()
+    for _ in range(2):                                         # twice: the scratch holds the first run's totals
+        _same(ctx1.assign_batch_lags(part_off, pid, lag, cons_off, ranks), exp, "empty large topic")
+
+
+def test_inline_launch_between_deferring_launches():
+    # big batch A defers tiles into one counter of the pair, small batch B takes the single-launch form
+    # (no wide kernel to zero the other counter), big batch C must start counting at zero again
+    from test_gpu_parity import _deferring_workload, _run_device
+    c = N.Context(0)
+    big = _deferring_workload()
+    small = synth.ragged(3, 40, 8, 8, negative=True)
+    exp_big = oracle.assign_flat(big.part_off, big.partition_id, big.lag, big.cons_off, big.cons_rank)
+    exp_small = oracle.assign_flat(small.part_off, small.partition_id, small.lag, small.cons_off, small.cons_rank)
+    for rep in range(3):
+        _same(_run_device(c, big, N.LA_ALGO_AUTO, use_lag=True), exp_big, "A/C rep %d" % rep)
+        _same(_run_device(c, small, N.LA_ALGO_AUTO, use_lag=True), exp_small, "B rep %d" % rep)
+    # a different, smaller deferring batch after the big one: a stale count would walk entries of the old list
+    half = synth.Workload("defer/2", 50000, big.part_off[:50001], big.partition_id[:big.part_off[50000]],
+                          big.begin[:big.part_off[50000]], big.end[:big.part_off[50000]],
+                          big.committed[:big.part_off[50000]], big.lag[:big.part_off[50000]],
+                          big.cons_off[:50001], big.cons_rank[:big.cons_off[50000]], 8, 8)
+    exp_half = oracle.assign_flat(half.part_off, half.partition_id, half.lag, half.cons_off, half.cons_rank)
+    _same(_run_device(c, big, N.LA_ALGO_AUTO, use_lag=True), exp_big, "A again")
+    _same(_run_device(c, small, N.LA_ALGO_AUTO, use_lag=True), exp_small, "B again")
+    _same(_run_device(c, half, N.LA_ALGO_AUTO, use_lag=True), exp_half, "C = half of A")
+    c.close()
