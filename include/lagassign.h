@@ -19,6 +19,7 @@
  *   la_group_by_member      building every member's List<TopicPartition>      Main.java:171-174, :264
  *   la_create_multi         the per-topic loop, sharded over the GPUs of a node Main.java:177-184
  *   la_plan_shards          (which topics of that loop each shard takes)
+ *   la_last_phase_times     nothing: measurement hook (radix-sort phase against the HBM roofline)
  *
  * Data model (SoA; TopicPartitionLag, Main.java:431-455, flattened):
  *   topic t owns partitions [part_off[t], part_off[t+1]) of the per-partition arrays and
@@ -93,6 +94,14 @@ extern "C" {
                                  * la_assign_batch decides this itself from the offsets.                */
 #define LA_FLAG_SHAPE_CLASSES 8 /* with LA_FLAG_RAGGED: always one launch per non-empty shape class,     *
                                  * whatever the cost estimate says (test hook)                          */
+#define LA_FLAG_PROFILE      16 /* measurement hook: HIP events around the phases of the first large-path  *
+                                 * topic of this call (keys, radix-sort passes, greedy); la_last_phase_times *
+                                 * reads them.  Device entry point only.                                  */
+#define LA_FLAG_NO_SAMPLE_SORT 32 /* large path: every greedy round sorts its consumer bins with the full   *
+                                 * bitonic network instead of the sample sort (test hook)                 */
+#define LA_FLAG_SAMPLE_TIGHT 64 /* large path: the sample sort gives a round up (falls back to the full network)  *
+                                 * above 6 bins per bucket instead of 96, so both kinds of round interleave  *
+                                 * in one topic (test hook)                                                */
 
 typedef struct la_ctx la_ctx;
 
@@ -228,6 +237,20 @@ int la_assign_batch_device(la_ctx *ctx, const la_device_batch *batch, void *stre
 
 /* Waits for `stream` and returns LA_OK or the first device-detected error. */
 int la_sync(la_ctx *ctx, void *stream);
+
+/* Phase times of the first large-path topic (one topic beyond the block path: device-wide radix sort, then the
+ * one-workgroup greedy) of the last la_assign_batch_device call that carried LA_FLAG_PROFILE.  Measurement only:
+ * it is how bench.py reports the radix-sort phase against the HBM roofline from inside one run.  Waits for that
+ * topic's kernels.  LA_EINVAL when no such topic was profiled. */
+typedef struct la_phase_times {
+    int64_t n_partitions;
+    int32_t id_passes;     /* active 8-bit passes over the partition-id digits (0 when ids arrive ascending)  */
+    int32_t key_passes;    /* active passes over the lag-key digits; constant digits are skipped on the device */
+    float keys_ms;         /* lag + keys + the 12 digit histograms, pass plan                                  */
+    float sort_ms;         /* tile counts + scans + stable scatter of every active pass                        */
+    float greedy_ms;       /* ids in assignment order + the greedy rounds                                      */
+} la_phase_times;
+int la_last_phase_times(la_ctx *ctx, la_phase_times *out);
 
 /* The context's own (non-blocking) hipStream_t, used by the host-buffer entry points. */
 void *la_stream(la_ctx *ctx);

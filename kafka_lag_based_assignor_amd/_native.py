@@ -19,6 +19,7 @@ LA_EINVAL, LA_ENOMEM, LA_EHIP, LA_ENODEV, LA_ESHAPE = -1, -2, -3, -4, -5
 LA_RESET_LATEST, LA_RESET_EARLIEST = 0, 1
 LA_ALGO_AUTO, LA_ALGO_ROUNDS, LA_ALGO_ARGMIN, LA_ALGO_ROUNDS_WIDE = 0, 1, 2, 3
 LA_FLAG_INDEX64, LA_FLAG_DEFER_WIDE, LA_FLAG_RAGGED, LA_FLAG_SHAPE_CLASSES = 1, 2, 4, 8
+LA_FLAG_PROFILE, LA_FLAG_NO_SAMPLE_SORT, LA_FLAG_SAMPLE_TIGHT = 16, 32, 64
 LA_CREATE_LANES_MASK, LA_CREATE_SPLIT_ALWAYS = 0xF, 0x10
 
 EXPORTED_SYMBOLS = (
@@ -26,7 +27,7 @@ EXPORTED_SYMBOLS = (
     "la_assign_batch", "la_assign_batch_lags", "la_assign_batch_device", "la_sync", "la_stream",
     "la_group_by_member", "la_group_by_member_device", "la_group_last_by_member",
     "la_device_count", "la_create_multi", "la_shard_count", "la_shard_device", "la_plan_shards",
-    "la_last_shard_bounds", "la_host_alloc", "la_host_free",
+    "la_last_shard_bounds", "la_host_alloc", "la_host_free", "la_last_phase_times",
 )
 
 _i64p = ctypes.POINTER(ctypes.c_int64)
@@ -54,6 +55,12 @@ class DeviceBatch(ctypes.Structure):
         ("d_out_total_lag", ctypes.c_void_p),
         ("h_part_off", _i64p), ("h_cons_off", _i64p),
     ]
+
+
+class PhaseTimes(ctypes.Structure):
+    """struct la_phase_times"""
+    _fields_ = [("n_partitions", ctypes.c_int64), ("id_passes", ctypes.c_int32), ("key_passes", ctypes.c_int32),
+                ("keys_ms", ctypes.c_float), ("sort_ms", ctypes.c_float), ("greedy_ms", ctypes.c_float)]
 
 
 _lib: Optional[ctypes.CDLL] = None
@@ -114,6 +121,8 @@ def load() -> ctypes.CDLL:
     L.la_assign_batch_device.argtypes = [ctypes.c_void_p, ctypes.POINTER(DeviceBatch), ctypes.c_void_p]
     L.la_sync.restype = ctypes.c_int
     L.la_sync.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+    L.la_last_phase_times.restype = ctypes.c_int
+    L.la_last_phase_times.argtypes = [ctypes.c_void_p, ctypes.POINTER(PhaseTimes)]
     L.la_stream.restype = ctypes.c_void_p
     L.la_stream.argtypes = [ctypes.c_void_p]
     L.la_group_by_member.restype = ctypes.c_int
@@ -326,6 +335,12 @@ class Context:
 
     def sync(self, stream: int = 0) -> None:
         self._check(self._lib.la_sync(self._h, ctypes.c_void_p(stream)))
+
+    def last_phase_times(self) -> PhaseTimes:
+        """Phase times of the large-path topic of the last assign_batch_device call with LA_FLAG_PROFILE."""
+        t = PhaseTimes()
+        self._check(self._lib.la_last_phase_times(self._h, ctypes.byref(t)))
+        return t
 
     @property
     def stream(self) -> int:

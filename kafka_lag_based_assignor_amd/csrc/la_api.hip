@@ -346,6 +346,7 @@ int launch_large_topics(la_ctx* ctx, Lane& ln, const la_device_batch* b, const B
         g.out_rank = b->d_out_member_rank;
         g.out_total = b->d_out_total_lag;
         g.reset_latest = (b->reset_mode == LA_RESET_LATEST) ? 1 : 0;
+        g.no_sample_sort = (b->flags & LA_FLAG_NO_SAMPLE_SORT) ? 1 : ((b->flags & LA_FLAG_SAMPLE_TIGHT) ? 2 : 0);
         g.status = ln.d_status;
         hipError_t e = la::large_topic_launch(ln.large, g, argmin, stream);
         if (e != hipSuccess)
@@ -420,6 +421,8 @@ int enqueue_batch(la_ctx* ctx, Lane& ln, const la_device_batch* b, hipStream_t s
             LA_HIP(ctx, hipMemsetAsync(b->d_out_total_lag, 0, (size_t)b->n_consumers * sizeof(int64_t), stream));
         return LA_OK;
     }
+    ln.large.prof.armed = (b->flags & LA_FLAG_PROFILE) != 0;
+    if (ln.large.prof.armed) ln.large.prof.recorded = false;
     const bool have_host = b->h_part_off && b->h_cons_off;
     const bool fits_hint = la::wave_tile_fits(b->max_partitions_per_topic, b->max_consumers_per_topic);
     if (fits_hint && !(have_host && (b->flags & LA_FLAG_RAGGED) && tile_mode == 0)) {
@@ -837,7 +840,7 @@ int group_shard_device(la_ctx* ctx, Shard& sh, int32_t n_members, bool want_topi
 }  // namespace
 
 // ---- C ABI --------------------------------------------------------------------------------------
-LA_API int la_version(void) { return 200; }   // 0.2.0
+LA_API int la_version(void) { return 201; }   // 0.2.1
 
 LA_API const char* la_last_error(const la_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
 
@@ -1199,6 +1202,31 @@ LA_API int la_group_last_by_member(la_ctx* ctx, int32_t n_members, int64_t* memb
         return rc;
     } catch (...) {
         return fail(ctx, LA_ENOMEM, "exception in la_group_last_by_member");
+    }
+}
+
+LA_API int la_last_phase_times(la_ctx* ctx, la_phase_times* out) {
+    if (!ctx) return LA_EINVAL;
+    try {
+        if (!out) return fail(ctx, LA_EINVAL, "out is NULL");
+        Shard& sh = ctx->shards[0];
+        LA_HIP(ctx, hipSetDevice(sh.device));
+        float ms[3] = {};
+        int passes[2] = {};
+        int64_t n = 0;
+        const hipError_t e = la::large_profile_read(sh.lanes[0].large, ms, passes, &n);
+        if (e == hipErrorNotReady)
+            return fail(ctx, LA_EINVAL, "no large-path topic was profiled (LA_FLAG_PROFILE on la_assign_batch_device)");
+        if (e != hipSuccess) return fail(ctx, LA_EHIP, "la_last_phase_times: %s", hipGetErrorString(e));
+        out->n_partitions = n;
+        out->id_passes = passes[0];
+        out->key_passes = passes[1];
+        out->keys_ms = ms[0];
+        out->sort_ms = ms[1];
+        out->greedy_ms = ms[2];
+        return LA_OK;
+    } catch (...) {
+        return fail(ctx, LA_ENOMEM, "exception in la_last_phase_times");
     }
 }
 

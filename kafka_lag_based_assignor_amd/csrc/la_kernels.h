@@ -121,9 +121,18 @@ inline int block_class(int64_t p, int64_t c) {
 hipError_t block_launch(BlockArgs a, int cls, hipStream_t stream);
 
 // ---- large-topic path (device-wide radix sort + one-workgroup greedy) ---------------------
+// LA_FLAG_PROFILE: HIP events around the phases of the first large topic of a call (la_last_phase_times)
+struct LargeProfile {
+    hipEvent_t ev[4] = {};      // before the keys kernel, after the plan, after the last pass, after the greedy
+    bool armed = false;         // the current call asked for it
+    bool recorded = false;      // ev[] hold a topic's phases
+    int64_t n = 0;              // its partitions
+};
+
 struct LargeScratch {
     void* buf = nullptr;
     size_t cap = 0;
+    LargeProfile prof;
 };
 
 struct LargeArgs {
@@ -140,10 +149,14 @@ struct LargeArgs {
     int64_t* out_total;
     uint32_t* status;
     int32_t reset_latest;
+    int32_t no_sample_sort;     // 1 = LA_FLAG_NO_SAMPLE_SORT: every greedy round sorts its bins with the full network;
+                                // 2 = LA_FLAG_SAMPLE_TIGHT: bucket limit 6, so sample-sorted and fallback rounds interleave
 };
 
 hipError_t large_topic_launch(LargeScratch& scratch, const LargeArgs& a, bool argmin, hipStream_t stream);
 void large_scratch_release(LargeScratch& scratch);
+// Waits for the profiled topic's events; ms[3] = keys + plan, sort passes, ids + greedy; passes[2] = active id / key passes.
+hipError_t large_profile_read(LargeScratch& scratch, float* ms, int* passes, int64_t* n);
 
 // Stable grouping of the n assignment entries by member rank (see la_group_by_member in lagassign.h).
 hipError_t group_by_member_launch(LargeScratch& scratch, int64_t n, int32_t n_members, int64_t n_topics,

@@ -411,9 +411,19 @@ __device__ __forceinline__ void dpp_fence(P64 (&rec)[EC]) {
 
 // LDS layout is register-major (slot r of thread t at r * blockDim + t): consecutive lanes touch consecutive
 // 8-byte words, where element order (t * EC + r) would put a 64-byte stride between lanes (16-way conflicts).
+// One barrier per step: consecutive steps ALTERNATE between two exchange buffers (ExchangeBufs::next), so a thread
+// that runs ahead writes the other buffer while slower threads still read this one; by the time a buffer comes
+// round again every thread has passed the barrier of the step in between, i.e. has finished reading it.
+struct ExchangeBufs {
+    uint64_t* buf[2];
+    int at = 0;
+    __device__ __forceinline__ uint64_t* next() { at ^= 1; return buf[at]; }
+};
+
 template <int EC>
-__device__ __forceinline__ void cross_wave_step(P64 (&rec)[EC], uint64_t* s_bin, int tid, int mask, int min_bit) {
+__device__ __forceinline__ void cross_wave_step(P64 (&rec)[EC], ExchangeBufs& xb, int tid, int mask, int min_bit) {
     const int nt = blockDim.x;
+    uint64_t* s_bin = xb.next();
 #pragma unroll
     for (int r = 0; r < EC; ++r) s_bin[r * nt + tid] = p64_value(rec[r]);
     __syncthreads();
@@ -426,37 +436,242 @@ __device__ __forceinline__ void cross_wave_step(P64 (&rec)[EC], uint64_t* s_bin,
         const uint64_t lo = o < x ? o : x, hi = o < x ? x : o;
         rec[r] = p64_from(keep_min ? lo : hi);
     }
+}
+
+#ifdef LA_ROUND_CLOCKS   // development build: thread 0 accumulates the cycles of every phase of a round (tools/cfg5_probe.py)
+__device__ unsigned long long g_round_clocks[16];
+#define LA_CLK(i)                                                          \
+    do {                                                                   \
+        if (threadIdx.x == 0) {                                            \
+            const unsigned long long now_ = clock64();                     \
+            g_round_clocks[i] += now_ - clk_;                              \
+            clk_ = now_;                                                   \
+        }                                                                  \
+    } while (0)
+#define LA_CLK_START unsigned long long clk_ = clock64()
+#else
+#define LA_CLK(i) do {} while (0)
+#define LA_CLK_START do {} while (0)
+#endif
+
+constexpr int kSampleThreads = 1024;
+constexpr uint32_t kMaxBucket = 96;
+
+constexpr int kSamplesPerThread = 1;                         // 1 024 splitters: buckets of ~EC bins (2 per thread: the
+                                                             // walk halves, but the sample sort's chain of steps grows more)
+
+struct SampleLds {
+    ulonglong2* stage;    // [n]  staged bins in bucket order: (bin, bucket size << 16 | slot); the final order
+                          //      (uint64 [n]) is written over it once every staged bin is back in a register
+    uint64_t* spl;        // [2 * NS] splitters in the first half; before that the two exchange buffers of the sample
+                          //      sort's LDS steps (nothing else may be in flight there: the staging area is still being read
+                          //      by slower threads when the fastest start the next round)
+    uint32_t* cnt;        // [NS + 1] bucket counts, then (first position | size << 16)
+    uint32_t* misc;       // [32] per-wavefront sums and maxima
+};
+
+__host__ __device__ constexpr size_t sample_lds_bytes(int ec) {
+    return ((size_t)ec * kSampleThreads + 2) * 16 + (size_t)kSamplesPerThread * kSampleThreads * (16 + 4) + 64 + 32 * 4;
+}
+
+__device__ __forceinline__ SampleLds sample_lds_carve(void* smem, int n) {
+    SampleLds L;
+    L.stage = reinterpret_cast<ulonglong2*>(smem);
+    L.spl = reinterpret_cast<uint64_t*>(L.stage + n + 2);      // stage[n], stage[n + 1]: sentinels, larger than any bin
+    L.cnt = reinterpret_cast<uint32_t*>(L.spl + 2 * kSamplesPerThread * kSampleThreads);
+    L.misc = L.cnt + kSamplesPerThread * kSampleThreads + 16;
+    return L;
+}
+
+// inclusive scan over the wavefront through DPP (row shifts, then the row broadcasts of GFX9)
+__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v) {
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, false);   // row_shr:1
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, false);   // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, false);   // row_shr:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, false);   // row_shr:8
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false);   // row_bcast:15 -> rows 1, 3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false);   // row_bcast:31 -> rows 2, 3
+    return v;
+}
+
+// max over the wavefront, in every lane, without the LDS pipe (DPP + v_permlane*_swap butterflies)
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
+    v = max(v, shfl_xor<1>(v));
+    v = max(v, shfl_xor<2>(v));
+    v = max(v, shfl_xor<4>(v));
+    v = max(v, shfl_xor<8>(v));
+    v = max(v, shfl_xor<16>(v));
+    v = max(v, shfl_xor<32>(v));
+    return v;
+}
+
+template <int EC>
+__device__ __forceinline__ bool sample_sort_bins(P64 (&rec)[EC], const SampleLds& L, int tid, uint32_t bucket_limit) {
+    constexpr int NT = kSampleThreads, N = EC * NT;
+    constexpr int SPT = (EC >= 2 * kSamplesPerThread) ? kSamplesPerThread : 1;   // samples per thread
+    constexpr int NS = SPT * NT;                                                   // splitters; NS + 1 buckets
+    const int lane = tid & 63, wave = tid >> 6;
+    LA_CLK_START;
+    // 1. splitters: the block-wide sort of SPT bins per thread (regular samples of last round's order).
+    //    (Tried: the same 1 024 samples sorted by four wavefronts with four samples per lane -- 3 LDS steps instead of
+    //    10 -- is slower, 18.4k cycles against 14k: the in-register network of one wavefront per SIMD is a longer chain.)
+    {
+        P64 smp[SPT];
+#pragma unroll
+        for (int u = 0; u < SPT; ++u) smp[u] = rec[(2 * u + 1) * EC / (2 * SPT)];
+        dpp_fence<SPT>(smp);
+        bitonic_sort_tile_p64<64, SPT>(smp);
+        ExchangeBufs xb{{L.spl, L.spl + NS}};
+        for (int K = 128 * SPT; K <= NS; K <<= 1) {
+            cross_wave_step<SPT>(smp, xb, tid, K - 1, K >> 1);
+            for (int j = K >> 2; j >= 64 * SPT; j >>= 1) cross_wave_step<SPT>(smp, xb, tid, j, j);
+            dpp_fence<SPT>(smp);
+            clean_p64<64, SPT, 32 * SPT, false>(smp);
+        }
+        __syncthreads();                             // the last step's reads, before the splitters go over its buffer
+#pragma unroll
+        for (int u = 0; u < SPT; ++u) {
+            L.spl[tid * SPT + u] = p64_value(smp[u]);
+            L.cnt[tid * SPT + u] = 0;
+        }
+        if (tid == 0) L.cnt[NS] = 0;
+    }
     __syncthreads();
+    LA_CLK(0);
+    // 2. bucket of every bin = number of splitters below it (0 .. NS); a slot inside the bucket
+    uint64_t x[EC];
+    uint32_t b[EC], slot[EC];
+#pragma unroll
+    for (int r = 0; r < EC; ++r) { x[r] = p64_value(rec[r]); b[r] = 0; }
+#pragma unroll
+    for (int step = NS / 2; step >= 1; step >>= 1) {
+#pragma unroll
+        for (int r = 0; r < EC; ++r) b[r] += (L.spl[b[r] + step - 1] < x[r]) ? (uint32_t)step : 0u;
+    }
+    {
+        const uint64_t top = L.spl[NS - 1];
+#pragma unroll
+        for (int r = 0; r < EC; ++r) b[r] += (top < x[r]) ? 1u : 0u;     // only where b is already NS - 1
+    }
+    LA_CLK(1);
+#pragma unroll
+    for (int r = 0; r < EC; ++r) slot[r] = atomicAdd(&L.cnt[b[r]], 1u);
+    __syncthreads();
+    {   // exclusive scan of the counts (thread t owns buckets t*SPT ..; bucket NS is what is left), largest bucket
+        uint32_t c[SPT], sum = 0, m = 0;
+#pragma unroll
+        for (int u = 0; u < SPT; ++u) { c[u] = L.cnt[tid * SPT + u]; sum += c[u]; m = max(m, c[u]); }
+        const uint32_t incl = wave_incl_scan_u32(sum);
+        if (tid == 0) m = max(m, L.cnt[NS]);
+        m = wave_max_u32(m);
+        if (lane == 63) L.misc[wave] = incl;
+        if (lane == 0) L.misc[16 + wave] = m;
+        __syncthreads();
+        const uint4* mv = reinterpret_cast<const uint4*>(L.misc);          // 16 sums, 16 maxima: eight 16-byte reads
+        uint32_t base = 0, mx = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const uint4 sv = mv[q], xv = mv[4 + q];
+            base += (4 * q + 0 < wave ? sv.x : 0u) + (4 * q + 1 < wave ? sv.y : 0u) + (4 * q + 2 < wave ? sv.z : 0u) +
+                    (4 * q + 3 < wave ? sv.w : 0u);
+            mx = max(max(mx, max(xv.x, xv.y)), max(xv.z, xv.w));
+        }
+        if (mx > bucket_limit) return false;          // workgroup-uniform: the caller sorts with the full network
+        uint32_t first = base + incl - sum;
+#pragma unroll
+        for (int u = 0; u < SPT; ++u) {
+            L.cnt[tid * SPT + u] = first | (c[u] << 16);
+            first += c[u];
+        }
+        if (tid == NT - 1) L.cnt[NS] = first | (((uint32_t)N - first) << 16);
+    }
+    __syncthreads();
+    LA_CLK(2);
+    // 3. stage bucket by bucket, with (bucket size << 16 | slot) beside every staged bin
+#pragma unroll
+    for (int r = 0; r < EC; ++r) {
+        const uint32_t sc = L.cnt[b[r]];
+        L.stage[(sc & 0xFFFFu) + slot[r]] = make_ulonglong2(x[r], (uint64_t)((sc & 0xFFFF0000u) | slot[r]));
+    }
+    __syncthreads();
+    LA_CLK(3);
+    // Walk the staged bins wave-striped: 64 consecutive positions per step, a handful of consecutive buckets.
+    // Final position = bucket start + members below the bin.  Reading past the bucket's end is harmless -- the bins
+    // of later buckets are all larger, and two sentinels close the array -- so the loop has no per-lane bound.
+    uint32_t pos[EC];
+    uint64_t y[EC];
+    const uint64_t* keys = reinterpret_cast<const uint64_t*>(L.stage);       // staged bin j at keys[2 * j]
+#pragma unroll
+    for (int it = 0; it < EC; ++it) {
+        const uint32_t j = (uint32_t)(wave * 64 * EC + it * 64 + lane);
+        const ulonglong2 e = L.stage[j];
+        y[it] = e.x;
+        const uint32_t inf = (uint32_t)e.y;
+        const uint32_t s0 = j - (inf & 0xFFFFu);
+        const uint32_t cmax = wave_max_u32(inf >> 16);
+        uint32_t below = 0;
+        for (uint32_t k = 0; k < cmax; k += 2) {
+            const uint32_t at = min(s0 + k, (uint32_t)N);            // N, N + 1: the sentinels
+            const uint64_t o0 = keys[2 * at], o1 = keys[2 * at + 2];
+            below += (o0 < y[it] ? 1u : 0u) + (o1 < y[it] ? 1u : 0u);
+        }
+        pos[it] = s0 + below;
+    }
+    LA_CLK(4);
+    __syncthreads();                                 // every staged bin is in a register: the final order goes over them
+    // 4. final order, back to blocked registers
+    uint64_t* sorted = reinterpret_cast<uint64_t*>(L.stage);
+#pragma unroll
+    for (int it = 0; it < EC; ++it) sorted[pos[it]] = y[it];
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < EC; ++r) rec[r] = p64_from(sorted[tid * EC + r]);
+    LA_CLK(5);
+    return true;
 }
 
 template <int EC>
 __device__ void greedy_rounds_packed(const LargeArgs& a, const uint64_t* key, int64_t P, int C, int64_t rounds,
-                                     int idx_bits, uint64_t* s_bin) {
+                                     int idx_bits, void* smem) {
     const int tid = threadIdx.x;
     const int n = EC * blockDim.x;
     constexpr int kSpan = 64 * EC;                       // elements of one wavefront
     const uint32_t idx_mask = (1u << idx_bits) - 1;
+    uint64_t* s_bin = reinterpret_cast<uint64_t*>(smem);
+    [[maybe_unused]] const SampleLds L = sample_lds_carve(smem, n);
+    [[maybe_unused]] const bool use_sample = (EC >= 2) && blockDim.x == kSampleThreads && a.no_sample_sort != 1;
+    if (use_sample && tid < 2) L.stage[n + tid] = make_ulonglong2(~0ull, 0);      // first read after many barriers
     P64 rec[EC];
     uint64_t lag[EC];
 #pragma unroll
     for (int r = 0; r < EC; ++r) {
         const int i = tid * EC + r;
-        rec[r] = p64_from(i < C ? (uint64_t)i : ~0ull);
+        // pads (slots beyond the C consumers) sort behind every bin and, like the bins, are all different
+        rec[r] = p64_from(i < C ? (uint64_t)i : ((~0ull << idx_bits) | (uint64_t)i));
         lag[r] = (i < C && i < P) ? (key[i] ^ kLagKeyFlip) : 0;
     }
     for (int64_t q = 0; q < rounds; ++q) {
         if (q > 0) {
-            // sort the n bins: inside every wavefront first, then merges across wavefronts
-            dpp_fence<EC>(rec);
-            bitonic_sort_tile_p64<64, EC>(rec);
-            for (int K = 2 * kSpan; K <= n; K <<= 1) {
-                cross_wave_step<EC>(rec, s_bin, tid, K - 1, K >> 1);                     // mirror: i <-> i ^ (K-1)
-                for (int j = K >> 2; j >= kSpan; j >>= 1) cross_wave_step<EC>(rec, s_bin, tid, j, j);
+            bool sorted = false;
+            if constexpr (EC >= 2) {
+                if (use_sample) sorted = sample_sort_bins<EC>(rec, L, tid, a.no_sample_sort == 2 ? 6u : kMaxBucket);
+            }
+            if (!sorted) {
+                // sort the n bins: inside every wavefront first, then merges across wavefronts
                 dpp_fence<EC>(rec);
-                clean_p64<64, EC, kSpan / 2, false>(rec);                                 // i <-> i ^ j, j < span
+                bitonic_sort_tile_p64<64, EC>(rec);
+                ExchangeBufs xb{{s_bin, s_bin + n}};
+                for (int K = 2 * kSpan; K <= n; K <<= 1) {
+                    cross_wave_step<EC>(rec, xb, tid, K - 1, K >> 1);                        // mirror: i <-> i ^ (K-1)
+                    for (int j = K >> 2; j >= kSpan; j >>= 1) cross_wave_step<EC>(rec, xb, tid, j, j);
+                    dpp_fence<EC>(rec);
+                    clean_p64<64, EC, kSpan / 2, false>(rec);                                 // i <-> i ^ j, j < span
+                }
+                if (n > kSpan) __syncthreads();      // the last step's reads, before anything else goes over its buffer
             }
         }
         // position i of the sorted bins takes partition q*C + i; the next round's lags are fetched now
+        LA_CLK_START;
         uint64_t next_lag[EC];
 #pragma unroll
         for (int r = 0; r < EC; ++r) {
@@ -471,16 +686,18 @@ __device__ void greedy_rounds_packed(const LargeArgs& a, const uint64_t* key, in
             if (i < C && s < P) {
                 const uint64_t nb = p64_value(rec[r]) + (lag[r] << idx_bits);          // Main.java:265
                 rec[r] = p64_from(nb);
-                a.out_rank[a.p0 + s] = a.cons_rank[a.c0 + ((uint32_t)nb & idx_mask)];
+                a.out_rank[a.p0 + s] = (int32_t)((uint32_t)nb & idx_mask);      // consumer index; map_ranks_kernel turns it into the rank
             }
             lag[r] = next_lag[r];
         }
+        LA_CLK(6);
     }
     if (a.out_total) {
 #pragma unroll
         for (int r = 0; r < EC; ++r) {
             const uint64_t v = p64_value(rec[r]);
-            if (v != ~0ull) a.out_total[a.c0 + ((uint32_t)v & idx_mask)] = (int64_t)(v >> idx_bits);
+            const uint32_t who = (uint32_t)v & idx_mask;
+            if (who < (uint32_t)C) a.out_total[a.c0 + who] = (int64_t)(v >> idx_bits);
         }
     }
 }
@@ -508,7 +725,7 @@ __global__ __launch_bounds__(1024) void greedy_rounds_kernel(LargeArgs a, SortBu
         const int lag_bits = lmax > 0 ? 64 - __builtin_clzll((unsigned long long)lmax) : 0;
         const int round_bits = 64 - __builtin_clzll((unsigned long long)rounds);
         if (lmin >= 0 && lag_bits + round_bits + idx_bits <= 62) {
-            greedy_rounds_packed<EC>(a, key, P, C, rounds, idx_bits, reinterpret_cast<uint64_t*>(smem));
+            greedy_rounds_packed<EC>(a, key, P, C, rounds, idx_bits, smem);
             return;
         }
     }
@@ -572,7 +789,7 @@ __global__ __launch_bounds__(1024) void greedy_rounds_kernel(LargeArgs a, SortBu
                 const uint64_t t = (((uint64_t)rec[r].hi << 32) | rec[r].lo) + lag;      // Main.java:265
                 rec[r].hi = (uint32_t)(t >> 32);
                 rec[r].lo = (uint32_t)t;
-                a.out_rank[a.p0 + s] = a.cons_rank[a.c0 + rec[r].tb];
+                a.out_rank[a.p0 + s] = (int32_t)rec[r].tb;                       // consumer index, as above
             }
         }
     }
@@ -636,9 +853,20 @@ __global__ __launch_bounds__(1024) void greedy_argmin_kernel(LargeArgs a, SortBu
             a.out_total[a.c0 + i] = (int64_t)((((uint64_t)s_hi[i] << 32) | s_lo[i]) ^ kTotalBias);
 }
 
+// The rounds kernels store the chosen consumer's INDEX (position in the topic's rank-sorted list): looking the rank up
+// there would put a dependent global load into every round of the one-workgroup chain (~6 us of 27 per round at
+// 8 192 consumers).  This pass, over all CUs, turns the indices into member ranks.
+__global__ __launch_bounds__(256) void map_ranks_kernel(LargeArgs a) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.n_part; i += stride)
+        a.out_rank[a.p0 + i] = a.cons_rank[a.c0 + a.out_rank[a.p0 + i]];
+}
+
 template <int EC>
 hipError_t launch_rounds(const LargeArgs& a, const SortBufs& b, int threads, hipStream_t stream) {
-    const size_t lds = (size_t)3 * EC * threads * sizeof(uint32_t);
+    // packed bins: two exchange buffers of 8 B per bin; 96-bit bins: 12 B per bin; sample sort (EC >= 2): its own layout
+    size_t lds = (size_t)4 * EC * threads * sizeof(uint32_t);
+    if (EC >= 2 && sample_lds_bytes(EC) > lds) lds = sample_lds_bytes(EC);
     static PerDeviceOnce lds_opt_in;
     const hipError_t e = lds_opt_in.run([] {
         return hipFuncSetAttribute((const void*)greedy_rounds_kernel<EC>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -646,6 +874,8 @@ hipError_t launch_rounds(const LargeArgs& a, const SortBufs& b, int threads, hip
     });
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL((greedy_rounds_kernel<EC>), dim3(1), dim3(threads), lds, stream, a, b);
+    int grid = (int)((a.n_part + 255) / 256);
+    hipLaunchKernelGGL(map_ranks_kernel, dim3(grid > 2048 ? 2048 : grid), dim3(256), 0, stream, a);
     return hipGetLastError();
 }
 
@@ -756,8 +986,9 @@ static hipError_t sort_prepare(LargeScratch& scratch, int64_t n, hipStream_t str
 }
 
 // plan + the 12 (mostly skipped) passes; keys/vals/hist/unsorted flag must already be in buffer 0
-static void sort_run_passes(const SortBufs& b, hipStream_t stream) {
+static void sort_run_passes(const SortBufs& b, hipStream_t stream, hipEvent_t planned = nullptr) {
     hipLaunchKernelGGL(plan_kernel, dim3(1), dim3(256), 0, stream, b);
+    if (planned) (void)hipEventRecord(planned, stream);
     for (int p = 0; p < kDigits; ++p) {
         hipLaunchKernelGGL(tile_count_kernel, dim3(b.n_tiles < 2048 ? b.n_tiles : 2048), dim3(kSortThreads), 0, stream, b, p);
         hipLaunchKernelGGL(scan_group_sums_kernel, dim3(b.n_groups), dim3(kRadix), 0, stream, b, p);
@@ -780,8 +1011,22 @@ hipError_t large_topic_launch(LargeScratch& scratch, const LargeArgs& a, bool ar
     if ((e = sort_prepare(scratch, n, stream, &b)) != hipSuccess) return e;
     int grid = (int)((n + 255) / 256);
     if (grid > 2048) grid = 2048;
+    LargeProfile& pf = scratch.prof;
+    const bool profile = pf.armed && !pf.recorded;
+    if (profile) {
+        for (hipEvent_t& ev : pf.ev)
+            if (!ev && (e = hipEventCreate(&ev)) != hipSuccess) return e;
+        pf.n = n;
+        pf.recorded = true;
+        (void)hipEventRecord(pf.ev[0], stream);
+    }
+    struct Done {                                   // the last event, on every way out
+        LargeProfile& pf; bool on; hipStream_t st;
+        ~Done() { if (on) (void)hipEventRecord(pf.ev[3], st); }
+    } done{pf, profile, stream};
     hipLaunchKernelGGL(build_keys_kernel, dim3(grid), dim3(256), 0, stream, a, b);
-    sort_run_passes(b, stream);
+    sort_run_passes(b, stream, profile ? pf.ev[1] : nullptr);
+    if (profile) (void)hipEventRecord(pf.ev[2], stream);
     hipLaunchKernelGGL(emit_ids_kernel, dim3(grid), dim3(256), 0, stream, a, b, a.n_cons == 0 ? 1 : 0);
     if ((e = hipGetLastError()) != hipSuccess) return e;
     if (a.n_cons == 0) return hipSuccess;
@@ -828,10 +1073,40 @@ hipError_t group_by_member_launch(LargeScratch& scratch, int64_t n, int32_t n_me
     return hipGetLastError();
 }
 
+#ifdef LA_ROUND_CLOCKS
+extern "C" __attribute__((visibility("default"))) int la_debug_round_clocks(unsigned long long* out, int reset) {
+    hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(g_round_clocks), sizeof(g_round_clocks));
+    if (e == hipSuccess && reset) {
+        unsigned long long zero[16] = {};
+        e = hipMemcpyToSymbol(HIP_SYMBOL(g_round_clocks), zero, sizeof zero);
+    }
+    return e == hipSuccess ? 0 : -3;
+}
+#endif
+
 void large_scratch_release(LargeScratch& s) {
     if (s.buf) (void)hipFree(s.buf);
     s.buf = nullptr;
     s.cap = 0;
+    for (hipEvent_t& ev : s.prof.ev) {
+        if (ev) (void)hipEventDestroy(ev);
+        ev = nullptr;
+    }
+}
+
+hipError_t large_profile_read(LargeScratch& s, float* ms, int* passes, int64_t* n) {
+    if (!s.prof.recorded || !s.buf) return hipErrorNotReady;
+    hipError_t e;
+    if ((e = hipEventSynchronize(s.prof.ev[3])) != hipSuccess) return e;
+    for (int i = 0; i < 3; ++i)
+        if ((e = hipEventElapsedTime(&ms[i], s.prof.ev[i], s.prof.ev[i + 1])) != hipSuccess) return e;
+    SortCtl ctl;                                    // the control block sits at the start of the scratch
+    if ((e = hipMemcpy(&ctl, s.buf, sizeof ctl, hipMemcpyDeviceToHost)) != hipSuccess) return e;
+    passes[0] = passes[1] = 0;
+    for (int p = 0; p < kDigits; ++p)
+        if (!ctl.skip[p]) ++passes[p < 4 ? 0 : 1];
+    *n = s.prof.n;
+    return hipSuccess;
 }
 
 }  // namespace la

@@ -616,6 +616,48 @@ def test_fuzz_large_topics(ctx, seed):
         np.testing.assert_array_equal(g, e, err_msg="%s p=%d c=%d %s" % (what, p, c, kind))
 
 
+# ---- large path, > 1 024 consumers: every greedy round is a sample sort of the bins (la_large.hip) --------------
+def _pareto_topic(seed, p, c):
+    rng = np.random.default_rng(seed)
+    u = 1.0 - rng.random(p)
+    lag = np.floor(np.minimum(float(1 << 40), 1000.0 * u ** (-1.0 / 1.5))).astype(np.int64)
+    w = synth.Workload("pareto", 1, np.array([0, p], np.int64), rng.permutation(p).astype(np.int32),
+                       np.zeros(p, np.int64), lag.copy(), np.zeros(p, np.int64), lag,
+                       np.array([0, c], np.int64), np.arange(c, dtype=np.int32), p, c)
+    return w
+
+
+@pytest.mark.parametrize("p,c,kind", [
+    (20000, 1500, "u40"), (30000, 2049, "u40"), (40000, 3000, "pareto"), (70000, 4096, "ties"),
+    (100000, 8192, "zero"), (50000, 5000, "u40"), (262144, 8192, "pareto"), (9000, 8192, "u63"),
+    (60000, 4097, "pareto"), (33000, 1025, "ties"),
+])
+def test_large_sample_sort_rounds(ctx, p, c, kind):
+    """sample-sorted rounds == rounds sorted by the full network == rounds where both interleave == the oracle"""
+    if kind == "pareto":
+        w = _pareto_topic(p + c, p, c)
+    else:
+        po, pid, lag, co, ranks = _single_topic(p ^ c, p, c, kind)
+        w = synth.Workload(kind, 1, np.asarray(po, np.int64), pid, np.zeros(p, np.int64), lag.copy(),
+                           np.zeros(p, np.int64), lag, np.asarray(co, np.int64), ranks, p, c)
+    exp = oracle.assign_flat(w.part_off, w.partition_id, w.lag, w.cons_off, w.cons_rank)
+    for flags, what in ((0, "sample sort"), (N.LA_FLAG_NO_SAMPLE_SORT, "full network"),
+                        (N.LA_FLAG_SAMPLE_TIGHT, "interleaved")):
+        got = _run_device(ctx, w, N.LA_ALGO_AUTO, use_lag=True, flags=flags)
+        for g, e, name in zip(got, exp, ("partition order", "member", "totals")):
+            np.testing.assert_array_equal(g, e, err_msg="%s, %s" % (name, what))
+
+
+def test_large_phase_times(ctx):
+    w = _pareto_topic(3, 300000, 4096)
+    _run_device(ctx, w, N.LA_ALGO_AUTO, use_lag=True, flags=N.LA_FLAG_PROFILE)
+    t = ctx.last_phase_times()
+    assert t.n_partitions == 300000 and t.id_passes == 3 and 1 <= t.key_passes <= 8      # ids < 2^24 shuffled
+    assert t.keys_ms > 0 and t.sort_ms > 0 and t.greedy_ms > 0
+    _run_device(ctx, synth.config("cfg3", 0.01), N.LA_ALGO_AUTO)                          # no large topic, no flag
+    assert ctx.last_phase_times().n_partitions == 300000                                  # the record stays
+
+
 # ---- block path: one workgroup per topic, 1 024 < P <= 8 192 or 64 < C <= 2 048 ------------------------------
 @pytest.mark.parametrize("p,c,kind", [
     (1025, 1, "u40"), (8192, 2048, "u40"), (100, 65, "ties"), (1, 65, "u40"), (0, 100, "zero"), (5000, 0, "u40"),
