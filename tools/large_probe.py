@@ -22,9 +22,10 @@ def main():
     dev = torch.device("cuda", 0)
     ctx = N.Context(0)
     P, C = args.partitions, args.consumers
-    w = bench.make_device_workload(torch, dev, 1, P, C, seed=7, dist=args.dist)
-    outs = bench.alloc_outputs(torch, dev, 1, P, C)
-    b, keep = bench.make_batch(N, w, outs, 1, P, C, False, "auto")
+    from kafka_lag_based_assignor_amd import synth
+    hw = bench.sort_phase_workload(P) if C == 0 else synth.make_uniform("large", 12, 1, P, C, args.dist)
+    sh = bench.DeviceShard(torch, N, dev, hw, 0, 1, False, "auto")
+    b = sh.batch
     stream = torch.cuda.current_stream().cuda_stream
     ctx.assign_batch_device(b, stream); ctx.sync(stream)
     torch.cuda.synchronize()
@@ -36,10 +37,10 @@ def main():
     print("large topic: %d partitions x %d consumers: %.3f ms per launch, %.3g assignments/s" % (P, C, dt * 1e3, P / dt))
     if args.check:
         from oracle import oracle
-        h = {k: v.cpu().numpy() for k, v in w.items()}
-        lag = oracle.compute_lags(h["begin"], h["end"], h["committed"], False)
-        e = oracle.assign_flat(h["part_off"], h["pid"], lag, h["cons_off"], h["cons_rank"])
-        ok = all(np.array_equal(a, b) for a, b in zip(e, (outs["pid"].cpu().numpy(), outs["rank"].cpu().numpy(), outs["total"].cpu().numpy())))
+        lag = oracle.compute_lags(hw.begin, hw.end, hw.committed, False)
+        e = oracle.assign_flat(hw.part_off, hw.partition_id, lag, hw.cons_off, hw.cons_rank)
+        got = (sh.out_pid[:P].cpu().numpy(), sh.out_rank[:P].cpu().numpy(), sh.out_total[:C].cpu().numpy())
+        ok = all(np.array_equal(a, b) for a, b in zip(e, got))
         print("bit-exact vs oracle:", ok)
     ctx.close()
 

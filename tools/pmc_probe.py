@@ -42,6 +42,7 @@ def main():
     import torch
     import bench
     from kafka_lag_based_assignor_amd import _native as N
+    from kafka_lag_based_assignor_amd import synth
 
     dev = torch.device("cuda", 0)
     ctx = N.Context(0)
@@ -57,9 +58,10 @@ def main():
     # 2. the hot path
     T, P, C = args.topics, args.partitions, args.consumers
     if T > 0:
-        w = bench.make_device_workload(torch, dev, T, P, C, seed=0x5EED)
-        outs = bench.alloc_outputs(torch, dev, T, P, C)
-        b, keep = bench.make_batch(N, w, outs, T, P, C, args.reset_mode == "latest", args.algo)
+        # the bench's own vectors when the shape is the target's (synth.config), the same generator otherwise
+        w = synth.config("target") if (T, P, C) == (100000, 256, 32) else synth.make_uniform("custom", 11, T, P, C, "zipf")
+        sh = bench.DeviceShard(torch, N, dev, w, 0, T, args.reset_mode == "latest", args.algo)
+        b = sh.batch
         stream = torch.cuda.current_stream().cuda_stream
         for _ in range(args.launches):
             ctx.assign_batch_device(b, stream)
@@ -68,9 +70,9 @@ def main():
     # 3. optional: one large topic (device radix sort + one-workgroup greedy)
     if args.large_partitions > 0:
         P2, C2 = args.large_partitions, args.large_consumers
-        w2 = bench.make_device_workload(torch, dev, 1, P2, C2, seed=0x5EED + 1, dist="uniform40")
-        outs2 = bench.alloc_outputs(torch, dev, 1, P2, C2)
-        b2, keep2 = bench.make_batch(N, w2, outs2, 1, P2, C2, args.reset_mode == "latest", "auto")
+        w2 = bench.sort_phase_workload(P2) if C2 == 0 else synth.make_uniform("large", 12, 1, P2, C2, "uniform40")
+        sh2 = bench.DeviceShard(torch, N, dev, w2, 0, 1, args.reset_mode == "latest", "auto")
+        b2 = sh2.batch
         stream = torch.cuda.current_stream().cuda_stream
         for _ in range(2):
             ctx.assign_batch_device(b2, stream)

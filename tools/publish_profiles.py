@@ -29,7 +29,7 @@ def main():
             for r in rows:
                 r[0] = r[0][:160]
                 w.writerow(r)
-    for b in ("bench", "bench_latest", "bench_wide", "bench_cfg4"):
+    for b in ("bench", "bench_driver", "bench_sort", "bench_strong_cfg4", "bench_latest", "bench_wide", "bench_cfg4"):
         p = os.path.join(src, b + ".json")
         if os.path.exists(p):
             lines = [l for l in open(p) if l.startswith("{")]
