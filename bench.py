@@ -279,10 +279,10 @@ def main():
     T = w.n_topics
     strong = args.scaling == "strong"
     if strong:
-        bounds = N.plan_shards(w.part_off, world)                 # la_plan_shards: what la_create_multi uses itself
-        t0, t1 = int(bounds[rank]), int(bounds[rank + 1])
-        counts = [int(w.part_off[bounds[r + 1]] - w.part_off[bounds[r]]) for r in range(world)]
-        cap = max(counts)                                         # ncclAllGather needs equal counts: pad to the largest
+        # la_plan_shards (what la_create_multi uses itself); ncclAllGather needs equal counts: buffers padded to `cap`
+        ranges, counts, cap = sharding.strong_plan(w.part_off, world)
+        bounds = [r[0] for r in ranges] + [ranges[-1][1]]
+        t0, t1 = ranges[rank]
         sh = DeviceShard(torch, N, dev, w, t0, t1, latest, args.algo, out_cap=cap)
         n_total = w.n_partitions
         gather = True
@@ -376,8 +376,7 @@ def main():
     if strong and rank == 0:
         if use_dist:
             gp, gr = gathered_pid.cpu().numpy(), gathered_rank.cpu().numpy()
-            gathered_host = (np.concatenate([gp[r * cap: r * cap + counts[r]] for r in range(world)]),
-                             np.concatenate([gr[r * cap: r * cap + counts[r]] for r in range(world)]))
+            gathered_host = (sharding.strip_padding(gp, counts, cap), sharding.strip_padding(gr, counts, cap))
         else:
             gathered_host = (sh.out_pid[:n_part].cpu().numpy(), sh.out_rank[:n_part].cpu().numpy())
 

@@ -1,30 +1,79 @@
-/* lagassign_jni.c -- the thin JNI -> C-ABI shim.  SOURCE ONLY (no jni.h in the build image).
- *
- *   cc -shared -fPIC -I$JAVA_HOME/include -I$JAVA_HOME/include/linux -I../../include \
- *      lagassign_jni.c -L../../kafka_lag_based_assignor_amd -llagassign -o liblagassign_jni.so
+/* lagassign_jni.c -- the thin JNI -> C-ABI shim: one GetDirectBufferAddress per argument, one call.
+ * NOT COMPILED in the image this repository is built in (no jni.h there); `make -C java/jni` builds it wherever a
+ * JDK exists (JAVA_HOME), java/run_reference_tests.sh does so before running the reference's JUnit class.
  */
 #include <jni.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "lagassign.h"
 
 #define ADDR(env, buf) ((buf) ? (*(env))->GetDirectBufferAddress((env), (buf)) : NULL)
+#define CTX(h) ((la_ctx *)(intptr_t)(h))
+
+JNIEXPORT jint JNICALL
+Java_com_github_grantneale_kafka_gpu_LagAssignNative_deviceCount(JNIEnv *env, jclass cls) {
+    (void)env; (void)cls;
+    return la_device_count();
+}
 
 JNIEXPORT jlong JNICALL
-Java_com_github_grantneale_kafka_gpu_LagAssignNative_create(JNIEnv *env, jclass cls, jint device) {
+Java_com_github_grantneale_kafka_gpu_LagAssignNative_createMulti(JNIEnv *env, jclass cls, jintArray device_ids) {
     la_ctx *ctx = NULL;
-    int rc = la_create(&ctx, device, 0);
+    int rc;
+    jsize n = device_ids ? (*env)->GetArrayLength(env, device_ids) : 0;
+    (void)cls;
+    if (n > 0) {
+        jint *ids = (*env)->GetIntArrayElements(env, device_ids, NULL);
+        if (!ids) return 0;                                   /* OutOfMemoryError is pending */
+        rc = la_create_multi(&ctx, (int)n, (const int *)ids, 0);
+        (*env)->ReleaseIntArrayElements(env, device_ids, ids, JNI_ABORT);
+    } else {
+        rc = la_create_multi(&ctx, 0, NULL, 0);               /* every device of the node */
+    }
     if (rc != LA_OK) {
         jclass ex = (*env)->FindClass(env, "java/lang/IllegalStateException");
-        (*env)->ThrowNew(env, ex, la_last_error(NULL));
+        if (ex) (*env)->ThrowNew(env, ex, la_last_error(NULL));
         return 0;
     }
     return (jlong)(intptr_t)ctx;
 }
 
+JNIEXPORT jint JNICALL
+Java_com_github_grantneale_kafka_gpu_LagAssignNative_shardCount(JNIEnv *env, jclass cls, jlong ctx) {
+    (void)env; (void)cls;
+    return la_shard_count(CTX(ctx));
+}
+
 JNIEXPORT void JNICALL
 Java_com_github_grantneale_kafka_gpu_LagAssignNative_destroy(JNIEnv *env, jclass cls, jlong ctx) {
-    la_destroy((la_ctx *)(intptr_t)ctx);
+    (void)env; (void)cls;
+    la_destroy(CTX(ctx));
+}
+
+JNIEXPORT jobject JNICALL
+Java_com_github_grantneale_kafka_gpu_LagAssignNative_hostAlloc(JNIEnv *env, jclass cls, jlong ctx, jlong bytes) {
+    void *p;
+    (void)cls;
+    if (bytes < 0) return NULL;
+    p = la_host_alloc(CTX(ctx), (size_t)bytes);
+    if (!p) return NULL;
+    return (*env)->NewDirectByteBuffer(env, p, bytes);
+}
+
+JNIEXPORT void JNICALL
+Java_com_github_grantneale_kafka_gpu_LagAssignNative_hostFree(JNIEnv *env, jclass cls, jlong ctx, jobject buffer) {
+    (void)cls;
+    la_host_free(CTX(ctx), ADDR(env, buffer));
+}
+
+JNIEXPORT jint JNICALL
+Java_com_github_grantneale_kafka_gpu_LagAssignNative_computeLag(
+    JNIEnv *env, jclass cls, jlong ctx, jlong n, jobject begin, jobject end, jobject committed, jint reset_mode,
+    jobject out_lag) {
+    (void)cls;
+    return la_compute_lag(CTX(ctx), (int64_t)n, (const int64_t *)ADDR(env, begin), (const int64_t *)ADDR(env, end),
+                          (const int64_t *)ADDR(env, committed), reset_mode, (int64_t *)ADDR(env, out_lag));
 }
 
 JNIEXPORT jint JNICALL
@@ -32,7 +81,8 @@ Java_com_github_grantneale_kafka_gpu_LagAssignNative_assignBatch(
     JNIEnv *env, jclass cls, jlong ctx, jint n_topics, jobject part_off, jobject partition_id,
     jobject begin, jobject end, jobject committed, jint reset_mode, jobject cons_off, jobject cons_rank,
     jobject out_partition, jobject out_member_rank, jobject out_total_lag) {
-    return la_assign_batch((la_ctx *)(intptr_t)ctx, n_topics,
+    (void)cls;
+    return la_assign_batch(CTX(ctx), n_topics,
                            (const int64_t *)ADDR(env, part_off), (const int32_t *)ADDR(env, partition_id),
                            (const int64_t *)ADDR(env, begin), (const int64_t *)ADDR(env, end),
                            (const int64_t *)ADDR(env, committed), reset_mode,
@@ -42,24 +92,29 @@ Java_com_github_grantneale_kafka_gpu_LagAssignNative_assignBatch(
 }
 
 JNIEXPORT jint JNICALL
-Java_com_github_grantneale_kafka_gpu_LagAssignNative_groupByMember(
-    JNIEnv *env, jclass cls, jlong ctx, jint n_topics, jobject part_off, jobject out_partition,
-    jobject out_member_rank, jint n_members, jobject member_off, jobject grouped_topic, jobject grouped_partition) {
-    return la_group_by_member((la_ctx *)(intptr_t)ctx, n_topics, (const int64_t *)ADDR(env, part_off),
-                              (const int32_t *)ADDR(env, out_partition), (const int32_t *)ADDR(env, out_member_rank),
-                              n_members, (int64_t *)ADDR(env, member_off), (int32_t *)ADDR(env, grouped_topic),
-                              (int32_t *)ADDR(env, grouped_partition));
+Java_com_github_grantneale_kafka_gpu_LagAssignNative_assignBatchLags(
+    JNIEnv *env, jclass cls, jlong ctx, jint n_topics, jobject part_off, jobject partition_id, jobject lag,
+    jobject cons_off, jobject cons_rank, jobject out_partition, jobject out_member_rank, jobject out_total_lag) {
+    (void)cls;
+    return la_assign_batch_lags(CTX(ctx), n_topics,
+                                (const int64_t *)ADDR(env, part_off), (const int32_t *)ADDR(env, partition_id),
+                                (const int64_t *)ADDR(env, lag),
+                                (const int64_t *)ADDR(env, cons_off), (const int32_t *)ADDR(env, cons_rank),
+                                (int32_t *)ADDR(env, out_partition), (int32_t *)ADDR(env, out_member_rank),
+                                (int64_t *)ADDR(env, out_total_lag));
 }
 
 JNIEXPORT jint JNICALL
 Java_com_github_grantneale_kafka_gpu_LagAssignNative_groupLastByMember(
     JNIEnv *env, jclass cls, jlong ctx, jint n_members, jobject member_off, jobject grouped_topic,
     jobject grouped_partition) {
-    return la_group_last_by_member((la_ctx *)(intptr_t)ctx, n_members, (int64_t *)ADDR(env, member_off),
+    (void)cls;
+    return la_group_last_by_member(CTX(ctx), n_members, (int64_t *)ADDR(env, member_off),
                                    (int32_t *)ADDR(env, grouped_topic), (int32_t *)ADDR(env, grouped_partition));
 }
 
 JNIEXPORT jstring JNICALL
 Java_com_github_grantneale_kafka_gpu_LagAssignNative_lastError(JNIEnv *env, jclass cls, jlong ctx) {
+    (void)cls;
     return (*env)->NewStringUTF(env, la_last_error((const la_ctx *)(intptr_t)ctx));
 }

@@ -3,8 +3,8 @@ package com.github.grantneale.kafka.gpu;
 import java.nio.ByteBuffer;
 
 /**
- * JNI face of include/lagassign.h (liblagassign.so).  SOURCE ONLY: there is no JDK in the
- * build image, so this file and jni/lagassign_jni.c have not been compiled here.
+ * JNI face of include/lagassign.h (liblagassign.so).  NOT COMPILED in the image this repository is built in (it has
+ * no JDK): java/run_reference_tests.sh builds and tests it wherever a JDK 8+ and the two jars exist.
  *
  * All buffers are DIRECT ByteBuffers in native byte order; the shim passes their addresses
  * straight to the C ABI (GetDirectBufferAddress), so nothing is copied on the Java side.
@@ -21,11 +21,35 @@ final class LagAssignNative {
 
     private LagAssignNative() { }
 
-    /** la_create; returns the context handle or throws IllegalStateException(la_last_error). */
-    static native long create(int deviceId);
+    /** la_device_count: HIP devices visible to the process (negative: the la_* error code). */
+    static native int deviceCount();
+
+    /**
+     * la_create_multi over {@code deviceIds}, or over EVERY device of the node when it is null or empty: one shard per
+     * device, a batch is split into contiguous topic ranges balanced by partition count and every shard's results land
+     * at their offset in the caller's buffers.  Returns the context handle or throws
+     * IllegalStateException(la_last_error).
+     */
+    static native long createMulti(int[] deviceIds);
+
+    /** la_shard_count */
+    static native int shardCount(long ctx);
 
     /** la_destroy */
     static native void destroy(long ctx);
+
+    /**
+     * la_host_alloc wrapped by NewDirectByteBuffer: {@code bytes} of pinned host memory (copies to and from it are
+     * plain DMA).  The buffer must be returned with {@link #hostFree}; it is NOT garbage collected.  null on failure.
+     */
+    static native ByteBuffer hostAlloc(long ctx, long bytes);
+
+    /** la_host_free */
+    static native void hostFree(long ctx, ByteBuffer buffer);
+
+    /** la_compute_lag: begin/end/committed/outLag int64[n]; begin may be null for RESET_LATEST. */
+    static native int computeLag(long ctx, long n, ByteBuffer begin, ByteBuffer end, ByteBuffer committed,
+                                 int resetMode, ByteBuffer outLag);
 
     /**
      * la_assign_batch.  partOff/consOff: int64[T+1]; partitionId/consRank: int32;
@@ -39,18 +63,17 @@ final class LagAssignNative {
                                   ByteBuffer consOff, ByteBuffer consRank, ByteBuffer outPartition,
                                   ByteBuffer outMemberRank, ByteBuffer outTotalLag);
 
-    /**
-     * la_group_by_member: every member's list in the reference's order, as slices.
-     * memberOff: int64[M+1]; groupedTopic/groupedPartition: int32[N].  Member r owns
-     * [memberOff[r], memberOff[r+1]); positions before memberOff[0] belong to topics without consumers.
-     */
-    static native int groupByMember(long ctx, int nTopics, ByteBuffer partOff, ByteBuffer outPartition,
-                                    ByteBuffer outMemberRank, int nMembers, ByteBuffer memberOff,
-                                    ByteBuffer groupedTopic, ByteBuffer groupedPartition);
+    /** la_assign_batch_lags: the static assign(Map,Map) seam, on precomputed lags (any int64). */
+    static native int assignBatchLags(long ctx, int nTopics, ByteBuffer partOff, ByteBuffer partitionId,
+                                      ByteBuffer lag, ByteBuffer consOff, ByteBuffer consRank,
+                                      ByteBuffer outPartition, ByteBuffer outMemberRank, ByteBuffer outTotalLag);
 
     /**
-     * la_group_last_by_member: groupByMember on the results the last assignBatch call of this context left on the
-     * device (that call may be given outPartition = outMemberRank = null), so the assignment crosses PCIe once.
+     * la_group_last_by_member: every member's list in the reference's order, as slices, from the results the last
+     * assignBatch / assignBatchLags call of this context left on the device (that call may be given outPartition =
+     * outMemberRank = null, so the assignment crosses PCIe once).  memberOff: int64[M+1]; groupedTopic /
+     * groupedPartition: int32[N].  Member r owns [memberOff[r], memberOff[r+1]); positions before memberOff[0] belong
+     * to topics without consumers.
      */
     static native int groupLastByMember(long ctx, int nMembers, ByteBuffer memberOff, ByteBuffer groupedTopic,
                                         ByteBuffer groupedPartition);

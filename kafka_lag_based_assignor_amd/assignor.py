@@ -71,6 +71,17 @@ class LagBasedPartitionAssignor:
         """Per-topic per-member total lag of the last assign() (the reference's debug summary)."""
         return {t: dict(v) for t, v in self._impl.last_topic_totals().items()}
 
+    def last_order_exact(self) -> bool:
+        """False when the last assign() met a HashMap bucket a JVM would have turned into a tree bin: the C++ host's
+        container model has none, so the ORDER of topics inside the members' lists is then a guess (who gets what
+        is unaffected; the Java host uses the real HashMap).  Also reported through the warn hook."""
+        return bool(self._impl.last_order_exact())
+
+    @staticmethod
+    def last_static_order_exact() -> bool:
+        """The same for the last assign_lags() on this thread."""
+        return bool(_host().LagBasedPartitionAssignor.last_static_order_exact())
+
     def set_warn(self, fn: Callable[[str], None]) -> None:
         self._impl.set_warn(fn)
 

@@ -83,6 +83,14 @@ inline bool equals_ignore_case_latest(const std::string& mode) {
 // chosen int id (index into the caller's own storage); the map only tracks order.
 class JavaHashMapOrder {
  public:
+    JavaHashMapOrder() = default;                               // new HashMap<>()
+    // new HashMap<>(initialCapacity): threshold = tableSizeFor(initialCapacity); the first resize() allocates a table
+    // of that size (Main.java:216 builds consumerTotalLags with consumers.size(), duplicates included)
+    explicit JavaHashMapOrder(size_t initial_capacity) {
+        size_t cap = 1;
+        while (cap < initial_capacity) cap <<= 1;
+        threshold_ = cap;
+    }
     // HashMap.put of a NEW key (caller guarantees absence)
     void put_new(int id, int32_t hash_code) {
         if (table_.empty()) resize();
@@ -118,14 +126,26 @@ class JavaHashMapOrder {
         const uint32_t h = static_cast<uint32_t>(hc);
         return h ^ (h >> 16);
     }
+    // HashMap.resize(): oldCap > 0 -> double (threshold doubles only from 16 slots up, else 0.75 * newCap, truncated);
+    // oldCap == 0 with a threshold set by the capacity constructor -> that many slots; else 16 / 12.
     void resize() {
-        if (table_.empty()) { table_.resize(16); threshold_ = 12; return; }
         const size_t old_cap = table_.size();
-        std::vector<std::vector<std::pair<uint32_t, int>>> fresh(old_cap * 2);
+        size_t new_cap, new_thr = 0;
+        if (old_cap > 0) {
+            new_cap = old_cap * 2;
+            if (old_cap >= 16) new_thr = threshold_ * 2;
+        } else if (threshold_ > 0) {
+            new_cap = threshold_;
+        } else {
+            new_cap = 16;
+            new_thr = 12;
+        }
+        if (new_thr == 0) new_thr = (size_t)((float)new_cap * 0.75f);
+        std::vector<std::vector<std::pair<uint32_t, int>>> fresh(new_cap);
         for (size_t j = 0; j < old_cap; ++j)
             for (const auto& n : table_[j]) fresh[(n.first & old_cap) ? j + old_cap : j].push_back(n);
         table_.swap(fresh);
-        threshold_ *= 2;
+        threshold_ = new_thr;
     }
     void treeify_bin() {
         if (table_.size() < 64) resize();

@@ -31,6 +31,10 @@ la_ctx* shared_ctx_locked() {
     return g_ctx;
 }
 
+// Whether the list order of the last static assign() on this thread is the modelled HashMap's exact order
+// (false: a bucket of consumersPerTopic reached tree-bin size, which java_compat.hpp does not model).
+thread_local bool t_last_order_exact = true;
+
 void check(la_ctx* ctx, int rc) {
     if (rc == LA_OK) return;
     const std::string msg = std::string("liblagassign error ") + std::to_string(rc) + ": " + la_last_error(ctx);
@@ -173,7 +177,7 @@ Assignment run_native(const Plan& plan, const std::vector<const TopicData*>& dat
     if (debug && *debug) {
         // Main.java:279-306.  consumerTotalLags is a HashMap filled with put() in consumers-list order (:216-225).
         for (size_t t = 0; t < plan.topics.size(); ++t) {
-            JavaHashMapOrder order;
+            JavaHashMapOrder order(plan.topic_members[t].size());          // new HashMap<>(consumers.size()), :216
             std::vector<int> uniq;
             for (int m : plan.topic_members[t])
                 if (std::find(uniq.begin(), uniq.end(), m) == uniq.end()) {
@@ -227,6 +231,8 @@ std::vector<std::string> consumersPerTopicOrder(const GroupSubscription& subscri
     return make_plan(subscriptions).topics;
 }
 
+bool LagBasedPartitionAssignor::lastStaticOrderExact() { return t_last_order_exact; }
+
 LagBasedPartitionAssignor::LagBasedPartitionAssignor() = default;
 LagBasedPartitionAssignor::~LagBasedPartitionAssignor() = default;
 
@@ -271,6 +277,7 @@ Assignment LagBasedPartitionAssignor::assign(const OrderedMap<std::vector<TopicP
         auto it = by_topic.find(t);
         data.push_back(it == by_topic.end() ? nullptr : &it->second);            // getOrDefault(..., emptyList()), :182
     }
+    t_last_order_exact = plan.order_exact;
     return run_native(plan, data, false, LA_RESET_LATEST, nullptr);
 }
 
@@ -294,8 +301,14 @@ Assignment LagBasedPartitionAssignor::assign(const Cluster& metadata, const Grou
             }
         }
         for (int i : order.order()) hashed.push_back(*entries[i]);
+        last_order_exact_ = order.order_exact();
     }
     const Plan plan = make_plan(hashed);
+    last_order_exact_ = last_order_exact_ && plan.order_exact;
+    if (!last_order_exact_)
+        warn("list order may differ from the JVM's: a HashMap bucket reached tree-bin size (>= 9 colliding keys in a "
+             ">= 64-slot table), which the C++ host's container model does not reproduce; the partition -> member "
+             "map is unaffected");
 
     // readTopicPartitionLags, Main.java:317-365 -- batched: one request per kind for all topics
     std::vector<TopicPartition> all;

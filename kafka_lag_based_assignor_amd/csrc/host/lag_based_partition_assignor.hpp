@@ -102,6 +102,14 @@ class LagBasedPartitionAssignor {
     // numbers, Main.java:279-306): topic -> (memberId -> total lag).
     const std::map<std::string, std::map<std::string, int64_t>>& lastTopicTotals() const { return last_totals_; }
 
+    // List order (parity level P2, SURVEY 8a note 4) follows HashMap iteration order, which this C++ host reproduces
+    // with a model of OpenJDK's HashMap (java_compat.hpp) that has no tree bins.  false = the last assign met a bucket
+    // that a real HashMap would have treeified (>= 9 colliding keys in a >= 64-slot table): who-gets-what is still
+    // exact, the ORDER of topics inside the members' lists is then a guess.  The instance-level assign also says so
+    // through `warn`.  (The Java host uses the real HashMap and has no such caveat.)
+    bool lastOrderExact() const { return last_order_exact_; }
+    static bool lastStaticOrderExact();            // same, for the last static assign() on the calling thread
+
     // Hook for log lines the reference emits through slf4j (warn on missing metadata, :359).
     std::function<void(const std::string&)> warn = [](const std::string&) {};
 
@@ -115,6 +123,7 @@ class LagBasedPartitionAssignor {
     std::map<std::string, std::string> consumer_group_props_;
     std::map<std::string, std::string> metadata_consumer_props_;
     std::map<std::string, std::map<std::string, int64_t>> last_totals_;
+    bool last_order_exact_ = true;
 };
 
 // Exposed for tests of the host-side string logic (no GPU involved).

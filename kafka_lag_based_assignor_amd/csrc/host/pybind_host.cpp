@@ -81,13 +81,14 @@ PYBIND11_MODULE(_host, m) {
     m.def("equals_ignore_case_latest", &equals_ignore_case_latest);
     m.def("rank_members", &rankMembers);
     m.def("consumers_per_topic_order", &consumersPerTopicOrder);
-    m.def("hashmap_put_order", [](const std::vector<std::string>& keys) {
-        JavaHashMapOrder o;
+    m.def("hashmap_put_order", [](const std::vector<std::string>& keys, py::object initial_capacity) {
+        JavaHashMapOrder o = initial_capacity.is_none() ? JavaHashMapOrder()
+                                                        : JavaHashMapOrder(initial_capacity.cast<size_t>());
         for (size_t i = 0; i < keys.size(); ++i) o.put_new((int)i, java_string_hash(keys[i]));
         std::vector<std::string> out;
         for (int i : o.order()) out.push_back(keys[i]);
-        return out;
-    });
+        return py::make_tuple(out, o.order_exact());
+    }, py::arg("keys"), py::arg("initial_capacity") = py::none());
 
     py::class_<LagBasedPartitionAssignor>(m, "LagBasedPartitionAssignor")
         .def(py::init<>())
@@ -95,6 +96,8 @@ PYBIND11_MODULE(_host, m) {
         .def("name", &LagBasedPartitionAssignor::name)
         .def("metadata_consumer_props", &LagBasedPartitionAssignor::metadataConsumerProps)
         .def("last_topic_totals", &LagBasedPartitionAssignor::lastTopicTotals)
+        .def("last_order_exact", &LagBasedPartitionAssignor::lastOrderExact)
+        .def_static("last_static_order_exact", &LagBasedPartitionAssignor::lastStaticOrderExact)
         .def("set_warn", [](LagBasedPartitionAssignor& self, std::function<void(const std::string&)> f) { self.warn = std::move(f); })
         .def("set_debug", [](LagBasedPartitionAssignor& self, std::function<void(const std::string&)> f) { self.debug = std::move(f); })
         .def("assign",

@@ -33,6 +33,23 @@ def shard_slices(part_off: np.ndarray, cons_off: np.ndarray, t0: int, t1: int):
     return po - po[0], co - co[0], slice(int(po[0]), int(po[-1])), slice(int(co[0]), int(co[-1]))
 
 
+def strong_plan(part_off: np.ndarray, world_size: int):
+    """The split of ONE batch over `world_size` ranks (strong scaling): (bounds, counts, cap) with
+    bounds[r]..bounds[r+1] the topics of rank r (la_plan_shards), counts[r] its partitions and cap the largest
+    count -- ncclAllGather moves equal counts, so every rank's result buffers are `cap` long and the tail is padding."""
+    bounds = shard_bounds(part_off, world_size)
+    counts = [int(part_off[t1] - part_off[t0]) for t0, t1 in bounds]
+    return bounds, counts, (max(counts) if counts else 0)
+
+
+def strip_padding(gathered, counts: List[int], cap: int):
+    """[world * cap] all-gathered array -> the global array (rank order = topic order: shards are contiguous)."""
+    import torch
+    if isinstance(gathered, np.ndarray):
+        return np.concatenate([gathered[r * cap: r * cap + counts[r]] for r in range(len(counts))])
+    return torch.cat([gathered[r * cap: r * cap + counts[r]] for r in range(len(counts))])
+
+
 def gather_results(local_pid, local_rank, counts: List[int], group=None):
     """All-gathers the per-rank result arrays into the global arrays (topic order = rank
     order, because shards are contiguous).  ``counts[r]`` = partitions owned by rank r.
@@ -50,6 +67,6 @@ def gather_results(local_pid, local_rank, counts: List[int], group=None):
         send[: x.numel()] = x
         recv = torch.empty(world * cap, dtype=x.dtype, device=dev)
         dist.all_gather_into_tensor(recv, send, group=group)
-        return torch.cat([recv[r * cap: r * cap + counts[r]] for r in range(world)])
+        return strip_padding(recv, counts, cap)
 
     return one(local_pid), one(local_rank)

@@ -57,28 +57,42 @@ def _spread(h: int) -> int:
 
 
 class JavaHashMap(Generic[V]):
-    """Order-faithful model of ``new HashMap<String, V>()`` (default constructor)."""
+    """Order-faithful model of ``new HashMap<String, V>()`` and ``new HashMap<String, V>(initialCapacity)``."""
 
-    def __init__(self) -> None:
+    def __init__(self, initial_capacity: Optional[int] = None) -> None:
         self._table: Optional[List[List[Tuple[int, str]]]] = None
         self._threshold = 0
+        if initial_capacity is not None:            # HashMap(int): threshold = tableSizeFor(initialCapacity)
+            cap = 1
+            while cap < initial_capacity:
+                cap <<= 1
+            self._threshold = cap
         self._size = 0
         self._values: Dict[str, V] = {}
 
     # -- internals -----------------------------------------------------------
     def _resize(self) -> None:
-        if self._table is None:
-            self._table = [[] for _ in range(16)]
-            self._threshold = 12
-            return
-        old = self._table
+        """HashMap.resize(): double (the threshold doubles only from 16 slots up, else int(0.75f * newCap)); an empty
+        table takes the capacity the constructor left in `threshold`, or 16 / 12."""
+        old = self._table or []
         old_cap = len(old)
-        new: List[List[Tuple[int, str]]] = [[] for _ in range(old_cap * 2)]
+        new_thr = 0
+        if old_cap > 0:
+            new_cap = old_cap * 2
+            if old_cap >= 16:
+                new_thr = self._threshold * 2
+        elif self._threshold > 0:
+            new_cap = self._threshold
+        else:
+            new_cap, new_thr = 16, 12
+        if new_thr == 0:
+            new_thr = int(new_cap * 0.75)
+        new: List[List[Tuple[int, str]]] = [[] for _ in range(new_cap)]
         for j, chain in enumerate(old):
             for node in chain:                      # lo/hi split keeps relative order
                 new[j + old_cap if (node[0] & old_cap) else j].append(node)
         self._table = new
-        self._threshold *= 2
+        self._threshold = new_thr
 
     def _treeify_bin(self) -> None:
         assert self._table is not None

@@ -180,8 +180,9 @@ def test_debug_summary_matches_reference_format():
     for msg, topic in zip(messages, ["topic1", "topic2"]):
         for m in cumulative:
             cumulative[m] += [tp for tp in got[m] if tp[0] == topic]
-        hm = JavaHashMap()
-        for m in [m for m, ts in subs.items() if topic in ts]:
+        consumers = [m for m, ts in subs.items() if topic in ts]
+        hm = JavaHashMap(len(consumers))                         # new HashMap<>(consumers.size()), Main.java:216
+        for m in consumers:
             hm.put(m, 0)
         exp = "Assignment for %s:\n" % topic
         for m in hm.keys():
@@ -190,3 +191,44 @@ def test_debug_summary_matches_reference_format():
                 exp += "\t\t%s-%d\n" % (t, p)
         assert msg == exp
     assert "\tconsumer-1 (total_lag=100500)\n\t\ttopic1-0\n\t\ttopic1-2\n" in messages[0]
+
+
+def test_order_exact_is_surfaced_when_a_bucket_would_treeify():
+    """>= 9 topic names in one bucket of a >= 64-slot consumersPerTopic table.  The C++ host cannot
+    reproduce a tree bin's iteration order: it must say so (flag + warn) and still assign every partition exactly."""
+    from oracle.java_collections import java_string_hash
+
+    def bucket(k, mask):
+        x = java_string_hash(k) & 0xFFFFFFFF
+        return (x ^ (x >> 16)) & mask
+
+    colliding, i = [], 0
+    while len(colliding) < 9:
+        k = "topic-%d" % i
+        if bucket(k, 255) == 0:
+            colliding.append(k)
+        i += 1
+    filler = [k for k in ("f%d" % j for j in range(300)) if bucket(k, 15) != 0][:60]
+    topics = filler + colliding
+    rng = random.Random(11)
+    lags = {t: [TopicPartitionLag(t, p, rng.randint(0, 10 ** 6)) for p in range(5)] for t in topics}
+    subs = {"consumer-%d" % c: list(topics) for c in range(3)}
+    got = LagBasedPartitionAssignor.assign_lags(lags, subs)
+    assert LagBasedPartitionAssignor.last_static_order_exact() is False
+    # who gets what: topic by topic against the oracle (the per-topic problem does not depend on any map order)
+    for t in topics:
+        exp = oracle.assign_named({t: [tuple(e) for e in lags[t]]}, {m: [t] for m in subs})
+        for m in subs:
+            assert [tp for tp in got[m] if tp[0] == t] == exp[m]
+    # the flag is per call: an ordinary call resets it
+    LagBasedPartitionAssignor.assign_lags({"t0": [TopicPartitionLag("t0", 0, 1)]}, {"C0": ["t0"]})
+    assert LagBasedPartitionAssignor.last_static_order_exact() is True
+    # instance level: flag + warn
+    a = LagBasedPartitionAssignor()
+    a.configure({"group.id": "g"})
+    warnings = []
+    a.set_warn(warnings.append)
+    metadata = {t: [0, 1] for t in topics}
+    zeros = {(t, p): 0 for t in topics for p in (0, 1)}
+    a.assign(metadata, subs, FakeOffsets(zeros, {k: 7 for k in zeros}, {}))
+    assert a.last_order_exact() is False and any("tree-bin" in w for w in warnings)

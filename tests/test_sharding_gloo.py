@@ -39,14 +39,20 @@ def _worker(rank, world, port, ret):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from oracle import oracle
     w = synth.ragged(42, 97, 60, 9)
-    bounds = sharding.shard_bounds(w.part_off, world)
+    bounds, counts, cap = sharding.strong_plan(w.part_off, world)       # what bench.py --scaling strong does
     t0, t1 = bounds[rank]
     po, co, ps, cs = sharding.shard_slices(w.part_off, w.cons_off, t0, t1)
     pid, rk, _ = oracle.assign_flat(po, w.partition_id[ps], w.lag[ps], co, w.cons_rank[cs])
-    counts = [int(w.part_off[b] - w.part_off[a]) for a, b in bounds]
+    assert counts == [int(w.part_off[b] - w.part_off[a]) for a, b in bounds] and cap == max(counts)
     g_pid, g_rank = sharding.gather_results(torch.from_numpy(pid), torch.from_numpy(rk), counts)
     e_pid, e_rank, _ = oracle.assign_flat(w.part_off, w.partition_id, w.lag, w.cons_off, w.cons_rank)
     ok = np.array_equal(g_pid.numpy(), e_pid) and np.array_equal(g_rank.numpy(), e_rank)
+    # bench.py's form: result buffers already `cap` long (zero tail), ONE all_gather_into_tensor per array
+    send = torch.zeros(cap, dtype=torch.int32)
+    send[: pid.size] = torch.from_numpy(pid)
+    recv = torch.empty(world * cap, dtype=torch.int32)
+    dist.all_gather_into_tensor(recv, send)
+    ok = ok and np.array_equal(sharding.strip_padding(recv.numpy(), counts, cap), e_pid)
     ret[rank] = bool(ok)
     dist.barrier()
     dist.destroy_process_group()
