@@ -22,25 +22,21 @@ for rep in range(4):
     dt = time.perf_counter() - t
     print("C call, touched outputs: rc=%d %.1f ms  (%.2e assignments/s)" % (rc, dt * 1e3, w.n_partitions / dt))
 print("same result:", np.array_equal(op, r[0]), np.array_equal(om, r[1]), np.array_equal(ot, r[2]))
-if hasattr(lib, "la_host_alloc"):
-    lib.la_host_alloc.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_void_p)]
-    def pinned(a):
-        ptr = ctypes.c_void_p()
-        assert lib.la_host_alloc(ctx._h, a.nbytes, ctypes.byref(ptr)) == 0
-        buf = (ctypes.c_char * a.nbytes).from_address(ptr.value)
-        out = np.frombuffer(buf, dtype=a.dtype)
-        out[:] = a
-        return out
-    P = {k: pinned(getattr(w, k)) for k in ("part_off", "partition_id", "begin", "end", "committed", "cons_off", "cons_rank")}
-    pop, pom, pot = pinned(op * 0), pinned(om * 0), pinned(ot * 0)
-    for rep in range(4):
-        t = time.perf_counter()
-        rc = lib.la_assign_batch(ctx._h, w.n_topics, p64(P["part_off"]), p32(P["partition_id"]), p64(P["begin"]), p64(P["end"]),
-                                 p64(P["committed"]), N.LA_RESET_EARLIEST, p64(P["cons_off"]), p32(P["cons_rank"]),
-                                 p32(pop), p32(pom), p64(pot))
-        dt = time.perf_counter() - t
-        print("C call, pinned buffers: rc=%d %.1f ms  (%.2e assignments/s)" % (rc, dt * 1e3, w.n_partitions / dt))
-    print("same result:", np.array_equal(pop, r[0]), np.array_equal(pom, r[1]), np.array_equal(pot, r[2]))
+# pinned host arrays (la_host_alloc: what the Java host's direct buffers are made of)
+def pinned(a):
+    out = ctx.host_alloc(a.shape, a.dtype)
+    out[...] = a
+    return out
+P = {k: pinned(getattr(w, k)) for k in ("part_off", "partition_id", "begin", "end", "committed", "cons_off", "cons_rank")}
+pop, pom, pot = pinned(op * 0), pinned(om * 0), pinned(ot * 0)
+for rep in range(4):
+    t = time.perf_counter()
+    rc = lib.la_assign_batch(ctx._h, w.n_topics, p64(P["part_off"]), p32(P["partition_id"]), p64(P["begin"]), p64(P["end"]),
+                             p64(P["committed"]), N.LA_RESET_EARLIEST, p64(P["cons_off"]), p32(P["cons_rank"]),
+                             p32(pop), p32(pom), p64(pot))
+    dt = time.perf_counter() - t
+    print("C call, pinned buffers: rc=%d %.1f ms  (%.2e assignments/s)" % (rc, dt * 1e3, w.n_partitions / dt))
+print("same result:", np.array_equal(pop, r[0]), np.array_equal(pom, r[1]), np.array_equal(pot, r[2]))
 
 # the Java host's flow: assign, then every member's list.  (a) download the result, upload it again for the
 # grouping call; (b) keep it on the device and download only the grouped form
@@ -65,3 +61,13 @@ for rep in range(3):
     dt = time.perf_counter() - t
     print("assign (results stay) + group_last_by_member: rc=%d,%d %.1f ms  (%.2e assignments/s)" % (rc1, rc2, dt * 1e3, w.n_partitions / dt))
 print("same lists:", np.array_equal(off, ref[0]), np.array_equal(gt, ref[1]), np.array_equal(gp, ref[2]))
+
+pgt, pgp, poff = pinned(gt * 0), pinned(gp * 0), pinned(off * 0)
+for rep in range(3):
+    t = time.perf_counter()
+    rc1 = lib.la_assign_batch(ctx._h, w.n_topics, p64(P["part_off"]), p32(P["partition_id"]), p64(P["begin"]), p64(P["end"]),
+                              p64(P["committed"]), N.LA_RESET_EARLIEST, p64(P["cons_off"]), p32(P["cons_rank"]), None, None, p64(pot))
+    rc2 = lib.la_group_last_by_member(ctx._h, M, p64(poff), p32(pgt), p32(pgp))
+    dt = time.perf_counter() - t
+    print("pinned: assign (results stay) + group_last_by_member: rc=%d,%d %.1f ms  (%.2e assignments/s)" % (rc1, rc2, dt * 1e3, w.n_partitions / dt))
+print("same lists:", np.array_equal(poff, ref[0]), np.array_equal(pgt, ref[1]), np.array_equal(pgp, ref[2]))

@@ -40,7 +40,18 @@ def main():
             tgp.test_ragged_tile_batch_by_shape_class(ctx, int(rng.integers(300, 9000)), int(rng.choice([2, 3, 50])))
         except AssertionError as e:
             bad += 1; print("MIXED seed", seed, "FAILED:", str(e)[:200])
-    print("stress done: %d tile + %d large + %d block seeds, %d failures" % (nt, nl, nb, bad))
+    # large path with more than 1 024 consumers: sample-sorted greedy rounds, full network, both interleaved
+    ns = int(sys.argv[4]) if len(sys.argv) > 4 else 60
+    for seed in range(100, 100 + ns):
+        rng = np.random.default_rng(seed)
+        c = int(rng.integers(1025, 8193))
+        p = int(rng.integers(c, min(40 * c, int(4e8) // c) + 1))
+        kind = str(rng.choice(["u40", "ties", "zero", "u63", "pareto"]))
+        try:
+            tgp.test_large_sample_sort_rounds(ctx, p, c, kind)
+        except AssertionError as e:
+            bad += 1; print("SAMPLE seed", seed, "p", p, "c", c, kind, "FAILED:", str(e)[:200])
+    print("stress done: %d tile + %d large + %d block + %d sample-sort seeds, %d failures" % (nt, nl, nb, ns, bad))
     ctx.close()
 
 if __name__ == "__main__":
