@@ -382,6 +382,7 @@ def main():
 
     if rank != 0:
         if use_dist:
+            dist.barrier()                     # rank 0 is still checking against the oracle: leave together
             dist.destroy_process_group()
         return
 
@@ -529,8 +530,9 @@ def main():
         "parity": parity,
         "host_boundary": host_leg,
     }
-    print(json.dumps(line))
+    print(json.dumps(line), flush=True)
     if use_dist:
+        dist.barrier()
         dist.destroy_process_group()
     if parity is not None and not parity["bit_exact"]:
         sys.exit(2)
