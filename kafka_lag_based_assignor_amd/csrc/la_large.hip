@@ -456,6 +456,7 @@ __device__ unsigned long long g_round_clocks[16];
 
 constexpr int kSampleThreads = 1024;
 constexpr uint32_t kMaxBucket = 96;
+constexpr uint32_t kMaxBucket2 = 192;                        // second level: samples per super-sample bucket (~16)
 
 constexpr int kSamplesPerThread = 1;                         // 1 024 splitters: buckets of ~EC bins (2 per thread: the
                                                              // walk halves, but the sample sort's chain of steps grows more)
@@ -467,11 +468,11 @@ struct SampleLds {
                           //      sort's LDS steps (nothing else may be in flight there: the staging area is still being read
                           //      by slower threads when the fastest start the next round)
     uint32_t* cnt;        // [NS + 1] bucket counts, then (first position | size << 16)
-    uint32_t* misc;       // [32] per-wavefront sums and maxima
+    uint32_t* misc;       // [32] per-wavefront sums and maxima; [32 .. 32 + 66) second-level bucket counts, flag
 };
 
 __host__ __device__ constexpr size_t sample_lds_bytes(int ec) {
-    return ((size_t)ec * kSampleThreads + 2) * 16 + (size_t)kSamplesPerThread * kSampleThreads * (16 + 4) + 64 + 32 * 4;
+    return ((size_t)ec * kSampleThreads + 2) * 16 + (size_t)kSamplesPerThread * kSampleThreads * (16 + 4) + 64 + (32 + 128) * 4;
 }
 
 __device__ __forceinline__ SampleLds sample_lds_carve(void* smem, int n) {
@@ -512,10 +513,75 @@ __device__ __forceinline__ bool sample_sort_bins(P64 (&rec)[EC], const SampleLds
     constexpr int NS = SPT * NT;                                                   // splitters; NS + 1 buckets
     const int lane = tid & 63, wave = tid >> 6;
     LA_CLK_START;
-    // 1. splitters: the block-wide sort of SPT bins per thread (regular samples of last round's order).
-    //    (Tried: the same 1 024 samples sorted by four wavefronts with four samples per lane -- 3 LDS steps instead of
-    //    10 -- is slower, 18.4k cycles against 14k: the in-register network of one wavefront per SIMD is a longer chain.)
+    // 1. splitters: regular samples of last round's order, one bin per thread, SORTED -- by the same scheme one level
+    //    down: 64 of the 1 024 samples are sorted by one wavefront (one per lane, DPP only), every sample finds its
+    //    bucket among them (6 LDS reads), takes a slot, is staged, and is ranked by the walk over its bucket (~16
+    //    samples).  6 barriers and ~50 LDS operations per thread, where the block-wide network over the samples
+    //    needs 45 DPP steps, 10 LDS exchanges and 11 barriers -- a chain of latencies, 14k cycles of a 53k-cycle round.
+    //    A second-level bucket above kMaxBucket2 sends the samples through the network instead.
+    static_assert(SPT == 1, "one sample per thread");
+    bool samples_sorted = false;
     {
+        constexpr int S2 = 64;                                    // super-samples = lanes of the sorting wavefront
+        uint64_t* smpbuf = L.spl + NS;                            // not the staging area: slower threads may still be
+        uint32_t* cnt2 = L.misc + 32;                             // reading last round's final order out of it
+        const uint64_t mine = p64_value(rec[EC / 2]);
+        smpbuf[tid] = mine;
+        L.cnt[tid] = 0;
+        if (tid == 0) L.cnt[NS] = 0;
+        if (tid < S2 + 2) cnt2[tid] = 0;
+        __syncthreads();                                          // (1) from here on the staging area is free
+        uint64_t* sup = reinterpret_cast<uint64_t*>(L.stage);     // [64] sorted super-samples
+        ulonglong2* stage2 = L.stage + 64;                        // [NS + 2] staged samples
+        if (wave == 0) {
+            P64 v = p64_from(smpbuf[lane * (NS / S2) + NS / (2 * S2)]);
+            asm volatile("s_nop 1" : "+v"(v.lo), "+v"(v.hi));
+            bitonic_sort_lanes_p64<64>(v);
+            sup[lane] = p64_value(v);
+        } else if (wave == 1 && lane < 2) {
+            stage2[NS + lane] = make_ulonglong2(~0ull, 0);        // sentinels of the walk below
+        }
+        __syncthreads();                                          // (2)
+        uint32_t b2 = 0;
+#pragma unroll
+        for (int step = S2 / 2; step >= 1; step >>= 1) b2 += (sup[b2 + step - 1] < mine) ? (uint32_t)step : 0u;
+        b2 += (sup[S2 - 1] < mine) ? 1u : 0u;
+        const uint32_t slot2 = atomicAdd(&cnt2[b2], 1u);
+        __syncthreads();                                          // (3)
+        if (wave == 0) {                                          // first positions of the 65 buckets; the largest one
+            const uint32_t c = cnt2[lane];
+            const uint32_t incl = wave_incl_scan_u32(c);
+            const uint32_t last = cnt2[S2];
+            const uint32_t mx = wave_max_u32(max(c, last));
+            __builtin_amdgcn_wave_barrier();
+            cnt2[lane] = (incl - c) | (c << 16);
+            if (lane == 63) { cnt2[S2] = incl | (last << 16); cnt2[S2 + 1] = mx; }
+        }
+        __syncthreads();                                          // (4)
+        // (the test hook that tightens the first level tightens this one too, so that all three forms of a round mix)
+        if (cnt2[S2 + 1] <= (bucket_limit < kMaxBucket ? 24u : kMaxBucket2)) {      // workgroup-uniform
+            const uint32_t sc = cnt2[b2];
+            stage2[(sc & 0xFFFFu) + slot2] = make_ulonglong2(mine, (uint64_t)((sc & 0xFFFF0000u) | slot2));
+            __syncthreads();                                      // (5)
+            const ulonglong2 e = stage2[tid];
+            const uint32_t inf = (uint32_t)e.y;
+            const uint32_t s0 = (uint32_t)tid - (inf & 0xFFFFu);
+            const uint32_t cmax = wave_max_u32(inf >> 16);
+            const uint64_t* keys2 = reinterpret_cast<const uint64_t*>(stage2);
+            uint32_t below = 0;
+#pragma unroll 4
+            for (uint32_t k = 0; k < cmax; k += 2) {
+                const uint32_t at = min(s0 + k, (uint32_t)NS);
+                const uint64_t o0 = keys2[2 * at], o1 = keys2[2 * at + 2];
+                below += (o0 < e.x ? 1u : 0u) + (o1 < e.x ? 1u : 0u);
+            }
+            L.spl[s0 + below] = e.x;
+            samples_sorted = true;
+        }
+    }
+    if (!samples_sorted) {
+        // the block-wide network over the samples (one per thread)
+        __syncthreads();
         P64 smp[SPT];
 #pragma unroll
         for (int u = 0; u < SPT; ++u) smp[u] = rec[(2 * u + 1) * EC / (2 * SPT)];
@@ -530,11 +596,7 @@ __device__ __forceinline__ bool sample_sort_bins(P64 (&rec)[EC], const SampleLds
         }
         __syncthreads();                             // the last step's reads, before the splitters go over its buffer
 #pragma unroll
-        for (int u = 0; u < SPT; ++u) {
-            L.spl[tid * SPT + u] = p64_value(smp[u]);
-            L.cnt[tid * SPT + u] = 0;
-        }
-        if (tid == 0) L.cnt[NS] = 0;
+        for (int u = 0; u < SPT; ++u) L.spl[tid * SPT + u] = p64_value(smp[u]);
     }
     __syncthreads();
     LA_CLK(0);
@@ -610,6 +672,7 @@ __device__ __forceinline__ bool sample_sort_bins(P64 (&rec)[EC], const SampleLds
         const uint32_t s0 = j - (inf & 0xFFFFu);
         const uint32_t cmax = wave_max_u32(inf >> 16);
         uint32_t below = 0;
+#pragma unroll 4
         for (uint32_t k = 0; k < cmax; k += 2) {
             const uint32_t at = min(s0 + k, (uint32_t)N);            // N, N + 1: the sentinels
             const uint64_t o0 = keys[2 * at], o1 = keys[2 * at + 2];
