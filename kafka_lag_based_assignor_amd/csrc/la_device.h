@@ -212,6 +212,15 @@ __device__ __forceinline__ void wave_lds_fence() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// Workgroup barrier for data exchanged through LDS only.  __syncthreads() is a workgroup-scope fence + s_barrier, and
+// the fence makes every wavefront wait for ALL its outstanding memory operations (s_waitcnt vmcnt(0)) -- including global
+// loads issued only to be used much later (the next round's lags) and fire-and-forget global stores.  Here only the
+// LDS traffic must have landed: lgkmcnt(0), then the barrier; global accesses stay in flight across it.  The "memory"
+// clobber keeps the compiler from moving LDS accesses over the barrier.
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 __device__ __forceinline__ int wave_max_i32(int v) {
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) v = max(v, __shfl_xor(v, d));

@@ -414,10 +414,13 @@ __device__ __forceinline__ void dpp_fence(P64 (&rec)[EC]) {
 // One barrier per step: consecutive steps ALTERNATE between two exchange buffers (ExchangeBufs::next), so a thread
 // that runs ahead writes the other buffer while slower threads still read this one; by the time a buffer comes
 // round again every thread has passed the barrier of the step in between, i.e. has finished reading it.
+// (Base + offset, not an array of two pointers: indexed dynamically the array lands in scratch memory, the pointers
+// come back from there as generic ones, and every LDS access of the exchange turns into a flat_load / flat_store.)
 struct ExchangeBufs {
-    uint64_t* buf[2];
+    uint64_t* base;
+    int stride;                                     // words between the two buffers
     int at = 0;
-    __device__ __forceinline__ uint64_t* next() { at ^= 1; return buf[at]; }
+    __device__ __forceinline__ uint64_t* next() { at ^= 1; return base + (at ? stride : 0); }
 };
 
 template <int EC>
@@ -426,7 +429,7 @@ __device__ __forceinline__ void cross_wave_step(P64 (&rec)[EC], ExchangeBufs& xb
     uint64_t* s_bin = xb.next();
 #pragma unroll
     for (int r = 0; r < EC; ++r) s_bin[r * nt + tid] = p64_value(rec[r]);
-    __syncthreads();
+    lds_barrier();
 #pragma unroll
     for (int r = 0; r < EC; ++r) {
         const int i = tid * EC + r;
@@ -530,7 +533,7 @@ __device__ __forceinline__ bool sample_sort_bins(P64 (&rec)[EC], const SampleLds
         L.cnt[tid] = 0;
         if (tid == 0) L.cnt[NS] = 0;
         if (tid < S2 + 2) cnt2[tid] = 0;
-        __syncthreads();                                          // (1) from here on the staging area is free
+        lds_barrier();                                          // (1) from here on the staging area is free
         uint64_t* sup = reinterpret_cast<uint64_t*>(L.stage);     // [64] sorted super-samples
         ulonglong2* stage2 = L.stage + 64;                        // [NS + 2] staged samples
         if (wave == 0) {
@@ -541,13 +544,13 @@ __device__ __forceinline__ bool sample_sort_bins(P64 (&rec)[EC], const SampleLds
         } else if (wave == 1 && lane < 2) {
             stage2[NS + lane] = make_ulonglong2(~0ull, 0);        // sentinels of the walk below
         }
-        __syncthreads();                                          // (2)
+        lds_barrier();                                          // (2)
         uint32_t b2 = 0;
 #pragma unroll
         for (int step = S2 / 2; step >= 1; step >>= 1) b2 += (sup[b2 + step - 1] < mine) ? (uint32_t)step : 0u;
         b2 += (sup[S2 - 1] < mine) ? 1u : 0u;
         const uint32_t slot2 = atomicAdd(&cnt2[b2], 1u);
-        __syncthreads();                                          // (3)
+        lds_barrier();                                          // (3)
         if (wave == 0) {                                          // first positions of the 65 buckets; the largest one
             const uint32_t c = cnt2[lane];
             const uint32_t incl = wave_incl_scan_u32(c);
@@ -557,12 +560,12 @@ __device__ __forceinline__ bool sample_sort_bins(P64 (&rec)[EC], const SampleLds
             cnt2[lane] = (incl - c) | (c << 16);
             if (lane == 63) { cnt2[S2] = incl | (last << 16); cnt2[S2 + 1] = mx; }
         }
-        __syncthreads();                                          // (4)
+        lds_barrier();                                          // (4)
         // (the test hook that tightens the first level tightens this one too, so that all three forms of a round mix)
         if (cnt2[S2 + 1] <= (bucket_limit < kMaxBucket ? 24u : kMaxBucket2)) {      // workgroup-uniform
             const uint32_t sc = cnt2[b2];
             stage2[(sc & 0xFFFFu) + slot2] = make_ulonglong2(mine, (uint64_t)((sc & 0xFFFF0000u) | slot2));
-            __syncthreads();                                      // (5)
+            lds_barrier();                                      // (5)
             const ulonglong2 e = stage2[tid];
             const uint32_t inf = (uint32_t)e.y;
             const uint32_t s0 = (uint32_t)tid - (inf & 0xFFFFu);
@@ -581,24 +584,24 @@ __device__ __forceinline__ bool sample_sort_bins(P64 (&rec)[EC], const SampleLds
     }
     if (!samples_sorted) {
         // the block-wide network over the samples (one per thread)
-        __syncthreads();
+        lds_barrier();
         P64 smp[SPT];
 #pragma unroll
         for (int u = 0; u < SPT; ++u) smp[u] = rec[(2 * u + 1) * EC / (2 * SPT)];
         dpp_fence<SPT>(smp);
         bitonic_sort_tile_p64<64, SPT>(smp);
-        ExchangeBufs xb{{L.spl, L.spl + NS}};
+        ExchangeBufs xb{L.spl, NS};
         for (int K = 128 * SPT; K <= NS; K <<= 1) {
             cross_wave_step<SPT>(smp, xb, tid, K - 1, K >> 1);
             for (int j = K >> 2; j >= 64 * SPT; j >>= 1) cross_wave_step<SPT>(smp, xb, tid, j, j);
             dpp_fence<SPT>(smp);
             clean_p64<64, SPT, 32 * SPT, false>(smp);
         }
-        __syncthreads();                             // the last step's reads, before the splitters go over its buffer
+        lds_barrier();                             // the last step's reads, before the splitters go over its buffer
 #pragma unroll
         for (int u = 0; u < SPT; ++u) L.spl[tid * SPT + u] = p64_value(smp[u]);
     }
-    __syncthreads();
+    lds_barrier();
     LA_CLK(0);
     // 2. bucket of every bin = number of splitters below it (0 .. NS); a slot inside the bucket
     uint64_t x[EC];
@@ -618,7 +621,7 @@ __device__ __forceinline__ bool sample_sort_bins(P64 (&rec)[EC], const SampleLds
     LA_CLK(1);
 #pragma unroll
     for (int r = 0; r < EC; ++r) slot[r] = atomicAdd(&L.cnt[b[r]], 1u);
-    __syncthreads();
+    lds_barrier();
     {   // exclusive scan of the counts (thread t owns buckets t*SPT ..; bucket NS is what is left), largest bucket
         uint32_t c[SPT], sum = 0, m = 0;
 #pragma unroll
@@ -628,7 +631,7 @@ __device__ __forceinline__ bool sample_sort_bins(P64 (&rec)[EC], const SampleLds
         m = wave_max_u32(m);
         if (lane == 63) L.misc[wave] = incl;
         if (lane == 0) L.misc[16 + wave] = m;
-        __syncthreads();
+        lds_barrier();
         const uint4* mv = reinterpret_cast<const uint4*>(L.misc);          // 16 sums, 16 maxima: eight 16-byte reads
         uint32_t base = 0, mx = 0;
 #pragma unroll
@@ -647,7 +650,7 @@ __device__ __forceinline__ bool sample_sort_bins(P64 (&rec)[EC], const SampleLds
         }
         if (tid == NT - 1) L.cnt[NS] = first | (((uint32_t)N - first) << 16);
     }
-    __syncthreads();
+    lds_barrier();
     LA_CLK(2);
     // 3. stage bucket by bucket, with (bucket size << 16 | slot) beside every staged bin
 #pragma unroll
@@ -655,7 +658,7 @@ __device__ __forceinline__ bool sample_sort_bins(P64 (&rec)[EC], const SampleLds
         const uint32_t sc = L.cnt[b[r]];
         L.stage[(sc & 0xFFFFu) + slot[r]] = make_ulonglong2(x[r], (uint64_t)((sc & 0xFFFF0000u) | slot[r]));
     }
-    __syncthreads();
+    lds_barrier();
     LA_CLK(3);
     // Walk the staged bins wave-striped: 64 consecutive positions per step, a handful of consecutive buckets.
     // Final position = bucket start + members below the bin.  Reading past the bucket's end is harmless -- the bins
@@ -681,12 +684,12 @@ __device__ __forceinline__ bool sample_sort_bins(P64 (&rec)[EC], const SampleLds
         pos[it] = s0 + below;
     }
     LA_CLK(4);
-    __syncthreads();                                 // every staged bin is in a register: the final order goes over them
+    lds_barrier();                                 // every staged bin is in a register: the final order goes over them
     // 4. final order, back to blocked registers
     uint64_t* sorted = reinterpret_cast<uint64_t*>(L.stage);
 #pragma unroll
     for (int it = 0; it < EC; ++it) sorted[pos[it]] = y[it];
-    __syncthreads();
+    lds_barrier();
 #pragma unroll
     for (int r = 0; r < EC; ++r) rec[r] = p64_from(sorted[tid * EC + r]);
     LA_CLK(5);
@@ -705,13 +708,17 @@ __device__ void greedy_rounds_packed(const LargeArgs& a, const uint64_t* key, in
     [[maybe_unused]] const bool use_sample = (EC >= 2) && blockDim.x == kSampleThreads && a.no_sample_sort != 1;
     if (use_sample && tid < 2) L.stage[n + tid] = make_ulonglong2(~0ull, 0);      // first read after many barriers
     P64 rec[EC];
+    // raw sorted keys of the round's partitions, one round ahead.  The loads are UNCONDITIONAL (index clamped) and
+    // issued back to back: a branch around a load makes hipcc wait for it before issuing the next one -- eight
+    // serialized memory round trips per round here, 6k of a round's 52k cycles; the select happens at the use, a
+    // whole round of sorting later.
     uint64_t lag[EC];
 #pragma unroll
     for (int r = 0; r < EC; ++r) {
         const int i = tid * EC + r;
         // pads (slots beyond the C consumers) sort behind every bin and, like the bins, are all different
         rec[r] = p64_from(i < C ? (uint64_t)i : ((~0ull << idx_bits) | (uint64_t)i));
-        lag[r] = (i < C && i < P) ? (key[i] ^ kLagKeyFlip) : 0;
+        lag[r] = key[i < P ? i : P - 1];
     }
     for (int64_t q = 0; q < rounds; ++q) {
         if (q > 0) {
@@ -723,14 +730,14 @@ __device__ void greedy_rounds_packed(const LargeArgs& a, const uint64_t* key, in
                 // sort the n bins: inside every wavefront first, then merges across wavefronts
                 dpp_fence<EC>(rec);
                 bitonic_sort_tile_p64<64, EC>(rec);
-                ExchangeBufs xb{{s_bin, s_bin + n}};
+                ExchangeBufs xb{s_bin, n};
                 for (int K = 2 * kSpan; K <= n; K <<= 1) {
                     cross_wave_step<EC>(rec, xb, tid, K - 1, K >> 1);                        // mirror: i <-> i ^ (K-1)
                     for (int j = K >> 2; j >= kSpan; j >>= 1) cross_wave_step<EC>(rec, xb, tid, j, j);
                     dpp_fence<EC>(rec);
                     clean_p64<64, EC, kSpan / 2, false>(rec);                                 // i <-> i ^ j, j < span
                 }
-                if (n > kSpan) __syncthreads();      // the last step's reads, before anything else goes over its buffer
+                if (n > kSpan) lds_barrier();      // the last step's reads, before anything else goes over its buffer
             }
         }
         // position i of the sorted bins takes partition q*C + i; the next round's lags are fetched now
@@ -738,16 +745,15 @@ __device__ void greedy_rounds_packed(const LargeArgs& a, const uint64_t* key, in
         uint64_t next_lag[EC];
 #pragma unroll
         for (int r = 0; r < EC; ++r) {
-            const int i = tid * EC + r;
-            const int64_t s = (q + 1) * C + i;
-            next_lag[r] = (i < C && s < P) ? (key[s] ^ kLagKeyFlip) : 0;
+            const int64_t s = (q + 1) * C + tid * EC + r;
+            next_lag[r] = key[s < P ? s : P - 1];
         }
 #pragma unroll
         for (int r = 0; r < EC; ++r) {
             const int i = tid * EC + r;
             const int64_t s = q * C + i;
             if (i < C && s < P) {
-                const uint64_t nb = p64_value(rec[r]) + (lag[r] << idx_bits);          // Main.java:265
+                const uint64_t nb = p64_value(rec[r]) + ((lag[r] ^ kLagKeyFlip) << idx_bits);   // Main.java:265
                 rec[r] = p64_from(nb);
                 a.out_rank[a.p0 + s] = (int32_t)((uint32_t)nb & idx_mask);      // consumer index; map_ranks_kernel turns it into the rank
             }

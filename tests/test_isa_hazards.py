@@ -78,3 +78,22 @@ def test_asm_statements_with_salu_logic_declare_scc():
                     offenders.append("%s: %s" % (name, " ".join(body.split())[:100]))
     assert seen >= 3            # the check is looking at the right statements
     assert not offenders, offenders
+
+
+def test_lds_exchanges_stay_lds_instructions(isa):
+    """Round 2 regression: the two exchange buffers of the greedy's cross-wavefront steps were first kept as an array of
+    two pointers indexed at run time; hipcc put the array in scratch memory, the pointers came back as generic ones and
+    every LDS access of the exchange became a flat_load / flat_store (the full network got 15 % slower, silently).  No
+    kernel of this library dereferences a pointer it cannot place: the ISA must hold no flat_* memory instruction, and
+    the hot kernels no dynamically indexed scratch."""
+    for path in isa:
+        text = open(path).read()
+        flat = re.findall(r"^\s*(flat_(?:load|store|atomic)\w*)", text, re.M)
+        # (la_block: one flat_load per kernel entry -- the topic index comes from a device list or from the kernel
+        # arguments, a select between two address spaces, once per workgroup)
+        allowed = 2 if os.path.basename(path) == "la_block.s" else 0
+        assert len(flat) <= allowed, "%s: %d flat memory instructions (%s ...)" % (os.path.basename(path), len(flat), flat[0])
+        # spills are tolerated (a handful in the one-workgroup greedy at its 128-VGPR cap); scratch addressed through an
+        # SGPR offset is a private ARRAY in memory, which is what the bug looked like
+        dyn = re.findall(r"^\s*scratch_(?:load|store)\w*\s+[^;\n]*\bs\d+\b[^;\n]*$", text, re.M)
+        assert not dyn, "%s: dynamically addressed scratch: %s" % (os.path.basename(path), dyn[0].strip())
