@@ -43,6 +43,9 @@ struct Lane {
     hipStream_t stream = nullptr;
     uint32_t* d_status = nullptr;        // 256 B: word 0 = status bits, words 16..19 = deferred-tile counters
     uint32_t* h_status = nullptr;        // pinned word the status is copied to (one stream sync per call)
+    uint32_t* status_word = nullptr;     // small-batch call: the status word lives inside the call's one device staging
+                                         // buffer (uploaded as zero with the inputs, downloaded with the results)
+    uint32_t* status() const { return status_word ? status_word : d_status; }
     // tile path: list of tiles the packed kernel leaves to the wide kernel, and which of the two
     // counters (d_status + 16 / + 17 words) the next launch uses
     DevBuf defer;
@@ -75,9 +78,15 @@ struct Shard {
     hipEvent_t ready = nullptr;          // the shard's offsets are on the device (lane 0's stream)
     std::vector<int64_t> local_part_off, local_cons_off;   // offsets rebased to the shard's first topic (shards > 0)
     HostBuf g_off, g_topic, g_part;      // multi-shard la_group_last_by_member: this shard's CSR before the merge
-    // results of the last host-buffer assign call, still in part_off / out_pid / out_rank (la_group_last_by_member)
+    // results of the last host-buffer assign call, still on the device (la_group_last_by_member)
     int32_t last_t0 = 0, last_topics = 0;
     int64_t last_p0 = 0, last_n = 0;
+    const int64_t* last_part_off = nullptr;
+    const int32_t *last_out_pid = nullptr, *last_out_rank = nullptr;
+    // small batches (what a real group leader sends): inputs and results of a call travel as ONE H2D and ONE D2H copy
+    // through these two staging buffers (device, pinned host) instead of eight copies of caller arrays
+    DevBuf small_d, small_g;
+    HostBuf small_h, small_gh;
 };
 
 struct la_ctx {
@@ -120,6 +129,8 @@ int reserve(la_ctx* ctx, DevBuf& b, size_t bytes) {
     b.cap = want;
     return LA_OK;
 }
+
+int reserve_host(la_ctx* ctx, HostBuf& b, size_t bytes);
 
 void release(DevBuf& b) {
     if (b.p) (void)hipFree(b.p);
@@ -298,7 +309,7 @@ int launch_block_topics(la_ctx* ctx, Lane& ln, const la_device_batch* b, const B
     g.out_pid = b->d_out_partition;
     g.out_rank = b->d_out_member_rank;
     g.out_total = b->d_out_total_lag;
-    g.status = ln.d_status;
+    g.status = ln.status();
     g.reset_latest = (b->reset_mode == LA_RESET_LATEST) ? 1 : 0;
     if (!d_lists) {
         // a handful of block topics: their indices travel in the kernel arguments (no copy, no event)
@@ -347,7 +358,7 @@ int launch_large_topics(la_ctx* ctx, Lane& ln, const la_device_batch* b, const B
         g.out_total = b->d_out_total_lag;
         g.reset_latest = (b->reset_mode == LA_RESET_LATEST) ? 1 : 0;
         g.no_sample_sort = (b->flags & LA_FLAG_NO_SAMPLE_SORT) ? 1 : ((b->flags & LA_FLAG_SAMPLE_TIGHT) ? 2 : 0);
-        g.status = ln.d_status;
+        g.status = ln.status();
         hipError_t e = la::large_topic_launch(ln.large, g, argmin, stream);
         if (e != hipSuccess)
             return fail(ctx, e == hipErrorOutOfMemory ? LA_ENOMEM : LA_EHIP, "large topic %lld: %s", (long long)t,
@@ -384,7 +395,7 @@ int enqueue_batch(la_ctx* ctx, Lane& ln, const la_device_batch* b, hipStream_t s
     a.out_pid = b->d_out_partition;
     a.out_rank = b->d_out_member_rank;
     a.out_total = b->d_out_total_lag;
-    a.status = ln.d_status;
+    a.status = ln.status();
     a.reset_latest = (b->reset_mode == LA_RESET_LATEST) ? 1 : 0;
     a.n_total = b->n_partitions;
     a.flags = b->flags & (LA_FLAG_INDEX64 | LA_FLAG_DEFER_WIDE);
@@ -716,6 +727,109 @@ int run_workers(la_ctx* ctx, int n, F&& fn) {
     return LA_OK;
 }
 
+// ---- small batches: one H2D, the kernels, one D2H ----------------------------------------------------------------
+// A real group leader's rebalance is ONE call over a few dozen topics.  The chunked pipeline above is built for bandwidth;
+// at this size the call is API latency: 7 H2D copies of caller arrays, 3 D2H copies, the status word, ~8 us each -- 105 us
+// for a three-partition batch.  Here the inputs are packed into one pinned staging buffer (a memcpy of kilobytes), go up
+// in ONE copy together with a zeroed status word, and status + results come back in ONE copy.
+constexpr size_t kSmallBytes = 2u << 20;
+
+struct SmallLayout {
+    size_t po, co, pid, end, com, beg, cr, status, ot, op, orank, total;
+};
+
+SmallLayout small_layout(const HostCall& c) {
+    const size_t T = (size_t)c.T, n = (size_t)c.shape.n, k = (size_t)c.shape.k;
+    size_t off = 0;
+    auto carve = [&](size_t bytes) { const size_t o = off; off = (off + bytes + 16 + 255) & ~(size_t)255; return o; };
+    SmallLayout L{};
+    L.po = carve((T + 1) * 8);
+    L.co = carve((T + 1) * 8);
+    L.pid = carve(n * 4);
+    L.end = carve(n * 8);                                     // the lags, for la_assign_batch_lags
+    L.com = carve(c.lag ? 0 : n * 8);
+    L.beg = carve(c.use_begin ? n * 8 : 0);
+    L.cr = carve(k * 4);
+    L.status = carve(256);                                    // last word of the upload, first of the download
+    L.ot = carve(k * 8);
+    L.op = carve(n * 4);
+    L.orank = carve(n * 4);
+    L.total = off;
+    return L;
+}
+
+int assign_small(la_ctx* ctx, const HostCall& c, Shard& sh, const SmallLayout& L) {
+    LA_HIP(ctx, hipSetDevice(sh.device));
+    Lane& ln = sh.lanes[0];
+    hipStream_t st = ln.stream;
+    const size_t T = (size_t)c.T, n = (size_t)c.shape.n, k = (size_t)c.shape.k;
+    if (int rc = reserve(ctx, sh.small_d, L.total)) return rc;
+    if (int rc = reserve_host(ctx, sh.small_h, L.total)) return rc;
+    char* h = (char*)sh.small_h.p;
+    char* d = (char*)sh.small_d.p;
+    memcpy(h + L.po, c.part_off, (T + 1) * 8);
+    memcpy(h + L.co, c.cons_off, (T + 1) * 8);
+    if (n) {
+        memcpy(h + L.pid, c.pid, n * 4);
+        memcpy(h + L.end, c.lag ? c.lag : c.end, n * 8);
+        if (!c.lag) memcpy(h + L.com, c.committed, n * 8);
+        if (c.use_begin) memcpy(h + L.beg, c.begin, n * 8);
+    }
+    if (k) memcpy(h + L.cr, c.cons_rank, k * 4);
+    memset(h + L.status, 0, 256);
+    LA_HIP(ctx, hipMemcpyAsync(d, h, L.status + 256, hipMemcpyHostToDevice, st));
+    ln.status_word = (uint32_t*)(d + L.status);
+    struct Restore { Lane& l; ~Restore() { l.status_word = nullptr; } } restore{ln};
+    if (k)
+        LA_HIP(ctx, la::check_consumers_launch(c.T, (const int64_t*)(d + L.co), (const int32_t*)(d + L.cr),
+                                               ln.status_word, st));
+    la_device_batch b{};
+    b.n_topics = c.T;
+    b.reset_mode = c.reset_mode == LA_RESET_LATEST ? LA_RESET_LATEST : LA_RESET_EARLIEST;
+    b.algo = LA_ALGO_AUTO;
+    b.flags = LA_FLAG_RAGGED;
+    b.n_partitions = c.shape.n;
+    b.n_consumers = c.shape.k;
+    b.max_partitions_per_topic = c.shape.max_p;
+    b.max_consumers_per_topic = c.shape.max_c;
+    b.d_part_off = (const int64_t*)(d + L.po);
+    b.d_partition_id = (const int32_t*)(d + L.pid);
+    b.d_begin_off = c.use_begin ? (const int64_t*)(d + L.beg) : nullptr;
+    b.d_end_off = (const int64_t*)(d + L.end);
+    b.d_committed_off = (const int64_t*)(d + L.com);
+    b.d_lag = c.lag ? (const int64_t*)(d + L.end) : nullptr;
+    b.d_cons_off = (const int64_t*)(d + L.co);
+    b.d_cons_rank = (const int32_t*)(d + L.cr);
+    b.d_out_partition = (int32_t*)(d + L.op);
+    b.d_out_member_rank = (int32_t*)(d + L.orank);
+    b.d_out_total_lag = (int64_t*)(d + L.ot);                 // always: it sits between the status and the results
+    b.h_part_off = c.part_off;
+    b.h_cons_off = c.cons_off;
+    if (int rc = enqueue_batch(ctx, ln, &b, st)) {
+        (void)hipStreamSynchronize(st);
+        return rc;
+    }
+    // status | totals | partition order | member ranks: as far as the caller wants them
+    const size_t upto = c.out_pid ? L.total : L.op;
+    LA_HIP(ctx, hipMemcpyAsync(h + L.status, d + L.status, upto - L.status, hipMemcpyDeviceToHost, st));
+    LA_HIP(ctx, hipStreamSynchronize(st));
+    const uint32_t status = *(const uint32_t*)(h + L.status);
+    if (status) {
+        if (status & la::kStatusUnsorted)
+            return fail(ctx, LA_EINVAL, "a topic's cons_rank segment is not strictly ascending");
+        return fail(ctx, LA_ESHAPE, "a topic exceeds the batch's shape hint");
+    }
+    if (c.out_total && k) memcpy(c.out_total, h + L.ot, k * 8);
+    if (c.out_pid && n) {
+        memcpy(c.out_pid, h + L.op, n * 4);
+        memcpy(c.out_rank, h + L.orank, n * 4);
+    }
+    sh.last_part_off = (const int64_t*)(d + L.po);
+    sh.last_out_pid = (const int32_t*)(d + L.op);
+    sh.last_out_rank = (const int32_t*)(d + L.orank);
+    return LA_OK;
+}
+
 int assign_host(la_ctx* ctx, int32_t T, const int64_t* part_off, const int32_t* pid, const int64_t* begin,
                 const int64_t* end, const int64_t* committed, const int64_t* lag, int32_t reset_mode,
                 const int64_t* cons_off, const int32_t* cons_rank, int32_t* out_pid, int32_t* out_rank,
@@ -749,6 +863,16 @@ int assign_host(la_ctx* ctx, int32_t T, const int64_t* part_off, const int32_t* 
     if (S > T) S = T;
     plan_ranges(part_off, 0, T, S, ctx->last_bounds);
     ctx->last_shards = S;
+    if (S == 1 && !ctx->split_always && s.n > 0) {
+        const SmallLayout L = small_layout(c);
+        if (L.total <= kSmallBytes) {
+            Shard& sh = ctx->shards[0];
+            sh.last_t0 = 0; sh.last_topics = T; sh.last_p0 = 0; sh.last_n = s.n;
+            if (int rc = assign_small(ctx, c, sh, L)) return rc;
+            ctx->last_valid = true;
+            return LA_OK;
+        }
+    }
     std::vector<ShardPlan> plans((size_t)S);
     struct Work { int shard, lane; };
     std::vector<Work> work;
@@ -761,7 +885,11 @@ int assign_host(la_ctx* ctx, int32_t T, const int64_t* part_off, const int32_t* 
         sp.K0 = cons_off[sp.t0]; sp.k = cons_off[sp.t1] - sp.K0;
         sh.last_t0 = sp.t0; sh.last_topics = sp.t1 - sp.t0; sh.last_p0 = sp.P0; sh.last_n = sp.n;
         if (sp.t1 == sp.t0) continue;
-        if (int rc = prepare_shard(ctx, c, sh, sp)) {
+        const int rc_prepare = prepare_shard(ctx, c, sh, sp);
+        sh.last_part_off = (const int64_t*)sh.part_off.p;       // (after the reserves of prepare_shard)
+        sh.last_out_pid = (const int32_t*)sh.out_pid.p;
+        sh.last_out_rank = (const int32_t*)sh.out_rank.p;
+        if (int rc = rc_prepare) {
             for (int j = 0; j <= i; ++j)                         // nothing of this call stays in flight
                 if (hipSetDevice(ctx->shards[(size_t)j].device) == hipSuccess)
                     (void)hipStreamSynchronize(ctx->shards[(size_t)j].lanes[0].stream);
@@ -817,21 +945,26 @@ int reserve_host(la_ctx* ctx, HostBuf& b, size_t bytes) {
     return LA_OK;
 }
 
-// grouping of one shard's last results, on its lane 0; the CSR stays in pid (grouped partition), cons_rank
-// (grouped topic, shard-local indices) and out_total (member_off) -- their old contents are no longer needed
-int group_shard_device(la_ctx* ctx, Shard& sh, int32_t n_members, bool want_topic) {
+// grouping of one shard's last results, on its lane 0, into the given device arrays (null: the shard's own pid =
+// grouped partition, cons_rank = grouped topic with shard-local indices, out_total = member_off -- their old contents
+// are no longer needed)
+int group_shard_device(la_ctx* ctx, Shard& sh, int32_t n_members, bool want_topic, int64_t* d_off = nullptr,
+                       int32_t* d_topic = nullptr, int32_t* d_part = nullptr) {
     const int64_t n = sh.last_n;
-    const size_t nb4 = (size_t)n * 4, mb = ((size_t)n_members + 1) * 8;
-    int rc;
-    if ((rc = reserve(ctx, sh.pid, nb4 + 16)) || (rc = reserve(ctx, sh.cons_rank, nb4 + 16)) ||
-        (rc = reserve(ctx, sh.out_total, mb + 16)))
-        return rc;
     if (n > 0x7FFFFFFF) return fail(ctx, LA_ESHAPE, "at most 2^31-1 entries per shard are supported");
-    hipError_t e = la::group_by_member_launch(sh.lanes[0].large, n, n_members, sh.last_topics,
-                                              (const int64_t*)sh.part_off.p, (const int32_t*)sh.out_pid.p,
-                                              (const int32_t*)sh.out_rank.p, (int64_t*)sh.out_total.p,
-                                              want_topic ? (int32_t*)sh.cons_rank.p : nullptr, (int32_t*)sh.pid.p,
-                                              nullptr, sh.lanes[0].stream);
+    if (!d_off) {
+        const size_t nb4 = (size_t)n * 4, mb = ((size_t)n_members + 1) * 8;
+        int rc;
+        if ((rc = reserve(ctx, sh.pid, nb4 + 16)) || (rc = reserve(ctx, sh.cons_rank, nb4 + 16)) ||
+            (rc = reserve(ctx, sh.out_total, mb + 16)))
+            return rc;
+        d_off = (int64_t*)sh.out_total.p;
+        d_topic = (int32_t*)sh.cons_rank.p;
+        d_part = (int32_t*)sh.pid.p;
+    }
+    hipError_t e = la::group_by_member_launch(sh.lanes[0].large, n, n_members, sh.last_topics, sh.last_part_off,
+                                              sh.last_out_pid, sh.last_out_rank, d_off, want_topic ? d_topic : nullptr,
+                                              d_part, nullptr, sh.lanes[0].stream);
     if (e != hipSuccess)
         return fail(ctx, e == hipErrorOutOfMemory ? LA_ENOMEM : LA_EHIP, "group_by_member: %s", hipGetErrorString(e));
     return LA_OK;
@@ -916,9 +1049,9 @@ LA_API void la_destroy(la_ctx* ctx) {
         (void)hipSetDevice(sh.device);
         for (Lane& ln : sh.lanes) destroy_lane(ln);
         for (DevBuf* b : {&sh.part_off, &sh.pid, &sh.begin, &sh.end, &sh.committed, &sh.cons_off, &sh.cons_rank,
-                          &sh.out_pid, &sh.out_rank, &sh.out_total})
+                          &sh.out_pid, &sh.out_rank, &sh.out_total, &sh.small_d, &sh.small_g})
             release(*b);
-        for (HostBuf* h : {&sh.g_off, &sh.g_topic, &sh.g_part})
+        for (HostBuf* h : {&sh.g_off, &sh.g_topic, &sh.g_part, &sh.small_h, &sh.small_gh})
             if (h->p) (void)hipHostFree(h->p);
         if (sh.ready) (void)hipEventDestroy(sh.ready);
     }
@@ -1126,9 +1259,29 @@ LA_API int la_group_last_by_member(la_ctx* ctx, int32_t n_members, int64_t* memb
             // one shard: its CSR is the answer, straight into the caller's arrays
             Shard& sh = ctx->shards[0];
             LA_HIP(ctx, hipSetDevice(sh.device));
-            if (int rc = group_shard_device(ctx, sh, n_members, grouped_topic != nullptr)) return rc;
             hipStream_t st = sh.lanes[0].stream;
             const size_t nb4 = (size_t)n * 4;
+            const size_t o_topic = (mb + 16 + 255) & ~(size_t)255, o_part = (o_topic + nb4 + 16 + 255) & ~(size_t)255;
+            const size_t g_total = o_part + nb4 + 16;
+            if (g_total <= kSmallBytes) {
+                // small batch: the CSR is built in one staging buffer and crosses in one copy (see assign_small)
+                int rc;
+                if ((rc = reserve(ctx, sh.small_g, g_total)) || (rc = reserve_host(ctx, sh.small_gh, g_total))) return rc;
+                char* d = (char*)sh.small_g.p;
+                char* h = (char*)sh.small_gh.p;
+                if ((rc = group_shard_device(ctx, sh, n_members, grouped_topic != nullptr, (int64_t*)d,
+                                             (int32_t*)(d + o_topic), (int32_t*)(d + o_part))))
+                    return rc;
+                LA_HIP(ctx, hipMemcpyAsync(h, d, g_total, hipMemcpyDeviceToHost, st));
+                LA_HIP(ctx, hipStreamSynchronize(st));
+                memcpy(member_off, h, mb);
+                if (n) {
+                    memcpy(grouped_partition, h + o_part, nb4);
+                    if (grouped_topic) memcpy(grouped_topic, h + o_topic, nb4);
+                }
+                return LA_OK;
+            }
+            if (int rc = group_shard_device(ctx, sh, n_members, grouped_topic != nullptr)) return rc;
             LA_HIP(ctx, hipMemcpyAsync(member_off, sh.out_total.p, mb, hipMemcpyDeviceToHost, st));
             if (n) {
                 LA_HIP(ctx, hipMemcpyAsync(grouped_partition, sh.pid.p, nb4, hipMemcpyDeviceToHost, st));

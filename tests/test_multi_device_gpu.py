@@ -235,3 +235,56 @@ def test_inline_launch_between_deferring_launches():
     _same(_run_device(c, small, N.LA_ALGO_AUTO, use_lag=True), exp_small, "B again")
     _same(_run_device(c, half, N.LA_ALGO_AUTO, use_lag=True), exp_half, "C = half of A")
     c.close()
+
+
+def test_small_batches_take_the_one_copy_form_and_agree_with_the_pipeline(ctx1, ctx1_chunked):
+    """A call whose inputs and results fit 2 MB travels as one H2D + one D2H through a staging buffer (la_api.hip,
+    assign_small); everything else takes the chunked pipeline.  Same results either way, around the threshold, with
+    offsets or lags, with the results kept on the device for la_group_last_by_member, and when calls of both kinds
+    alternate on one context."""
+    for n_topics in (1, 40, 900, 1100, 1400, 3000):               # x 50 partitions x 5 consumers: 2 MB is ~1 130 topics
+        w = synth.make_uniform("small", 21, n_topics, 50, 5, "uniform40")
+        lag = oracle.compute_lags(w.begin, w.end, w.committed, False)
+        exp = oracle.assign_flat(w.part_off, w.partition_id, lag, w.cons_off, w.cons_rank)
+        for c, what in ((ctx1, "default context"), (ctx1_chunked, "pipeline forced")):
+            got = c.assign_batch(w.part_off, w.partition_id, w.begin, w.end, w.committed, N.LA_RESET_EARLIEST,
+                                 w.cons_off, w.cons_rank)
+            _same(got, exp, "%d topics, offsets, %s" % (n_topics, what))
+            _same(c.assign_batch_lags(w.part_off, w.partition_id, lag, w.cons_off, w.cons_rank), exp,
+                  "%d topics, lags, %s" % (n_topics, what))
+            lag_latest = oracle.compute_lags(w.begin, w.end, w.committed, True)
+            e_p, e_m, e_t = oracle.assign_flat(w.part_off, w.partition_id, lag_latest, w.cons_off, w.cons_rank)
+            want = ctx1.group_by_member(w.part_off, e_p, e_m, 5)      # (a host-buffer call: before the one under test)
+            p, m, t = c.assign_batch(w.part_off, w.partition_id, None, w.end, w.committed, N.LA_RESET_LATEST,
+                                     w.cons_off, w.cons_rank, keep_on_device=True)
+            assert p is None and m is None
+            np.testing.assert_array_equal(t, e_t)
+            got_g = c.group_last_by_member(w.n_partitions, 5)
+            for g, e, name in zip(got_g, want, ("member_off", "grouped_topic", "grouped_partition")):
+                np.testing.assert_array_equal(g, e, err_msg="%s, %d topics, %s" % (name, n_topics, what))
+
+
+def test_small_batch_errors_and_mixed_shapes(ctx1):
+    # unsorted ranks are reported by the small form too, and the context works afterwards
+    with pytest.raises(N.LagAssignError) as ei:
+        ctx1.assign_batch_lags([0, 2], [0, 1], [5, 6], [0, 2], [3, 1])
+    assert ei.value.code == N.LA_EINVAL
+    # tile + block + large topics in one small call
+    part_off, pid, lag, cons_off, ranks = _mixed_batch(4)
+    exp = oracle.assign_flat(part_off, pid, lag, cons_off, ranks)
+    for _ in range(2):
+        _same(ctx1.assign_batch_lags(part_off, pid, lag, cons_off, ranks), exp, "mixed shapes, small form")
+    # a big call between two small ones: the results la_group_last_by_member groups are the LAST call's
+    big = synth.config("cfg4", 0.2)
+    small = synth.config("cfg3", 0.004)
+    for w in (small, big, small):
+        lag_w = oracle.compute_lags(w.begin, w.end, w.committed, False)
+        e_p, e_m, e_t = oracle.assign_flat(w.part_off, w.partition_id, lag_w, w.cons_off, w.cons_rank)
+        ctx1.assign_batch(w.part_off, w.partition_id, w.begin, w.end, w.committed, N.LA_RESET_EARLIEST, w.cons_off,
+                          w.cons_rank, keep_on_device=True)
+        n_members = int(w.cons_rank.max()) + 1
+        want = (np.concatenate([[0], np.cumsum(np.bincount(e_m, minlength=n_members))]),)
+        got_g = ctx1.group_last_by_member(w.n_partitions, n_members)
+        np.testing.assert_array_equal(got_g[0], want[0], err_msg=w.name)
+        order = np.argsort(e_m, kind="stable")
+        np.testing.assert_array_equal(got_g[2], e_p[order], err_msg=w.name)
