@@ -12,7 +12,7 @@ from typing import Optional, Tuple
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "liblagassign.so")
+LIB_PATH = os.environ.get("LA_LIB_PATH") or os.path.join(_HERE, "liblagassign.so")   # LA_LIB_PATH: A/B runs of two builds
 
 LA_OK = 0
 LA_EINVAL, LA_ENOMEM, LA_EHIP, LA_ENODEV, LA_ESHAPE = -1, -2, -3, -4, -5

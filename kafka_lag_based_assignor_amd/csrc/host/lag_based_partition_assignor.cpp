@@ -22,7 +22,7 @@ la_ctx* g_ctx = nullptr;
 
 la_ctx* shared_ctx_locked() {
     if (!g_ctx) {
-        int rc = la_create(&g_ctx, 0, 0);
+        int rc = la_create_multi(&g_ctx, 0, nullptr, 0);      // every GPU of the node, like the Java host
         if (rc != LA_OK) {
             g_ctx = nullptr;
             throw std::runtime_error(std::string("liblagassign: ") + la_last_error(nullptr));

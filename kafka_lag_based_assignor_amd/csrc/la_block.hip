@@ -406,20 +406,50 @@ __global__ __launch_bounds__(1024) void block_topic_kernel(BlockArgs a) {
     uint64_t lag_or = 0;
     uint32_t id_or = 0;
 #pragma unroll
-    for (int r = 0; r < E; ++r) {
-        const int src = r * nt_eff + tid;
-        lag[r] = 0;
-        pid[r] = 0;
-        if (tid < nt_eff && src < P) {
-            const int64_t g = p0 + src;
-            if (a.lag) {
-                lag[r] = a.lag[g];
+    for (int r = 0; r < E; ++r) { lag[r] = 0; pid[r] = 0; }
+    if (P > 0) {
+        // UNCONDITIONAL loads, index clamped, all of a kind issued back to back: a branch around a load makes hipcc
+        // wait for it before issuing the next one, and with `if (valid) { committed; begin?; end; id }` per record
+        // that was ~4 dependent memory round trips for each of the E records of a thread -- tens of microseconds on
+        // the critical path of a workgroup that has nothing else to run.  Now: one round trip for committed / end /
+        // id (or the lags), one more for `begin` where there is no committed offset (lanes that do not need it all
+        // read the topic's first word: one cache line per wavefront, Main.java:384-396).
+        int64_t g[E];
+        bool valid[E];
+#pragma unroll
+        for (int r = 0; r < E; ++r) {
+            const int src = r * nt_eff + tid;
+            valid[r] = tid < nt_eff && src < P;
+            g[r] = p0 + (valid[r] ? src : 0);
+        }
+        int32_t idv[E];
+#pragma unroll
+        for (int r = 0; r < E; ++r) idv[r] = a.pid[g[r]];
+        if (a.lag) {
+            int64_t lv[E];
+#pragma unroll
+            for (int r = 0; r < E; ++r) lv[r] = a.lag[g[r]];
+#pragma unroll
+            for (int r = 0; r < E; ++r) lag[r] = valid[r] ? lv[r] : 0;
+        } else {
+            int64_t cm[E], en[E], bg[E];
+#pragma unroll
+            for (int r = 0; r < E; ++r) cm[r] = a.committed[g[r]];
+#pragma unroll
+            for (int r = 0; r < E; ++r) en[r] = a.end[g[r]];
+            if (!latest && a.begin) {
+#pragma unroll
+                for (int r = 0; r < E; ++r) bg[r] = a.begin[(valid[r] && cm[r] < 0) ? g[r] : p0];
             } else {
-                const int64_t cm = a.committed[g];
-                const int64_t bg = (cm < 0 && !latest && a.begin) ? a.begin[g] : 0;
-                lag[r] = partition_lag(bg, a.end[g], cm, latest);
+#pragma unroll
+                for (int r = 0; r < E; ++r) bg[r] = 0;
             }
-            pid[r] = a.pid[g];
+#pragma unroll
+            for (int r = 0; r < E; ++r) lag[r] = valid[r] ? partition_lag(bg[r], en[r], cm[r], latest) : 0;
+        }
+#pragma unroll
+        for (int r = 0; r < E; ++r) {
+            pid[r] = valid[r] ? idv[r] : 0;
             lag_or |= (uint64_t)lag[r];
             id_or |= (uint32_t)pid[r];
         }

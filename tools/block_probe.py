@@ -9,7 +9,7 @@ dev = torch.device("cuda", 0)
 ctx = N.Context(0)
 rng = np.random.default_rng(1)
 
-def run(t, p, c, algo=N.LA_ALGO_AUTO, reps=5, lag_bits=34):
+def run(t, p, c, algo=N.LA_ALGO_AUTO, reps=5, lag_bits=34, offsets=False):
     n, k = t * p, t * c
     part_off = np.arange(t + 1, dtype=np.int64) * p
     cons_off = np.arange(t + 1, dtype=np.int64) * c
@@ -26,6 +26,14 @@ def run(t, p, c, algo=N.LA_ALGO_AUTO, reps=5, lag_bits=34):
     b.d_part_off, b.d_partition_id = d_po.data_ptr(), pid.data_ptr()
     b.d_begin_off = b.d_end_off = b.d_committed_off = None
     b.d_lag = lag.data_ptr()
+    if offsets:                      # offsets in: committed (2 % none), end = committed + lag, begin = 0; earliest
+        com = torch.randint(0, 1 << 20, (n,), device=dev, dtype=torch.int64)
+        end = com + lag
+        com = torch.where(torch.rand(n, device=dev) < 0.02, torch.full_like(com, -1), com)
+        beg = torch.zeros(n, device=dev, dtype=torch.int64)
+        b.d_lag = None
+        b.reset_mode = N.LA_RESET_EARLIEST
+        b.d_begin_off, b.d_end_off, b.d_committed_off = beg.data_ptr(), end.data_ptr(), com.data_ptr()
     b.d_cons_off, b.d_cons_rank = d_co.data_ptr(), ranks.data_ptr()
     b.d_out_partition, b.d_out_member_rank, b.d_out_total_lag = out_pid.data_ptr(), out_rank.data_ptr(), out_total.data_ptr()
     b.h_part_off = part_off.ctypes.data_as(ctypes.POINTER(ctypes.c_int64))
@@ -42,7 +50,8 @@ def run(t, p, c, algo=N.LA_ALGO_AUTO, reps=5, lag_bits=34):
 for (t, p, c) in [(1000, 2000, 100), (5000, 200, 100), (200, 8000, 16), (2000, 1000, 500), (64, 8192, 2048),
                   (1, 2000, 100), (1, 8192, 2048), (20000, 100, 65), (300, 5000, 3), (1, 100, 65), (1, 1025, 8), (20000, 300, 10)]:
     ms = run(t, p, c) * 1e3
-    print("T=%6d P=%5d C=%5d : %8.3f ms  %.3e assignments/s" % (t, p, c, ms, t * p / ms * 1e3), flush=True)
+    ms_off = run(t, p, c, offsets=True) * 1e3
+    print("T=%6d P=%5d C=%5d : %8.3f ms  %.3e assignments/s; from offsets %8.3f ms" % (t, p, c, ms, t * p / ms * 1e3, ms_off), flush=True)
 print("-- P=8000 sweep over C")
 for c in (2000, 300, 100, 64, 16, 4):
     ms = run(200, 8000, c) * 1e3
