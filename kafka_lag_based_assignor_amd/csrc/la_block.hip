@@ -244,23 +244,33 @@ __device__ __forceinline__ void greedy_one_wave(const BlockArgs& a, const uint64
 template <int EC, int L>
 __device__ __forceinline__ void greedy_one_wave_packed(const BlockArgs& a, const uint64_t* s_key, const int32_t* s_rank,
                                                        int64_t p0, int64_t c0, int P, int C, int idx_bits, int lane) {
+    // The chain of rounds is: sort the bins -> add the round's lags -> sort ...  Everything else is kept OFF that chain:
+    //  * LDS reads are unconditional (index clamped; a branch around a read makes the wavefront wait for it on the
+    //    spot) and issued a round ahead: next round's lags, and the member ranks of LAST round's winners;
+    //  * a round's ranks are stored one round late, after the sort that hid their lookup.
     const uint32_t idx_mask = (1u << idx_bits) - 1;
     P64 bin[EC];
-    uint64_t lag[EC];
+    uint64_t lag[EC];                                    // raw sorted keys of the round's partitions
+    uint32_t won[EC];                                    // consumer position that took slot r's partition last round
+    bool had[EC];
+    const int last = P > 0 ? P - 1 : 0;                 // clamp for the reads that run past the topic
 #pragma unroll
     for (int r = 0; r < EC; ++r) {
         const int e = lane * EC + r;
         bin[r] = p64_from(e < C ? (uint64_t)e : ~0ull);
-        lag[r] = (e < C && e < P) ? (s_key[e] ^ kLagKeyFlip) : 0;
+        lag[r] = s_key[e < P ? e : last];
+        won[r] = 0;
+        had[r] = false;
     }
     const int rounds = (P + C - 1) / C;
     for (int q = 0; q < rounds; ++q) {
         uint64_t next[EC];
+        int32_t rk[EC];
 #pragma unroll
         for (int r = 0; r < EC; ++r) {
-            const int e = lane * EC + r;
-            const int s = (q + 1) * C + e;
-            next[r] = (e < C && s < P) ? (s_key[s] ^ kLagKeyFlip) : 0;
+            const int s = (q + 1) * C + lane * EC + r;
+            next[r] = s_key[s < P ? s : last];
+            rk[r] = s_rank[won[r]];
         }
         if (q > 0) {
             // the networks read these registers through DPP: 2 wait states after their last compiler-generated write
@@ -272,14 +282,19 @@ __device__ __forceinline__ void greedy_one_wave_packed(const BlockArgs& a, const
         for (int r = 0; r < EC; ++r) {
             const int e = lane * EC + r;
             const int s = q * C + e;
-            if (e < C && s < P) {
-                const uint64_t nb = p64_value(bin[r]) + (lag[r] << idx_bits);              // Main.java:265
+            if (had[r]) a.out_rank[p0 + s - C] = rk[r];                                    // last round's assignment
+            had[r] = e < C && s < P;
+            if (had[r]) {
+                const uint64_t nb = p64_value(bin[r]) + ((lag[r] ^ kLagKeyFlip) << idx_bits);   // Main.java:265
                 bin[r] = p64_from(nb);
-                a.out_rank[p0 + s] = s_rank[(uint32_t)nb & idx_mask];
+                won[r] = (uint32_t)nb & idx_mask;
             }
             lag[r] = next[r];
         }
     }
+#pragma unroll
+    for (int r = 0; r < EC; ++r)
+        if (had[r]) a.out_rank[p0 + (rounds - 1) * C + lane * EC + r] = s_rank[won[r]];
     if (a.out_total) {
 #pragma unroll
         for (int r = 0; r < EC; ++r) {
