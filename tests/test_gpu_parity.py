@@ -649,6 +649,11 @@ def test_large_sample_sort_rounds(ctx, p, c, kind):
 
 
 def test_large_phase_times(ctx):
+    fresh = N.Context(0)
+    with pytest.raises(N.LagAssignError) as ei:                                            # nothing profiled yet
+        fresh.last_phase_times()
+    assert ei.value.code == N.LA_EINVAL
+    fresh.close()
     w = _pareto_topic(3, 300000, 4096)
     _run_device(ctx, w, N.LA_ALGO_AUTO, use_lag=True, flags=N.LA_FLAG_PROFILE)
     t = ctx.last_phase_times()
