@@ -51,7 +51,32 @@ def main():
             tgp.test_large_sample_sort_rounds(ctx, p, c, kind)
         except AssertionError as e:
             bad += 1; print("SAMPLE seed", seed, "p", p, "c", c, kind, "FAILED:", str(e)[:200])
-    print("stress done: %d tile + %d large + %d block + %d sample-sort seeds, %d failures" % (nt, nl, nb, ns, bad))
+    # the host-buffer pipeline: random ragged batches through shards x lanes x chunks (4 logical shards on device 0,
+    # LA_CREATE_SPLIT_ALWAYS), results straight into the caller's arrays, and the grouped lists across shards
+    nm = int(sys.argv[5]) if len(sys.argv) > 5 else 60
+    from kafka_lag_based_assignor_amd import synth
+    from oracle import oracle
+    multi = [N.Context([0, 0, 0, 0], flags=N.LA_CREATE_SPLIT_ALWAYS), N.Context([0, 0], flags=N.LA_CREATE_SPLIT_ALWAYS | 2),
+             N.Context(0, flags=N.LA_CREATE_SPLIT_ALWAYS | 3)]
+    for seed in range(100, 100 + nm):
+        rng = np.random.default_rng(seed)
+        w = synth.ragged(seed, int(rng.integers(1, 400)), int(rng.choice([5, 60, 300, 1500])), int(rng.choice([1, 8, 40, 90])),
+                         negative=bool(rng.integers(0, 2)))
+        exp = oracle.assign_flat(w.part_off, w.partition_id, w.lag, w.cons_off, w.cons_rank)
+        n_members = int(w.cons_rank.max()) + 1 if w.cons_rank.size else 0
+        want = ctx.group_by_member(w.part_off, exp[0], exp[1], n_members)
+        for c in multi:
+            try:
+                got = c.assign_batch_lags(w.part_off, w.partition_id, w.lag, w.cons_off, w.cons_rank)
+                assert all(np.array_equal(g, e) for g, e in zip(got, exp)), "assignment"
+                c.assign_batch_lags(w.part_off, w.partition_id, w.lag, w.cons_off, w.cons_rank, keep_on_device=True)
+                gl = c.group_last_by_member(w.n_partitions, n_members)
+                assert all(np.array_equal(g, e) for g, e in zip(gl, want)), "grouped lists"
+            except (AssertionError, N.LagAssignError) as e:
+                bad += 1; print("MULTI seed", seed, "shards", c.shard_count, "FAILED:", str(e)[:200])
+    for c in multi:
+        c.close()
+    print("stress done: %d tile + %d large + %d block + %d sample-sort + %d multi-shard seeds, %d failures" % (nt, nl, nb, ns, nm, bad))
     ctx.close()
 
 if __name__ == "__main__":
