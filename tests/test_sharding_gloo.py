@@ -72,3 +72,35 @@ def test_two_rank_gloo_gather_equals_single_process():
             p.join(240)
             assert p.exitcode == 0
         assert dict(ret) == {0: True, 1: True}
+
+
+def test_plan_shards_properties_through_the_c_abi():
+    """la_plan_shards is pure host code (no device needed): contiguous, covering, monotone, balanced to within the
+    largest topic; degenerate inputs (no partitions at all, more shards than topics, one giant topic) are legal."""
+    from kafka_lag_based_assignor_amd import _native as N
+    rng = np.random.default_rng(7)
+    for trial in range(200):
+        t = int(rng.integers(1, 500))
+        kind = trial % 4
+        if kind == 0:
+            ps = rng.integers(0, 300, t)
+        elif kind == 1:
+            ps = np.zeros(t, dtype=np.int64)                                  # topics without metadata only
+        elif kind == 2:
+            ps = rng.integers(0, 10, t)
+            ps[int(rng.integers(0, t))] = 1_000_000                           # one giant topic
+        else:
+            ps = np.full(t, 256)
+        part_off = np.concatenate([[0], np.cumsum(ps)]).astype(np.int64)
+        for shards in (1, 2, 3, 8, 64, t + 5):
+            b = N.plan_shards(part_off, shards)
+            assert b.size == shards + 1 and b[0] == 0 and b[-1] == t
+            assert np.all(np.diff(b) >= 0)
+            loads = part_off[b[1:]] - part_off[b[:-1]]
+            assert loads.sum() == part_off[-1]
+            if part_off[-1] > 0:
+                assert loads.max() <= part_off[-1] / shards + ps.max() + 1
+    with pytest.raises(N.LagAssignError):
+        N.plan_shards(np.array([0, 5, 3], dtype=np.int64), 2)                 # offsets decrease
+    with pytest.raises(N.LagAssignError):
+        N.plan_shards(np.array([0, 5], dtype=np.int64), 0)
