@@ -170,6 +170,18 @@ class DeviceShard:
         self.batch = b
 
 
+def measured_sort_traffic(n):
+    """HBM bytes of the radix-sort phase on an n-partition topic from the committed PMC summary (tools/gpu_session_large.sh)."""
+    try:
+        with open(TRAFFIC_FILE) as fh:
+            for e in json.load(fh).get("entries", []):
+                if e.get("kind") == "sort_phase" and e.get("partitions") == n:
+                    return e
+    except (OSError, ValueError, KeyError):
+        pass
+    return None
+
+
 def measured_traffic(T, P, C, mode, algo):
     """HBM bytes per launch from the PMC passes (tools/pmc_probe.py + tools/pmc_parse.py), if a
     summary for exactly this workload is committed; rocprofv3 cannot wrap itself from inside here."""
@@ -177,6 +189,8 @@ def measured_traffic(T, P, C, mode, algo):
         with open(TRAFFIC_FILE) as fh:
             t = json.load(fh)
         for e in t.get("entries", []):
+            if e.get("kind") == "sort_phase":
+                continue
             if (e["topics"], e["partitions"], e["consumers"], e["reset_mode"], e["algo"]) == (T, P, C, mode, algo):
                 return e
     except (OSError, ValueError, KeyError):
@@ -219,8 +233,10 @@ def run_sort_phase(torch, N, ctx, dev, n, reps, stream):
     perm_lag = lag_dev[inv[pid]]
     ok = bool(((perm_lag[:-1] > perm_lag[1:]) | ((perm_lag[:-1] == perm_lag[1:]) & (pid[:-1] < pid[1:]))).all()) if n > 1 else True
     del pid, lag_dev, perm_lag, inv
+    tr = measured_sort_traffic(n)
     return {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": tr["hbm_bytes_per_launch"] if tr else None,
+            "traffic_source": tr["source"] if tr else None,
             "kernel": "tile_count+scan_group_sums+scan_offsets+tile_scatter (every active 8-bit pass)",
             "kernel_ms": round(ms, 4), "partitions": n, "id_passes": int(t.id_passes), "key_passes": int(t.key_passes),
             "algorithmic_bytes_per_launch": int(algo_bytes),
@@ -497,7 +513,7 @@ def main():
             torch.cuda.empty_cache()
             sp = run_sort_phase(torch, N, ctx, dev, SORT_PHASE_PARTITIONS, 5, stream)
             sort_phase = {k: sp[k] for k in ("frac", "achieved", "unit", "kernel", "kernel_ms", "partitions", "id_passes",
-                                             "key_passes", "algorithmic_bytes_per_launch", "sorted_ok", "source")}
+                                             "key_passes", "algorithmic_bytes_per_launch", "traffic", "sorted_ok", "source")}
         except Exception as exc:  # noqa: BLE001 -- a reported extra
             sort_phase = {"error": str(exc)}
 

@@ -13,7 +13,11 @@ timeout 600 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/
 timeout 600 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -- $PROBE > $O/pmc_write.log 2>&1
 cd $R
 python tools/pmc_parse.py $O/pmc_fetch $O/pmc_write > $O/pmc_summary.json 2> $O/pmc_parse.err
-for cfg in "1048576 8192" "10000 128"; do set -- $cfg; python tools/large_probe.py --partitions $1 --consumers $2 --launches 5 --check 2>&1 | grep "large topic\|bit-exact" >> $O/configs.txt; done
+# cfg5 itself under the kernel trace: the one-workgroup greedy with sample-sorted rounds (+ the index -> rank pass)
+cd /tmp
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_cfg5 -- python $R/tools/large_probe.py --partitions 1048576 --consumers 8192 --launches 8 --dist pareto > $O/stats_cfg5.log 2>&1
+cd $R
+for cfg in "1048576 8192" "10000 128"; do set -- $cfg; python tools/large_probe.py --partitions $1 --consumers $2 --launches 5 --dist pareto --check 2>&1 | grep "large topic\|bit-exact" >> $O/configs.txt; done
 find $O -name "*.db" -delete 2>/dev/null
 find $O -name "*kernel_trace.csv" -size +2M -delete 2>/dev/null
 tail -3 $O/timeline.txt; cat $O/configs.txt

@@ -57,6 +57,12 @@ def main():
                           name, summ["calibration"]["fetch_bytes_per_count"],
                           summ["calibration"]["write_bytes_per_count"]),
         })
+    # keep what other sessions put there (the sort-phase entry of tools/gpu_session_large.sh)
+    try:
+        old = json.load(open(os.path.join(dst, "traffic.json"))).get("entries", [])
+    except (OSError, ValueError):
+        old = []
+    entries += [e for e in old if e.get("kind") == "sort_phase"]
     json.dump({"entries": entries}, open(os.path.join(dst, "traffic.json"), "w"), indent=1)
     print(json.dumps(entries, indent=1))
 
