@@ -330,3 +330,27 @@ def test_java_sources_are_lexically_sane():
         for imp in re.findall(r"^\s*import\s+(?:static\s+)?[\w.]+\.(\w+)\s*;", code, re.M):
             body = re.sub(r"^\s*import\s+.*$", "", code, flags=re.M)
             assert re.search(r"\b%s\b" % imp, body), "%s: unused import %s" % (os.path.basename(path), imp)
+
+
+def test_bench_workloads_are_the_fixture_generator():
+    """bench.py times the vectors of synth.config (it used torch's RNG); its sort-phase topic carries a
+    permutation of 0..n-1 as partition ids, also for sizes that are not a power of two."""
+    import argparse
+    import bench
+    from kafka_lag_based_assignor_amd import synth
+    ns = argparse.Namespace(workload="cfg3", topics=None, partitions=None, consumers=None, dist=None)
+    w, name, dist = bench.make_workload(ns)
+    ref = synth.config("cfg3")
+    assert name == "cfg3" and dist == "Zipf(1.1)"
+    for k in ("part_off", "partition_id", "begin", "end", "committed", "cons_off", "cons_rank"):
+        np.testing.assert_array_equal(getattr(w, k), getattr(ref, k))
+    ns = argparse.Namespace(workload="target", topics=50, partitions=40, consumers=7, dist="uniform40")
+    w, name, _ = bench.make_workload(ns)
+    assert name == "custom" and (w.n_topics, w.max_partitions, w.max_consumers) == (50, 40, 7)
+    for n in (1, 1000, 4096, 100003):
+        s = bench.sort_phase_workload(n)
+        assert s.n_topics == 1 and s.cons_rank.size == 0 and s.n_partitions == n
+        np.testing.assert_array_equal(np.sort(s.partition_id), np.arange(n, dtype=np.int32))
+        assert s.lag.min() >= 0 and s.lag.max() < (1 << 40)
+        if n > 1000:
+            assert np.any(np.diff(s.partition_id) < 0)                 # not already in id order: the id passes run
