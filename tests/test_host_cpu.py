@@ -336,6 +336,7 @@ def test_bench_workloads_are_the_fixture_generator():
     """bench.py times the vectors of synth.config (it used torch's RNG); its sort-phase topic carries a
     permutation of 0..n-1 as partition ids, also for sizes that are not a power of two."""
     import argparse
+    import numpy as np
     import bench
     from kafka_lag_based_assignor_amd import synth
     ns = argparse.Namespace(workload="cfg3", topics=None, partitions=None, consumers=None, dist=None)
