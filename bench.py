@@ -259,13 +259,31 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product path has no CPU fallback")
+    # LA_BENCH_BACKEND=gloo: a test hook for boxes with fewer GPUs than ranks -- the ranks share the devices there are
+    # (RCCL refuses two ranks on one GPU) and the collectives run over gloo on host copies.  It exercises everything of
+    # the N > 1 path but the RCCL transport: the la_plan_shards split, per-rank upload, padded all-gather, reassembly,
+    # the oracle check of the gathered arrays, barrier and max-reduce.  Never a performance number.
+    backend = os.environ.get("LA_BENCH_BACKEND", "nccl")
+    if backend == "gloo":
+        local_rank = local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     # LA_BENCH_FORCE_DIST=1 runs the RCCL legs (init, barrier, all-gather, max-reduce) at world size 1 too, so that the
     # N>1 code path can be exercised under torchrun on a one-GPU box
     use_dist = world > 1 or os.environ.get("LA_BENCH_FORCE_DIST") == "1"
     if use_dist:
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "gloo":
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
+
+    def all_gather(dst, src):
+        if backend == "gloo":                                     # through host copies (see above)
+            h = torch.empty(dst.numel(), dtype=dst.dtype)
+            dist.all_gather_into_tensor(h, src.cpu())
+            dst.copy_(h)
+        else:
+            dist.all_gather_into_tensor(dst, src)
     if args.gpus != world and rank == 0:
         print("warning: --gpus %d but WORLD_SIZE=%d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
 
@@ -317,8 +335,8 @@ def main():
     def step():
         ctx.assign_batch_device(b, stream)
         if gather and use_dist:
-            dist.all_gather_into_tensor(gathered_pid, sh.out_pid[:cap])
-            dist.all_gather_into_tensor(gathered_rank, sh.out_rank[:cap])
+            all_gather(gathered_pid, sh.out_pid[:cap])
+            all_gather(gathered_rank, sh.out_rank[:cap])
 
     def barrier():
         torch.cuda.synchronize()
@@ -356,8 +374,8 @@ def main():
             ctx.assign_batch_device(b, stream)
             pair[1].record()
             if gather and use_dist:
-                dist.all_gather_into_tensor(gathered_pid, sh.out_pid[:cap])
-                dist.all_gather_into_tensor(gathered_rank, sh.out_rank[:cap])
+                all_gather(gathered_pid, sh.out_pid[:cap])
+                all_gather(gathered_rank, sh.out_rank[:cap])
     barrier()
     elapsed = time.perf_counter() - t0c
     ctx.sync(stream)
@@ -365,7 +383,7 @@ def main():
     # HIP-event duration of the assign launch on the stream it runs on (the kernels of one step, without the gather)
     kern_ms = float(np.mean([a.elapsed_time(z) for a, z in ev.values()]))
 
-    t = torch.tensor([elapsed, kern_ms], device=dev, dtype=torch.float64)
+    t = torch.tensor([elapsed, kern_ms], device="cpu" if backend == "gloo" else dev, dtype=torch.float64)
     if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed, kern_ms_max = float(t[0].item()), float(t[1].item())
@@ -536,6 +554,7 @@ def main():
                                   else " per GPU", dist_name, args.reset_mode),
                    "topics": T, "partitions_per_topic": P, "consumers_per_topic": C,
                    "topics_on_rank0": int(b.n_topics), "gather": bool(gather and use_dist), "algo": args.algo,
+                   "backend": ("rccl" if backend == "nccl" else "gloo, ranks sharing devices (test hook: not a performance number)") if use_dist else None,
                    "settle_ms": args.settle_ms, "settle_steps": settle_steps},
         "roofline": roofline,
         "cold_call_ms": cold["ms"] if cold else None,
