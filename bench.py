@@ -23,12 +23,14 @@ a second -- is timed separately and reported as `cold_call_ms`; it is never `val
 
 Multi-GPU.  Topics are independent (Main.java:177-184), so they shard across ranks with no
 data-path collective.
-  --scaling weak   (default) every rank owns a full copy of the workload; `--gather` adds the
-                   all-gather of the result arrays.
-  --scaling strong ONE workload is split over the ranks by the library's own planner
-                   (la_plan_shards of the C ABI), every rank runs the hot path on its shard and the
-                   result arrays are reassembled on every rank by ONE RCCL all-gather per array
-                   inside the timed region (BASELINE config 4: cfg4; also `--workload target`).
+  --scaling strong (default when WORLD_SIZE > 1: the north star's workload) ONE batch -- the
+                   100 000-topic target, or BASELINE config 4 with `--workload cfg4` -- is split
+                   over the ranks by the library's own planner (la_plan_shards of the C ABI), every
+                   rank runs the hot path on its shard, and the global assignment is reassembled on
+                   every rank by ONE RCCL all-gather per step inside the timed region: a rank's two
+                   result arrays are the two halves of one [2, cap] int32 buffer.
+  --scaling weak   (default at one rank) every rank owns a full copy of the workload; `--gather`
+                   adds the same single all-gather.
 
 Prints ONE JSON line on rank 0.
 """
@@ -75,9 +77,11 @@ def parse_args():
     ap.add_argument("--reset-mode", choices=["latest", "earliest"], default="earliest",
                     help="earliest reads all four marshalled arrays (the 36 B/partition of SURVEY 8d)")
     ap.add_argument("--algo", choices=["auto", "wide", "argmin"], default="auto")
-    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default=None,
+                    help="default: strong when WORLD_SIZE > 1 (ONE batch sharded over the ranks + one all-gather per step: "
+                         "the north star's multi-GPU workload), weak at one rank")
     ap.add_argument("--gather", action="store_true",
-                    help="weak scaling: also all-gather the result arrays (RCCL) in the timed region; strong scaling always does")
+                    help="weak scaling: also all-gather the packed result buffer (RCCL) in the timed region; strong scaling always does")
     ap.add_argument("--phase", choices=["assign", "sort"], default="assign",
                     help="sort: time the radix-sort phase of the large path on one topic of --partitions partitions "
                          "(default 33 554 432, no consumers) and report it against the HBM roofline")
@@ -137,10 +141,14 @@ class DeviceShard:
         up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)          # noqa: E731
         self.d = dict(part_off=up(po), cons_off=up(co), pid=up(w.partition_id[ps]), begin=up(w.begin[ps]),
                       end=up(w.end[ps]), committed=up(w.committed[ps]), cons_rank=up(w.cons_rank[cs]))
-        cap = self.n if out_cap is None else out_cap
-        # zero-filled once: in strong scaling the tail beyond this shard's partitions is all-gathered as padding
-        self.out_pid = torch.zeros(max(cap, 1), device=dev, dtype=torch.int32)
-        self.out_rank = torch.zeros(max(cap, 1), device=dev, dtype=torch.int32)
+        cap = max(self.n if out_cap is None else out_cap, 1)
+        # The two result arrays are the two halves of ONE [2, cap] int32 buffer, so that the global assignment is
+        # reassembled by a single all-gather per step.  Zero-filled once: in strong scaling the tail beyond this
+        # shard's partitions is all-gathered as padding.
+        self.cap = cap
+        self.out2 = torch.zeros(2 * cap, device=dev, dtype=torch.int32)
+        self.out_pid = self.out2[:cap]
+        self.out_rank = self.out2[cap:]
         self.out_total = torch.zeros(max(self.k, 1), device=dev, dtype=torch.int64)
         lens_p = np.diff(po)
         lens_c = np.diff(co)
@@ -272,10 +280,12 @@ def main():
     # N>1 code path can be exercised under torchrun on a one-GPU box
     use_dist = world > 1 or os.environ.get("LA_BENCH_FORCE_DIST") == "1"
     if use_dist:
+        import datetime
+        patience = datetime.timedelta(minutes=30)                 # rank 0 measures its extras while the others wait
         if backend == "gloo":
-            dist.init_process_group("gloo")
+            dist.init_process_group("gloo", timeout=patience)
         else:
-            dist.init_process_group("nccl", device_id=dev)
+            dist.init_process_group("nccl", device_id=dev, timeout=patience)
 
     def all_gather(dst, src):
         if backend == "gloo":                                     # through host copies (see above)
@@ -311,7 +321,9 @@ def main():
     # ---- workload: ONE generator for bench, tests and golden digests ----------------------------------------
     w, wname, dist_name = make_workload(args)
     T = w.n_topics
-    strong = args.scaling == "strong"
+    # N > 1 defaults to the north star's multi-GPU workload: ONE batch sharded over the ranks, one all-gather per step
+    scaling = args.scaling or ("strong" if world > 1 else "weak")
+    strong = scaling == "strong"
     if strong:
         # la_plan_shards (what la_create_multi uses itself); ncclAllGather needs equal counts: buffers padded to `cap`
         ranges, counts, cap = sharding.strong_plan(w.part_off, world)
@@ -323,20 +335,19 @@ def main():
     else:
         sh = DeviceShard(torch, N, dev, w, 0, T, latest, args.algo)
         counts = [sh.n] * world
-        cap = sh.n
         n_total = world * sh.n
         gather = bool(args.gather and use_dist)
-    if gather and use_dist:
-        gathered_pid = torch.empty(world * cap, device=dev, dtype=torch.int32)
-        gathered_rank = torch.empty(world * cap, device=dev, dtype=torch.int32)
+    cap = sh.cap
+    do_gather = gather and use_dist
+    if do_gather:
+        gathered = torch.empty(world * 2 * cap, device=dev, dtype=torch.int32)     # [world][2][cap]
     n_part = sh.n
     b = sh.batch
 
     def step():
         ctx.assign_batch_device(b, stream)
-        if gather and use_dist:
-            all_gather(gathered_pid, sh.out_pid[:cap])
-            all_gather(gathered_rank, sh.out_rank[:cap])
+        if do_gather:
+            all_gather(gathered, sh.out2)                           # THE collective of a step: both result arrays at once
 
     def barrier():
         torch.cuda.synchronize()
@@ -349,7 +360,14 @@ def main():
     ctx.sync(stream)                                               # first touch: scratch, code objects
     settle_steps = 0
     t_settle = time.perf_counter()
-    while (time.perf_counter() - t_settle) * 1e3 < args.settle_ms:
+    while True:
+        # every rank runs the same number of settle steps (a collective sits in each): rank 0's clock decides
+        go = torch.tensor([1.0 if (time.perf_counter() - t_settle) * 1e3 < args.settle_ms else 0.0],
+                          device="cpu" if backend == "gloo" else dev)
+        if use_dist and world > 1:
+            dist.broadcast(go, 0)
+        if go.item() == 0.0:
+            break
         for _ in range(20):
             step()
         settle_steps += 20
@@ -359,66 +377,72 @@ def main():
 
     # ---- timed region: exactly K steps, bracketed by barrier + synchronize on both sides --------------------
     # HIP events around about 200 of the steps (every step when K <= 200): an event record is a marker packet
-    # in the queue, and two per step would be a measurable part of a 160 us step
+    # in the queue, and three per step would be a measurable part of a 160 us step
     stride = max(1, args.steps // 200)
-    ev = {s: (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-          for s in range(0, args.steps, stride)}
+    ev = {s: tuple(torch.cuda.Event(enable_timing=True) for _ in range(3)) for s in range(0, args.steps, stride)}
     barrier()
     t0c = time.perf_counter()
     for s in range(args.steps):
-        pair = ev.get(s)
-        if pair is None:
+        trio = ev.get(s)
+        if trio is None:
             step()
         else:
-            pair[0].record()
+            trio[0].record()
             ctx.assign_batch_device(b, stream)
-            pair[1].record()
-            if gather and use_dist:
-                all_gather(gathered_pid, sh.out_pid[:cap])
-                all_gather(gathered_rank, sh.out_rank[:cap])
+            trio[1].record()
+            if do_gather:
+                all_gather(gathered, sh.out2)
+                trio[2].record()
     barrier()
     elapsed = time.perf_counter() - t0c
     ctx.sync(stream)
 
-    # HIP-event duration of the assign launch on the stream it runs on (the kernels of one step, without the gather)
-    kern_ms = float(np.mean([a.elapsed_time(z) for a, z in ev.values()]))
+    # HIP-event durations on the stream the work runs on: the assign launch (the kernels of one step), and the gather
+    kern_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in ev.values()]))
+    gather_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in ev.values()])) if do_gather else 0.0
 
-    t = torch.tensor([elapsed, kern_ms], device="cpu" if backend == "gloo" else dev, dtype=torch.float64)
+    cdev = "cpu" if backend == "gloo" else dev
+    t = torch.tensor([elapsed, kern_ms, gather_ms], device=cdev, dtype=torch.float64)
+    per_rank = torch.zeros(2 * world, device=cdev, dtype=torch.float64)
+    per_rank[rank] = kern_ms
+    per_rank[world + rank] = gather_ms
     if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed, kern_ms_max = float(t[0].item()), float(t[1].item())
+        dist.all_reduce(per_rank, op=dist.ReduceOp.SUM)
+    elapsed, kern_ms_max, gather_ms_max = float(t[0].item()), float(t[1].item()), float(t[2].item())
+    per_rank = per_rank.cpu().numpy()
 
-    # ---- what one rebalance sees: the first call after a second of idle --------------------------------------
-    cold = None
-    if not use_dist or world == 1:
-        torch.cuda.synchronize()
-        time.sleep(1.0)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        c0 = time.perf_counter()
-        e0.record()
-        ctx.assign_batch_device(b, stream)
-        e1.record()
-        ctx.sync(stream)
-        cold_wall = (time.perf_counter() - c0) * 1e3
-        cold = {"ms": round(float(e0.elapsed_time(e1)), 4), "wall_ms": round(cold_wall, 4),
-                "value": round(n_part / (e0.elapsed_time(e1) * 1e-3), 1),
-                "what": "ONE la_assign_batch_device call (HIP events around it; wall = enqueue + la_sync) after the GPU "
-                        "idled for 1 s: clocks and power state as a rebalance finds them"}
-
-    # strong scaling: the gathered arrays, stripped of their padding, are the global assignment -- checked below
+    # strong scaling: the gathered buffer, stripped of its padding, is the global assignment -- checked below
     gathered_host = None
     if strong and rank == 0:
-        if use_dist:
-            gp, gr = gathered_pid.cpu().numpy(), gathered_rank.cpu().numpy()
-            gathered_host = (sharding.strip_padding(gp, counts, cap), sharding.strip_padding(gr, counts, cap))
+        if do_gather:
+            g = gathered.cpu().numpy().reshape(world, 2, cap)
+            gathered_host = (sharding.strip_padding(np.ascontiguousarray(g[:, 0, :]).reshape(-1), counts, cap),
+                             sharding.strip_padding(np.ascontiguousarray(g[:, 1, :]).reshape(-1), counts, cap))
         else:
             gathered_host = (sh.out_pid[:n_part].cpu().numpy(), sh.out_rank[:n_part].cpu().numpy())
 
     if rank != 0:
         if use_dist:
-            dist.barrier()                     # rank 0 is still checking against the oracle: leave together
+            dist.barrier()                     # rank 0 is still measuring its extras and checking the oracle: leave together
             dist.destroy_process_group()
         return
+
+    # ---- what one rebalance sees: the first call after a second of idle (rank 0; the other ranks wait at the barrier) ----
+    torch.cuda.synchronize()
+    time.sleep(1.0)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    c0 = time.perf_counter()
+    e0.record()
+    ctx.assign_batch_device(b, stream)
+    e1.record()
+    ctx.sync(stream)
+    cold_wall = (time.perf_counter() - c0) * 1e3
+    cold_ms = float(e0.elapsed_time(e1))
+    cold = {"ms": round(cold_ms, 4), "wall_ms": round(cold_wall, 4), "value": round(n_part / (cold_ms * 1e-3), 1),
+            "what": "ONE la_assign_batch_device call (HIP events around it; wall = enqueue + la_sync) after the GPU "
+                    "idled for 1 s: clocks and power state as a rebalance finds them%s"
+                    % (" (rank 0's shard, no gather)" if world > 1 else "")}
 
     ms_per_step = elapsed / args.steps * 1e3
     value = n_total * args.steps / elapsed
@@ -438,7 +462,12 @@ def main():
                 "kernel_ms_source": "HIP events around %d of the %d timed launches, on the stream they run on (rank 0%s)"
                                     % (len(ev), args.steps, "; max over ranks %.4f" % kern_ms_max if world > 1 else ""),
                 "algorithmic_bytes_per_partition": bpp,
-                "algorithmic_bytes_per_launch": bpp * n_part}
+                "algorithmic_bytes_per_launch": bpp * n_part,
+                # the same bytes over the time of ONE call after a second of idle: the regime a real rebalance lives in
+                "frac_cold": round(bpp * n_part / (cold_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+    if world > 1 or do_gather:
+        roofline["per_rank_kernel_ms"] = [round(float(x), 4) for x in per_rank[:world]]
+        roofline["per_rank_gather_ms"] = [round(float(x), 4) for x in per_rank[world:]]
     if tr:
         roofline["traffic_source"] = "%s (PMC passes cannot run inside this process; committed summary of the same workload)" % tr.get("source")
 
@@ -525,7 +554,7 @@ def main():
 
     # ---- the north star's other figure: the radix-sort phase against the HBM roofline, measured in this run --------
     sort_phase = None
-    if world == 1 and not args.no_sort_phase:
+    if not args.no_sort_phase:                                  # rank 0 (the other ranks wait at the closing barrier)
         try:
             del sh.d                                             # the batch is done with: make room
             torch.cuda.empty_cache()
@@ -544,7 +573,7 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 4),
         "higher_is_better": True,
-        "scaling": args.scaling,
+        "scaling": scaling,
         "vs_baseline": None,
         "dtype": "int64",
         "data": "synthetic",
@@ -553,11 +582,15 @@ def main():
                                % (wname, T, P, C, " in all, sharded over %d GPUs by la_plan_shards" % world if strong
                                   else " per GPU", dist_name, args.reset_mode),
                    "topics": T, "partitions_per_topic": P, "consumers_per_topic": C,
-                   "topics_on_rank0": int(b.n_topics), "gather": bool(gather and use_dist), "algo": args.algo,
+                   "topics_on_rank0": int(b.n_topics), "gather": bool(do_gather), "algo": args.algo,
+                   "collectives_per_step": 1 if do_gather else 0,
+                   "collective": ("ONE all_gather_into_tensor of the [2, %d] int32 result buffer (partition order | member "
+                                  "rank) per step, inside the timed region: %.4f ms by HIP events (max over ranks)"
+                                  % (cap, gather_ms_max)) if do_gather else None,
                    "backend": ("rccl" if backend == "nccl" else "gloo, ranks sharing devices (test hook: not a performance number)") if use_dist else None,
                    "settle_ms": args.settle_ms, "settle_steps": settle_steps},
         "roofline": roofline,
-        "cold_call_ms": cold["ms"] if cold else None,
+        "cold_call_ms": cold["ms"],
         "cold_call": cold,
         "sort_phase": sort_phase,
         "lag_ratio": lag_ratio,

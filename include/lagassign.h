@@ -159,7 +159,9 @@ const char *la_last_error(const la_ctx *ctx);
 int la_version(void);
 
 /* computePartitionLag over n partitions (host buffers).  begin_off may be NULL when
- * reset_mode == LA_RESET_LATEST.  Main.java:376-404. */
+ * reset_mode == LA_RESET_LATEST.  Main.java:376-404.
+ * Reuses the device scratch the last assign call's results live in: after it (and after la_group_by_member)
+ * la_group_last_by_member returns LA_EINVAL until the next la_assign_batch / la_assign_batch_lags. */
 int la_compute_lag(la_ctx *ctx, int64_t n,
                    const int64_t *begin_off, const int64_t *end_off,
                    const int64_t *committed_off, int32_t reset_mode,
@@ -264,7 +266,9 @@ void *la_stream(la_ctx *ctx);
  *                                      consumer (rank -1), which the reference leaves unassigned
  *   grouped_topic[j], grouped_partition[j]   topic index (into part_off) and partition id of the j-th entry,
  *                                      in exactly the order the reference's list for that member holds them
- * It is a stable device radix sort of the entry indices by member rank.  grouped_topic may be NULL. */
+ * It is a stable device radix sort of the entry indices by member rank.  grouped_topic may be NULL.
+ * Like la_compute_lag this call takes over the scratch of the last assign call: the results held for
+ * la_group_last_by_member are gone afterwards. */
 int la_group_by_member(la_ctx *ctx, int32_t n_topics, const int64_t *part_off,
                        const int32_t *out_partition, const int32_t *out_member_rank, int32_t n_members,
                        int64_t *member_off, int32_t *grouped_topic, int32_t *grouped_partition);

@@ -54,11 +54,14 @@ Java_com_github_grantneale_kafka_gpu_LagAssignNative_destroy(JNIEnv *env, jclass
 JNIEXPORT jobject JNICALL
 Java_com_github_grantneale_kafka_gpu_LagAssignNative_hostAlloc(JNIEnv *env, jclass cls, jlong ctx, jlong bytes) {
     void *p;
+    jobject buf;
     (void)cls;
-    if (bytes < 0) return NULL;
+    if (bytes < 0 || bytes > 0x7FFFFFFFLL) return NULL;     /* a ByteBuffer's capacity is an int */
     p = la_host_alloc(CTX(ctx), (size_t)bytes);
     if (!p) return NULL;
-    return (*env)->NewDirectByteBuffer(env, p, bytes);
+    buf = (*env)->NewDirectByteBuffer(env, p, bytes);
+    if (!buf) la_host_free(CTX(ctx), p);                    /* OutOfMemoryError pending: do not leak the pinned block */
+    return buf;
 }
 
 JNIEXPORT void JNICALL

@@ -5,7 +5,6 @@ import java.util.HashMap;
 import java.util.List;
 import java.util.Map;
 
-import org.apache.kafka.clients.consumer.OffsetAndMetadata;
 import org.apache.kafka.common.TopicPartition;
 
 import com.github.grantneale.kafka.gpu.GpuLagBasedPartitionAssignor;
@@ -32,11 +31,9 @@ public class LagBasedPartitionAssignor extends GpuLagBasedPartitionAssignor {
         return assignLags(lags, subscriptions);
     }
 
-    static long computePartitionLag(OffsetAndMetadata partitionMetadata, long beginOffset, long endOffset,
-                                    String autoOffsetResetMode) {
-        return GpuLagBasedPartitionAssignor.computePartitionLag(partitionMetadata, beginOffset, endOffset,
-            autoOffsetResetMode);
-    }
+    // computePartitionLag(OffsetAndMetadata, long, long, String): the reference's test calls it through this class's
+    // name and resolves to the PUBLIC static inherited from GpuLagBasedPartitionAssignor.  (Re-declaring it here
+    // package-private, as the reference does, would not compile: a hiding static may not reduce access, JLS 8.4.8.3.)
 
     static class TopicPartitionLag {
         private final String topic;

@@ -126,7 +126,8 @@ public class GpuLagBasedPartitionAssignor implements ConsumerPartitionAssignor, 
     public GroupAssignment assign(Cluster metadata, GroupSubscription groupSubscription) {
         try {
             return assignOnGpu(metadata, groupSubscription);
-        } catch (IllegalStateException | LinkageError nativeFailure) {     // la_* error, or the library itself is missing
+        } catch (NativeAssignException | LinkageError nativeFailure) {     // la_* error, or the library itself is missing;
+            // anything the side KafkaConsumer throws (closed, fenced, timed out) is NOT a GPU failure and propagates
             final ConsumerPartitionAssignor other = fallback();
             if (other == null) {
                 throw nativeFailure;
@@ -381,6 +382,19 @@ public class GpuLagBasedPartitionAssignor implements ConsumerPartitionAssignor, 
     // native context + buffers: created once, grow-only, reused by every rebalance
     // ------------------------------------------------------------------------------------------------------------
 
+    /**
+     * A failure of the native library (an la_* error code, no usable device, a marshalling array too large).  It is an
+     * IllegalStateException, so that without a fallback class it leaves assign() exactly as before; assign() delegates to
+     * the fallback ONLY for this type and for LinkageError -- never for what the side KafkaConsumer throws.
+     */
+    public static final class NativeAssignException extends IllegalStateException {
+        private static final long serialVersionUID = 1L;
+
+        NativeAssignException(String message) {
+            super(message);
+        }
+    }
+
     /** One pinned (la_host_alloc) direct buffer with its typed views; grows, never shrinks. */
     private static final class Buf {
         ByteBuffer bytes;
@@ -392,12 +406,16 @@ public class GpuLagBasedPartitionAssignor implements ConsumerPartitionAssignor, 
             if (bytes != null && bytes.capacity() >= wantBytes) {
                 return;
             }
+            if (wantBytes > Integer.MAX_VALUE) {    // a ByteBuffer's capacity is an int: fail before marshalling, not in it
+                throw new NativeAssignException("a marshalling array of " + wantBytes + " bytes exceeds the 2^31-1 bytes a "
+                    + "direct ByteBuffer can hold (" + (wantBytes / 8) + " partitions or consumer entries in one rebalance)");
+            }
             release(owner);
-            final long cap = Math.max(64, wantBytes + wantBytes / 4);
+            final long cap = Math.max(64, Math.min((long) Integer.MAX_VALUE, wantBytes + wantBytes / 4));
             ByteBuffer b = LagAssignNative.hostAlloc(owner.ctx, cap);
             pinned = b != null;
             if (b == null) {                        // pinned memory exhausted: pageable works too, only slower
-                b = ByteBuffer.allocateDirect((int) Math.min(Integer.MAX_VALUE, cap));
+                b = ByteBuffer.allocateDirect((int) cap);
             }
             bytes = b.order(ByteOrder.nativeOrder());
             longs = bytes.asLongBuffer();
@@ -435,7 +453,11 @@ public class GpuLagBasedPartitionAssignor implements ConsumerPartitionAssignor, 
 
         void open() {
             if (ctx == 0) {
-                ctx = LagAssignNative.createMulti(devices);      // throws IllegalStateException(la_last_error)
+                try {
+                    ctx = LagAssignNative.createMulti(devices);  // the shim throws IllegalStateException(la_last_error)
+                } catch (IllegalStateException e) {
+                    throw new NativeAssignException(e.getMessage());
+                }
                 LOGGER.debug("liblagassign context over {} device(s) of {}", LagAssignNative.shardCount(ctx),
                     LagAssignNative.deviceCount());
             }
@@ -459,7 +481,7 @@ public class GpuLagBasedPartitionAssignor implements ConsumerPartitionAssignor, 
 
         void check(int rc) {
             if (rc != 0) {
-                throw new IllegalStateException("liblagassign error " + rc + ": " + LagAssignNative.lastError(ctx));
+                throw new NativeAssignException("liblagassign error " + rc + ": " + LagAssignNative.lastError(ctx));
             }
         }
 

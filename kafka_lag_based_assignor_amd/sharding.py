@@ -21,9 +21,32 @@ def shard_bounds(part_off: np.ndarray, world_size: int) -> List[Tuple[int, int]]
     This IS the library's planner (``la_plan_shards`` of include/lagassign.h, pure host code): the split a
     one-process-per-GPU launcher makes here is the split a multi-device context (``la_create_multi``) makes
     inside ``la_assign_batch``."""
-    from . import _native
-    b = _native.plan_shards(part_off, world_size)
+    try:
+        from . import _native
+        b = _native.plan_shards(part_off, world_size)
+    except (OSError, ImportError):
+        # liblagassign.so (and with it the HIP runtime) cannot be loaded on this host -- a launcher node, a gloo-only
+        # test: the planner is pure host arithmetic, so the same formula is restated here.  tests/test_sharding_gloo.py
+        # asserts that the two agree.
+        b = plan_shards_numpy(part_off, world_size)
     return [(int(b[r]), int(b[r + 1])) for r in range(world_size)]
+
+
+def plan_shards_numpy(part_off: np.ndarray, n_shards: int) -> np.ndarray:
+    """la_plan_shards restated: bounds[r] = first topic boundary at or after r/n_shards of the partitions
+    (target = base + (total // S) * r + (total % S) * r // S), searched from the previous bound on."""
+    po = np.ascontiguousarray(part_off, dtype=np.int64)
+    t = po.size - 1
+    if t < 0 or n_shards < 1 or np.any(np.diff(po) < 0):
+        raise ValueError("bad offsets or shard count")
+    base, total = int(po[0]), int(po[t] - po[0])
+    bounds = np.zeros(n_shards + 1, dtype=np.int32)
+    for r in range(1, n_shards):
+        target = base + (total // n_shards) * r + (total % n_shards) * r // n_shards
+        lo = int(bounds[r - 1])
+        bounds[r] = min(t, lo + int(np.searchsorted(po[lo:], target, side="left")))
+    bounds[n_shards] = t
+    return bounds
 
 
 def shard_slices(part_off: np.ndarray, cons_off: np.ndarray, t0: int, t1: int):

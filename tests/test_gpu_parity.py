@@ -375,6 +375,45 @@ def test_cfg5_full_size(ctx):
         np.testing.assert_array_equal(g, e, err_msg="oracle: " + what)
 
 
+def test_target_full_size_other_modes(ctx):
+    """The 25.6 M-partition target in the forms test_target_full_size leaves out: auto.offset.reset=latest
+    (Main.java:391-392), 64-bit element indexing, and wide (96-bit) records forced -- each bit-exact against the
+    literal oracle on every partition."""
+    w = synth.config("target")
+    exp = {}
+    for latest in (True, False):
+        lag = oracle.compute_lags(w.begin, w.end, w.committed, latest)
+        exp[latest] = oracle.assign_flat(w.part_off, w.partition_id, lag, w.cons_off, w.cons_rank)
+    assert not np.array_equal(exp[True][2], exp[False][2])          # the reset mode matters on this workload
+    for latest, algo, flags, what in ((True, N.LA_ALGO_AUTO, 0, "latest"),
+                                      (False, N.LA_ALGO_AUTO, N.LA_FLAG_INDEX64, "earliest, INDEX64"),
+                                      (True, N.LA_ALGO_AUTO, N.LA_FLAG_INDEX64, "latest, INDEX64"),
+                                      (False, N.LA_ALGO_ROUNDS_WIDE, 0, "earliest, wide records"),
+                                      (True, N.LA_ALGO_ROUNDS_WIDE, 0, "latest, wide records")):
+        got = _run_device(ctx, w, algo, use_lag=False, latest=latest, flags=flags)
+        for g, e, name in zip(got, exp[latest], ("partition order", "member", "totals")):
+            np.testing.assert_array_equal(g, e, err_msg="target %s: %s" % (what, name))
+    # the host-buffer entry point in latest mode (begin_off = NULL is legal there)
+    got = ctx.assign_batch(w.part_off, w.partition_id, None, w.end, w.committed, N.LA_RESET_LATEST, w.cons_off, w.cons_rank)
+    for g, e in zip(got, exp[True]):
+        np.testing.assert_array_equal(g, e)
+
+
+def test_cfg5_full_size_latest(ctx):
+    """cfg5 (1 048 576 partitions x 8 192 consumers) with auto.offset.reset=latest: the 1 % of partitions without a
+    committed offset have lag 0 there (Main.java:391-392), which moves them to the tail of the sorted order."""
+    w = synth.config("cfg5")
+    lag = oracle.compute_lags(w.begin, w.end, w.committed, True)
+    assert not np.array_equal(lag, oracle.compute_lags(w.begin, w.end, w.committed, False))
+    got = ctx.assign_batch(w.part_off, w.partition_id, None, w.end, w.committed, N.LA_RESET_LATEST, w.cons_off, w.cons_rank)
+    for g, e, what in zip(got, _round_form(w.part_off, w.partition_id, lag, w.cons_off, w.cons_rank),
+                          ("partition order", "member", "totals")):
+        np.testing.assert_array_equal(g, e, err_msg="round form: " + what)
+    for g, e, what in zip(got, oracle.assign_flat(w.part_off, w.partition_id, lag, w.cons_off, w.cons_rank),
+                          ("partition order", "member", "totals")):
+        np.testing.assert_array_equal(g, e, err_msg="oracle: " + what)
+
+
 # ---- device-resident entry point; round form == literal wavefront argmin ------------------------------
 def _run_device(ctx, w, algo, use_lag=False, latest=True, flags=0, host_offsets=True):
     import ctypes

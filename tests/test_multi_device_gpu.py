@@ -68,6 +68,29 @@ def test_create_multi_shapes(ctx4):
     assert ei.value.code == N.LA_ENODEV
 
 
+def test_distinct_devices_when_the_box_has_them():
+    """Fires the day a box with >= 2 GPUs runs the tests: la_create_multi over DISTINCT device ids, the form an 8-GPU
+    Kafka group leader uses.  Same checks as the logical-shard tests: cfg4 at full size, a mixed batch, the lists."""
+    n = N.device_count()
+    if n < 2:
+        pytest.skip("one GPU on this box: distinct-device shards are exercised as logical shards on device 0")
+    c = N.Context(list(range(n)), flags=N.LA_CREATE_SPLIT_ALWAYS)
+    try:
+        assert c.shard_count == n and [c.shard_device(i) for i in range(n)] == list(range(n))
+        w = synth.config("cfg4")
+        lag = oracle.compute_lags(w.begin, w.end, w.committed, False)
+        exp = oracle.assign_flat(w.part_off, w.partition_id, lag, w.cons_off, w.cons_rank)
+        got = c.assign_batch(w.part_off, w.partition_id, w.begin, w.end, w.committed, N.LA_RESET_EARLIEST,
+                             w.cons_off, w.cons_rank)
+        _same(got, exp, "cfg4 on %d devices" % n)
+        assert list(c.last_shard_bounds()) == list(N.plan_shards(w.part_off, n))
+        part_off, pid, lag2, cons_off, ranks = _mixed_batch(5)
+        _same(c.assign_batch_lags(part_off, pid, lag2, cons_off, ranks),
+              oracle.assign_flat(part_off, pid, lag2, cons_off, ranks), "mixed batch on %d devices" % n)
+    finally:
+        c.close()
+
+
 def test_four_shards_cfg4_full_size(ctx4):
     w = synth.config("cfg4")                                   # 100 000 topics x 64 partitions x 8 consumers
     for mode in (N.LA_RESET_LATEST, N.LA_RESET_EARLIEST):

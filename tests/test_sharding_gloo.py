@@ -94,6 +94,7 @@ def test_plan_shards_properties_through_the_c_abi():
         part_off = np.concatenate([[0], np.cumsum(ps)]).astype(np.int64)
         for shards in (1, 2, 3, 8, 64, t + 5):
             b = N.plan_shards(part_off, shards)
+            assert np.array_equal(b, sharding.plan_shards_numpy(part_off, shards))     # the no-library fallback agrees
             assert b.size == shards + 1 and b[0] == 0 and b[-1] == t
             assert np.all(np.diff(b) >= 0)
             loads = part_off[b[1:]] - part_off[b[:-1]]
