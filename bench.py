@@ -52,9 +52,10 @@ HBM_PEAK_GBS = 8000.0          # MI355X spec, /opt/skills/guides/MI355X_MICROARC
 # read begin 8 + end 8 + committed 8 + partition id 4, write id-in-assignment-order 4 +
 # member rank 4 = 36 B/partition.  auto.offset.reset=latest never reads `begin`: 28 B/partition there.
 BYTES_PER_PARTITION = {"earliest": 36, "latest": 28}
-# radix-sort phase: a pass over a partition-id digit reads 4 B (count) + 12 B and writes 12 B
-# (scatter of the 8 B key + 4 B id) = 28 B/partition; a pass over a key digit reads 8 B in its count: 32 B.
-SORT_BYTES_ID_PASS, SORT_BYTES_KEY_PASS = 28, 32
+# radix-sort phase.  Single-kernel passes (decoupled look-back, the default): a pass reads the 8 B key +
+# 4 B id of every partition once and writes them once = 24 B/partition.  Four-kernel passes (--sort-form multi): the
+# count kernel re-reads the array that carries the digit: 4 B more for an id digit (28 B), 8 B more for a key digit (32 B).
+SORT_BYTES = {"single": (24, 24), "multi": (28, 32)}
 TRAFFIC_FILE = os.path.join(ROOT, "profiles", "traffic.json")   # written by tools/pmc_parse.py (separate --pmc passes)
 SORT_PHASE_PARTITIONS = 1 << 25                                 # past the 256 MiB Infinity Cache
 
@@ -85,6 +86,8 @@ def parse_args():
     ap.add_argument("--phase", choices=["assign", "sort"], default="assign",
                     help="sort: time the radix-sort phase of the large path on one topic of --partitions partitions "
                          "(default 33 554 432, no consumers) and report it against the HBM roofline")
+    ap.add_argument("--sort-form", choices=["single", "multi"], default="single",
+                    help="radix passes of the large path: single = one kernel per pass (decoupled look-back), multi = four")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg (rank 0, N=1)")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the oracle legs (parity check, cpu_baseline, host_boundary)")
     ap.add_argument("--no-sort-phase", action="store_true", help="skip the sort_phase leg of the default line")
@@ -178,12 +181,12 @@ class DeviceShard:
         self.batch = b
 
 
-def measured_sort_traffic(n):
+def measured_sort_traffic(n, form="single"):
     """HBM bytes of the radix-sort phase on an n-partition topic from the committed PMC summary (tools/gpu_session_large.sh)."""
     try:
         with open(TRAFFIC_FILE) as fh:
             for e in json.load(fh).get("entries", []):
-                if e.get("kind") == "sort_phase" and e.get("partitions") == n:
+                if e.get("kind") == "sort_phase" and e.get("partitions") == n and e.get("form", "multi") == form:
                     return e
     except (OSError, ValueError, KeyError):
         pass
@@ -214,11 +217,12 @@ def kernel_name(max_p, max_c):
     return "large-topic path (all kernels)"
 
 
-def run_sort_phase(torch, N, ctx, dev, n, reps, stream):
+def run_sort_phase(torch, N, ctx, dev, n, reps, stream, form="single"):
     """The radix-sort phase of the large path on one topic of n partitions (no consumers: keys, sort, ids).  Times come
     from HIP events the library records around its phases (LA_FLAG_PROFILE / la_last_phase_times)."""
     w = sort_phase_workload(n)
-    sh = DeviceShard(torch, N, dev, w, 0, 1, False, "auto", flags=N.LA_FLAG_PROFILE)
+    sh = DeviceShard(torch, N, dev, w, 0, 1, False, "auto",
+                     flags=N.LA_FLAG_PROFILE | (N.LA_FLAG_SORT_MULTIKERNEL if form == "multi" else 0))
     ctx.assign_batch_device(sh.batch, stream)                      # scratch allocation, first touch
     ctx.sync(stream)
     sort_ms, keys_ms, ids_ms = [], [], []
@@ -230,7 +234,8 @@ def run_sort_phase(torch, N, ctx, dev, n, reps, stream):
         sort_ms.append(t.sort_ms); keys_ms.append(t.keys_ms); ids_ms.append(t.greedy_ms)
     call_ms = (time.perf_counter() - t0) / reps * 1e3
     ms = float(np.mean(sort_ms))
-    algo_bytes = n * (t.id_passes * SORT_BYTES_ID_PASS + t.key_passes * SORT_BYTES_KEY_PASS)
+    bytes_id, bytes_key = SORT_BYTES[form]
+    algo_bytes = n * (t.id_passes * bytes_id + t.key_passes * bytes_key)
     achieved = algo_bytes / (ms * 1e-3) / 1e9
     # sortedness of what came out: ids in (lag desc, id asc) order
     pid = sh.out_pid[:n].to(torch.int64)
@@ -241,14 +246,16 @@ def run_sort_phase(torch, N, ctx, dev, n, reps, stream):
     perm_lag = lag_dev[inv[pid]]
     ok = bool(((perm_lag[:-1] > perm_lag[1:]) | ((perm_lag[:-1] == perm_lag[1:]) & (pid[:-1] < pid[1:]))).all()) if n > 1 else True
     del pid, lag_dev, perm_lag, inv
-    tr = measured_sort_traffic(n)
+    tr = measured_sort_traffic(n, form)
     return {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": tr["hbm_bytes_per_launch"] if tr else None,
             "traffic_source": tr["source"] if tr else None,
-            "kernel": "tile_count+scan_group_sums+scan_offsets+tile_scatter (every active 8-bit pass)",
+            "kernel": ("onesweep_pass_kernel (one launch per active 8-bit pass: stable scatter with decoupled look-back)"
+                       if form == "single" else "tile_count+scan_group_sums+scan_offsets+tile_scatter (every active 8-bit pass)"),
+            "form": form, "rank": "ds_add_rtn" if ctx.device_features(0) & N.LA_FEATURE_ATOMIC_RANK else "wave match",
             "kernel_ms": round(ms, 4), "partitions": n, "id_passes": int(t.id_passes), "key_passes": int(t.key_passes),
             "algorithmic_bytes_per_launch": int(algo_bytes),
-            "algorithmic_bytes": "%d B per id pass + %d B per key pass, per partition" % (SORT_BYTES_ID_PASS, SORT_BYTES_KEY_PASS),
+            "algorithmic_bytes": "%d B per id pass + %d B per key pass, per partition" % (bytes_id, bytes_key),
             "keys_ms": round(float(np.mean(keys_ms)), 4), "ids_ms": round(float(np.mean(ids_ms)), 4),
             "call_ms": round(call_ms, 4), "reps": reps, "sorted_ok": ok,
             "source": "measured in this run: HIP events inside liblagassign (la_last_phase_times), %d calls" % reps}
@@ -305,7 +312,7 @@ def main():
     if args.phase == "sort":
         n = args.partitions or SORT_PHASE_PARTITIONS
         reps = max(1, min(args.steps, 20))
-        sp = run_sort_phase(torch, N, ctx, dev, n, reps, stream)
+        sp = run_sort_phase(torch, N, ctx, dev, n, reps, stream, args.sort_form)
         if rank == 0:
             print(json.dumps({
                 "metric": "radix-sort phase of the large path, partitions sorted/sec", "value": round(n / (sp["kernel_ms"] * 1e-3), 1),
@@ -558,8 +565,9 @@ def main():
         try:
             del sh.d                                             # the batch is done with: make room
             torch.cuda.empty_cache()
-            sp = run_sort_phase(torch, N, ctx, dev, SORT_PHASE_PARTITIONS, 5, stream)
-            sort_phase = {k: sp[k] for k in ("frac", "achieved", "unit", "kernel", "kernel_ms", "partitions", "id_passes",
+            sp = run_sort_phase(torch, N, ctx, dev, SORT_PHASE_PARTITIONS, 5, stream, args.sort_form)
+            sort_phase = {k: sp[k] for k in ("frac", "achieved", "unit", "kernel", "form", "rank", "kernel_ms", "partitions", "id_passes",
+                                             "algorithmic_bytes",
                                              "key_passes", "algorithmic_bytes_per_launch", "traffic", "sorted_ok", "source")}
         except Exception as exc:  # noqa: BLE001 -- a reported extra
             sort_phase = {"error": str(exc)}

@@ -103,6 +103,9 @@ extern "C" {
                                  * above 6 bins per bucket instead of 96, so both kinds of round interleave  *
                                  * in one topic (test hook)                                                */
 
+#define LA_FLAG_SORT_MULTIKERNEL 128 /* large path: every radix pass as four kernels (tile counts, two scans, scatter)   *
+                                 * instead of the single-kernel pass with decoupled look-back (test hook / A-B)         */
+
 typedef struct la_ctx la_ctx;
 
 /* la_create / la_create_multi flags */
@@ -135,6 +138,12 @@ void la_destroy(la_ctx *ctx);
 /* Shards of the context, and the HIP device of shard i. */
 int la_shard_count(const la_ctx *ctx);
 int la_shard_device(const la_ctx *ctx, int shard);
+
+/* What the library found out about shard i's device when the context was created (bit mask; measurement / diagnostics):
+ *   LA_FEATURE_ATOMIC_RANK  the radix sort of the large path ranks equal digits with returning LDS atomics -- the device
+ *                           passed the lane-order check that form relies on (otherwise: wave-match ranking, same results). */
+#define LA_FEATURE_ATOMIC_RANK 1
+int la_device_features(const la_ctx *ctx, int shard);
 
 /* The planner the library uses for shards and for the chunks inside a shard: contiguous topic ranges
  * [bounds[r], bounds[r+1]) for r in [0, n_shards), balanced by partition count (bounds[r] = first topic boundary

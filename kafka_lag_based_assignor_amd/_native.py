@@ -20,6 +20,8 @@ LA_RESET_LATEST, LA_RESET_EARLIEST = 0, 1
 LA_ALGO_AUTO, LA_ALGO_ROUNDS, LA_ALGO_ARGMIN, LA_ALGO_ROUNDS_WIDE = 0, 1, 2, 3
 LA_FLAG_INDEX64, LA_FLAG_DEFER_WIDE, LA_FLAG_RAGGED, LA_FLAG_SHAPE_CLASSES = 1, 2, 4, 8
 LA_FLAG_PROFILE, LA_FLAG_NO_SAMPLE_SORT, LA_FLAG_SAMPLE_TIGHT = 16, 32, 64
+LA_FLAG_SORT_MULTIKERNEL = 128
+LA_FEATURE_ATOMIC_RANK = 1
 LA_CREATE_LANES_MASK, LA_CREATE_SPLIT_ALWAYS = 0xF, 0x10
 
 EXPORTED_SYMBOLS = (
@@ -27,7 +29,7 @@ EXPORTED_SYMBOLS = (
     "la_assign_batch", "la_assign_batch_lags", "la_assign_batch_device", "la_sync", "la_stream",
     "la_group_by_member", "la_group_by_member_device", "la_group_last_by_member",
     "la_device_count", "la_create_multi", "la_shard_count", "la_shard_device", "la_plan_shards",
-    "la_last_shard_bounds", "la_host_alloc", "la_host_free", "la_last_phase_times",
+    "la_last_shard_bounds", "la_host_alloc", "la_host_free", "la_last_phase_times", "la_device_features",
 )
 
 _i64p = ctypes.POINTER(ctypes.c_int64)
@@ -97,6 +99,8 @@ def load() -> ctypes.CDLL:
     L.la_shard_count.argtypes = [ctypes.c_void_p]
     L.la_shard_device.restype = ctypes.c_int
     L.la_shard_device.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    L.la_device_features.restype = ctypes.c_int
+    L.la_device_features.argtypes = [ctypes.c_void_p, ctypes.c_int]
     L.la_plan_shards.restype = ctypes.c_int
     L.la_plan_shards.argtypes = [ctypes.c_int32, _i64p, ctypes.c_int32, _i32p]
     L.la_last_shard_bounds.restype = ctypes.c_int
@@ -200,6 +204,10 @@ class Context:
 
     def shard_device(self, i: int) -> int:
         return int(self._lib.la_shard_device(self._h, i))
+
+    def device_features(self, i: int = 0) -> int:
+        """LA_FEATURE_* bits of shard i's device."""
+        return int(self._lib.la_device_features(self._h, i))
 
     def last_shard_bounds(self) -> np.ndarray:
         """Topic ranges the last host-buffer assign call gave to its shards (int32 [S + 1])."""

@@ -358,6 +358,7 @@ int launch_large_topics(la_ctx* ctx, Lane& ln, const la_device_batch* b, const B
         g.out_total = b->d_out_total_lag;
         g.reset_latest = (b->reset_mode == LA_RESET_LATEST) ? 1 : 0;
         g.no_sample_sort = (b->flags & LA_FLAG_NO_SAMPLE_SORT) ? 1 : ((b->flags & LA_FLAG_SAMPLE_TIGHT) ? 2 : 0);
+        g.sort_multi_kernel = (b->flags & LA_FLAG_SORT_MULTIKERNEL) ? 1 : 0;
         g.status = ln.status();
         hipError_t e = la::large_topic_launch(ln.large, g, argmin, stream);
         if (e != hipSuccess)
@@ -501,6 +502,8 @@ int sync_status(la_ctx* ctx, Lane& ln, hipStream_t stream) {
     if (st) {
         LA_HIP(ctx, hipMemsetAsync(ln.d_status, 0, sizeof st, stream));
         LA_HIP(ctx, hipStreamSynchronize(stream));
+        if (st & la::kStatusInternal)
+            return fail(ctx, LA_EHIP, "internal error: a radix-sort look-back gave up waiting for an earlier tile");
         if (st & la::kStatusUnsorted)
             return fail(ctx, LA_EINVAL, "a topic's cons_rank segment is not strictly ascending");
         return fail(ctx, LA_ESHAPE, "a topic exceeds the batch's shape hint");
@@ -815,6 +818,8 @@ int assign_small(la_ctx* ctx, const HostCall& c, Shard& sh, const SmallLayout& L
     LA_HIP(ctx, hipStreamSynchronize(st));
     const uint32_t status = *(const uint32_t*)(h + L.status);
     if (status) {
+        if (status & la::kStatusInternal)
+            return fail(ctx, LA_EHIP, "internal error: a radix-sort look-back gave up waiting for an earlier tile");
         if (status & la::kStatusUnsorted)
             return fail(ctx, LA_EINVAL, "a topic's cons_rank segment is not strictly ascending");
         return fail(ctx, LA_ESHAPE, "a topic exceeds the batch's shape hint");
@@ -964,7 +969,7 @@ int group_shard_device(la_ctx* ctx, Shard& sh, int32_t n_members, bool want_topi
     }
     hipError_t e = la::group_by_member_launch(sh.lanes[0].large, n, n_members, sh.last_topics, sh.last_part_off,
                                               sh.last_out_pid, sh.last_out_rank, d_off, want_topic ? d_topic : nullptr,
-                                              d_part, nullptr, sh.lanes[0].stream);
+                                              d_part, nullptr, sh.lanes[0].d_status, sh.lanes[0].stream);
     if (e != hipSuccess)
         return fail(ctx, e == hipErrorOutOfMemory ? LA_ENOMEM : LA_EHIP, "group_by_member: %s", hipGetErrorString(e));
     return LA_OK;
@@ -1027,6 +1032,8 @@ LA_API int la_create_multi(la_ctx** out, int n_devices, const int* device_ids, u
             if ((e = hipSetDevice(sh.device)) != hipSuccess ||
                 (e = hipEventCreateWithFlags(&sh.ready, hipEventDisableTiming)) != hipSuccess)
                 rc = fail(nullptr, LA_EHIP, "context setup: %s", hipGetErrorString(e));
+            if (rc == LA_OK && (e = la::large_init_device()) != hipSuccess)
+                rc = fail(nullptr, LA_EHIP, "context setup (device check): %s", hipGetErrorString(e));
             for (Lane& ln : sh.lanes)
                 if (rc == LA_OK) rc = create_lane(ln);
             if (rc != LA_OK) {
@@ -1063,6 +1070,12 @@ LA_API int la_shard_count(const la_ctx* ctx) { return ctx ? (int)ctx->shards.siz
 LA_API int la_shard_device(const la_ctx* ctx, int shard) {
     if (!ctx || shard < 0 || shard >= (int)ctx->shards.size()) return LA_EINVAL;
     return ctx->shards[(size_t)shard].device;
+}
+
+LA_API int la_device_features(const la_ctx* ctx, int shard) {
+    if (!ctx || shard < 0 || shard >= (int)ctx->shards.size()) return LA_EINVAL;
+    if (hipSetDevice(ctx->shards[(size_t)shard].device) != hipSuccess) return LA_EHIP;
+    return la::large_atomic_rank_supported() ? LA_FEATURE_ATOMIC_RANK : 0;
 }
 
 LA_API int la_plan_shards(int32_t n_topics, const int64_t* part_off, int32_t n_shards, int32_t* bounds) {
@@ -1191,7 +1204,8 @@ LA_API int la_group_by_member_device(la_ctx* ctx, int32_t n_topics, int64_t n_pa
         LA_HIP(ctx, hipSetDevice(sh.device));
         hipError_t e = la::group_by_member_launch(sh.lanes[0].large, n_partitions, n_members, n_topics, d_part_off,
                                                   d_out_partition, d_out_member_rank, d_member_off,
-                                                  d_grouped_topic, d_grouped_partition, nullptr, (hipStream_t)stream);
+                                                  d_grouped_topic, d_grouped_partition, nullptr, sh.lanes[0].d_status,
+                                                  (hipStream_t)stream);
         if (e != hipSuccess)
             return fail(ctx, e == hipErrorOutOfMemory ? LA_ENOMEM : LA_EHIP, "group_by_member: %s", hipGetErrorString(e));
         return LA_OK;

@@ -28,6 +28,8 @@ struct PerDeviceOnce {
 // device status word bits (la_ctx::d_status)
 constexpr uint32_t kStatusShape = 1u;      // a topic exceeded the shape hint
 constexpr uint32_t kStatusUnsorted = 2u;   // a topic's cons_rank segment is not strictly ascending
+constexpr uint32_t kStatusInternal = 4u;   // a look-back walk of the radix sort gave up waiting (never expected: a bounded spin
+                                           // exists so that a scheduling surprise ends as an error, not as a hung device)
 
 constexpr int32_t kTileSkipOversize = 4;  // TileArgs::flags: topics beyond the tile belong to another path, no error
 
@@ -151,8 +153,12 @@ struct LargeArgs {
     int32_t reset_latest;
     int32_t no_sample_sort;     // 1 = LA_FLAG_NO_SAMPLE_SORT: every greedy round sorts its bins with the full network;
                                 // 2 = LA_FLAG_SAMPLE_TIGHT: bucket limit 6, so sample-sorted and fallback rounds interleave
+    int32_t sort_multi_kernel;  // LA_FLAG_SORT_MULTIKERNEL: four kernels per radix pass (count, scans, scatter) instead of one
 };
 
+// Once per device at context creation (synchronous): checks the hardware property the radix sort's atomic ranking relies on.
+hipError_t large_init_device();
+int large_atomic_rank_supported();      // of the current device: 1 = ranks come from returning LDS atomics, 0 = match form
 hipError_t large_topic_launch(LargeScratch& scratch, const LargeArgs& a, bool argmin, hipStream_t stream);
 void large_scratch_release(LargeScratch& scratch);
 // Waits for the profiled topic's events; ms[3] = keys + plan, sort passes, ids + greedy; passes[2] = active id / key passes.
@@ -162,6 +168,6 @@ hipError_t large_profile_read(LargeScratch& scratch, float* ms, int* passes, int
 hipError_t group_by_member_launch(LargeScratch& scratch, int64_t n, int32_t n_members, int64_t n_topics,
                                   const int64_t* part_off, const int32_t* out_partition, const int32_t* member_rank,
                                   int64_t* member_off, int32_t* grouped_topic, int32_t* grouped_partition,
-                                  int32_t* grouped_entry, hipStream_t stream);
+                                  int32_t* grouped_entry, uint32_t* status, hipStream_t stream);
 
 }  // namespace la

@@ -51,9 +51,14 @@ struct SortBufs {
     uint32_t* val[2];
     uint32_t* tile_off;                // [n_tiles][256] (a tile's 256 digit counts / offsets are one 1 KB row)
     uint32_t* group_sum;               // [n_groups][256] digit counts of kScanRows consecutive tiles
+    // single-kernel passes (decoupled look-back): zeroed per sort together with ctl and hist
+    uint32_t* ticket;                  // [kDigits] arrival counter of every pass
+    uint32_t* gbase;                   // [kDigits][256] exclusive scan of hist: global first position of every digit
+    unsigned long long* tile_state;    // [n_tiles][256] granules {tag = (pass + 1) << 2 | status, count}; null: multi-kernel passes
     int64_t n;
     int n_tiles;
     int n_groups;
+    int atomic_rank;                   // ranks from returning LDS atomics (the device passed lds_atomic_order_test_kernel)
 };
 
 // bijection [0, n) -> [0, n): workgroups with equal (w % 8) get consecutive results
@@ -129,6 +134,25 @@ __global__ void plan_kernel(SortBufs b) {
             cur ^= (s ? 0u : 1u);
         }
         b.ctl->cur[kDigits] = cur;
+    }
+    // global first position of every digit of every pass (exclusive scan of its histogram): the single-kernel passes
+    // add a tile's look-back result to it
+    __shared__ uint32_t wsum[kRadix / kWave];
+    const int d = threadIdx.x, lane = d & 63, wave = d >> 6;
+    for (int p = 0; p < kDigits; ++p) {
+        const uint32_t h = b.hist[p * kRadix + d];
+        uint32_t incl = h;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t y = __shfl_up(incl, o);
+            if (lane >= o) incl += y;
+        }
+        __syncthreads();
+        if (lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        uint32_t run = incl - h;
+        for (int w = 0; w < wave; ++w) run += wsum[w];
+        b.gbase[p * kRadix + d] = run;
     }
 }
 
@@ -240,6 +264,102 @@ __global__ __launch_bounds__(kRadix) void scan_offsets_kernel(SortBufs b, int pa
     }
 }
 
+// ---- rank of an element among the equal digits of its wavefront's share of a tile --------------------------------
+// Order inside a tile = (wave, item, lane).  Two forms, same result:
+//   * ATOMIC: ONE returning LDS atomic per element, `ds_add_rtn_u32 cnt[wave][digit], 1`.  The lanes of one DS instruction
+//     that hit the same address are served in ascending lane order on gfx950, so the returned pre-values ARE the stable
+//     ranks.  That order is what the hardware does, not something the ISA manual promises: la::large_init_device() checks
+//     it once per device with lds_atomic_order_test_kernel (thousands of address patterns, several wavefronts at once) and
+//     the launchers fall back to the other form if it ever fails.
+//   * match: the wavefront finds every lane's peers (equal digits) with 8 ballots, the group's first lane advances the
+//     counter.  ~100 VALU instructions per element more than the atomic form: with it the scatter kernels spend 2 190
+//     VALU instructions per wavefront and tile and sit at 66 % VALU utilisation (profiles/r03_sort_pmc_*.json).
+template <bool ATOMIC>
+__device__ __forceinline__ void rank_in_wave(const uint64_t (&key)[kItems], const uint32_t (&val)[kItems],
+                                             uint32_t (&loc)[kItems], uint32_t* cnt_wave, int pass, int64_t w0, int64_t n,
+                                             int lane) {
+    if constexpr (ATOMIC) {
+#pragma unroll
+        for (int it = 0; it < kItems; ++it) {
+            const bool valid = w0 + it * kWave + lane < n;
+            const uint32_t d = digit_of(pass, key[it], val[it]);
+            uint32_t r = 0;
+            if (valid) r = atomicAdd(&cnt_wave[d], 1u);
+            loc[it] = (d << 16) | r;
+        }
+    } else {
+        const uint64_t lt = ((uint64_t)1 << lane) - 1;
+#pragma unroll
+        for (int it = 0; it < kItems; ++it) {
+            const bool valid = w0 + it * kWave + lane < n;
+            const uint32_t d = digit_of(pass, key[it], val[it]);
+            uint64_t peers = __ballot(valid);
+#pragma unroll
+            for (int bit = 0; bit < 8; ++bit) {
+                const bool one = (d >> bit) & 1;
+                const uint64_t bal = __ballot(one);
+                peers &= one ? bal : ~bal;
+            }
+            uint32_t old = 0;
+            if (valid) old = cnt_wave[d];                        // same address for all peers: broadcast
+            wave_lds_fence();
+            if (valid && (peers & lt) == 0) cnt_wave[d] = old + (uint32_t)__popcll(peers);   // group leader
+            wave_lds_fence();
+            loc[it] = (d << 16) | (old + (uint32_t)__popcll(peers & lt));
+        }
+    }
+}
+
+// One-off hardware check behind the ATOMIC form above: do the lanes of a returning LDS atomic that collide on an address
+// get their pre-values in lane order?  4 wavefronts at once, each on its own counters, address sets of 1 .. 256 words,
+// some lanes switched off, several atomics back to back as in the real loop.  *bad != 0: they do not.
+__global__ __launch_bounds__(256) void lds_atomic_order_test_kernel(uint32_t* bad) {
+    __shared__ uint32_t c[4][kRadix];              // counters the atomics advance
+    __shared__ uint32_t shadow[4][kRadix];         // the same counters advanced by the match form: what a stable rank is
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint64_t lt = ((uint64_t)1 << lane) - 1;
+    uint32_t wrong = 0;
+    for (uint32_t pattern = 0; pattern < 2048; ++pattern) {
+        for (int i = lane; i < kRadix; i += kWave) { c[wave][i] = 0; shadow[wave][i] = 0; }
+        wave_lds_fence();
+        const uint32_t span = 1u << ((pattern + wave) % 9);                       // 1, 2, 4 .. 256 distinct addresses
+        uint32_t got[4], want[4], addr[4];
+        bool on[4];
+#pragma unroll
+        for (int rep = 0; rep < 4; ++rep) {
+            uint32_t h = (uint32_t)lane * 2654435761u + pattern * 40503u + (uint32_t)rep * 97u + (uint32_t)wave * 7919u;
+            h ^= h >> 15; h *= 2246822519u; h ^= h >> 13;
+            addr[rep] = h & (span - 1);
+            on[rep] = ((h >> 20) & 7u) != 0;
+        }
+#pragma unroll
+        for (int rep = 0; rep < 4; ++rep) {
+            uint64_t peers = __ballot(on[rep]);
+#pragma unroll
+            for (int bit = 0; bit < 8; ++bit) {
+                const bool one = (addr[rep] >> bit) & 1;
+                const uint64_t bal = __ballot(one);
+                peers &= one ? bal : ~bal;
+            }
+            uint32_t old = 0;
+            if (on[rep]) old = shadow[wave][addr[rep]];
+            wave_lds_fence();
+            if (on[rep] && (peers & lt) == 0) shadow[wave][addr[rep]] = old + (uint32_t)__popcll(peers);
+            wave_lds_fence();
+            want[rep] = old + (uint32_t)__popcll(peers & lt);
+        }
+#pragma unroll
+        for (int rep = 0; rep < 4; ++rep) {                  // back to back, as in rank_in_wave
+            got[rep] = 0;
+            if (on[rep]) got[rep] = atomicAdd(&c[wave][addr[rep]], 1u);
+        }
+#pragma unroll
+        for (int rep = 0; rep < 4; ++rep) wrong |= (on[rep] && got[rep] != want[rep]) ? 1u : 0u;
+        wave_lds_fence();
+    }
+    if (wrong) atomicOr(bad, 1u);
+}
+
 // ---- per pass: stable scatter ----------------------------------------------------------------------
 // Order inside a tile = (wave, item, lane); elements are loaded wave-striped so every load is a
 // 64-element contiguous run.  Rank among equal digits: wave-level match (8 ballots), running
@@ -247,6 +367,7 @@ __global__ __launch_bounds__(kRadix) void scan_offsets_kernel(SortBufs b, int pa
 // atomics on the data path).  The tile is then REORDERED IN LDS by digit, so that consecutive lanes write
 // consecutive addresses of a digit's output run (a tile holds ~16 elements per digit: 128 B runs of keys,
 // 64 B of ids) instead of 64 unrelated 8-byte writes per wavefront.
+template <bool ATOMIC_RANK>
 __global__ __launch_bounds__(kSortThreads) void tile_scatter_kernel(SortBufs b, int pass) {
     if (b.ctl->skip[pass]) return;
     static_assert(kSortThreads == kRadix, "one thread per digit in the offset phase");
@@ -270,7 +391,6 @@ __global__ __launch_bounds__(kSortThreads) void tile_scatter_kernel(SortBufs b, 
     const int64_t t0 = (int64_t)tile * kTile;
     const int64_t w0 = t0 + (int64_t)wave * kItems * kWave;
     const int n_here = (int)((b.n - t0) < kTile ? (b.n - t0) : kTile);
-    const uint64_t lt = ((uint64_t)1 << lane) - 1;
 
     uint64_t key[kItems];
     uint32_t val[kItems];
@@ -282,25 +402,7 @@ __global__ __launch_bounds__(kSortThreads) void tile_scatter_kernel(SortBufs b, 
         key[it] = valid ? kin[i] : 0;
         val[it] = valid ? vin[i] : 0;
     }
-#pragma unroll
-    for (int it = 0; it < kItems; ++it) {
-        const int64_t i = w0 + it * kWave + lane;
-        const bool valid = i < b.n;
-        const uint32_t d = digit_of(pass, key[it], val[it]);
-        uint64_t peers = __ballot(valid);
-#pragma unroll
-        for (int bit = 0; bit < 8; ++bit) {
-            const bool one = (d >> bit) & 1;
-            const uint64_t bal = __ballot(one);
-            peers &= one ? bal : ~bal;
-        }
-        uint32_t old = 0;
-        if (valid) old = cnt[wave][d];                       // same address for all peers: broadcast
-        wave_lds_fence();
-        if (valid && (peers & lt) == 0) cnt[wave][d] = old + (uint32_t)__popcll(peers);   // group leader
-        wave_lds_fence();
-        loc[it] = (d << 16) | (old + (uint32_t)__popcll(peers & lt));
-    }
+    rank_in_wave<ATOMIC_RANK>(key, val, loc, cnt[wave], pass, w0, b.n, lane);
     __syncthreads();
     {   // thread d: exclusive scan of digit d's counters over the waves, then of the tile's digit counts
         const int d = threadIdx.x;
@@ -365,6 +467,218 @@ __global__ __launch_bounds__(kSortThreads) void tile_scatter_kernel(SortBufs b, 
         for (int it = 0; it < kItems; ++it)
             if (w0 + it * kWave + lane < b.n) s_stage[loc[it]] = key[it];
         __syncthreads();
+#pragma unroll
+        for (int it = 0; it < kItems; ++it) {
+            const int j = it * kSortThreads + threadIdx.x;
+            if (j < n_here) {
+                const uint64_t k = s_stage[j];
+                gpos[it] = bin_base[digit_of(pass, k, 0)] + (uint32_t)j;
+                kout[gpos[it]] = k;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < kItems; ++it)
+            if (w0 + it * kWave + lane < b.n) s_val[loc[it]] = val[it];
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < kItems; ++it) {
+            const int j = it * kSortThreads + threadIdx.x;
+            if (j < n_here) vout[gpos[it]] = s_val[j];
+        }
+    }
+}
+
+// ---- per pass, single-kernel form: stable scatter with decoupled look-back ----------------------------------------
+// One launch per pass instead of four (count, two scans, scatter): the count kernel's re-read of the digit array
+// (4-8 B per element) and the offset matrix are gone.  The global digit histograms come from build_keys_kernel
+// (b.gbase = their exclusive scans, plan_kernel); what a tile still needs is how many elements of each digit the tiles
+// BEFORE it hold.  Every tile publishes its 256 digit counts as granules {tag, count} -- ONE naturally aligned 8-byte
+// relaxed agent-scope store each, the data is its own flag (cdna_hip_programming.md section 6, Guideline 16, form R2:
+// the per-XCD L2s are not coherent, a plain store/load pair would go stale) -- first as an AGGREGATE (its own count),
+// then, after walking back over its predecessors until it meets an INCLUSIVE one, as the inclusive prefix.  tag =
+// (pass + 1) << 2 | status, so the state array is zeroed once per sort, not per pass.
+//
+// Which tile a workgroup takes is decided by an arrival ticket, never by blockIdx: tile = arrival number, so a tile only
+// ever waits for tiles whose workgroups are already running, and the walk cannot deadlock whatever the dispatch order is
+// (a bounded spin turns anything unforeseen into kStatusInternal instead of a hung device).  Tried and measured without
+// effect on this kernel (profiles/r03_sort_*): giving every XCD 4-32 consecutive tiles at a time (arrival- or
+// blockIdx-based) -- what made the four-kernel scatter 20 % faster -- and polling 4, 8 or 16 predecessors per hop.
+#ifndef LA_LOOK_WINDOW
+#define LA_LOOK_WINDOW 2
+#endif
+#ifdef LA_LOOKBACK_STATS   // development build: how far the walks go (tools/lookback_probe.py)
+__device__ unsigned long long g_lookback_stats[8];      // walks, hops, polls that found nothing, longest walk, cycles in walks
+#endif
+constexpr uint32_t kStateAggregate = 1u, kStateInclusive = 2u;
+constexpr int kLookWindow = LA_LOOK_WINDOW;           // predecessors a walk polls at once
+constexpr uint32_t kLookbackSpinLimit = 1u << 22;     // polls of one granule (~1 us each with the sleep) before giving up
+
+template <bool ATOMIC_RANK>
+__global__ __launch_bounds__(kSortThreads, 4) void onesweep_pass_kernel(SortBufs b, int pass, uint32_t* status) {
+    if (b.ctl->skip[pass]) return;
+    static_assert(kSortThreads == kRadix, "one thread per digit in the look-back");
+    __shared__ uint32_t cnt[kSortWaves][kRadix];
+    __shared__ uint32_t bin_start[kRadix];            // tile-local position of the digit's first element
+    __shared__ uint32_t bin_base[kRadix];             // global position of it, minus bin_start
+    __shared__ uint32_t wsum[kSortWaves];
+    __shared__ uint32_t s_ticket;
+    __shared__ uint64_t s_stage[kTile];               // the tile reordered by digit: one array at a time
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (threadIdx.x == 0) s_ticket = atomicAdd(&b.ticket[pass], 1u);
+    for (int i = threadIdx.x; i < kSortWaves * kRadix; i += kSortThreads) (&cnt[0][0])[i] = 0;
+    __syncthreads();
+    const uint32_t cur = b.ctl->cur[pass];
+    const uint64_t* kin = b.key[cur];
+    const uint32_t* vin = b.val[cur];
+    uint64_t* kout = b.key[cur ^ 1];
+    uint32_t* vout = b.val[cur ^ 1];
+    const int tile = (int)s_ticket;
+    const int64_t t0 = (int64_t)tile * kTile;
+    const int64_t w0 = t0 + (int64_t)wave * kItems * kWave;
+    const int n_here = (int)((b.n - t0) < kTile ? (b.n - t0) : kTile);
+    const uint32_t epoch = (uint32_t)(pass + 1) << 2;
+    unsigned long long* my_state = b.tile_state + (int64_t)tile * kRadix + threadIdx.x;
+
+    uint64_t key[kItems];
+    uint32_t val[kItems];
+    uint32_t loc[kItems];       // digit << 16 | rank inside (wave, digit)   (rank < 1024)
+#pragma unroll
+    for (int it = 0; it < kItems; ++it) {
+        const int64_t i = w0 + it * kWave + lane;
+        const bool valid = i < b.n;
+        key[it] = valid ? kin[i] : 0;
+        val[it] = valid ? vin[i] : 0;
+    }
+    rank_in_wave<ATOMIC_RANK>(key, val, loc, cnt[wave], pass, w0, b.n, lane);
+    __syncthreads();
+    // thread d: digit d's count in this tile; published at once, so that later tiles never wait for this tile's walk
+    uint32_t count = 0;
+    unsigned long long win[kLookWindow];
+    {
+        const int d = threadIdx.x;
+#pragma unroll
+        for (int w = 0; w < kSortWaves; ++w) {
+            const uint32_t c = cnt[w][d];
+            cnt[w][d] = count;
+            count += c;
+        }
+        __hip_atomic_store(my_state, ((unsigned long long)(epoch | (tile == 0 ? kStateInclusive : kStateAggregate)) << 32) | count,
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // the first window of the walk is in flight while the tile is staged below
+#pragma unroll
+        for (int i = 0; i < kLookWindow; ++i)
+            win[i] = i < tile ? __hip_atomic_load(my_state - (i + 1) * kRadix, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+        uint32_t incl = count;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t y = __shfl_up(incl, o);
+            if (lane >= o) incl += y;
+        }
+        if (lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        uint32_t woff = 0;
+        for (int w = 0; w < wave; ++w) woff += wsum[w];
+        bin_start[d] = woff + incl - count;
+    }
+    __syncthreads();
+    // tile-local sorted position of every element; the array that carries the pass's digit goes to the staging buffer
+#pragma unroll
+    for (int it = 0; it < kItems; ++it) {
+        const uint32_t d = loc[it] >> 16;
+        loc[it] = bin_start[d] + cnt[wave][d] + (loc[it] & 0xFFFFu);
+    }
+    uint32_t* s_val = reinterpret_cast<uint32_t*>(s_stage);
+    if (pass < 4) {
+#pragma unroll
+        for (int it = 0; it < kItems; ++it)
+            if (w0 + it * kWave + lane < b.n) s_val[loc[it]] = val[it];
+    } else {
+#pragma unroll
+        for (int it = 0; it < kItems; ++it)
+            if (w0 + it * kWave + lane < b.n) s_stage[loc[it]] = key[it];
+    }
+    {   // The walk: thread d adds up digit d's counts of the tiles before this one, nearest first, until it meets an
+        // inclusive prefix.  A hop costs a trip to the fabric (the granules are write-through, the per-XCD L2s are not
+        // coherent) behind this CU's own streaming loads and stores -- about 1 us -- and a walk passes ~28 tiles that have
+        // published only their aggregate (measured: tools/lookback_probe.py), so kLookWindow predecessors are polled at once.
+        const int d = threadIdx.x;
+        uint32_t excl = 0;
+        if (tile > 0) {
+            int next = tile - 1;                                 // the nearest tile not yet added
+            uint32_t spins = 0;
+#ifdef LA_LOOKBACK_STATS
+            unsigned long long hops = 0, empty = 0;
+            const unsigned long long clk0 = clock64();
+#endif
+            for (;;) {
+                bool done = false;
+                int used = 0;
+#pragma unroll
+                for (int i = 0; i < kLookWindow; ++i) {
+                    const uint32_t tag = (uint32_t)(win[i] >> 32);
+                    const bool ready = (tag & ~3u) == epoch && i < next + 1 && used == i && !done;
+                    if (ready) {
+                        excl += (uint32_t)win[i];
+                        used = i + 1;
+                        done = (tag & 3u) == kStateInclusive;
+                    }
+                }
+#ifdef LA_LOOKBACK_STATS
+                hops += (unsigned long long)used;
+                empty += used == 0 ? 1 : 0;
+#endif
+                if (done) break;
+                next -= used;                                    // tile 0 is always inclusive: next never drops below 0 here
+                if (used == 0) {
+                    if (++spins > kLookbackSpinLimit) { atomicOr(status, kStatusInternal); break; }
+                    __builtin_amdgcn_s_sleep(2);
+                } else {
+                    spins = 0;
+                }
+                const unsigned long long* look = b.tile_state + (int64_t)next * kRadix + d;
+#pragma unroll
+                for (int i = 0; i < kLookWindow; ++i)
+                    win[i] = i <= next ? __hip_atomic_load(look - i * kRadix, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+            }
+#ifdef LA_LOOKBACK_STATS
+            if (d == 0) {
+                atomicAdd(&g_lookback_stats[0], 1ull);
+                atomicAdd(&g_lookback_stats[1], hops);
+                atomicAdd(&g_lookback_stats[2], empty);
+                atomicMax(&g_lookback_stats[3], hops);
+                atomicAdd(&g_lookback_stats[4], (unsigned long long)(clock64() - clk0));
+            }
+#endif
+            __hip_atomic_store(my_state, ((unsigned long long)(epoch | kStateInclusive) << 32) | (excl + count),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        bin_base[d] = b.gbase[pass * kRadix + d] + excl - bin_start[d];
+    }
+    __syncthreads();
+    // the global position of tile-local position j is bin_base[digit of the element at j] + j
+    uint32_t gpos[kItems];
+    if (pass < 4) {
+#pragma unroll
+        for (int it = 0; it < kItems; ++it) {
+            const int j = it * kSortThreads + threadIdx.x;
+            if (j < n_here) {
+                const uint32_t v = s_val[j];
+                gpos[it] = bin_base[digit_of(pass, 0, v)] + (uint32_t)j;
+                vout[gpos[it]] = v;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < kItems; ++it)
+            if (w0 + it * kWave + lane < b.n) s_stage[loc[it]] = key[it];
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < kItems; ++it) {
+            const int j = it * kSortThreads + threadIdx.x;
+            if (j < n_here) kout[gpos[it]] = s_stage[j];
+        }
+    } else {
 #pragma unroll
         for (int it = 0; it < kItems; ++it) {
             const int j = it * kSortThreads + threadIdx.x;
@@ -1012,19 +1326,60 @@ size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 }  // namespace
 
-// Carves the sort's working set for n elements out of the grow-only scratch and zeroes ctl + hist.
-static hipError_t sort_prepare(LargeScratch& scratch, int64_t n, hipStream_t stream, SortBufs* out) {
+// Per device, once (la_create_multi; synchronous): are the pre-values of colliding lanes of a returning LDS atomic in lane
+// order (rank_in_wave)?  The launchers rank with the match form where they are not (or the check could not run).
+static std::atomic<int> g_atomic_rank_ok[32];       // 0 = not checked, 1 = no, 2 = yes
+
+hipError_t large_init_device() {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev < 0 || dev >= 32 || g_atomic_rank_ok[dev].load(std::memory_order_acquire) != 0) return hipSuccess;
+    int verdict = 1;
+    const char* env = getenv("LA_SORT_RANK");                  // "match": never the atomic form (A/B, tests)
+    if (!(env && env[0] == 'm')) {
+        uint32_t* d_bad = nullptr;
+        uint32_t h_bad = 1;
+        if ((e = hipMalloc((void**)&d_bad, sizeof(uint32_t))) != hipSuccess) return e;
+        if ((e = hipMemset(d_bad, 0, sizeof(uint32_t))) == hipSuccess) {
+            hipLaunchKernelGGL(lds_atomic_order_test_kernel, dim3(8), dim3(256), 0, nullptr, d_bad);
+            e = hipMemcpy(&h_bad, d_bad, sizeof(uint32_t), hipMemcpyDeviceToHost);
+        }
+        (void)hipFree(d_bad);
+        if (e != hipSuccess) return e;
+        verdict = h_bad == 0 ? 2 : 1;
+    }
+    g_atomic_rank_ok[dev].store(verdict, std::memory_order_release);
+    return hipSuccess;
+}
+
+int large_atomic_rank_supported() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 32) return 0;
+    return g_atomic_rank_ok[dev].load(std::memory_order_acquire) == 2 ? 1 : 0;
+}
+
+// Carves the sort's working set for n elements out of the grow-only scratch and zeroes what a sort expects zeroed:
+// ctl, hist and -- single-kernel passes -- the arrival tickets and the look-back granules.
+// `multi_kernel`: the four-kernel passes (count, scans, scatter) instead of the single-kernel ones; also taken when a
+// digit count would not fit a granule's 32-bit count with room for the tag arithmetic (n >= 2^30).
+static hipError_t sort_prepare(LargeScratch& scratch, int64_t n, hipStream_t stream, SortBufs* out, bool multi_kernel = false) {
     const int n_tiles = (int)((n + kTile - 1) / kTile);
+    if (n >= ((int64_t)1 << 30)) multi_kernel = true;
+    if (const char* env = getenv("LA_SORT_MULTIKERNEL")) multi_kernel = multi_kernel || atoi(env) != 0;
     size_t off = 0;
     auto carve = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
     const size_t o_ctl = carve(sizeof(SortCtl));
     const size_t o_hist = carve(sizeof(uint32_t) * kDigits * kRadix);
-    const size_t zero_bytes = off;                                  // ctl + hist are zeroed per sort
+    const size_t o_ticket = carve(sizeof(uint32_t) * kDigits);
+    const size_t o_state = carve(multi_kernel ? 0 : sizeof(unsigned long long) * kRadix * (size_t)n_tiles);
+    const size_t zero_bytes = off;                                  // everything up to here is zeroed per sort
+    const size_t o_gbase = carve(sizeof(uint32_t) * kDigits * kRadix);
     const size_t o_k0 = carve(sizeof(uint64_t) * n), o_k1 = carve(sizeof(uint64_t) * n);
     const size_t o_v0 = carve(sizeof(uint32_t) * n), o_v1 = carve(sizeof(uint32_t) * n);
-    const size_t o_to = carve(sizeof(uint32_t) * kRadix * (size_t)n_tiles);
     const int n_groups = (n_tiles + kScanRows - 1) / kScanRows;
-    const size_t o_gs = carve(sizeof(uint32_t) * kRadix * (size_t)n_groups);
+    const size_t o_to = carve(multi_kernel ? sizeof(uint32_t) * kRadix * (size_t)n_tiles : 0);
+    const size_t o_gs = carve(multi_kernel ? sizeof(uint32_t) * kRadix * (size_t)n_groups : 0);
     hipError_t e;
     if (off > scratch.cap) {
         if (scratch.buf) {
@@ -1041,6 +1396,9 @@ static hipError_t sort_prepare(LargeScratch& scratch, int64_t n, hipStream_t str
     SortBufs b{};
     b.ctl = (SortCtl*)(base + o_ctl);
     b.hist = (uint32_t*)(base + o_hist);
+    b.ticket = (uint32_t*)(base + o_ticket);
+    b.tile_state = multi_kernel ? nullptr : (unsigned long long*)(base + o_state);
+    b.gbase = (uint32_t*)(base + o_gbase);
     b.key[0] = (uint64_t*)(base + o_k0);
     b.key[1] = (uint64_t*)(base + o_k1);
     b.val[0] = (uint32_t*)(base + o_v0);
@@ -1050,6 +1408,7 @@ static hipError_t sort_prepare(LargeScratch& scratch, int64_t n, hipStream_t str
     b.n = n;
     b.n_tiles = n_tiles;
     b.n_groups = n_groups;
+    b.atomic_rank = large_atomic_rank_supported();
     *out = b;
     return hipMemsetAsync(base, 0, zero_bytes, stream);
 }
@@ -1059,16 +1418,23 @@ static hipError_t sort_prepare(LargeScratch& scratch, int64_t n, hipStream_t str
 // device-side plan still decides among the launched ones (a launched pass whose digit turns out constant returns at
 // once), and it marks every pass outside the mask as skipped by itself -- the caller guarantees those digits are
 // constant (key bits that cannot be set) or the ids ascending.
-static void sort_run_passes(const SortBufs& b, hipStream_t stream, hipEvent_t planned = nullptr,
+// A pass is ONE launch (onesweep_pass_kernel) -- or four, when the sort was prepared for the multi-kernel form.
+static void sort_run_passes(const SortBufs& b, hipStream_t stream, uint32_t* status, hipEvent_t planned = nullptr,
                             uint32_t pass_mask = (1u << kDigits) - 1) {
     hipLaunchKernelGGL(plan_kernel, dim3(1), dim3(256), 0, stream, b);
     if (planned) (void)hipEventRecord(planned, stream);
     for (int p = 0; p < kDigits; ++p) {
         if (!((pass_mask >> p) & 1u)) continue;
+        if (b.tile_state) {
+            if (b.atomic_rank) hipLaunchKernelGGL(onesweep_pass_kernel<true>, dim3(b.n_tiles), dim3(kSortThreads), 0, stream, b, p, status);
+            else hipLaunchKernelGGL(onesweep_pass_kernel<false>, dim3(b.n_tiles), dim3(kSortThreads), 0, stream, b, p, status);
+            continue;
+        }
         hipLaunchKernelGGL(tile_count_kernel, dim3(b.n_tiles < 2048 ? b.n_tiles : 2048), dim3(kSortThreads), 0, stream, b, p);
         hipLaunchKernelGGL(scan_group_sums_kernel, dim3(b.n_groups), dim3(kRadix), 0, stream, b, p);
         hipLaunchKernelGGL(scan_offsets_kernel, dim3(b.n_groups), dim3(kRadix), 0, stream, b, p);
-        hipLaunchKernelGGL(tile_scatter_kernel, dim3(b.n_tiles), dim3(kSortThreads), 0, stream, b, p);
+        if (b.atomic_rank) hipLaunchKernelGGL(tile_scatter_kernel<true>, dim3(b.n_tiles), dim3(kSortThreads), 0, stream, b, p);
+        else hipLaunchKernelGGL(tile_scatter_kernel<false>, dim3(b.n_tiles), dim3(kSortThreads), 0, stream, b, p);
     }
 }
 
@@ -1083,7 +1449,7 @@ hipError_t large_topic_launch(LargeScratch& scratch, const LargeArgs& a, bool ar
     if (n > 0x7FFFFFFF || a.n_cons > kLargeMaxConsumers) return hipErrorInvalidValue;
     SortBufs b{};
     hipError_t e;
-    if ((e = sort_prepare(scratch, n, stream, &b)) != hipSuccess) return e;
+    if ((e = sort_prepare(scratch, n, stream, &b, a.sort_multi_kernel != 0)) != hipSuccess) return e;
     int grid = (int)((n + 255) / 256);
     if (grid > 2048) grid = 2048;
     LargeProfile& pf = scratch.prof;
@@ -1100,7 +1466,7 @@ hipError_t large_topic_launch(LargeScratch& scratch, const LargeArgs& a, bool ar
         ~Done() { if (on) (void)hipEventRecord(pf.ev[3], st); }
     } done{pf, profile, stream};
     hipLaunchKernelGGL(build_keys_kernel, dim3(grid), dim3(256), 0, stream, a, b);
-    sort_run_passes(b, stream, profile ? pf.ev[1] : nullptr);
+    sort_run_passes(b, stream, a.status, profile ? pf.ev[1] : nullptr);
     if (profile) (void)hipEventRecord(pf.ev[2], stream);
     hipLaunchKernelGGL(emit_ids_kernel, dim3(grid), dim3(256), 0, stream, a, b, a.n_cons == 0 ? 1 : 0);
     if ((e = hipGetLastError()) != hipSuccess) return e;
@@ -1133,7 +1499,7 @@ hipError_t large_topic_launch(LargeScratch& scratch, const LargeArgs& a, bool ar
 hipError_t group_by_member_launch(LargeScratch& scratch, int64_t n, int32_t n_members, int64_t n_topics,
                                   const int64_t* part_off, const int32_t* out_partition, const int32_t* member_rank,
                                   int64_t* member_off, int32_t* grouped_topic, int32_t* grouped_partition,
-                                  int32_t* grouped_entry, hipStream_t stream) {
+                                  int32_t* grouped_entry, uint32_t* status, hipStream_t stream) {
     if (n < 0 || n > 0x7FFFFFFF || n_members < 0) return hipErrorInvalidValue;
     hipError_t e;
     if (n == 0) return hipMemsetAsync(member_off, 0, sizeof(int64_t) * ((size_t)n_members + 1), stream);
@@ -1147,11 +1513,22 @@ hipError_t group_by_member_launch(LargeScratch& scratch, int64_t n, int32_t n_me
     // cost four empty launches (~50 launches, ~190 us, for a 100-partition rebalance).
     uint32_t mask = 0;
     for (int d = 0; d < 8 && ((uint64_t)n_members >> (8 * d)) != 0; ++d) mask |= 1u << (4 + d);
-    sort_run_passes(b, stream, nullptr, mask);
+    sort_run_passes(b, stream, status, nullptr, mask);
     hipLaunchKernelGGL(member_emit_kernel, dim3(grid), dim3(256), 0, stream, b, n_members, n_topics, part_off,
                        out_partition, member_off, grouped_topic, grouped_partition, grouped_entry);
     return hipGetLastError();
 }
+
+#ifdef LA_LOOKBACK_STATS
+extern "C" __attribute__((visibility("default"))) int la_debug_lookback_stats(unsigned long long* out, int reset) {
+    hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(g_lookback_stats), sizeof(g_lookback_stats));
+    if (e == hipSuccess && reset) {
+        unsigned long long zero[8] = {};
+        e = hipMemcpyToSymbol(HIP_SYMBOL(g_lookback_stats), zero, sizeof zero);
+    }
+    return e == hipSuccess ? 0 : -3;
+}
+#endif
 
 #ifdef LA_ROUND_CLOCKS
 extern "C" __attribute__((visibility("default"))) int la_debug_round_clocks(unsigned long long* out, int reset) {

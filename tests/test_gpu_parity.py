@@ -681,10 +681,34 @@ def test_large_sample_sort_rounds(ctx, p, c, kind):
                            np.zeros(p, np.int64), lag, np.asarray(co, np.int64), ranks, p, c)
     exp = oracle.assign_flat(w.part_off, w.partition_id, w.lag, w.cons_off, w.cons_rank)
     for flags, what in ((0, "sample sort"), (N.LA_FLAG_NO_SAMPLE_SORT, "full network"),
-                        (N.LA_FLAG_SAMPLE_TIGHT, "interleaved")):
+                        (N.LA_FLAG_SAMPLE_TIGHT, "interleaved"), (N.LA_FLAG_SORT_MULTIKERNEL, "four-kernel radix passes")):
         got = _run_device(ctx, w, N.LA_ALGO_AUTO, use_lag=True, flags=flags)
         for g, e, name in zip(got, exp, ("partition order", "member", "totals")):
             np.testing.assert_array_equal(g, e, err_msg="%s, %s" % (name, what))
+
+
+@pytest.mark.parametrize("p,c,kind,shuffled", [
+    (4096 * 300 + 17, 5, "u40", True), (3_000_000, 7, "pareto", True), (4096 * 129, 3, "ties", True),
+    (2_500_000, 64, "u63", True), (1_000_000, 2, "zero", False), (5_000_001, 1, "u40", True),
+])
+def test_large_radix_pass_forms_agree(ctx, p, c, kind, shuffled):
+    """The device radix sort as single-kernel passes (decoupled look-back: a tile's digit offsets come from the
+    granules the tiles before it publish) and as four-kernel passes (tile counts, scans, scatter): the same result, the
+    oracle's, on topics of hundreds to thousands of tiles -- ragged last tile, one consumer, ties, ids already ascending."""
+    if kind == "pareto":
+        w = _pareto_topic(p + c, p, c)
+    else:
+        po, pid, lag, co, ranks = _single_topic(p ^ c, p, c, kind, shuffled=shuffled)
+        w = synth.Workload(kind, 1, np.asarray(po, np.int64), pid, np.zeros(p, np.int64), lag.copy(),
+                           np.zeros(p, np.int64), lag, np.asarray(co, np.int64), ranks, p, c)
+    exp = oracle.assign_flat(w.part_off, w.partition_id, w.lag, w.cons_off, w.cons_rank)
+    for rep in range(3):                                      # the look-back is a race by design: more than one run
+        got = _run_device(ctx, w, N.LA_ALGO_AUTO, use_lag=True)
+        for g, e, name in zip(got, exp, ("partition order", "member", "totals")):
+            np.testing.assert_array_equal(g, e, err_msg="%s, single-kernel passes, run %d" % (name, rep))
+    got = _run_device(ctx, w, N.LA_ALGO_AUTO, use_lag=True, flags=N.LA_FLAG_SORT_MULTIKERNEL)
+    for g, e, name in zip(got, exp, ("partition order", "member", "totals")):
+        np.testing.assert_array_equal(g, e, err_msg="%s, four-kernel passes" % name)
 
 
 def test_large_phase_times(ctx):
