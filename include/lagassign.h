@@ -18,6 +18,7 @@
  *   la_assign_batch_device  the same two, on buffers already resident in HBM
  *   la_group_by_member      building every member's List<TopicPartition>      Main.java:171-174, :264
  *   la_create_multi         the per-topic loop, sharded over the GPUs of a node Main.java:177-184
+ *   la_assign_batch_device_on  the same loop for a caller whose data already lives on every GPU
  *   la_plan_shards          (which topics of that loop each shard takes)
  *   la_last_phase_times     nothing: measurement hook (radix-sort phase against the HBM roofline)
  *
@@ -130,8 +131,9 @@ int la_create(la_ctx **out, int device_id, unsigned flags);
  * offset in the caller's output arrays -- that IS the reassembly of the global assignment; no device ever needs
  * another device's topics.  n_devices = 0 (device_ids NULL) = every device of the node.  An id may appear more than
  * once (several logical shards on one GPU; how the tests exercise the split on a one-GPU box).
- * The device-buffer entry points (la_assign_batch_device, la_group_by_member_device, la_sync, la_stream) and
- * la_compute_lag / la_group_by_member use the first device. */
+ * The device-buffer entry points without a shard argument (la_assign_batch_device, la_group_by_member_device, la_sync,
+ * la_stream) use the first device; their *_on forms take any shard.  la_compute_lag and la_group_by_member split large
+ * inputs over the shards like the assign calls do. */
 int la_create_multi(la_ctx **out, int n_devices, const int *device_ids, unsigned flags);
 void la_destroy(la_ctx *ctx);
 
@@ -249,6 +251,16 @@ int la_assign_batch_device(la_ctx *ctx, const la_device_batch *batch, void *stre
 /* Waits for `stream` and returns LA_OK or the first device-detected error. */
 int la_sync(la_ctx *ctx, void *stream);
 
+/* The device entry points on ANY shard of a multi-device context: a caller that keeps its data in HBM drives all the
+ * node's GPUs from one context (la_assign_batch_device / la_sync / la_stream are shard 0's).  The batch's pointers must
+ * belong to la_shard_device(ctx, shard); `stream` is a stream of that device (la_shard_stream gives the shard's own).
+ * Shards are independent -- their calls may be enqueued back to back from one host thread and run concurrently, which
+ * is the per-topic loop of assign(Map,Map) (Main.java:177-184) over several devices with the data already resident:
+ * split the topics with la_plan_shards, give shard i the range [bounds[i], bounds[i+1]), sync every shard. */
+void *la_shard_stream(la_ctx *ctx, int shard);
+int la_assign_batch_device_on(la_ctx *ctx, int shard, const la_device_batch *batch, void *stream);
+int la_sync_on(la_ctx *ctx, int shard, void *stream);
+
 /* Phase times of the first large-path topic (one topic beyond the block path: device-wide radix sort, then the
  * one-workgroup greedy) of the last la_assign_batch_device call that carried LA_FLAG_PROFILE.  Measurement only:
  * it is how bench.py reports the radix-sort phase against the HBM roofline from inside one run.  Waits for that
@@ -296,6 +308,13 @@ int la_group_by_member_device(la_ctx *ctx, int32_t n_topics, int64_t n_partition
                               const int32_t *d_out_member_rank, int32_t n_members,
                               int64_t *d_member_off, int32_t *d_grouped_topic, int32_t *d_grouped_partition,
                               void *stream);
+
+/* la_group_by_member_device on shard `shard` (buffers on that shard's device). */
+int la_group_by_member_device_on(la_ctx *ctx, int shard, int32_t n_topics, int64_t n_partitions,
+                                 const int64_t *d_part_off, const int32_t *d_out_partition,
+                                 const int32_t *d_out_member_rank, int32_t n_members,
+                                 int64_t *d_member_off, int32_t *d_grouped_topic, int32_t *d_grouped_partition,
+                                 void *stream);
 
 #ifdef __cplusplus
 }

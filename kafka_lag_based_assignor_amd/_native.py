@@ -30,6 +30,7 @@ EXPORTED_SYMBOLS = (
     "la_group_by_member", "la_group_by_member_device", "la_group_last_by_member",
     "la_device_count", "la_create_multi", "la_shard_count", "la_shard_device", "la_plan_shards",
     "la_last_shard_bounds", "la_host_alloc", "la_host_free", "la_last_phase_times", "la_device_features",
+    "la_shard_stream", "la_assign_batch_device_on", "la_sync_on", "la_group_by_member_device_on",
 )
 
 _i64p = ctypes.POINTER(ctypes.c_int64)
@@ -138,6 +139,16 @@ def load() -> ctypes.CDLL:
     L.la_group_by_member_device.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_void_p,
                                             ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p,
                                             ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+    L.la_shard_stream.restype = ctypes.c_void_p
+    L.la_shard_stream.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    L.la_assign_batch_device_on.restype = ctypes.c_int
+    L.la_assign_batch_device_on.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+    L.la_sync_on.restype = ctypes.c_int
+    L.la_sync_on.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+    L.la_group_by_member_device_on.restype = ctypes.c_int
+    L.la_group_by_member_device_on.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int32, ctypes.c_int64,
+                                               ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32,
+                                               ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
     _lib = L
     return L
 
@@ -330,19 +341,22 @@ class Context:
 
     def group_by_member_device(self, n_topics: int, n_partitions: int, d_part_off: int, d_out_partition: int,
                                d_out_member_rank: int, n_members: int, d_member_off: int, d_grouped_topic: int,
-                               d_grouped_partition: int, stream: int = 0) -> None:
-        self._check(self._lib.la_group_by_member_device(self._h, n_topics, n_partitions, d_part_off,
-                                                        d_out_partition, d_out_member_rank, n_members,
-                                                        d_member_off, d_grouped_topic, d_grouped_partition,
-                                                        ctypes.c_void_p(stream)))
+                               d_grouped_partition: int, stream: int = 0, shard: int = 0) -> None:
+        self._check(self._lib.la_group_by_member_device_on(self._h, shard, n_topics, n_partitions, d_part_off,
+                                                           d_out_partition, d_out_member_rank, n_members,
+                                                           d_member_off, d_grouped_topic, d_grouped_partition,
+                                                           ctypes.c_void_p(stream)))
 
     # -- device-resident entry point ------------------------------------------------
-    def assign_batch_device(self, batch: DeviceBatch, stream: int = 0) -> None:
-        """Enqueue on `stream` (a hipStream_t handle as an int; 0 = HIP's default stream)."""
-        self._check(self._lib.la_assign_batch_device(self._h, ctypes.byref(batch), ctypes.c_void_p(stream)))
+    def assign_batch_device(self, batch: DeviceBatch, stream: int = 0, shard: int = 0) -> None:
+        """Enqueue on `stream` (a hipStream_t handle as an int; 0 = HIP's default stream) of shard `shard`'s device."""
+        self._check(self._lib.la_assign_batch_device_on(self._h, shard, ctypes.byref(batch), ctypes.c_void_p(stream)))
 
-    def sync(self, stream: int = 0) -> None:
-        self._check(self._lib.la_sync(self._h, ctypes.c_void_p(stream)))
+    def sync(self, stream: int = 0, shard: int = 0) -> None:
+        self._check(self._lib.la_sync_on(self._h, shard, ctypes.c_void_p(stream)))
+
+    def shard_stream(self, shard: int) -> int:
+        return int(self._lib.la_shard_stream(self._h, shard) or 0)
 
     def last_phase_times(self) -> PhaseTimes:
         """Phase times of the large-path topic of the last assign_batch_device call with LA_FLAG_PROFILE."""

@@ -1126,23 +1126,38 @@ LA_API int la_compute_lag(la_ctx* ctx, int64_t n, const int64_t* begin_off, cons
         if (!end_off || !committed_off || !out_lag) return fail(ctx, LA_EINVAL, "null buffer");
         const bool latest = reset_mode == LA_RESET_LATEST;
         if (!latest && !begin_off) return fail(ctx, LA_EINVAL, "begin_off is required unless reset_mode is LA_RESET_LATEST");
-        Shard& sh = ctx->shards[0];                    // elementwise and PCIe-bound: the first device only
         ctx->last_valid = false;                       // reuses the scratch the last results live in
-        LA_HIP(ctx, hipSetDevice(sh.device));
-        const size_t nb = (size_t)n * 8;
-        int rc;
-        if ((rc = reserve(ctx, sh.end, nb)) || (rc = reserve(ctx, sh.committed, nb)) ||
-            (rc = reserve(ctx, sh.begin, latest ? 16 : nb)) || (rc = reserve(ctx, sh.out_total, nb)))
-            return rc;
-        hipStream_t st = sh.lanes[0].stream;
-        LA_HIP(ctx, hipMemcpyAsync(sh.end.p, end_off, nb, hipMemcpyHostToDevice, st));
-        LA_HIP(ctx, hipMemcpyAsync(sh.committed.p, committed_off, nb, hipMemcpyHostToDevice, st));
-        if (!latest) LA_HIP(ctx, hipMemcpyAsync(sh.begin.p, begin_off, nb, hipMemcpyHostToDevice, st));
-        LA_HIP(ctx, la::lag_launch(n, latest ? nullptr : (const int64_t*)sh.begin.p, (const int64_t*)sh.end.p,
-                                   (const int64_t*)sh.committed.p, latest, (int64_t*)sh.out_total.p, st));
-        LA_HIP(ctx, hipMemcpyAsync(out_lag, sh.out_total.p, nb, hipMemcpyDeviceToHost, st));
-        LA_HIP(ctx, hipStreamSynchronize(st));
-        return LA_OK;
+        // elementwise and PCIe-bound: contiguous element ranges over the shards (every device has its own link), each on
+        // its shard's first lane
+        int S = (int)ctx->shards.size();
+        if (!ctx->split_always) {
+            const int64_t by_size = n / (4 * kMinShardPartitions);
+            if (by_size < S) S = by_size < 1 ? 1 : (int)by_size;
+        }
+        if ((int64_t)S > n) S = (int)n;
+        auto run_range = [&](int i) -> int {
+            Shard& sh = ctx->shards[(size_t)i];
+            const int64_t e0 = n / S * i + (n % S) * i / S, e1 = n / S * (i + 1) + (n % S) * (i + 1) / S;
+            const int64_t m = e1 - e0;
+            if (m <= 0) return LA_OK;
+            LA_HIP(ctx, hipSetDevice(sh.device));
+            const size_t nb = (size_t)m * 8;
+            int rc;
+            if ((rc = reserve(ctx, sh.end, nb)) || (rc = reserve(ctx, sh.committed, nb)) ||
+                (rc = reserve(ctx, sh.begin, latest ? 16 : nb)) || (rc = reserve(ctx, sh.out_total, nb)))
+                return rc;
+            hipStream_t st = sh.lanes[0].stream;
+            LA_HIP(ctx, hipMemcpyAsync(sh.end.p, end_off + e0, nb, hipMemcpyHostToDevice, st));
+            LA_HIP(ctx, hipMemcpyAsync(sh.committed.p, committed_off + e0, nb, hipMemcpyHostToDevice, st));
+            if (!latest) LA_HIP(ctx, hipMemcpyAsync(sh.begin.p, begin_off + e0, nb, hipMemcpyHostToDevice, st));
+            LA_HIP(ctx, la::lag_launch(m, latest ? nullptr : (const int64_t*)sh.begin.p, (const int64_t*)sh.end.p,
+                                       (const int64_t*)sh.committed.p, latest, (int64_t*)sh.out_total.p, st));
+            LA_HIP(ctx, hipMemcpyAsync(out_lag + e0, sh.out_total.p, nb, hipMemcpyDeviceToHost, st));
+            LA_HIP(ctx, hipStreamSynchronize(st));
+            return LA_OK;
+        };
+        if (S == 1) return run_range(0);
+        return run_workers(ctx, S, run_range);
     } catch (...) {
         return fail(ctx, LA_ENOMEM, "exception in la_compute_lag");
     }
@@ -1174,11 +1189,12 @@ LA_API int la_assign_batch_lags(la_ctx* ctx, int32_t n_topics, const int64_t* pa
     }
 }
 
-LA_API int la_assign_batch_device(la_ctx* ctx, const la_device_batch* batch, void* stream) {
+LA_API int la_assign_batch_device_on(la_ctx* ctx, int shard, const la_device_batch* batch, void* stream) {
     if (!ctx) return LA_EINVAL;
     try {
+        if (shard < 0 || shard >= (int)ctx->shards.size()) return fail(ctx, LA_EINVAL, "shard %d of %d", shard, (int)ctx->shards.size());
         if (!batch) return fail(ctx, LA_EINVAL, "batch is NULL");
-        Shard& sh = ctx->shards[0];                    // device buffers belong to one device: the context's first
+        Shard& sh = ctx->shards[(size_t)shard];        // device buffers belong to one device: this shard's
         LA_HIP(ctx, hipSetDevice(sh.device));
         return enqueue_batch(ctx, sh.lanes[0], batch, (hipStream_t)stream);
     } catch (...) {
@@ -1186,21 +1202,39 @@ LA_API int la_assign_batch_device(la_ctx* ctx, const la_device_batch* batch, voi
     }
 }
 
-LA_API void* la_stream(la_ctx* ctx) { return ctx ? (void*)ctx->shards[0].lanes[0].stream : nullptr; }
+LA_API int la_assign_batch_device(la_ctx* ctx, const la_device_batch* batch, void* stream) {
+    return la_assign_batch_device_on(ctx, 0, batch, stream);
+}
+
+LA_API void* la_shard_stream(la_ctx* ctx, int shard) {
+    if (!ctx || shard < 0 || shard >= (int)ctx->shards.size()) return nullptr;
+    return (void*)ctx->shards[(size_t)shard].lanes[0].stream;
+}
+
+LA_API void* la_stream(la_ctx* ctx) { return la_shard_stream(ctx, 0); }
 
 LA_API int la_group_by_member_device(la_ctx* ctx, int32_t n_topics, int64_t n_partitions, const int64_t* d_part_off,
                                      const int32_t* d_out_partition, const int32_t* d_out_member_rank,
                                      int32_t n_members, int64_t* d_member_off, int32_t* d_grouped_topic,
                                      int32_t* d_grouped_partition, void* stream) {
+    return la_group_by_member_device_on(ctx, 0, n_topics, n_partitions, d_part_off, d_out_partition, d_out_member_rank,
+                                        n_members, d_member_off, d_grouped_topic, d_grouped_partition, stream);
+}
+
+LA_API int la_group_by_member_device_on(la_ctx* ctx, int shard, int32_t n_topics, int64_t n_partitions,
+                                        const int64_t* d_part_off, const int32_t* d_out_partition,
+                                        const int32_t* d_out_member_rank, int32_t n_members, int64_t* d_member_off,
+                                        int32_t* d_grouped_topic, int32_t* d_grouped_partition, void* stream) {
     if (!ctx) return LA_EINVAL;
     try {
+        if (shard < 0 || shard >= (int)ctx->shards.size()) return fail(ctx, LA_EINVAL, "shard %d of %d", shard, (int)ctx->shards.size());
         if (n_topics < 0 || n_partitions < 0 || n_members < 0) return fail(ctx, LA_EINVAL, "negative size");
         if (!d_member_off) return fail(ctx, LA_EINVAL, "member_off is NULL");
         if (n_partitions > 0 && (!d_out_partition || !d_out_member_rank || !d_grouped_partition ||
                                  (d_grouped_topic && !d_part_off)))
             return fail(ctx, LA_EINVAL, "null buffer");
         if (n_partitions > 0x7FFFFFFF) return fail(ctx, LA_ESHAPE, "at most 2^31-1 entries are supported");
-        Shard& sh = ctx->shards[0];
+        Shard& sh = ctx->shards[(size_t)shard];
         LA_HIP(ctx, hipSetDevice(sh.device));
         hipError_t e = la::group_by_member_launch(sh.lanes[0].large, n_partitions, n_members, n_topics, d_part_off,
                                                   d_out_partition, d_out_member_rank, d_member_off,
@@ -1214,6 +1248,115 @@ LA_API int la_group_by_member_device(la_ctx* ctx, int32_t n_topics, int64_t n_pa
     }
 }
 
+// Every member's list from the results the shards hold (Shard::last_*): one shard -> its CSR straight into the caller's
+// arrays; several -> grouped per shard on its device, merged by offset on the host.
+static int group_last_impl(la_ctx* ctx, int32_t n_members, int64_t* member_off, int32_t* grouped_topic,
+                           int32_t* grouped_partition) {
+    const int S = ctx->last_shards;
+    int64_t n = 0;
+    for (int i = 0; i < S; ++i) n += ctx->shards[(size_t)i].last_n;
+    if (!member_off || (n > 0 && !grouped_partition)) return fail(ctx, LA_EINVAL, "null buffer");
+    const size_t mb = ((size_t)n_members + 1) * 8;
+    if (S == 1) {
+        // one shard: its CSR is the answer, straight into the caller's arrays
+        Shard& sh = ctx->shards[0];
+        LA_HIP(ctx, hipSetDevice(sh.device));
+        hipStream_t st = sh.lanes[0].stream;
+        const size_t nb4 = (size_t)n * 4;
+        const size_t o_topic = (mb + 16 + 255) & ~(size_t)255, o_part = (o_topic + nb4 + 16 + 255) & ~(size_t)255;
+        const size_t g_total = o_part + nb4 + 16;
+        if (g_total <= kSmallBytes) {
+            // small batch: the CSR is built in one staging buffer and crosses in one copy (see assign_small)
+            int rc;
+            if ((rc = reserve(ctx, sh.small_g, g_total)) || (rc = reserve_host(ctx, sh.small_gh, g_total))) return rc;
+            char* d = (char*)sh.small_g.p;
+            char* h = (char*)sh.small_gh.p;
+            if ((rc = group_shard_device(ctx, sh, n_members, grouped_topic != nullptr, (int64_t*)d,
+                                         (int32_t*)(d + o_topic), (int32_t*)(d + o_part))))
+                return rc;
+            LA_HIP(ctx, hipMemcpyAsync(h, d, g_total, hipMemcpyDeviceToHost, st));
+            LA_HIP(ctx, hipStreamSynchronize(st));
+            memcpy(member_off, h, mb);
+            if (n) {
+                memcpy(grouped_partition, h + o_part, nb4);
+                if (grouped_topic) memcpy(grouped_topic, h + o_topic, nb4);
+            }
+            return LA_OK;
+        }
+        if (int rc = group_shard_device(ctx, sh, n_members, grouped_topic != nullptr)) return rc;
+        LA_HIP(ctx, hipMemcpyAsync(member_off, sh.out_total.p, mb, hipMemcpyDeviceToHost, st));
+        if (n) {
+            LA_HIP(ctx, hipMemcpyAsync(grouped_partition, sh.pid.p, nb4, hipMemcpyDeviceToHost, st));
+            if (grouped_topic) LA_HIP(ctx, hipMemcpyAsync(grouped_topic, sh.cons_rank.p, nb4, hipMemcpyDeviceToHost, st));
+        }
+        LA_HIP(ctx, hipStreamSynchronize(st));
+        return LA_OK;
+    }
+    // Several shards.  A member's list is its per-topic appends in topic order (Main.java:177-184, :264), and the
+    // shards are contiguous topic ranges: the list is the concatenation, in shard order, of the shards' lists.
+    // Phase 1, per shard in parallel: group on the device, CSR into pinned staging.  Then the global offsets
+    // (a scan over members x shards on the host), then phase 2, per shard in parallel: every member's slice to
+    // its place in the caller's arrays, topic indices moved from shard-local to the caller's numbering.
+    int rc = run_workers(ctx, S, [&](int i) -> int {
+        Shard& sh = ctx->shards[(size_t)i];
+        if (sh.last_topics == 0) return LA_OK;
+        LA_HIP(ctx, hipSetDevice(sh.device));
+        const size_t nb4 = (size_t)sh.last_n * 4;
+        int r;
+        if ((r = reserve_host(ctx, sh.g_off, mb)) || (r = reserve_host(ctx, sh.g_part, nb4 + 16)) ||
+            (grouped_topic && (r = reserve_host(ctx, sh.g_topic, nb4 + 16))))
+            return r;
+        if ((r = group_shard_device(ctx, sh, n_members, grouped_topic != nullptr))) return r;
+        hipStream_t st = sh.lanes[0].stream;
+        LA_HIP(ctx, hipMemcpyAsync(sh.g_off.p, sh.out_total.p, mb, hipMemcpyDeviceToHost, st));
+        if (sh.last_n) {
+            LA_HIP(ctx, hipMemcpyAsync(sh.g_part.p, sh.pid.p, nb4, hipMemcpyDeviceToHost, st));
+            if (grouped_topic) LA_HIP(ctx, hipMemcpyAsync(sh.g_topic.p, sh.cons_rank.p, nb4, hipMemcpyDeviceToHost, st));
+        }
+        LA_HIP(ctx, hipStreamSynchronize(st));
+        return LA_OK;
+    });
+    if (rc) return rc;
+    // group g = 0 is "no consumer" (rank -1: the entries before member_off[0]), g = r + 1 is member r
+    const size_t G = (size_t)n_members + 1;
+    std::vector<int64_t> base((size_t)S * G);          // destination of shard i's slice of group g
+    {
+        int64_t run = 0;
+        for (size_t g = 0; g < G; ++g) {
+            if (g >= 1) member_off[g - 1] = run;
+            for (int i = 0; i < S; ++i) {
+                const Shard& sh = ctx->shards[(size_t)i];
+                base[(size_t)i * G + g] = run;
+                if (sh.last_topics == 0) continue;
+                const int64_t* so = (const int64_t*)sh.g_off.p;
+                const int64_t lo = g == 0 ? 0 : so[g - 1], hi = g == G - 1 ? sh.last_n : so[g];
+                run += hi - lo;
+            }
+        }
+        member_off[n_members] = run;
+    }
+    rc = run_workers(ctx, S, [&](int i) -> int {
+        const Shard& sh = ctx->shards[(size_t)i];
+        if (sh.last_topics == 0 || sh.last_n == 0) return LA_OK;
+        const int64_t* so = (const int64_t*)sh.g_off.p;
+        const int32_t* sp = (const int32_t*)sh.g_part.p;
+        const int32_t* stp = (const int32_t*)sh.g_topic.p;
+        for (size_t g = 0; g < G; ++g) {
+            const int64_t lo = g == 0 ? 0 : so[g - 1], hi = g == G - 1 ? sh.last_n : so[g];
+            if (hi <= lo) continue;
+            const int64_t dst = base[(size_t)i * G + g];
+            memcpy(grouped_partition + dst, sp + lo, (size_t)(hi - lo) * 4);
+            if (grouped_topic) {
+                int32_t* gt = grouped_topic + dst;
+                const int32_t t0 = sh.last_t0;
+                for (int64_t j = lo; j < hi; ++j) gt[j - lo] = stp[j] + t0;
+            }
+        }
+        return LA_OK;
+    });
+    return rc;
+}
+
 LA_API int la_group_by_member(la_ctx* ctx, int32_t n_topics, const int64_t* part_off, const int32_t* out_partition,
                               const int32_t* out_member_rank, int32_t n_members, int64_t* member_off,
                               int32_t* grouped_topic, int32_t* grouped_partition) {
@@ -1225,6 +1368,49 @@ LA_API int la_group_by_member(la_ctx* ctx, int32_t n_topics, const int64_t* part
         const int64_t n = n_topics > 0 ? part_off[n_topics] : 0;
         if (n < 0) return fail(ctx, LA_EINVAL, "part_off decreases");
         if (n > 0 && (!out_partition || !out_member_rank || !grouped_partition)) return fail(ctx, LA_EINVAL, "null buffer");
+        // A large input is split like an assign call's: contiguous topic ranges over the shards (la_plan_shards), each
+        // grouped on its own device, the lists concatenated in shard order (a member's list is its per-topic appends in
+        // topic order, Main.java:177-184, :264) -- the code la_group_last_by_member runs on results already resident.
+        int S = (int)ctx->shards.size();
+        if (!ctx->split_always) {
+            const int64_t by_size = n / (4 * kMinShardPartitions);
+            if (by_size < S) S = by_size < 1 ? 1 : (int)by_size;
+        }
+        if (S > n_topics) S = n_topics;
+        if (S > 1) {
+            for (int32_t t = 0; t < n_topics; ++t)
+                if (part_off[t + 1] < part_off[t]) return fail(ctx, LA_EINVAL, "part_off decreases");
+            plan_ranges(part_off, 0, n_topics, S, ctx->last_bounds);
+            ctx->last_shards = S;
+            int rc = run_workers(ctx, S, [&](int i) -> int {
+                Shard& sh = ctx->shards[(size_t)i];
+                const int32_t t0 = ctx->last_bounds[i], t1 = ctx->last_bounds[i + 1];
+                const int64_t p0 = part_off[t0], m = part_off[t1] - p0;
+                sh.last_t0 = t0; sh.last_topics = t1 - t0; sh.last_p0 = p0; sh.last_n = m;
+                if (t1 == t0) return LA_OK;
+                LA_HIP(ctx, hipSetDevice(sh.device));
+                const size_t tb = (size_t)(t1 - t0 + 1) * 8, nb4 = (size_t)m * 4;
+                int r;
+                if ((r = reserve(ctx, sh.part_off, tb + 16)) || (r = reserve(ctx, sh.out_pid, nb4 + 16)) ||
+                    (r = reserve(ctx, sh.out_rank, nb4 + 16)))
+                    return r;
+                sh.local_part_off.resize((size_t)(t1 - t0) + 1);
+                for (int32_t t = 0; t <= t1 - t0; ++t) sh.local_part_off[(size_t)t] = part_off[t0 + t] - p0;
+                hipStream_t st = sh.lanes[0].stream;
+                LA_HIP(ctx, hipMemcpyAsync(sh.part_off.p, sh.local_part_off.data(), tb, hipMemcpyHostToDevice, st));
+                if (m) {
+                    LA_HIP(ctx, hipMemcpyAsync(sh.out_pid.p, out_partition + p0, nb4, hipMemcpyHostToDevice, st));
+                    LA_HIP(ctx, hipMemcpyAsync(sh.out_rank.p, out_member_rank + p0, nb4, hipMemcpyHostToDevice, st));
+                }
+                LA_HIP(ctx, hipStreamSynchronize(st));           // local_part_off is read by the copy until here
+                sh.last_part_off = (const int64_t*)sh.part_off.p;
+                sh.last_out_pid = (const int32_t*)sh.out_pid.p;
+                sh.last_out_rank = (const int32_t*)sh.out_rank.p;
+                return LA_OK;
+            });
+            if (rc) return rc;
+            return group_last_impl(ctx, n_members, member_off, grouped_topic, grouped_partition);
+        }
         Shard& sh = ctx->shards[0];                    // one stable sort of the whole array: the first device
         LA_HIP(ctx, hipSetDevice(sh.device));
         const size_t nb4 = (size_t)n * 4, tb = (size_t)(n_topics + 1) * 8, mb = ((size_t)n_members + 1) * 8;
@@ -1264,109 +1450,7 @@ LA_API int la_group_last_by_member(la_ctx* ctx, int32_t n_members, int64_t* memb
         if (!ctx->last_valid)
             return fail(ctx, LA_EINVAL, "no result of la_assign_batch / la_assign_batch_lags is held on the device");
         if (n_members < 0) return fail(ctx, LA_EINVAL, "negative size");
-        const int S = ctx->last_shards;
-        int64_t n = 0;
-        for (int i = 0; i < S; ++i) n += ctx->shards[(size_t)i].last_n;
-        if (!member_off || (n > 0 && !grouped_partition)) return fail(ctx, LA_EINVAL, "null buffer");
-        const size_t mb = ((size_t)n_members + 1) * 8;
-        if (S == 1) {
-            // one shard: its CSR is the answer, straight into the caller's arrays
-            Shard& sh = ctx->shards[0];
-            LA_HIP(ctx, hipSetDevice(sh.device));
-            hipStream_t st = sh.lanes[0].stream;
-            const size_t nb4 = (size_t)n * 4;
-            const size_t o_topic = (mb + 16 + 255) & ~(size_t)255, o_part = (o_topic + nb4 + 16 + 255) & ~(size_t)255;
-            const size_t g_total = o_part + nb4 + 16;
-            if (g_total <= kSmallBytes) {
-                // small batch: the CSR is built in one staging buffer and crosses in one copy (see assign_small)
-                int rc;
-                if ((rc = reserve(ctx, sh.small_g, g_total)) || (rc = reserve_host(ctx, sh.small_gh, g_total))) return rc;
-                char* d = (char*)sh.small_g.p;
-                char* h = (char*)sh.small_gh.p;
-                if ((rc = group_shard_device(ctx, sh, n_members, grouped_topic != nullptr, (int64_t*)d,
-                                             (int32_t*)(d + o_topic), (int32_t*)(d + o_part))))
-                    return rc;
-                LA_HIP(ctx, hipMemcpyAsync(h, d, g_total, hipMemcpyDeviceToHost, st));
-                LA_HIP(ctx, hipStreamSynchronize(st));
-                memcpy(member_off, h, mb);
-                if (n) {
-                    memcpy(grouped_partition, h + o_part, nb4);
-                    if (grouped_topic) memcpy(grouped_topic, h + o_topic, nb4);
-                }
-                return LA_OK;
-            }
-            if (int rc = group_shard_device(ctx, sh, n_members, grouped_topic != nullptr)) return rc;
-            LA_HIP(ctx, hipMemcpyAsync(member_off, sh.out_total.p, mb, hipMemcpyDeviceToHost, st));
-            if (n) {
-                LA_HIP(ctx, hipMemcpyAsync(grouped_partition, sh.pid.p, nb4, hipMemcpyDeviceToHost, st));
-                if (grouped_topic) LA_HIP(ctx, hipMemcpyAsync(grouped_topic, sh.cons_rank.p, nb4, hipMemcpyDeviceToHost, st));
-            }
-            LA_HIP(ctx, hipStreamSynchronize(st));
-            return LA_OK;
-        }
-        // Several shards.  A member's list is its per-topic appends in topic order (Main.java:177-184, :264), and the
-        // shards are contiguous topic ranges: the list is the concatenation, in shard order, of the shards' lists.
-        // Phase 1, per shard in parallel: group on the device, CSR into pinned staging.  Then the global offsets
-        // (a scan over members x shards on the host), then phase 2, per shard in parallel: every member's slice to
-        // its place in the caller's arrays, topic indices moved from shard-local to the caller's numbering.
-        int rc = run_workers(ctx, S, [&](int i) -> int {
-            Shard& sh = ctx->shards[(size_t)i];
-            if (sh.last_topics == 0) return LA_OK;
-            LA_HIP(ctx, hipSetDevice(sh.device));
-            const size_t nb4 = (size_t)sh.last_n * 4;
-            int r;
-            if ((r = reserve_host(ctx, sh.g_off, mb)) || (r = reserve_host(ctx, sh.g_part, nb4 + 16)) ||
-                (grouped_topic && (r = reserve_host(ctx, sh.g_topic, nb4 + 16))))
-                return r;
-            if ((r = group_shard_device(ctx, sh, n_members, grouped_topic != nullptr))) return r;
-            hipStream_t st = sh.lanes[0].stream;
-            LA_HIP(ctx, hipMemcpyAsync(sh.g_off.p, sh.out_total.p, mb, hipMemcpyDeviceToHost, st));
-            if (sh.last_n) {
-                LA_HIP(ctx, hipMemcpyAsync(sh.g_part.p, sh.pid.p, nb4, hipMemcpyDeviceToHost, st));
-                if (grouped_topic) LA_HIP(ctx, hipMemcpyAsync(sh.g_topic.p, sh.cons_rank.p, nb4, hipMemcpyDeviceToHost, st));
-            }
-            LA_HIP(ctx, hipStreamSynchronize(st));
-            return LA_OK;
-        });
-        if (rc) return rc;
-        // group g = 0 is "no consumer" (rank -1: the entries before member_off[0]), g = r + 1 is member r
-        const size_t G = (size_t)n_members + 1;
-        std::vector<int64_t> base((size_t)S * G);          // destination of shard i's slice of group g
-        {
-            int64_t run = 0;
-            for (size_t g = 0; g < G; ++g) {
-                if (g >= 1) member_off[g - 1] = run;
-                for (int i = 0; i < S; ++i) {
-                    const Shard& sh = ctx->shards[(size_t)i];
-                    base[(size_t)i * G + g] = run;
-                    if (sh.last_topics == 0) continue;
-                    const int64_t* so = (const int64_t*)sh.g_off.p;
-                    const int64_t lo = g == 0 ? 0 : so[g - 1], hi = g == G - 1 ? sh.last_n : so[g];
-                    run += hi - lo;
-                }
-            }
-            member_off[n_members] = run;
-        }
-        rc = run_workers(ctx, S, [&](int i) -> int {
-            const Shard& sh = ctx->shards[(size_t)i];
-            if (sh.last_topics == 0 || sh.last_n == 0) return LA_OK;
-            const int64_t* so = (const int64_t*)sh.g_off.p;
-            const int32_t* sp = (const int32_t*)sh.g_part.p;
-            const int32_t* stp = (const int32_t*)sh.g_topic.p;
-            for (size_t g = 0; g < G; ++g) {
-                const int64_t lo = g == 0 ? 0 : so[g - 1], hi = g == G - 1 ? sh.last_n : so[g];
-                if (hi <= lo) continue;
-                const int64_t dst = base[(size_t)i * G + g];
-                memcpy(grouped_partition + dst, sp + lo, (size_t)(hi - lo) * 4);
-                if (grouped_topic) {
-                    int32_t* gt = grouped_topic + dst;
-                    const int32_t t0 = sh.last_t0;
-                    for (int64_t j = lo; j < hi; ++j) gt[j - lo] = stp[j] + t0;
-                }
-            }
-            return LA_OK;
-        });
-        return rc;
+        return group_last_impl(ctx, n_members, member_off, grouped_topic, grouped_partition);
     } catch (...) {
         return fail(ctx, LA_ENOMEM, "exception in la_group_last_by_member");
     }
@@ -1397,13 +1481,16 @@ LA_API int la_last_phase_times(la_ctx* ctx, la_phase_times* out) {
     }
 }
 
-LA_API int la_sync(la_ctx* ctx, void* stream) {
+LA_API int la_sync_on(la_ctx* ctx, int shard, void* stream) {
     if (!ctx) return LA_EINVAL;
     try {
-        Shard& sh = ctx->shards[0];
+        if (shard < 0 || shard >= (int)ctx->shards.size()) return fail(ctx, LA_EINVAL, "shard %d of %d", shard, (int)ctx->shards.size());
+        Shard& sh = ctx->shards[(size_t)shard];
         LA_HIP(ctx, hipSetDevice(sh.device));
         return sync_status(ctx, sh.lanes[0], (hipStream_t)stream);
     } catch (...) {
         return fail(ctx, LA_ENOMEM, "exception in la_sync");
     }
 }
+
+LA_API int la_sync(la_ctx* ctx, void* stream) { return la_sync_on(ctx, 0, stream); }

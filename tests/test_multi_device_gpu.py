@@ -105,6 +105,94 @@ def test_four_shards_cfg4_full_size(ctx4):
     assert ctx4.last_shard_bounds().tolist() == [0, 25000, 50000, 75000, 100000]
 
 
+
+def _device_shard(torch, w, t0, t1, dev):
+    """Topics [t0, t1) of w resident on `dev`, with result buffers and the la_device_batch over them."""
+    import ctypes
+    from kafka_lag_based_assignor_amd import sharding
+    po, co, ps, cs = sharding.shard_slices(w.part_off, w.cons_off, t0, t1)
+    po, co = np.ascontiguousarray(po), np.ascontiguousarray(co)
+    up = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)      # noqa: E731
+    d = dict(po=up(po), co=up(co), pid=up(w.partition_id[ps]), begin=up(w.begin[ps]), end=up(w.end[ps]),
+             com=up(w.committed[ps]), cr=up(w.cons_rank[cs]))
+    n, k = int(po[-1]), int(co[-1])
+    out = dict(pid=torch.full((max(n, 1),), -7, device=dev, dtype=torch.int32),
+               rank=torch.full((max(n, 1),), -7, device=dev, dtype=torch.int32),
+               total=torch.zeros(max(k, 1), device=dev, dtype=torch.int64))
+    b = N.DeviceBatch()
+    b.n_topics = t1 - t0
+    b.reset_mode = N.LA_RESET_EARLIEST
+    b.algo = N.LA_ALGO_AUTO
+    b.n_partitions, b.n_consumers = n, k
+    b.max_partitions_per_topic = int(np.diff(po).max()) if t1 > t0 else 0
+    b.max_consumers_per_topic = int(np.diff(co).max()) if t1 > t0 else 0
+    b.d_part_off, b.d_cons_off = d["po"].data_ptr(), d["co"].data_ptr()
+    b.d_partition_id, b.d_begin_off, b.d_end_off = d["pid"].data_ptr(), d["begin"].data_ptr(), d["end"].data_ptr()
+    b.d_committed_off, b.d_cons_rank = d["com"].data_ptr(), d["cr"].data_ptr()
+    b.d_out_partition, b.d_out_member_rank = out["pid"].data_ptr(), out["rank"].data_ptr()
+    b.d_out_total_lag = out["total"].data_ptr()
+    b.h_part_off = po.ctypes.data_as(ctypes.POINTER(ctypes.c_int64))
+    b.h_cons_off = co.ctypes.data_as(ctypes.POINTER(ctypes.c_int64))
+    return dict(b=b, d=d, out=out, n=n, k=k, keep=(po, co))
+
+
+def test_device_entry_points_on_every_shard(ctx4):
+    """la_assign_batch_device_on / la_sync_on / la_shard_stream: a caller whose data is already in HBM drives every shard
+    of one context -- cfg4 at full size split by la_plan_shards, each range enqueued on its shard's own stream back to
+    back from this one thread, then every shard synced; the concatenation is the oracle's result."""
+    import torch
+    w = synth.config("cfg4")
+    lag = oracle.compute_lags(w.begin, w.end, w.committed, False)
+    exp = oracle.assign_flat(w.part_off, w.partition_id, lag, w.cons_off, w.cons_rank)
+    S = ctx4.shard_count
+    bounds = N.plan_shards(w.part_off, S)
+    shards = []
+    for i in range(S):
+        dev = torch.device("cuda", ctx4.shard_device(i))
+        shards.append(_device_shard(torch, w, int(bounds[i]), int(bounds[i + 1]), dev))
+    torch.cuda.synchronize()
+    streams = [ctx4.shard_stream(i) for i in range(S)]
+    assert len(set(streams)) == S and all(streams)
+    for i in range(S):                                          # enqueue everywhere first ...
+        ctx4.assign_batch_device(shards[i]["b"], streams[i], shard=i)
+    for i in range(S):                                          # ... then wait
+        ctx4.sync(streams[i], shard=i)
+    got = tuple(np.concatenate([sh["out"][key][: sh[cnt]].cpu().numpy() for sh in shards])
+                for key, cnt in (("pid", "n"), ("rank", "n"), ("total", "k")))
+    _same(got, exp, "device entry points on 4 shards")
+    # a mixed batch (tile + block + large topics) on the LAST shard only: scratch is per shard
+    part_off, pid, lag2, cons_off, ranks = _mixed_batch(11)
+    z = np.zeros_like(lag2)
+    wm = synth.Workload("mixed", len(part_off) - 1, part_off, pid, z, lag2.copy(), z, lag2, cons_off, ranks, 0, 0)
+    one = _device_shard(torch, wm, 0, wm.n_topics, torch.device("cuda", ctx4.shard_device(S - 1)))
+    ctx4.assign_batch_device(one["b"], streams[S - 1], shard=S - 1)
+    ctx4.sync(streams[S - 1], shard=S - 1)
+    got = tuple(one["out"][key][: one[cnt]].cpu().numpy() for key, cnt in (("pid", "n"), ("rank", "n"), ("total", "k")))
+    _same(got, oracle.assign_flat(part_off, pid, lag2, cons_off, ranks), "mixed batch on the last shard")
+    with pytest.raises(N.LagAssignError) as ei:
+        ctx4.assign_batch_device(one["b"], 0, shard=S)
+    assert ei.value.code == N.LA_EINVAL
+
+
+def test_compute_lag_and_group_by_member_across_shards(ctx4, ctx1):
+    """la_compute_lag and la_group_by_member split large inputs over the shards (element ranges / topic ranges); the
+    results equal the one-device ones."""
+    w = synth.config("cfg4", 0.2)
+    for latest in (True, False):
+        exp = oracle.compute_lags(w.begin, w.end, w.committed, latest)
+        mode = N.LA_RESET_LATEST if latest else N.LA_RESET_EARLIEST
+        np.testing.assert_array_equal(ctx4.compute_lag(None if latest else w.begin, w.end, w.committed, mode), exp)
+        np.testing.assert_array_equal(ctx1.compute_lag(None if latest else w.begin, w.end, w.committed, mode), exp)
+    lag = oracle.compute_lags(w.begin, w.end, w.committed, False)
+    pid, rank, _ = oracle.assign_flat(w.part_off, w.partition_id, lag, w.cons_off, w.cons_rank)
+    a = ctx4.group_by_member(w.part_off, pid, rank, 8)
+    b = ctx1.group_by_member(w.part_off, pid, rank, 8)
+    for x, y, what in zip(a, b, ("member_off", "grouped_topic", "grouped_partition")):
+        np.testing.assert_array_equal(x, y, err_msg=what)
+    order = np.argsort(rank, kind="stable")                     # the reference's lists: stable by member
+    np.testing.assert_array_equal(a[2], pid[order])
+
+
 @pytest.mark.parametrize("seed", range(6))
 def test_four_shards_mixed_paths(ctx4, seed):
     part_off, pid, lag, cons_off, ranks = _mixed_batch(seed)
