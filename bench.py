@@ -547,7 +547,28 @@ def main():
                 dt = min(times)
                 ref_p = g_pid if not strong else gathered_host[0]
                 ref_m = g_rank if not strong else gathered_host[1]
+                # the same call on pinned arrays (la_host_alloc: what the Java host's direct ByteBuffers are made of): the
+                # library then needs no worker threads -- H2D, kernels and D2H on three streams chained by events
+                pin = [None if x is None or isinstance(x, int) else ctx.host_alloc(x.shape, x.dtype) for x in a]
+                for dst, src in zip(pin, a):
+                    if dst is not None:
+                        dst[...] = src
+                pa = tuple(p if p is not None else x for p, x in zip(pin, a))
+                pout = tuple(ctx.host_alloc(o.shape, o.dtype) for o in reuse)
+                ptimes = []
+                for _ in range(4):
+                    c0 = time.perf_counter()
+                    pp, pm, pt = ctx.assign_batch(*pa, out=pout)
+                    ptimes.append(time.perf_counter() - c0)
+                pdt = min(ptimes[1:])
+                pinned_ok = bool(np.array_equal(pp, ref_p) and np.array_equal(pm, ref_m)) and \
+                    ctx.last_pipeline() == N.LA_PIPELINE_STREAMS
                 host_leg = {"ms": round(dt * 1e3, 2), "value": round(w.n_partitions / dt, 1), "unit": "partition-assignments/sec",
+                            "pinned_ms": round(pdt * 1e3, 2), "pinned_value": round(w.n_partitions / pdt, 1),
+                            "pinned_ms_all": [round(x * 1e3, 2) for x in ptimes], "pinned_bit_exact_and_three_streams": pinned_ok,
+                            "h2d_floor_ms": round(w.n_partitions * (bpp - 8) / 57.2e9 * 1e3, 2),
+                            "h2d_floor": "the input bytes of the call at the 57.2 GB/s one pinned hipMemcpy sustains on this "
+                                         "link (tools/pcie_probe.py, profiles/r03_pcie_probe.txt): no host-buffer call can be faster",
                             "what": "one la_assign_batch call on pageable host buffers (results into reused, already touched "
                                     "buffers), PCIe copies included: best of 3; chunks of the batch overlap their H2D, kernels "
                                     "and D2H over the context's lanes",

@@ -158,6 +158,18 @@ int la_plan_shards(int32_t n_topics, const int64_t *part_off, int32_t n_shards, 
  * min(S + 1, capacity) bounds (bounds may be NULL). */
 int la_last_shard_bounds(const la_ctx *ctx, int32_t *bounds, int32_t capacity);
 
+/* How the last la_assign_batch / la_assign_batch_lags call moved its data (diagnostics, tests):
+ *   LA_PIPELINE_ONE_COPY  a small batch: one H2D and one D2H of a staging buffer
+ *   LA_PIPELINE_LANES     chunks over the shard's lanes, one short-lived host thread per lane (pageable caller arrays:
+ *                         their copies block the issuing thread)
+ *   LA_PIPELINE_STREAMS   every array of the call is pinned (la_host_alloc): no threads; all H2D copies in order on one
+ *                         stream, kernels on a second, D2H copies on a third, chained per chunk by events -- the input
+ *                         link stays busy from the first byte to the last */
+#define LA_PIPELINE_ONE_COPY 0
+#define LA_PIPELINE_LANES    1
+#define LA_PIPELINE_STREAMS  2
+int la_last_pipeline(const la_ctx *ctx);
+
 /* Pinned host memory for the arrays handed to the host-buffer calls (a JNI shim wraps it in a direct ByteBuffer
  * with NewDirectByteBuffer): the copies then run as plain DMA, without the runtime staging or pinning pageable
  * pages per call.  Optional -- every entry point takes pageable memory too.  NULL on failure. */

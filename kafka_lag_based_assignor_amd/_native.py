@@ -22,6 +22,7 @@ LA_FLAG_INDEX64, LA_FLAG_DEFER_WIDE, LA_FLAG_RAGGED, LA_FLAG_SHAPE_CLASSES = 1, 
 LA_FLAG_PROFILE, LA_FLAG_NO_SAMPLE_SORT, LA_FLAG_SAMPLE_TIGHT = 16, 32, 64
 LA_FLAG_SORT_MULTIKERNEL = 128
 LA_FEATURE_ATOMIC_RANK = 1
+LA_PIPELINE_ONE_COPY, LA_PIPELINE_LANES, LA_PIPELINE_STREAMS = 0, 1, 2
 LA_CREATE_LANES_MASK, LA_CREATE_SPLIT_ALWAYS = 0xF, 0x10
 
 EXPORTED_SYMBOLS = (
@@ -30,7 +31,7 @@ EXPORTED_SYMBOLS = (
     "la_group_by_member", "la_group_by_member_device", "la_group_last_by_member",
     "la_device_count", "la_create_multi", "la_shard_count", "la_shard_device", "la_plan_shards",
     "la_last_shard_bounds", "la_host_alloc", "la_host_free", "la_last_phase_times", "la_device_features",
-    "la_shard_stream", "la_assign_batch_device_on", "la_sync_on", "la_group_by_member_device_on",
+    "la_shard_stream", "la_assign_batch_device_on", "la_sync_on", "la_group_by_member_device_on", "la_last_pipeline",
 )
 
 _i64p = ctypes.POINTER(ctypes.c_int64)
@@ -139,6 +140,8 @@ def load() -> ctypes.CDLL:
     L.la_group_by_member_device.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_void_p,
                                             ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p,
                                             ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+    L.la_last_pipeline.restype = ctypes.c_int
+    L.la_last_pipeline.argtypes = [ctypes.c_void_p]
     L.la_shard_stream.restype = ctypes.c_void_p
     L.la_shard_stream.argtypes = [ctypes.c_void_p, ctypes.c_int]
     L.la_assign_batch_device_on.restype = ctypes.c_int
@@ -305,13 +308,21 @@ class Context:
         return out_p, out_m, out_t
 
     def assign_batch_lags(self, part_off, partition_id, lag, cons_off, cons_rank, want_totals: bool = True,
-                          keep_on_device: bool = False) -> Tuple[Optional[np.ndarray], Optional[np.ndarray], Optional[np.ndarray]]:
-        """keep_on_device: the results stay on the device for group_last_by_member() (None, None, totals come back)."""
+                          keep_on_device: bool = False, out=None
+                          ) -> Tuple[Optional[np.ndarray], Optional[np.ndarray], Optional[np.ndarray]]:
+        """keep_on_device: the results stay on the device for group_last_by_member() (None, None, totals come back).
+        out: caller-owned (int32[N], int32[N], int64[K] or None) result buffers, as for assign_batch."""
         part_off, cons_off = _a64(part_off), _a64(cons_off)
         partition_id, cons_rank, lag = _a32(partition_id), _a32(cons_rank), _a64(lag)
-        out_p = None if keep_on_device else np.empty(partition_id.size, dtype=np.int32)
-        out_m = None if keep_on_device else np.empty(partition_id.size, dtype=np.int32)
-        out_t = np.zeros(cons_rank.size, dtype=np.int64) if want_totals else None
+        if out is not None and not keep_on_device:
+            out_p, out_m, out_t = out
+            if out_p.size != partition_id.size or out_m.size != partition_id.size or out_p.dtype != np.int32 or \
+                    out_m.dtype != np.int32 or (out_t is not None and (out_t.size != cons_rank.size or out_t.dtype != np.int64)):
+                raise ValueError("out buffers must be int32[N], int32[N], int64[K]")
+        else:
+            out_p = None if keep_on_device else np.empty(partition_id.size, dtype=np.int32)
+            out_m = None if keep_on_device else np.empty(partition_id.size, dtype=np.int32)
+            out_t = np.zeros(cons_rank.size, dtype=np.int64) if want_totals else None
         self._check(self._lib.la_assign_batch_lags(self._h, part_off.size - 1, _p64(part_off),
                                                    _p32(partition_id), _p64(lag), _p64(cons_off),
                                                    _p32(cons_rank), _p32(out_p), _p32(out_m), _p64(out_t)))
@@ -354,6 +365,10 @@ class Context:
 
     def sync(self, stream: int = 0, shard: int = 0) -> None:
         self._check(self._lib.la_sync_on(self._h, shard, ctypes.c_void_p(stream)))
+
+    def last_pipeline(self) -> int:
+        """LA_PIPELINE_* of the last host-buffer assign call."""
+        return int(self._lib.la_last_pipeline(self._h))
 
     def shard_stream(self, shard: int) -> int:
         return int(self._lib.la_shard_stream(self._h, shard) or 0)

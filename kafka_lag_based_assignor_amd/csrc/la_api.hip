@@ -87,6 +87,13 @@ struct Shard {
     // through these two staging buffers (device, pinned host) instead of eight copies of caller arrays
     DevBuf small_d, small_g;
     HostBuf small_h, small_gh;
+    // pinned caller arrays (la_host_alloc): one host thread, three streams -- every H2D of the call in order on copy_in,
+    // the kernels on lane 0's stream, every D2H on copy_out, chained per chunk by events (run_shard_async)
+    static constexpr int kCopyIn = 2;    // input streams, alternating per chunk: a copy costs ~20 us of engine latency before its
+                                         // first byte moves; one chunk's gaps hide under the other stream's bytes.  (One stream
+                                         // per ARRAY, five copies in flight at once, was measured far worse: 19-26 ms against 15.)
+    hipStream_t copy_in[kCopyIn] = {}, copy_out = nullptr;
+    std::vector<hipEvent_t> chunk_ev;    // two per chunk: inputs landed, results ready
 };
 
 struct la_ctx {
@@ -95,6 +102,8 @@ struct la_ctx {
     bool split_always = false;           // LA_CREATE_SPLIT_ALWAYS: shard and chunk even tiny batches (tests)
     int64_t chunk_partitions = 0;        // LA_CHUNK_PARTITIONS override (0: automatic)
     bool last_valid = false;
+    int last_pipeline = 0;               // how the last host-buffer call moved its data: 0 = one copy each way (small batch),
+                                         // 1 = lanes (a host thread per stream; pageable arrays), 2 = three streams, no threads (pinned)
     int last_shards = 0;                 // shards the last call used
     int32_t last_bounds[65] = {};        // their topic ranges
 };
@@ -593,9 +602,14 @@ int prepare_shard(la_ctx* ctx, const HostCall& c, Shard& sh, ShardPlan& sp) {
     int n_chunks = 1;
     if (ctx->split_always) {
         n_chunks = Ts < 3 ? (Ts > 0 ? Ts : 1) : 3;
-    } else if ((int)sh.lanes.size() > 1) {
+    } else if ((int)sh.lanes.size() > 1 || ctx->last_pipeline == 2) {
+        // (pinned arrays, one enqueueing thread: finer chunks -- the call ends one chunk's kernels + result copy after
+        //  the last input byte has landed)
         int64_t target = ctx->chunk_partitions > 0 ? ctx->chunk_partitions : sp.n / 16;
         if (ctx->chunk_partitions <= 0 && target < kMinChunkPartitions) target = kMinChunkPartitions;
+        // three-stream form: chunks of ~1 M partitions (28 MB of input) measured best on the 25.6 M-partition batch -- 13.6 ms
+        // against 18-20 ms at 512 K, 14.4 at 2 M, 14.5 with few chunks that are small at both ends (profiles/r03_host_probe.txt)
+        if (ctx->chunk_partitions <= 0 && ctx->last_pipeline == 2) target = 1 << 20;
         const int64_t want = (sp.n + target - 1) / target;
         n_chunks = (int)(want < 1 ? 1 : (want > kMaxChunks ? kMaxChunks : want));
         if (n_chunks > Ts) n_chunks = Ts > 0 ? Ts : 1;
@@ -687,6 +701,128 @@ int run_lane(la_ctx* ctx, const HostCall& c, Shard& sh, ShardPlan& sp, int lane_
     }
     const int rs = sync_status(ctx, ln, st);     // also when stopping early: nothing of this lane stays in flight
     return rc ? rc : rs;
+}
+
+// true when [p, p + bytes) is pinned host memory the runtime knows (la_host_alloc, hipHostMalloc, hipHostRegister): copies
+// to and from it are plain DMA and hipMemcpyAsync returns at once.  NULL / zero bytes count as pinned.
+bool is_pinned(const void* p, size_t bytes) {
+    if (!p || bytes == 0) return true;
+    hipPointerAttribute_t at{};
+    if (hipPointerGetAttributes(&at, p) != hipSuccess) {
+        (void)hipGetLastError();                          // an ordinary malloc'ed pointer: not an error of ours
+        return false;
+    }
+    return at.type == hipMemoryTypeHost;
+}
+
+bool call_is_pinned(const HostCall& c) {
+    const size_t n = (size_t)c.shape.n, k = (size_t)c.shape.k;
+    return is_pinned(c.pid, n * 4) && is_pinned(c.end, n * 8) && is_pinned(c.committed, n * 8) && is_pinned(c.lag, n * 8) &&
+           (!c.use_begin || is_pinned(c.begin, n * 8)) && is_pinned(c.cons_rank, k * 4) && is_pinned(c.out_pid, n * 4) &&
+           is_pinned(c.out_rank, n * 4) && is_pinned(c.out_total, k * 8);
+}
+
+// One shard of a call whose arrays are all pinned: no worker threads.  The calling thread enqueues, per chunk,
+//   copy_in[]: H2D of the chunk's slices, chunks alternating over two streams -> event "in"
+//   lane 0   : wait "in"; check_consumers; the kernels over its topics     -> event "out"
+//   copy_out : wait "out"; D2H of the chunk's results straight into the caller's arrays
+// so the link carries input bytes back to back from the first chunk to the last (the H2D leg IS the floor of the call:
+// 717 MB at the 57 GB/s this link sustains = 12.5 ms for the 25.6 M-partition batch, profiles/r03_pcie_probe.txt) while
+// kernels and result copies of earlier chunks run beside it.  Returns after enqueueing; finish_shard_async waits.
+int run_shard_async(la_ctx* ctx, const HostCall& c, Shard& sh, ShardPlan& sp) {
+    LA_HIP(ctx, hipSetDevice(sh.device));
+    for (hipStream_t& st : sh.copy_in)
+        if (!st) LA_HIP(ctx, hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    if (!sh.copy_out) LA_HIP(ctx, hipStreamCreateWithFlags(&sh.copy_out, hipStreamNonBlocking));
+    const int n_chunks = (int)sp.chunk.size() - 1;
+    while ((int)sh.chunk_ev.size() < 2 * n_chunks + 1) {
+        hipEvent_t e = nullptr;
+        LA_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        sh.chunk_ev.push_back(e);
+    }
+    Lane& ln = sh.lanes[0];
+    hipStream_t sk = ln.stream, so = sh.copy_out;
+    // the consumer ranks of the whole shard go up once (4 B per entry: too small to be worth a copy per chunk)
+    if (sp.k) {
+        LA_HIP(ctx, hipMemcpyAsync(sh.cons_rank.p, c.cons_rank + sp.K0, (size_t)sp.k * 4, hipMemcpyHostToDevice, sh.copy_in[1]));
+        LA_HIP(ctx, hipEventRecord(sh.chunk_ev[(size_t)(2 * n_chunks)], sh.copy_in[1]));
+        LA_HIP(ctx, hipStreamWaitEvent(sk, sh.chunk_ev[(size_t)(2 * n_chunks)], 0));
+    }
+    for (int ci = 0; ci < n_chunks; ++ci) {
+        const int32_t a = sp.chunk[(size_t)ci], z = sp.chunk[(size_t)ci + 1];
+        const int64_t p0 = sp.lpo[a], p1 = sp.lpo[z], k0 = sp.lco[a], k1 = sp.lco[z];
+        const int64_t gp = sp.P0 + p0, gk = sp.K0 + k0;
+        const size_t np = (size_t)(p1 - p0), nk = (size_t)(k1 - k0);
+        hipEvent_t ev_in = sh.chunk_ev[(size_t)(2 * ci)], ev_out = sh.chunk_ev[(size_t)(2 * ci + 1)];
+        hipStream_t si = sh.copy_in[ci % Shard::kCopyIn];
+        if (np) {
+            LA_HIP(ctx, hipMemcpyAsync((int32_t*)sh.pid.p + p0, c.pid + gp, np * 4, hipMemcpyHostToDevice, si));
+            if (c.lag) {
+                LA_HIP(ctx, hipMemcpyAsync((int64_t*)sh.end.p + p0, c.lag + gp, np * 8, hipMemcpyHostToDevice, si));
+            } else {
+                LA_HIP(ctx, hipMemcpyAsync((int64_t*)sh.end.p + p0, c.end + gp, np * 8, hipMemcpyHostToDevice, si));
+                LA_HIP(ctx, hipMemcpyAsync((int64_t*)sh.committed.p + p0, c.committed + gp, np * 8, hipMemcpyHostToDevice, si));
+                if (c.use_begin)
+                    LA_HIP(ctx, hipMemcpyAsync((int64_t*)sh.begin.p + p0, c.begin + gp, np * 8, hipMemcpyHostToDevice, si));
+            }
+            LA_HIP(ctx, hipEventRecord(ev_in, si));
+            LA_HIP(ctx, hipStreamWaitEvent(sk, ev_in, 0));
+        }
+        if (nk)
+            LA_HIP(ctx, la::check_consumers_launch(z - a, (const int64_t*)sh.cons_off.p + a, (const int32_t*)sh.cons_rank.p,
+                                                   ln.d_status, sk));
+        la_device_batch b{};
+        b.n_topics = z - a;
+        b.reset_mode = c.reset_mode == LA_RESET_LATEST ? LA_RESET_LATEST : LA_RESET_EARLIEST;
+        b.algo = LA_ALGO_AUTO;
+        b.n_partitions = sp.n;
+        b.n_consumers = sp.k;
+        b.max_partitions_per_topic = c.shape.max_p;
+        b.max_consumers_per_topic = c.shape.max_c;
+        b.d_part_off = (const int64_t*)sh.part_off.p + a;
+        b.d_partition_id = (const int32_t*)sh.pid.p;
+        b.d_begin_off = c.use_begin ? (const int64_t*)sh.begin.p : nullptr;
+        b.d_end_off = (const int64_t*)sh.end.p;
+        b.d_committed_off = (const int64_t*)sh.committed.p;
+        b.d_lag = c.lag ? (const int64_t*)sh.end.p : nullptr;
+        b.d_cons_off = (const int64_t*)sh.cons_off.p + a;
+        b.d_cons_rank = (const int32_t*)sh.cons_rank.p;
+        b.d_out_partition = (int32_t*)sh.out_pid.p;
+        b.d_out_member_rank = (int32_t*)sh.out_rank.p;
+        b.d_out_total_lag = c.out_total ? (int64_t*)sh.out_total.p : nullptr;
+        b.h_part_off = sp.lpo + a;
+        b.h_cons_off = sp.lco + a;
+        b.flags = LA_FLAG_RAGGED;
+        if (np == 0) {
+            if (c.out_total && nk) LA_HIP(ctx, hipMemsetAsync((int64_t*)sh.out_total.p + k0, 0, nk * 8, sk));
+        } else if (int rc = enqueue_batch(ctx, ln, &b, sk)) {
+            return rc;
+        }
+        LA_HIP(ctx, hipEventRecord(ev_out, sk));
+        const bool any_out = (np && c.out_pid) || (c.out_total && nk);
+        if (any_out) LA_HIP(ctx, hipStreamWaitEvent(so, ev_out, 0));
+        if (np && c.out_pid) {
+            LA_HIP(ctx, hipMemcpyAsync(c.out_pid + gp, (const int32_t*)sh.out_pid.p + p0, np * 4, hipMemcpyDeviceToHost, so));
+            LA_HIP(ctx, hipMemcpyAsync(c.out_rank + gp, (const int32_t*)sh.out_rank.p + p0, np * 4, hipMemcpyDeviceToHost, so));
+        }
+        if (c.out_total && nk)
+            LA_HIP(ctx, hipMemcpyAsync(c.out_total + gk, (const int64_t*)sh.out_total.p + k0, nk * 8, hipMemcpyDeviceToHost, so));
+    }
+    return LA_OK;
+}
+
+// Waits for everything run_shard_async enqueued on this shard (also after an error elsewhere: nothing stays in flight).
+int finish_shard_async(la_ctx* ctx, Shard& sh) {
+    LA_HIP(ctx, hipSetDevice(sh.device));
+    const int rs = sync_status(ctx, sh.lanes[0], sh.lanes[0].stream);
+    hipError_t e1 = hipSuccess;
+    for (hipStream_t st : sh.copy_in)
+        if (st) { const hipError_t e = hipStreamSynchronize(st); if (e != hipSuccess) e1 = e; }
+    hipError_t e2 = sh.copy_out ? hipStreamSynchronize(sh.copy_out) : hipSuccess;
+    if (rs) return rs;
+    if (e1 != hipSuccess || e2 != hipSuccess)
+        return fail(ctx, LA_EHIP, "copy stream: %s", hipGetErrorString(e1 != hipSuccess ? e1 : e2));
+    return LA_OK;
 }
 
 struct WorkerResult {
@@ -873,6 +1009,7 @@ int assign_host(la_ctx* ctx, int32_t T, const int64_t* part_off, const int32_t* 
         if (L.total <= kSmallBytes) {
             Shard& sh = ctx->shards[0];
             sh.last_t0 = 0; sh.last_topics = T; sh.last_p0 = 0; sh.last_n = s.n;
+            ctx->last_pipeline = 0;
             if (int rc = assign_small(ctx, c, sh, L)) return rc;
             ctx->last_valid = true;
             return LA_OK;
@@ -881,6 +1018,8 @@ int assign_host(la_ctx* ctx, int32_t T, const int64_t* part_off, const int32_t* 
     std::vector<ShardPlan> plans((size_t)S);
     struct Work { int shard, lane; };
     std::vector<Work> work;
+    const bool pinned = call_is_pinned(c) && !getenv("LA_NO_ASYNC_PIPELINE");
+    ctx->last_pipeline = pinned ? 2 : 1;
     for (int i = 0; i < S; ++i) {
         ShardPlan& sp = plans[(size_t)i];
         Shard& sh = ctx->shards[(size_t)i];
@@ -902,7 +1041,23 @@ int assign_host(la_ctx* ctx, int32_t T, const int64_t* part_off, const int32_t* 
         }
         const int n_chunks = (int)sp.chunk.size() - 1;
         const int lanes = n_chunks < (int)sh.lanes.size() ? n_chunks : (int)sh.lanes.size();
-        for (int l = 0; l < lanes; ++l) work.push_back({i, l});
+        if (!pinned)
+            for (int l = 0; l < lanes; ++l) work.push_back({i, l});
+    }
+    if (pinned) {
+        // pinned caller arrays: this thread enqueues every shard's chunks (nothing blocks), then waits shard by shard
+        int rc = LA_OK;
+        for (int i = 0; i < S && rc == LA_OK; ++i)
+            if (plans[(size_t)i].t1 > plans[(size_t)i].t0)
+                rc = run_shard_async(ctx, c, ctx->shards[(size_t)i], plans[(size_t)i]);
+        for (int i = 0; i < S; ++i) {
+            if (plans[(size_t)i].t1 == plans[(size_t)i].t0) continue;
+            const int rf = finish_shard_async(ctx, ctx->shards[(size_t)i]);
+            if (rc == LA_OK) rc = rf;
+        }
+        if (rc) return rc;
+        ctx->last_valid = true;
+        return LA_OK;
     }
     std::atomic<bool> stop{false};
     const int rc = run_workers(ctx, (int)work.size(), [&](int w) {
@@ -1061,6 +1216,10 @@ LA_API void la_destroy(la_ctx* ctx) {
         for (HostBuf* h : {&sh.g_off, &sh.g_topic, &sh.g_part, &sh.small_h, &sh.small_gh})
             if (h->p) (void)hipHostFree(h->p);
         if (sh.ready) (void)hipEventDestroy(sh.ready);
+        for (hipEvent_t e : sh.chunk_ev) (void)hipEventDestroy(e);
+        for (hipStream_t st : sh.copy_in)
+            if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
+        if (sh.copy_out) { (void)hipStreamSynchronize(sh.copy_out); (void)hipStreamDestroy(sh.copy_out); }
     }
     delete ctx;
 }
@@ -1099,6 +1258,8 @@ LA_API int la_last_shard_bounds(const la_ctx* ctx, int32_t* bounds, int32_t capa
         for (int i = 0; i <= S && i < capacity; ++i) bounds[i] = ctx->last_bounds[i];
     return S;
 }
+
+LA_API int la_last_pipeline(const la_ctx* ctx) { return ctx ? ctx->last_pipeline : LA_EINVAL; }
 
 LA_API void* la_host_alloc(la_ctx* ctx, size_t bytes) {
     if (!ctx || ctx->shards.empty()) return nullptr;

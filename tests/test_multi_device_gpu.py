@@ -308,6 +308,70 @@ def test_pinned_host_arrays(ctx1):
     got = ctx1.assign_batch(pin["part_off"], pin["partition_id"], pin["begin"], pin["end"], pin["committed"],
                             N.LA_RESET_EARLIEST, pin["cons_off"], pin["cons_rank"], out=out)
     _same(got, exp, "pinned")
+    assert ctx1.last_pipeline() == N.LA_PIPELINE_STREAMS        # every array pinned: three streams, no worker threads
+    got = ctx1.assign_batch(w.part_off, w.partition_id, w.begin, w.end, w.committed, N.LA_RESET_EARLIEST, w.cons_off, w.cons_rank)
+    _same(got, exp, "pageable")
+    assert ctx1.last_pipeline() == N.LA_PIPELINE_LANES
+    # one pageable array among pinned ones is enough to need the threads
+    got = ctx1.assign_batch(pin["part_off"], pin["partition_id"], w.begin, pin["end"], pin["committed"],
+                            N.LA_RESET_EARLIEST, pin["cons_off"], pin["cons_rank"], out=out)
+    _same(got, exp, "mixed pinned / pageable")
+    assert ctx1.last_pipeline() == N.LA_PIPELINE_LANES
+
+
+def _pin(ctx, a):
+    out = ctx.host_alloc(a.shape, a.dtype)
+    out[...] = a
+    return out
+
+
+@pytest.mark.parametrize("which", ["4 shards", "1 shard, 3 chunks", "default context"])
+def test_stream_pipeline_on_pinned_arrays(ctx4, ctx1_chunked, ctx1, which):
+    """The three-stream form (pinned caller arrays) over shards x chunks: a mixed batch through tile, block and large
+    paths, the target shape, results left on the device + grouped lists, LATEST mode without begin, and an unsorted
+    cons_rank segment in a late chunk -- same results and errors as the lanes form."""
+    c = {"4 shards": ctx4, "1 shard, 3 chunks": ctx1_chunked, "default context": ctx1}[which]
+    part_off, pid, lag, cons_off, ranks = _mixed_batch(3)
+    exp = oracle.assign_flat(part_off, pid, lag, cons_off, ranks)
+    P = [_pin(c, np.ascontiguousarray(a)) for a in (part_off, pid, lag, cons_off, ranks)]
+    out = (c.host_alloc((pid.size,), np.int32), c.host_alloc((pid.size,), np.int32), c.host_alloc((ranks.size,), np.int64))
+    _same(c.assign_batch_lags(*P, out=out), exp, "mixed batch, pinned, " + which)
+    if which != "default context":                              # (the default context sends a batch this small in one copy)
+        assert c.last_pipeline() == N.LA_PIPELINE_STREAMS
+    w = synth.config("target", 0.03 if which == "default context" else 0.01)
+    names = ("part_off", "partition_id", "begin", "end", "committed", "cons_off", "cons_rank")
+    pw = {k: _pin(c, getattr(w, k)) for k in names}
+    for latest in (False, True):
+        mode = N.LA_RESET_LATEST if latest else N.LA_RESET_EARLIEST
+        lags = oracle.compute_lags(w.begin, w.end, w.committed, latest)
+        e = oracle.assign_flat(w.part_off, w.partition_id, lags, w.cons_off, w.cons_rank)
+        o = (c.host_alloc((w.n_partitions,), np.int32), c.host_alloc((w.n_partitions,), np.int32),
+             c.host_alloc((w.cons_rank.size,), np.int64))
+        got = c.assign_batch(pw["part_off"], pw["partition_id"], None if latest else pw["begin"], pw["end"], pw["committed"],
+                             mode, pw["cons_off"], pw["cons_rank"], out=o)
+        _same(got, e, "target, pinned, latest=%s, %s" % (latest, which))
+        assert c.last_pipeline() == N.LA_PIPELINE_STREAMS
+    # results stay on the device, only the grouped lists come back
+    c.assign_batch(pw["part_off"], pw["partition_id"], pw["begin"], pw["end"], pw["committed"], N.LA_RESET_EARLIEST,
+                   pw["cons_off"], pw["cons_rank"], want_totals=False, keep_on_device=True)
+    off, g_t, g_p = c.group_last_by_member(w.n_partitions, 32)
+    lags = oracle.compute_lags(w.begin, w.end, w.committed, False)
+    e_p, e_m, _ = oracle.assign_flat(w.part_off, w.partition_id, lags, w.cons_off, w.cons_rank)
+    order = np.argsort(e_m, kind="stable")
+    np.testing.assert_array_equal(g_p, e_p[order])
+    np.testing.assert_array_equal(off, np.searchsorted(e_m[order], np.arange(33)))
+    # an unsorted consumer segment in the LAST topic: reported, nothing left in flight, the next call works
+    bad = pw["cons_rank"].copy()
+    badp = _pin(c, bad)
+    badp[-1], badp[-2] = bad[-2], bad[-1]
+    with pytest.raises(N.LagAssignError) as ei:
+        c.assign_batch(pw["part_off"], pw["partition_id"], pw["begin"], pw["end"], pw["committed"], N.LA_RESET_EARLIEST,
+                       pw["cons_off"], badp, out=o)
+    assert ei.value.code == N.LA_EINVAL and c.last_pipeline() == N.LA_PIPELINE_STREAMS
+    got = c.assign_batch(pw["part_off"], pw["partition_id"], pw["begin"], pw["end"], pw["committed"], N.LA_RESET_EARLIEST,
+                         pw["cons_off"], pw["cons_rank"], out=o)
+    np.testing.assert_array_equal(got[0], e_p)
+    np.testing.assert_array_equal(got[1], e_m)
 
 
 def test_large_path_topic_without_partitions_reports_zero_totals(ctx1):

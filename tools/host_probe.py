@@ -20,7 +20,7 @@ for rep in range(4):
     rc = lib.la_assign_batch(ctx._h, w.n_topics, p64(w.part_off), p32(w.partition_id), p64(w.begin), p64(w.end), p64(w.committed),
                              N.LA_RESET_EARLIEST, p64(w.cons_off), p32(w.cons_rank), p32(op), p32(om), p64(ot))
     dt = time.perf_counter() - t
-    print("C call, touched outputs: rc=%d %.1f ms  (%.2e assignments/s)" % (rc, dt * 1e3, w.n_partitions / dt))
+    print("C call, touched outputs: rc=%d %.1f ms  (%.2e assignments/s)  pipeline %d" % (rc, dt * 1e3, w.n_partitions / dt, ctx.last_pipeline()))
 print("same result:", np.array_equal(op, r[0]), np.array_equal(om, r[1]), np.array_equal(ot, r[2]))
 # pinned host arrays (la_host_alloc: what the Java host's direct buffers are made of)
 def pinned(a):
@@ -35,7 +35,7 @@ for rep in range(4):
                              p64(P["committed"]), N.LA_RESET_EARLIEST, p64(P["cons_off"]), p32(P["cons_rank"]),
                              p32(pop), p32(pom), p64(pot))
     dt = time.perf_counter() - t
-    print("C call, pinned buffers: rc=%d %.1f ms  (%.2e assignments/s)" % (rc, dt * 1e3, w.n_partitions / dt))
+    print("C call, pinned buffers: rc=%d %.1f ms  (%.2e assignments/s)  pipeline %d" % (rc, dt * 1e3, w.n_partitions / dt, ctx.last_pipeline()))
 print("same result:", np.array_equal(pop, r[0]), np.array_equal(pom, r[1]), np.array_equal(pot, r[2]))
 
 # the Java host's flow: assign, then every member's list.  (a) download the result, upload it again for the
