@@ -1056,22 +1056,56 @@ __device__ void greedy_rounds_packed(const LargeArgs& a, const uint64_t* key, in
         }
         // position i of the sorted bins takes partition q*C + i; the next round's lags are fetched now
         LA_CLK_START;
+        // A thread's EC positions are consecutive (blocked layout), so are its keys and its results: 16 bytes per
+        // instruction -- two keys per load, four results per store -- instead of one element each.  This kernel runs on
+        // ONE CU, whose address path handled 16 narrow instructions per thread and round, 64 cache lines apiece.
         uint64_t next_lag[EC];
+        if constexpr (EC >= 2) {
+            struct __attribute__((aligned(8))) U64x2 { uint64_t x, y; };
 #pragma unroll
-        for (int r = 0; r < EC; ++r) {
-            const int64_t s = (q + 1) * C + tid * EC + r;
-            next_lag[r] = key[s < P ? s : P - 1];
+            for (int r = 0; r < EC; r += 2) {
+                const int64_t s = (q + 1) * C + tid * EC + r;
+                const int64_t base = P >= 2 ? (s < P - 2 ? s : P - 2) : 0;      // the pair stays inside the array
+                U64x2 v;
+                if (P >= 2) v = *reinterpret_cast<const U64x2*>(key + base);    // (uniform branch)
+                else v.x = v.y = key[0];
+                next_lag[r] = base == s ? v.x : v.y;        // s == P - 1: its key is the pair's second word
+                next_lag[r + 1] = v.y;                      // (positions past P - 1 are never used)
+            }
+        } else {
+            const int64_t s = (q + 1) * C + tid;
+            next_lag[0] = key[s < P ? s : P - 1];
         }
+        int32_t who[EC];
+        bool live[EC];
 #pragma unroll
         for (int r = 0; r < EC; ++r) {
             const int i = tid * EC + r;
             const int64_t s = q * C + i;
-            if (i < C && s < P) {
-                const uint64_t nb = p64_value(rec[r]) + ((lag[r] ^ kLagKeyFlip) << idx_bits);   // Main.java:265
-                rec[r] = p64_from(nb);
-                a.out_rank[a.p0 + s] = (int32_t)((uint32_t)nb & idx_mask);      // consumer index; map_ranks_kernel turns it into the rank
-            }
+            live[r] = i < C && s < P;
+            const uint64_t nb = p64_value(rec[r]) + ((lag[r] ^ kLagKeyFlip) << idx_bits);       // Main.java:265
+            if (live[r]) rec[r] = p64_from(nb);
+            who[r] = (int32_t)((uint32_t)nb & idx_mask);    // consumer index; map_ranks_kernel turns it into the rank
             lag[r] = next_lag[r];
+        }
+        if constexpr (EC >= 4) {
+            typedef int I32x4 __attribute__((ext_vector_type(4), aligned(4)));
+#pragma unroll
+            for (int r = 0; r < EC; r += 4) {
+                int32_t* dst = a.out_rank + a.p0 + q * C + tid * EC + r;
+                if (live[r + 3]) {                          // the fourth is live: so are the three before it
+                    const I32x4 v = {who[r], who[r + 1], who[r + 2], who[r + 3]};
+                    *reinterpret_cast<I32x4*>(dst) = v;
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 3; ++k)
+                        if (live[r + k]) dst[k] = who[r + k];
+                }
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < EC; ++r)
+                if (live[r]) a.out_rank[a.p0 + q * C + tid * EC + r] = who[r];
         }
         LA_CLK(6);
     }
