@@ -59,6 +59,7 @@ struct SortBufs {
     int n_tiles;
     int n_groups;
     int atomic_rank;                   // ranks from returning LDS atomics (the device passed lds_atomic_order_test_kernel)
+    int sweep_threads;                 // workgroup size of the single-kernel passes: 512 (tiles of 8 192) or 256 (4 096)
 };
 
 // bijection [0, n) -> [0, n): workgroups with equal (w % 8) get consecutive results
@@ -514,19 +515,21 @@ constexpr uint32_t kStateAggregate = 1u, kStateInclusive = 2u;
 constexpr int kLookWindow = LA_LOOK_WINDOW;           // predecessors a walk polls at once
 constexpr uint32_t kLookbackSpinLimit = 1u << 22;     // polls of one granule (~1 us each with the sleep) before giving up
 
-template <bool ATOMIC_RANK>
-__global__ __launch_bounds__(kSortThreads, 4) void onesweep_pass_kernel(SortBufs b, int pass, uint32_t* status) {
+template <bool ATOMIC_RANK, int THREADS>
+__global__ __launch_bounds__(THREADS, 4) void onesweep_pass_kernel(SortBufs b, int pass, uint32_t* status) {
     if (b.ctl->skip[pass]) return;
-    static_assert(kSortThreads == kRadix, "one thread per digit in the look-back");
-    __shared__ uint32_t cnt[kSortWaves][kRadix];
+    static_assert(THREADS >= kRadix && THREADS % kWave == 0, "one thread per digit in the look-back");
+    constexpr int WAVES = THREADS / kWave, TILE = THREADS * kItems;
+    __shared__ uint32_t cnt[WAVES][kRadix];
     __shared__ uint32_t bin_start[kRadix];            // tile-local position of the digit's first element
     __shared__ uint32_t bin_base[kRadix];             // global position of it, minus bin_start
-    __shared__ uint32_t wsum[kSortWaves];
+    __shared__ uint32_t wsum[kRadix / kWave];
     __shared__ uint32_t s_ticket;
-    __shared__ uint64_t s_stage[kTile];               // the tile reordered by digit: one array at a time
+    __shared__ uint64_t s_stage[TILE];                // the tile reordered by digit: one array at a time
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bool digit_thread = threadIdx.x < kRadix;   // (whole wavefronts: 0 .. 3)
     if (threadIdx.x == 0) s_ticket = atomicAdd(&b.ticket[pass], 1u);
-    for (int i = threadIdx.x; i < kSortWaves * kRadix; i += kSortThreads) (&cnt[0][0])[i] = 0;
+    for (int i = threadIdx.x; i < WAVES * kRadix; i += THREADS) (&cnt[0][0])[i] = 0;
     __syncthreads();
     const uint32_t cur = b.ctl->cur[pass];
     const uint64_t* kin = b.key[cur];
@@ -534,11 +537,11 @@ __global__ __launch_bounds__(kSortThreads, 4) void onesweep_pass_kernel(SortBufs
     uint64_t* kout = b.key[cur ^ 1];
     uint32_t* vout = b.val[cur ^ 1];
     const int tile = (int)s_ticket;
-    const int64_t t0 = (int64_t)tile * kTile;
+    const int64_t t0 = (int64_t)tile * TILE;
     const int64_t w0 = t0 + (int64_t)wave * kItems * kWave;
-    const int n_here = (int)((b.n - t0) < kTile ? (b.n - t0) : kTile);
+    const int n_here = (int)((b.n - t0) < TILE ? (b.n - t0) : TILE);
     const uint32_t epoch = (uint32_t)(pass + 1) << 2;
-    unsigned long long* my_state = b.tile_state + (int64_t)tile * kRadix + threadIdx.x;
+    unsigned long long* my_state = b.tile_state + (int64_t)tile * kRadix + (threadIdx.x & (kRadix - 1));
 
     uint64_t key[kItems];
     uint32_t val[kItems];
@@ -553,12 +556,12 @@ __global__ __launch_bounds__(kSortThreads, 4) void onesweep_pass_kernel(SortBufs
     rank_in_wave<ATOMIC_RANK>(key, val, loc, cnt[wave], pass, w0, b.n, lane);
     __syncthreads();
     // thread d: digit d's count in this tile; published at once, so that later tiles never wait for this tile's walk
-    uint32_t count = 0;
+    uint32_t count = 0, incl = 0;
     unsigned long long win[kLookWindow];
-    {
+    if (digit_thread) {
         const int d = threadIdx.x;
 #pragma unroll
-        for (int w = 0; w < kSortWaves; ++w) {
+        for (int w = 0; w < WAVES; ++w) {
             const uint32_t c = cnt[w][d];
             cnt[w][d] = count;
             count += c;
@@ -569,17 +572,19 @@ __global__ __launch_bounds__(kSortThreads, 4) void onesweep_pass_kernel(SortBufs
 #pragma unroll
         for (int i = 0; i < kLookWindow; ++i)
             win[i] = i < tile ? __hip_atomic_load(my_state - (i + 1) * kRadix, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
-        uint32_t incl = count;
+        incl = count;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
             const uint32_t y = __shfl_up(incl, o);
             if (lane >= o) incl += y;
         }
         if (lane == 63) wsum[wave] = incl;
-        __syncthreads();
+    }
+    __syncthreads();
+    if (digit_thread) {
         uint32_t woff = 0;
         for (int w = 0; w < wave; ++w) woff += wsum[w];
-        bin_start[d] = woff + incl - count;
+        bin_start[threadIdx.x] = woff + incl - count;
     }
     __syncthreads();
     // tile-local sorted position of every element; the array that carries the pass's digit goes to the staging buffer
@@ -598,6 +603,7 @@ __global__ __launch_bounds__(kSortThreads, 4) void onesweep_pass_kernel(SortBufs
         for (int it = 0; it < kItems; ++it)
             if (w0 + it * kWave + lane < b.n) s_stage[loc[it]] = key[it];
     }
+    if (digit_thread)
     {   // The walk: thread d adds up digit d's counts of the tiles before this one, nearest first, until it meets an
         // inclusive prefix.  A hop costs a trip to the fabric (the granules are write-through, the per-XCD L2s are not
         // coherent) behind this CU's own streaming loads and stores -- about 1 us -- and a walk passes ~28 tiles that have
@@ -661,7 +667,7 @@ __global__ __launch_bounds__(kSortThreads, 4) void onesweep_pass_kernel(SortBufs
     if (pass < 4) {
 #pragma unroll
         for (int it = 0; it < kItems; ++it) {
-            const int j = it * kSortThreads + threadIdx.x;
+            const int j = it * THREADS + threadIdx.x;
             if (j < n_here) {
                 const uint32_t v = s_val[j];
                 gpos[it] = bin_base[digit_of(pass, 0, v)] + (uint32_t)j;
@@ -675,13 +681,13 @@ __global__ __launch_bounds__(kSortThreads, 4) void onesweep_pass_kernel(SortBufs
         __syncthreads();
 #pragma unroll
         for (int it = 0; it < kItems; ++it) {
-            const int j = it * kSortThreads + threadIdx.x;
+            const int j = it * THREADS + threadIdx.x;
             if (j < n_here) kout[gpos[it]] = s_stage[j];
         }
     } else {
 #pragma unroll
         for (int it = 0; it < kItems; ++it) {
-            const int j = it * kSortThreads + threadIdx.x;
+            const int j = it * THREADS + threadIdx.x;
             if (j < n_here) {
                 const uint64_t k = s_stage[j];
                 gpos[it] = bin_base[digit_of(pass, k, 0)] + (uint32_t)j;
@@ -695,7 +701,7 @@ __global__ __launch_bounds__(kSortThreads, 4) void onesweep_pass_kernel(SortBufs
         __syncthreads();
 #pragma unroll
         for (int it = 0; it < kItems; ++it) {
-            const int j = it * kSortThreads + threadIdx.x;
+            const int j = it * THREADS + threadIdx.x;
             if (j < n_here) vout[gpos[it]] = s_val[j];
         }
     }
@@ -774,6 +780,9 @@ __device__ unsigned long long g_round_clocks[16];
 constexpr int kSampleThreads = 1024;
 constexpr uint32_t kMaxBucket = 96;
 constexpr uint32_t kMaxBucket2 = 192;                        // second level: samples per super-sample bucket (~16)
+// The rank walks read a bucket four staged bins at a time and may run past its end -- past the end of the staged array for
+// the last bucket: that many sentinels (all ones: larger than any bin) close the array, so the loops need no clamp.
+constexpr int kWalkPad = (int)kMaxBucket + 4, kWalkPad2 = (int)kMaxBucket2 + 4;
 
 constexpr int kSamplesPerThread = 1;                         // 1 024 splitters: buckets of ~EC bins (2 per thread: the
                                                              // walk halves, but the sample sort's chain of steps grows more)
@@ -789,13 +798,13 @@ struct SampleLds {
 };
 
 __host__ __device__ constexpr size_t sample_lds_bytes(int ec) {
-    return ((size_t)ec * kSampleThreads + 2) * 16 + (size_t)kSamplesPerThread * kSampleThreads * (16 + 4) + 64 + (32 + 128) * 4;
+    return ((size_t)ec * kSampleThreads + kWalkPad) * 16 + (size_t)kSamplesPerThread * kSampleThreads * (16 + 4) + 64 + (32 + 128) * 4;
 }
 
 __device__ __forceinline__ SampleLds sample_lds_carve(void* smem, int n) {
     SampleLds L;
     L.stage = reinterpret_cast<ulonglong2*>(smem);
-    L.spl = reinterpret_cast<uint64_t*>(L.stage + n + 2);      // stage[n], stage[n + 1]: sentinels, larger than any bin
+    L.spl = reinterpret_cast<uint64_t*>(L.stage + n + kWalkPad);   // stage[n ..): sentinels, larger than any bin
     L.cnt = reinterpret_cast<uint32_t*>(L.spl + 2 * kSamplesPerThread * kSampleThreads);
     L.misc = L.cnt + kSamplesPerThread * kSampleThreads + 16;
     return L;
@@ -855,8 +864,8 @@ __device__ __forceinline__ bool sample_sort_bins(P64 (&rec)[EC], const SampleLds
             asm volatile("s_nop 1" : "+v"(v.lo), "+v"(v.hi));
             bitonic_sort_lanes_p64<64>(v);
             sup[lane] = p64_value(v);
-        } else if (wave == 1 && lane < 2) {
-            stage2[NS + lane] = make_ulonglong2(~0ull, 0);        // sentinels of the walk below
+        } else if (tid - 64 < kWalkPad2) {
+            stage2[NS + tid - 64] = make_ulonglong2(~0ull, 0);    // sentinels of the walk below
         }
         lds_barrier();                                          // (2)
         uint32_t b2 = 0;
@@ -884,13 +893,12 @@ __device__ __forceinline__ bool sample_sort_bins(P64 (&rec)[EC], const SampleLds
             const uint32_t inf = (uint32_t)e.y;
             const uint32_t s0 = (uint32_t)tid - (inf & 0xFFFFu);
             const uint32_t cmax = wave_max_u32(inf >> 16);
-            const uint64_t* keys2 = reinterpret_cast<const uint64_t*>(stage2);
+            const uint64_t* keys2 = reinterpret_cast<const uint64_t*>(stage2 + s0);      // the bucket's first staged sample
             uint32_t below = 0;
-#pragma unroll 4
-            for (uint32_t k = 0; k < cmax; k += 2) {
-                const uint32_t at = min(s0 + k, (uint32_t)NS);
-                const uint64_t o0 = keys2[2 * at], o1 = keys2[2 * at + 2];
-                below += (o0 < e.x ? 1u : 0u) + (o1 < e.x ? 1u : 0u);
+#pragma unroll 2
+            for (uint32_t k = 0; k < cmax; k += 4) {
+                const uint64_t o0 = keys2[2 * k], o1 = keys2[2 * k + 2], o2 = keys2[2 * k + 4], o3 = keys2[2 * k + 6];
+                below += (o0 < e.x ? 1u : 0u) + (o1 < e.x ? 1u : 0u) + (o2 < e.x ? 1u : 0u) + (o3 < e.x ? 1u : 0u);
             }
             L.spl[s0 + below] = e.x;
             samples_sorted = true;
@@ -988,12 +996,12 @@ __device__ __forceinline__ bool sample_sort_bins(P64 (&rec)[EC], const SampleLds
         const uint32_t inf = (uint32_t)e.y;
         const uint32_t s0 = j - (inf & 0xFFFFu);
         const uint32_t cmax = wave_max_u32(inf >> 16);
+        const uint64_t* bk = keys + 2 * s0;                          // the bucket's first staged bin
         uint32_t below = 0;
-#pragma unroll 4
-        for (uint32_t k = 0; k < cmax; k += 2) {
-            const uint32_t at = min(s0 + k, (uint32_t)N);            // N, N + 1: the sentinels
-            const uint64_t o0 = keys[2 * at], o1 = keys[2 * at + 2];
-            below += (o0 < y[it] ? 1u : 0u) + (o1 < y[it] ? 1u : 0u);
+#pragma unroll 2
+        for (uint32_t k = 0; k < cmax; k += 4) {                     // past the array's end: kWalkPad sentinels
+            const uint64_t o0 = bk[2 * k], o1 = bk[2 * k + 2], o2 = bk[2 * k + 4], o3 = bk[2 * k + 6];
+            below += (o0 < y[it] ? 1u : 0u) + (o1 < y[it] ? 1u : 0u) + (o2 < y[it] ? 1u : 0u) + (o3 < y[it] ? 1u : 0u);
         }
         pos[it] = s0 + below;
     }
@@ -1020,7 +1028,7 @@ __device__ void greedy_rounds_packed(const LargeArgs& a, const uint64_t* key, in
     uint64_t* s_bin = reinterpret_cast<uint64_t*>(smem);
     [[maybe_unused]] const SampleLds L = sample_lds_carve(smem, n);
     [[maybe_unused]] const bool use_sample = (EC >= 2) && blockDim.x == kSampleThreads && a.no_sample_sort != 1;
-    if (use_sample && tid < 2) L.stage[n + tid] = make_ulonglong2(~0ull, 0);      // first read after many barriers
+    if (use_sample && tid < kWalkPad) L.stage[n + tid] = make_ulonglong2(~0ull, 0);      // first read after many barriers
     P64 rec[EC];
     // raw sorted keys of the round's partitions, one round ahead.  The loads are UNCONDITIONAL (index clamped) and
     // issued back to back: a branch around a load makes hipcc wait for it before issuing the next one -- eight
@@ -1398,9 +1406,16 @@ int large_atomic_rank_supported() {
 // `multi_kernel`: the four-kernel passes (count, scans, scatter) instead of the single-kernel ones; also taken when a
 // digit count would not fit a granule's 32-bit count with room for the tag arithmetic (n >= 2^30).
 static hipError_t sort_prepare(LargeScratch& scratch, int64_t n, hipStream_t stream, SortBufs* out, bool multi_kernel = false) {
-    const int n_tiles = (int)((n + kTile - 1) / kTile);
     if (n >= ((int64_t)1 << 30)) multi_kernel = true;
     if (const char* env = getenv("LA_SORT_MULTIKERNEL")) multi_kernel = multi_kernel || atoi(env) != 0;
+    // Tiles of 16 elements per thread: the larger the workgroup, the fewer tiles publish and walk (the look-back costs a
+    // tile ~10 us whatever its size) and the longer the runs a tile writes per digit -- 33.5 M partitions: 2.25 / 2.02 / 1.93 ms
+    // with 256 / 512 / 1 024 threads on the same box, four-kernel passes 2.56; but a 1 M-partition topic (cfg5) has only 64
+    // tiles of 16 384: 0.136 / 0.125 / 0.144 ms (profiles/r03_sort_tile_sizes.txt)
+    int sweep_threads = n >= (3 << 20) ? 1024 : (n >= (1 << 17) ? 512 : 256);
+    if (const char* env = getenv("LA_SWEEP_THREADS")) { const int w = atoi(env); sweep_threads = w == 256 || w == 1024 ? w : 512; }
+    const int64_t tile = multi_kernel ? kTile : (int64_t)sweep_threads * kItems;
+    const int n_tiles = (int)((n + tile - 1) / tile);
     size_t off = 0;
     auto carve = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
     const size_t o_ctl = carve(sizeof(SortCtl));
@@ -1443,6 +1458,7 @@ static hipError_t sort_prepare(LargeScratch& scratch, int64_t n, hipStream_t str
     b.n_tiles = n_tiles;
     b.n_groups = n_groups;
     b.atomic_rank = large_atomic_rank_supported();
+    b.sweep_threads = sweep_threads;
     *out = b;
     return hipMemsetAsync(base, 0, zero_bytes, stream);
 }
@@ -1460,8 +1476,17 @@ static void sort_run_passes(const SortBufs& b, hipStream_t stream, uint32_t* sta
     for (int p = 0; p < kDigits; ++p) {
         if (!((pass_mask >> p) & 1u)) continue;
         if (b.tile_state) {
-            if (b.atomic_rank) hipLaunchKernelGGL(onesweep_pass_kernel<true>, dim3(b.n_tiles), dim3(kSortThreads), 0, stream, b, p, status);
-            else hipLaunchKernelGGL(onesweep_pass_kernel<false>, dim3(b.n_tiles), dim3(kSortThreads), 0, stream, b, p, status);
+            const dim3 grid(b.n_tiles);
+            if (b.sweep_threads == 1024) {
+                if (b.atomic_rank) hipLaunchKernelGGL((onesweep_pass_kernel<true, 1024>), grid, dim3(1024), 0, stream, b, p, status);
+                else hipLaunchKernelGGL((onesweep_pass_kernel<false, 1024>), grid, dim3(1024), 0, stream, b, p, status);
+            } else if (b.sweep_threads == 512) {
+                if (b.atomic_rank) hipLaunchKernelGGL((onesweep_pass_kernel<true, 512>), grid, dim3(512), 0, stream, b, p, status);
+                else hipLaunchKernelGGL((onesweep_pass_kernel<false, 512>), grid, dim3(512), 0, stream, b, p, status);
+            } else {
+                if (b.atomic_rank) hipLaunchKernelGGL((onesweep_pass_kernel<true, 256>), grid, dim3(256), 0, stream, b, p, status);
+                else hipLaunchKernelGGL((onesweep_pass_kernel<false, 256>), grid, dim3(256), 0, stream, b, p, status);
+            }
             continue;
         }
         hipLaunchKernelGGL(tile_count_kernel, dim3(b.n_tiles < 2048 ? b.n_tiles : 2048), dim3(kSortThreads), 0, stream, b, p);
