@@ -113,18 +113,30 @@ def make_workload(args):
     return w, "custom", {"zipf": "Zipf(1.1)", "uniform40": "uniform [0, 2^40)", "pareto": "Pareto(1.5)"}[d]
 
 
-def sort_phase_workload(n):
-    """One topic of n partitions, no consumers, lags uniform on [0, 2^40) from the SplitMix64 generator; ids are the
-    permutation i -> (a*i + c) mod n' restricted to [0, n) -- shuffled enough that every id digit pass runs, and cheap
-    (an argsort of 33.5 M random keys costs more host time than the whole bench)."""
+def sort_phase_workload(n, torch=None, dev=None):
+    """One topic of n partitions, no consumers, lags uniform on [0, 2^40) from the SplitMix64 generator; ids are a random
+    permutation of [0, n): the stable argsort of a second SplitMix64 stream (sorted on the device when one is given: an
+    argsort of 33.5 M keys costs ten seconds of one host core).
+    Until round 3 the ids were the affine permutation i -> (a*i + c) mod 2^k restricted to [0, n) (LA_SORT_IDS=affine
+    still gives it).  With it every tile of an id pass holds EXACTLY the same number of elements of each of the 256
+    digits, so a tile's 256 output runs sit at exact multiples of n/256 elements from each other -- 512 KB / 1 MB apart
+    for n = 2^25: one set of memory channels.  The id passes then take 241 us where the key passes take 179
+    (profiles/r03_large_timeline.txt); partition ids of a real topic do not arrive as an arithmetic progression."""
     from kafka_lag_based_assignor_amd import synth
     lag = (synth.splitmix64(0x9E3779B97F4A7C15 ^ 12, n, 1) >> np.uint64(24)).astype(np.int64)
-    m = 1
-    while m < n:
-        m <<= 1
-    i = np.arange(m, dtype=np.int64)
-    perm = (i * 0x9E3779B1 + 0x7F4A7C15) & (m - 1)              # odd multiplier: a bijection on [0, 2^k)
-    pid = perm[perm < n].astype(np.int32)
+    if os.environ.get("LA_SORT_IDS") == "affine":
+        m = 1
+        while m < n:
+            m <<= 1
+        i = np.arange(m, dtype=np.int64)
+        perm = (i * 0x9E3779B1 + 0x7F4A7C15) & (m - 1)          # odd multiplier: a bijection on [0, 2^k)
+        pid = perm[perm < n].astype(np.int32)
+    else:
+        keys = (synth.splitmix64(0x9E3779B97F4A7C15 ^ 12, n, 2) >> np.uint64(1)).astype(np.int64)   # 63 bits: order as int64
+        if torch is not None and dev is not None:
+            pid = torch.argsort(torch.from_numpy(keys).to(dev), stable=True).to(torch.int32).cpu().numpy()
+        else:
+            pid = np.argsort(keys, kind="stable").astype(np.int32)
     return synth.Workload("sort_phase", 1, np.array([0, n], np.int64), pid, np.zeros(n, np.int64), lag.copy(),
                           np.zeros(n, np.int64), lag, np.array([0, 0], np.int64), np.zeros(0, np.int32), n, 0)
 
@@ -220,7 +232,8 @@ def kernel_name(max_p, max_c):
 def run_sort_phase(torch, N, ctx, dev, n, reps, stream, form="single"):
     """The radix-sort phase of the large path on one topic of n partitions (no consumers: keys, sort, ids).  Times come
     from HIP events the library records around its phases (LA_FLAG_PROFILE / la_last_phase_times)."""
-    w = sort_phase_workload(n)
+    w = sort_phase_workload(n, torch, dev)
+    torch.cuda.empty_cache()
     sh = DeviceShard(torch, N, dev, w, 0, 1, False, "auto",
                      flags=N.LA_FLAG_PROFILE | (N.LA_FLAG_SORT_MULTIKERNEL if form == "multi" else 0))
     ctx.assign_batch_device(sh.batch, stream)                      # scratch allocation, first touch
@@ -318,7 +331,7 @@ def main():
                 "metric": "radix-sort phase of the large path, partitions sorted/sec", "value": round(n / (sp["kernel_ms"] * 1e-3), 1),
                 "unit": "partitions/sec", "n_gpus": 1, "steps": reps, "warmup": 1, "ms_per_step": sp["kernel_ms"],
                 "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int64", "data": "synthetic",
-                "config": {"workload": "1 topic x %d partitions x 0 consumers, uniform [0, 2^40) lags, permuted ids" % n,
+                "config": {"workload": "1 topic x %d partitions x 0 consumers, uniform [0, 2^40) lags, randomly permuted ids" % n,
                            "phase": "sort"},
                 "roofline": sp}))
         if use_dist:

@@ -118,7 +118,27 @@ __global__ __launch_bounds__(256) void build_keys_kernel(LargeArgs a, SortBufs b
 }
 
 // ---- plan: which passes are no-ops, where the data lives before each pass --------------------
-__global__ void plan_kernel(SortBufs b) {
+__global__ __launch_bounds__(kRadix) void plan_kernel(SortBufs b) {
+    // block p: global first position of every digit of pass p (exclusive scan of its histogram): the single-kernel passes
+    // add a tile's look-back result to it
+    __shared__ uint32_t wsum[kRadix / kWave];
+    {
+        const int p = blockIdx.x, d = threadIdx.x, lane = d & 63, wave = d >> 6;
+        const uint32_t h = b.hist[p * kRadix + d];
+        uint32_t incl = h;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t y = __shfl_up(incl, o);
+            if (lane >= o) incl += y;
+        }
+        if (lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        uint32_t run = incl - h;
+        for (int w = 0; w < wave; ++w) run += wsum[w];
+        b.gbase[p * kRadix + d] = run;
+    }
+    if (blockIdx.x != 0) return;
+    // block 0: which passes are no-ops, where the data lives before each pass
     __shared__ uint32_t skip[kDigits];
     if (threadIdx.x < kDigits) skip[threadIdx.x] = 0;
     __syncthreads();
@@ -135,25 +155,6 @@ __global__ void plan_kernel(SortBufs b) {
             cur ^= (s ? 0u : 1u);
         }
         b.ctl->cur[kDigits] = cur;
-    }
-    // global first position of every digit of every pass (exclusive scan of its histogram): the single-kernel passes
-    // add a tile's look-back result to it
-    __shared__ uint32_t wsum[kRadix / kWave];
-    const int d = threadIdx.x, lane = d & 63, wave = d >> 6;
-    for (int p = 0; p < kDigits; ++p) {
-        const uint32_t h = b.hist[p * kRadix + d];
-        uint32_t incl = h;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const uint32_t y = __shfl_up(incl, o);
-            if (lane >= o) incl += y;
-        }
-        __syncthreads();
-        if (lane == 63) wsum[wave] = incl;
-        __syncthreads();
-        uint32_t run = incl - h;
-        for (int w = 0; w < wave; ++w) run += wsum[w];
-        b.gbase[p * kRadix + d] = run;
     }
 }
 
@@ -320,7 +321,7 @@ __global__ __launch_bounds__(256) void lds_atomic_order_test_kernel(uint32_t* ba
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint64_t lt = ((uint64_t)1 << lane) - 1;
     uint32_t wrong = 0;
-    for (uint32_t pattern = 0; pattern < 2048; ++pattern) {
+    for (uint32_t pattern = 0; pattern < 384; ++pattern) {
         for (int i = lane; i < kRadix; i += kWave) { c[wave][i] = 0; shadow[wave][i] = 0; }
         wave_lds_fence();
         const uint32_t span = 1u << ((pattern + wave) % 9);                       // 1, 2, 4 .. 256 distinct addresses
@@ -1471,7 +1472,7 @@ static hipError_t sort_prepare(LargeScratch& scratch, int64_t n, hipStream_t str
 // A pass is ONE launch (onesweep_pass_kernel) -- or four, when the sort was prepared for the multi-kernel form.
 static void sort_run_passes(const SortBufs& b, hipStream_t stream, uint32_t* status, hipEvent_t planned = nullptr,
                             uint32_t pass_mask = (1u << kDigits) - 1) {
-    hipLaunchKernelGGL(plan_kernel, dim3(1), dim3(256), 0, stream, b);
+    hipLaunchKernelGGL(plan_kernel, dim3(kDigits), dim3(kRadix), 0, stream, b);
     if (planned) (void)hipEventRecord(planned, stream);
     for (int p = 0; p < kDigits; ++p) {
         if (!((pass_mask >> p) & 1u)) continue;

@@ -340,24 +340,15 @@ __device__ __forceinline__ void sort_into_slice(uint64_t* slice, int gl, P64 (&r
 // LC = lanes the bins' network spans: the group width L, or less when every topic of the wavefront has at most LC
 // consumers (a 1 000-partition topic with 3 consumers sits in a 64-lane group; its 334 rounds then sort 4 lanes,
 // 3 steps, instead of 64 lanes, 21 steps).  Lanes >= C hold the all-ones sentinel, so any LC >= C sorts the same.
-// Are the bins of every group of the wavefront in ascending order already?  Lane i looks at lane i - 1 through one DPP
-// wave shift per dword (no LDS pipe) and one 64-bit compare.  It happens more often than not: the bins come out of a round
-// as (ascending totals) + (descending lags), which stays ascending wherever the gaps between totals exceed the drops between
-// lags -- all-zero lags, a Zipf tail (the second round of the 100 000 x 256 x 32 target), topics with few distinct lags.
-__device__ __forceinline__ bool bins_in_order(const P64& bin, int gl) {
-    const uint32_t plo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)bin.lo, 0x138, 0xF, 0xF, false);   // wave_shr:1
-    const uint32_t phi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)bin.hi, 0x138, 0xF, 0xF, false);
-    const uint64_t prev = ((uint64_t)phi << 32) | plo;
-    const bool bad = (gl > 0) && (prev > p64_value(bin));          // bins are distinct; the sentinels of idle lanes are equal
-    return __builtin_amdgcn_ballot_w64(bad) == 0;
-}
-
+// Rounds whose bins are in ascending order already skip their sort (lanes_in_order_p64, la_sort64.h: one DPP wave shift
+// per dword and one 64-bit compare): all-zero lags, a Zipf tail (the second round of the 100 000 x 256 x 32 target),
+// topics with few consumers or few distinct lags.
 template <int L, int LC>
 __device__ __forceinline__ void greedy_rounds_tile(P64& bin, uint64_t* slice, int P, int C, int gl, int sh,
                                                    uint64_t lag_max, uint32_t pid_mask, int max_rounds) {
     for (int q = 0; q < max_rounds; ++q) {
         // round 0 starts sorted: all totals 0, indices ascending
-        if (q >= 1 && kSkipSortedRounds && bins_in_order(bin, gl)) {
+        if (q >= 1 && kSkipSortedRounds && lanes_in_order_p64(bin, gl)) {
             // nothing to sort
         } else if (q == 1) {
             // After round 0 consumer k holds the k-th largest lag: if those lags are STRICTLY descending over

@@ -23,7 +23,7 @@ def main():
     ctx = N.Context(0)
     P, C = args.partitions, args.consumers
     from kafka_lag_based_assignor_amd import synth
-    hw = bench.sort_phase_workload(P) if C == 0 else synth.make_uniform("large", 12, 1, P, C, args.dist)
+    hw = bench.sort_phase_workload(P, torch, dev) if C == 0 else synth.make_uniform("large", 12, 1, P, C, args.dist)
     sh = bench.DeviceShard(torch, N, dev, hw, 0, 1, False, "auto")
     b = sh.batch
     stream = torch.cuda.current_stream().cuda_stream

@@ -70,7 +70,7 @@ def main():
     # 3. optional: one large topic (device radix sort + one-workgroup greedy)
     if args.large_partitions > 0:
         P2, C2 = args.large_partitions, args.large_consumers
-        w2 = bench.sort_phase_workload(P2) if C2 == 0 else synth.make_uniform("large", 12, 1, P2, C2, "uniform40")
+        w2 = bench.sort_phase_workload(P2, torch, dev) if C2 == 0 else synth.make_uniform("large", 12, 1, P2, C2, "uniform40")
         sh2 = bench.DeviceShard(torch, N, dev, w2, 0, 1, args.reset_mode == "latest", "auto")
         b2 = sh2.batch
         stream = torch.cuda.current_stream().cuda_stream
