@@ -312,7 +312,12 @@ __device__ __forceinline__ uint64_t p64_of_prev_lane(const P64& r) {
 
 // every group of the wavefront ascending already?  (wavefront-uniform answer)
 __device__ __forceinline__ bool lanes_in_order_p64(const P64& r, int gl) {
-    const bool bad = (gl > 0) && (p64_of_prev_lane(r) > p64_value(r));
+    // The shift is a cross-lane operation: EVERY lane executes it, before any lane-dependent condition.  (Written as
+    // `gl > 0 && p64_of_prev_lane(r) > ...` the DPP moves run only in lanes with gl > 0, and a lane whose source -- the
+    // first lane of a group -- is masked off reads `old` = 0: "in order" whatever the bins are.  Fifty-two parity tests
+    // said so.)
+    const uint64_t prev = p64_of_prev_lane(r);
+    const bool bad = (gl > 0) & (prev > p64_value(r));
     return __builtin_amdgcn_ballot_w64(bad) == 0;
 }
 

@@ -717,19 +717,27 @@ static hipError_t launch_one(const TileArgs& a, int mode, hipStream_t stream) {
     using Cfg = TileCfg<L, E>;
     const int64_t blocks = (a.n_topics + Cfg::kTopicsPerBlock - 1) / Cfg::kTopicsPerBlock;
     if (blocks <= 0) return hipSuccess;
-    // per instantiation; every device this library accepts is the same part (la_create rejects anything but gfx950),
-    // so one set of occupancy figures serves all of them.  Atomics: lanes of several shards may launch concurrently.
-    static std::atomic<int> s_inline{0}, s_wide{0}, s_argmin{0};
+    // Resident workgroups per instantiation AND per device: every device this library accepts is gfx950, but two of them
+    // need not expose the same number of CUs (partition modes).  Atomics: lanes of several shards may launch concurrently.
+    struct Res { std::atomic<int> inl{0}, wide{0}, argmin{0}; };
+    static Res s_res[33];                                        // device ids 0 .. 31; [32]: any other id, never cached
     hipError_t e;
-    int res_inline = s_inline.load(std::memory_order_acquire), res_wide = s_wide.load(std::memory_order_relaxed),
+    int dev = 0;
+    if ((e = hipGetDevice(&dev)) != hipSuccess) return e;
+    const bool cached = dev >= 0 && dev < 32;
+    Res& rs = s_res[cached ? dev : 32];
+    std::atomic<int>&s_inline = rs.inl, &s_wide = rs.wide, &s_argmin = rs.argmin;
+    int res_inline = cached ? s_inline.load(std::memory_order_acquire) : 0, res_wide = s_wide.load(std::memory_order_relaxed),
         res_argmin = s_argmin.load(std::memory_order_relaxed);
     if (res_inline == 0) {
         if ((e = resident_blocks(wave_tile_packed_kernel<L, E, uint32_t, true>, Cfg::kThreads, &res_inline)) != hipSuccess) return e;
         if ((e = resident_blocks(wave_tile_wide_kernel<L, E, false>, Cfg::kThreads, &res_wide)) != hipSuccess) return e;
         if ((e = resident_blocks(wave_tile_wide_kernel<L, E, true>, Cfg::kThreads, &res_argmin)) != hipSuccess) return e;
-        s_wide.store(res_wide, std::memory_order_relaxed);
-        s_argmin.store(res_argmin, std::memory_order_relaxed);
-        s_inline.store(res_inline, std::memory_order_release);
+        if (cached) {
+            s_wide.store(res_wide, std::memory_order_relaxed);
+            s_argmin.store(res_argmin, std::memory_order_relaxed);
+            s_inline.store(res_inline, std::memory_order_release);
+        }
 #ifdef LA_LAB
         printf("resident blocks: inline %d wide %d argmin %d (needed %lld)\n", res_inline, res_wide, res_argmin, (long long)blocks);
 #endif

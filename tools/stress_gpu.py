@@ -72,6 +72,18 @@ def main():
                 c.assign_batch_lags(w.part_off, w.partition_id, w.lag, w.cons_off, w.cons_rank, keep_on_device=True)
                 gl = c.group_last_by_member(w.n_partitions, n_members)
                 assert all(np.array_equal(g, e) for g, e in zip(gl, want)), "grouped lists"
+                # the same through pinned arrays: the three-stream form (no worker threads)
+                def pin(a):
+                    a = np.ascontiguousarray(a)
+                    o = c.host_alloc(a.shape, a.dtype)
+                    o[...] = a
+                    return o
+                pw = [pin(x) for x in (w.part_off, w.partition_id, w.lag, w.cons_off, w.cons_rank)]
+                po = (c.host_alloc((w.n_partitions,), np.int32), c.host_alloc((w.n_partitions,), np.int32),
+                      c.host_alloc((w.cons_rank.size,), np.int64))
+                got = c.assign_batch_lags(*pw, out=po)
+                assert all(np.array_equal(g, e) for g, e in zip(got, exp)), "assignment, pinned arrays"
+                assert w.n_partitions == 0 or c.last_pipeline() == N.LA_PIPELINE_STREAMS, "pipeline %d" % c.last_pipeline()
             except (AssertionError, N.LagAssignError) as e:
                 bad += 1; print("MULTI seed", seed, "shards", c.shard_count, "FAILED:", str(e)[:200])
     for c in multi:
