@@ -3,6 +3,8 @@
 Runs only on a real MI355X (`-m gpu`).  The oracle is the checker; the product path is
 kafka_lag_based_assignor_amd._native -> liblagassign.so -> HIP kernels.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -709,6 +711,39 @@ def test_large_radix_pass_forms_agree(ctx, p, c, kind, shuffled):
     got = _run_device(ctx, w, N.LA_ALGO_AUTO, use_lag=True, flags=N.LA_FLAG_SORT_MULTIKERNEL)
     for g, e, name in zip(got, exp, ("partition order", "member", "totals")):
         np.testing.assert_array_equal(g, e, err_msg="%s, four-kernel passes" % name)
+
+
+def test_large_path_rank_forms_in_fresh_processes():
+    """The radix sort ranks equal digits with returning LDS atomics when the device passes the lane-order self-test of
+    la_create (LA_FEATURE_ATOMIC_RANK) and with wave-match ballots otherwise; LA_SORT_RANK=match forces the second form.
+    The choice is made once per process, so each form gets its own: same topics, the oracle's result, both pass forms."""
+    import subprocess
+    import sys
+    code = r"""
+import numpy as np, sys
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+from kafka_lag_based_assignor_amd import _native as N
+from oracle import oracle
+import test_gpu_parity as t
+ctx = N.Context(0)
+want_atomic = %d
+if want_atomic == 0:      # (whether a device passes the self-test is the device's business; forcing the match form is ours)
+    assert not (ctx.device_features(0) & N.LA_FEATURE_ATOMIC_RANK)
+for p, c, kind in ((300_000, 5, "u40"), (70_000, 2048, "ties"), (4096 * 40 + 7, 3, "u63"), (20_000, 3000, "zero")):
+    po, pid, lag, co, ranks = t._single_topic(p + c, p, c, kind)
+    exp = oracle.assign_flat(po, pid, lag, co, ranks)
+    got = ctx.assign_batch_lags(po, pid, lag, co, ranks)
+    assert all(np.array_equal(g, e) for g, e in zip(got, exp)), (p, c, kind)
+    off, g_t, g_p = ctx.group_by_member(po, exp[0], exp[1], int(ranks.max()) + 1)
+    assert np.array_equal(g_p, exp[0][np.argsort(exp[1], kind="stable")]), "lists"
+print("ok")
+"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for env_rank, want_atomic in (("match", 0), ("atomic", 1)):
+        env = dict(os.environ, LA_SORT_RANK=env_rank)
+        out = subprocess.run([sys.executable, "-c", code % (root, os.path.join(root, "tests"), want_atomic)],
+                             env=env, capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0 and "ok" in out.stdout, (env_rank, out.stdout[-1500:], out.stderr[-1500:])
 
 
 def test_large_phase_times(ctx):
