@@ -107,6 +107,9 @@ extern "C" {
 #define LA_FLAG_SORT_MULTIKERNEL 128 /* large path: every radix pass as four kernels (tile counts, two scans, scatter)   *
                                  * instead of the single-kernel pass with decoupled look-back (test hook / A-B)         */
 
+#define LA_FLAG_NO_RUN_MERGE 256 /* large path: greedy rounds whose bins form a few ascending runs sort them like any other   *
+                                 * round instead of merging the runs (test hook / A-B)                                  */
+
 typedef struct la_ctx la_ctx;
 
 /* la_create / la_create_multi flags */

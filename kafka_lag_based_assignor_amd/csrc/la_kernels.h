@@ -153,6 +153,7 @@ struct LargeArgs {
     int32_t reset_latest;
     int32_t no_sample_sort;     // 1 = LA_FLAG_NO_SAMPLE_SORT: every greedy round sorts its bins with the full network;
                                 // 2 = LA_FLAG_SAMPLE_TIGHT: bucket limit 6, so sample-sorted and fallback rounds interleave
+    int32_t no_run_merge;       // LA_FLAG_NO_RUN_MERGE: greedy rounds never merge ascending runs (they sort as if there were none)
     int32_t sort_multi_kernel;  // LA_FLAG_SORT_MULTIKERNEL: four kernels per radix pass (count, scans, scatter) instead of one
 };
 

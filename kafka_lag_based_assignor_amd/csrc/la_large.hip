@@ -1019,6 +1019,115 @@ __device__ __forceinline__ bool sample_sort_bins(P64 (&rec)[EC], const SampleLds
     return true;
 }
 
+// ---- a round whose bins are a few ascending runs: merge them ------------------------------------------------------------
+// Out of a round the bins are (ascending totals) + (descending lags).  Where the lags of a round take few distinct values
+// -- the flat tail of a power-law topic, ties, zero lags -- the new values are a handful of ascending RUNS (cfg5: 1 700
+// runs in round 2, 95 in round 16, 30 in round 32, 4 - 16 from round 48 on; one run = already in order).  Sorting them is
+// then a tree of pairwise merges of adjacent runs, ceil(log2 R) levels, each level one pass of the bins through LDS:
+// every thread owns 8 consecutive OUTPUT positions, finds where its first output starts in the two runs of its pair
+// (merge path: one binary search), and merges sequentially from there -- ~45 dependent LDS reads per thread and level
+// where a sample-sorted round costs ~350 LDS operations and 16 barriers.
+// Returns false (and leaves rec alone) when there are more than kMaxRuns runs: the caller sorts as before.  *runs_out = the
+// number of runs found, so that the caller can decide when to look again.
+#ifndef LA_MAX_RUNS
+#define LA_MAX_RUNS 32
+#endif
+constexpr int kMaxRuns = LA_MAX_RUNS;
+
+template <int EC>
+__device__ __forceinline__ bool merge_runs_bins(P64 (&rec)[EC], const SampleLds& L, int tid, int* runs_out) {
+    constexpr int NT = kSampleThreads, N = EC * NT;
+    const int lane = tid & 63, wave = tid >> 6;
+    uint64_t* buf_a = reinterpret_cast<uint64_t*>(L.stage);          // [N] the runs
+    uint64_t* buf_b = buf_a + N;                                     // [N] the merged runs of a level
+    uint32_t* bnd = L.cnt;                                           // [R + 1] first position of every run, then N
+    uint32_t* wsum = L.misc;                                         // [16] descents per wavefront
+    // Position p of the sorted order lives at word (p % EC) * NT + p / EC of a buffer (register-major): a thread's EC
+    // consecutive positions are NT words apart, so the 64 lanes of every blocked read or write hit 64 consecutive words
+    // (position-major, they would sit 64 bytes apart: 16-way bank conflicts on every level's output).
+    auto at = [](uint32_t p) -> uint32_t { return (p % EC) * NT + p / EC; };
+    lds_barrier();                                                   // last round's readers of the staging area are done
+    uint64_t v[EC];
+#pragma unroll
+    for (int r = 0; r < EC; ++r) { v[r] = p64_value(rec[r]); buf_a[r * NT + tid] = v[r]; }
+    lds_barrier();
+    // descents: position p starts a new run when bins[p - 1] > bins[p]  (p = tid * EC + r; the bins are distinct)
+    const uint64_t before = tid > 0 ? buf_a[(EC - 1) * NT + tid - 1] : 0;
+    uint32_t starts = 0, mine = 0;                                   // bit r: my r-th position starts a run
+#pragma unroll
+    for (int r = 0; r < EC; ++r) {
+        const bool st = (r == 0 ? before : v[r - 1]) > v[r];
+        starts |= st ? (1u << r) : 0u;
+        mine += st ? 1u : 0u;
+    }
+    const uint32_t incl = wave_incl_scan_u32(mine);
+    if (lane == 63) wsum[wave] = incl;
+    lds_barrier();
+    uint32_t base = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < NT / 64; ++w) {
+        const uint32_t x = wsum[w];
+        base += w < wave ? x : 0u;
+        total += x;
+    }
+    const int R = (int)total + 1;
+    *runs_out = R;
+    if (R > kMaxRuns) return false;                                  // workgroup-uniform
+    if (R == 1) return true;                                         // in order already: rec is untouched and right
+    {
+        uint32_t at = 1 + base + incl - mine;                        // run number of my first start
+#pragma unroll
+        for (int r = 0; r < EC; ++r)
+            if (starts & (1u << r)) bnd[at++] = (uint32_t)(tid * EC + r);
+        if (tid == 0) { bnd[0] = 0; bnd[R] = (uint32_t)N; }
+    }
+    lds_barrier();
+    // the tree: at level `stride` the runs are bnd[0], bnd[stride], bnd[2 stride] ..; pair k merges runs 2k and 2k + 1 of them
+    uint64_t* src = buf_a;
+    uint64_t* dst = buf_b;
+    for (int stride = 1; stride < R; stride <<= 1) {
+        auto at_run = [&](int i) -> uint32_t { return bnd[i < R ? i : R]; };
+        const int n_pairs = (R + 2 * stride - 1) / (2 * stride);
+        const uint32_t o = (uint32_t)(tid * EC);                     // my first output position
+        // the pair my first output falls into: the last k with at_run(2 k stride) <= o
+        int k = 0;
+        for (int step = kMaxRuns / 2; step >= 1; step >>= 1)         // n_pairs <= kMaxRuns / 2
+            if (k + step < n_pairs && at_run(2 * (k + step) * stride) <= o) k += step;
+        uint32_t a0 = at_run(2 * k * stride), a1 = at_run((2 * k + 1) * stride), a2 = at_run((2 * k + 2) * stride);
+        // merge path: of the d = o - a0 outputs before mine, i come from the first run and d - i from the second
+        const uint32_t d = o - a0, len_a = a1 - a0, len_b = a2 - a1;
+        uint32_t lo = d > len_b ? d - len_b : 0u, hi = d < len_a ? d : len_a;
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (src[at(a0 + mid)] < src[at(a1 + (d - mid - 1))]) lo = mid + 1; else hi = mid;
+        }
+        uint32_t ia = a0 + lo, ib = a1 + (d - lo);                   // next element of either run
+        uint64_t xa = ia < a1 ? src[at(ia)] : ~0ull, xb = ib < a2 ? src[at(ib)] : ~0ull;
+        uint64_t out[EC];
+#pragma unroll
+        for (int r = 0; r < EC; ++r) {
+            if (ia >= a1 && ib >= a2) {                              // my outputs run on into the next pair
+                ++k;
+                a0 = a2; a1 = at_run((2 * k + 1) * stride); a2 = at_run((2 * k + 2) * stride);
+                ia = a0; ib = a1;
+                xa = ia < a1 ? src[at(ia)] : ~0ull;
+                xb = ib < a2 ? src[at(ib)] : ~0ull;
+            }
+            const bool take_a = ib >= a2 || (ia < a1 && xa < xb);
+            out[r] = take_a ? xa : xb;
+            if (take_a) { ++ia; xa = ia < a1 ? src[at(ia)] : ~0ull; }
+            else { ++ib; xb = ib < a2 ? src[at(ib)] : ~0ull; }
+        }
+#pragma unroll
+        for (int r = 0; r < EC; ++r) dst[r * NT + tid] = out[r];
+        lds_barrier();
+        uint64_t* t = src; src = dst; dst = t;
+    }
+#pragma unroll
+    for (int r = 0; r < EC; ++r) rec[r] = p64_from(src[r * NT + tid]);
+    return true;
+}
+
 template <int EC>
 __device__ void greedy_rounds_packed(const LargeArgs& a, const uint64_t* key, int64_t P, int C, int64_t rounds,
                                      int idx_bits, void* smem) {
@@ -1043,11 +1152,23 @@ __device__ void greedy_rounds_packed(const LargeArgs& a, const uint64_t* key, in
         rec[r] = p64_from(i < C ? (uint64_t)i : ((~0ull << idx_bits) | (uint64_t)i));
         lag[r] = key[i < P ? i : P - 1];
     }
+    [[maybe_unused]] int64_t next_look = 1;              // the next round that looks whether its bins are a few ascending runs
     for (int64_t q = 0; q < rounds; ++q) {
         if (q > 0) {
             bool sorted = false;
             if constexpr (EC >= 2) {
-                if (use_sample) sorted = sample_sort_bins<EC>(rec, L, tid, a.no_sample_sort == 2 ? 6u : kMaxBucket);
+                // few ascending runs?  The number of runs falls from round to round on the topics that have the property
+                // and stays in the thousands on those that do not: look again after as many rounds as the last look
+                // missed by (a factor of two per round is about what cfg5 does), every round once it has held.
+                if (use_sample && a.no_run_merge == 0 && q >= next_look) {
+                    int runs = 0;
+                    sorted = merge_runs_bins<EC>(rec, L, tid, &runs);
+                    int wait = 0;
+                    for (int x = runs; x > 2 * kMaxRuns && wait < 16; x >>= 1) ++wait;
+                    next_look = q + 1 + wait;
+                    if (!sorted) lds_barrier();              // (its LDS use ends before the sample sort's begins)
+                }
+                if (!sorted && use_sample) sorted = sample_sort_bins<EC>(rec, L, tid, a.no_sample_sort == 2 ? 6u : kMaxBucket);
             }
             if (!sorted) {
                 // sort the n bins: inside every wavefront first, then merges across wavefronts

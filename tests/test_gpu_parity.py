@@ -683,7 +683,8 @@ def test_large_sample_sort_rounds(ctx, p, c, kind):
                            np.zeros(p, np.int64), lag, np.asarray(co, np.int64), ranks, p, c)
     exp = oracle.assign_flat(w.part_off, w.partition_id, w.lag, w.cons_off, w.cons_rank)
     for flags, what in ((0, "sample sort"), (N.LA_FLAG_NO_SAMPLE_SORT, "full network"),
-                        (N.LA_FLAG_SAMPLE_TIGHT, "interleaved"), (N.LA_FLAG_SORT_MULTIKERNEL, "four-kernel radix passes")):
+                        (N.LA_FLAG_SAMPLE_TIGHT, "interleaved"), (N.LA_FLAG_SORT_MULTIKERNEL, "four-kernel radix passes"),
+                        (N.LA_FLAG_NO_RUN_MERGE, "no run merge"), (N.LA_FLAG_NO_RUN_MERGE | N.LA_FLAG_SAMPLE_TIGHT, "no run merge, interleaved")):
         got = _run_device(ctx, w, N.LA_ALGO_AUTO, use_lag=True, flags=flags)
         for g, e, name in zip(got, exp, ("partition order", "member", "totals")):
             np.testing.assert_array_equal(g, e, err_msg="%s, %s" % (name, what))
@@ -711,6 +712,36 @@ def test_large_radix_pass_forms_agree(ctx, p, c, kind, shuffled):
     got = _run_device(ctx, w, N.LA_ALGO_AUTO, use_lag=True, flags=N.LA_FLAG_SORT_MULTIKERNEL)
     for g, e, name in zip(got, exp, ("partition order", "member", "totals")):
         np.testing.assert_array_equal(g, e, err_msg="%s, four-kernel passes" % name)
+
+
+@pytest.mark.parametrize("p,c,kind", [
+    (400_000, 8192, "pareto"), (524_288, 4096, "pareto"), (300_000, 2048, "pareto"), (200_000, 8192, "ties"),
+    (150_000, 5000, "zero"), (100_000, 3000, "few"), (250_000, 8000, "steps"), (90_000, 2049, "steps"),
+])
+def test_large_rounds_merge_ascending_runs(ctx, p, c, kind):
+    """Greedy rounds whose bins form a few ascending runs (a flat tail of lags, ties, zero lags: one run) merge the runs
+    instead of sorting: the same result as with LA_FLAG_NO_RUN_MERGE, the oracle's."""
+    rng = np.random.default_rng(p + c)
+    if kind == "pareto":
+        w = _pareto_topic(p + c, p, c)
+    else:
+        if kind == "ties":
+            lag = rng.integers(0, 5, p) * 1000
+        elif kind == "zero":
+            lag = np.zeros(p, dtype=np.int64)
+        elif kind == "few":
+            lag = rng.choice(np.array([7, 7, 7, 8, 1_000_000]), p)           # rounds with two or three distinct lags
+        else:
+            lag = (np.arange(p) // 997)[::-1] + rng.integers(0, 2, p)        # a staircase: a run per step and then some
+        lag = np.ascontiguousarray(lag, dtype=np.int64)
+        w = synth.Workload(kind, 1, np.array([0, p], np.int64), rng.permutation(p).astype(np.int32), np.zeros(p, np.int64),
+                           lag.copy(), np.zeros(p, np.int64), lag, np.array([0, c], np.int64),
+                           np.sort(rng.choice(3 * c + 1, c, replace=False)).astype(np.int32), p, c)
+    exp = oracle.assign_flat(w.part_off, w.partition_id, w.lag, w.cons_off, w.cons_rank)
+    for flags, what in ((0, "runs merged"), (N.LA_FLAG_NO_RUN_MERGE, "runs sorted")):
+        got = _run_device(ctx, w, N.LA_ALGO_AUTO, use_lag=True, flags=flags)
+        for g, e, name in zip(got, exp, ("partition order", "member", "totals")):
+            np.testing.assert_array_equal(g, e, err_msg="%s, %s" % (name, what))
 
 
 def test_large_path_rank_forms_in_fresh_processes():
