@@ -324,6 +324,19 @@ int la_group_by_member_device(la_ctx *ctx, int32_t n_topics, int64_t n_partition
                               int64_t *d_member_off, int32_t *d_grouped_topic, int32_t *d_grouped_partition,
                               void *stream);
 
+/* The north star's single RCCL all-gather, in native code, for a caller that drives every GPU of the node from ONE process
+ * (la_create_multi + la_assign_batch_device_on): every shard's result buffer to every shard's device.
+ *   d_send[i]  `count` int32 on shard i's device (e.g. its [2, cap] result buffer: partition order | member rank)
+ *   d_recv[i]  n_shards * count int32 on shard i's device; shard j's block lands at d_recv[i] + j * count
+ * One ncclAllGather per shard inside one ncclGroupStart / ncclGroupEnd, enqueued on la_shard_stream(ctx, i) -- i.e. behind
+ * whatever la_assign_batch_device_on enqueued there; la_sync_on waits for it.  ncclAllGather moves equal counts: pad the
+ * shards to the largest (la_plan_shards balances them to within one topic).  The communicators are created on first use
+ * (ncclCommInitAll over the context's devices) and live as long as the context.
+ * librccl is loaded at run time, on first use (dlopen; a copy already in the process is preferred): LA_ENODEV when it is
+ * not there.  RCCL wants one DISTINCT device per rank: LA_EINVAL for a context with several shards on one device.
+ * (One process per GPU -- bench.py, torch.distributed -- calls RCCL through its own framework instead.) */
+int la_allgather_results(la_ctx *ctx, int64_t count, const int32_t *const *d_send, int32_t *const *d_recv);
+
 /* la_group_by_member_device on shard `shard` (buffers on that shard's device). */
 int la_group_by_member_device_on(la_ctx *ctx, int shard, int32_t n_topics, int64_t n_partitions,
                                  const int64_t *d_part_off, const int32_t *d_out_partition,

@@ -33,6 +33,7 @@ EXPORTED_SYMBOLS = (
     "la_device_count", "la_create_multi", "la_shard_count", "la_shard_device", "la_plan_shards",
     "la_last_shard_bounds", "la_host_alloc", "la_host_free", "la_last_phase_times", "la_device_features",
     "la_shard_stream", "la_assign_batch_device_on", "la_sync_on", "la_group_by_member_device_on", "la_last_pipeline",
+    "la_allgather_results",
 )
 
 _i64p = ctypes.POINTER(ctypes.c_int64)
@@ -141,6 +142,9 @@ def load() -> ctypes.CDLL:
     L.la_group_by_member_device.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64, ctypes.c_void_p,
                                             ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32, ctypes.c_void_p,
                                             ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+    L.la_allgather_results.restype = ctypes.c_int
+    L.la_allgather_results.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.POINTER(ctypes.c_void_p),
+                                       ctypes.POINTER(ctypes.c_void_p)]
     L.la_last_pipeline.restype = ctypes.c_int
     L.la_last_pipeline.argtypes = [ctypes.c_void_p]
     L.la_shard_stream.restype = ctypes.c_void_p
@@ -366,6 +370,13 @@ class Context:
 
     def sync(self, stream: int = 0, shard: int = 0) -> None:
         self._check(self._lib.la_sync_on(self._h, shard, ctypes.c_void_p(stream)))
+
+    def allgather_results(self, count: int, d_send, d_recv) -> None:
+        """la_allgather_results: d_send / d_recv are lists of device pointers (ints), one per shard."""
+        n = self.shard_count
+        send = (ctypes.c_void_p * n)(*[ctypes.c_void_p(int(x)) for x in d_send])
+        recv = (ctypes.c_void_p * n)(*[ctypes.c_void_p(int(x)) for x in d_recv])
+        self._check(self._lib.la_allgather_results(self._h, count, send, recv))
 
     def last_pipeline(self) -> int:
         """LA_PIPELINE_* of the last host-buffer assign call."""

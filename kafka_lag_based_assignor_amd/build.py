@@ -73,7 +73,7 @@ def build(force: bool = False, verbose: bool = False, host: bool = True) -> str:
     with ThreadPoolExecutor(max_workers=min(os.cpu_count() or 4, 8, max(1, len(jobs)))) as ex:
         list(ex.map(run, jobs))
     if force or jobs or _stale(LIB, objs):
-        run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,--no-undefined", "-o", LIB, *objs])
+        run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,--no-undefined", "-o", LIB, *objs, "-ldl"])
     if host:
         build_host(force=force, verbose=verbose)
     return LIB

@@ -6,6 +6,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <dlfcn.h>
+
 #include <algorithm>
 #include <atomic>
 #include <cstdarg>
@@ -14,6 +16,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -104,6 +107,7 @@ struct la_ctx {
     bool last_valid = false;
     int last_pipeline = 0;               // how the last host-buffer call moved its data: 0 = one copy each way (small batch),
                                          // 1 = lanes (a host thread per stream; pageable arrays), 2 = three streams, no threads (pinned)
+    std::vector<void*> comms;            // la_allgather_results: one ncclComm_t per shard, created on first use
     int last_shards = 0;                 // shards the last call used
     int32_t last_bounds[65] = {};        // their topic ranges
 };
@@ -1072,6 +1076,46 @@ int assign_host(la_ctx* ctx, int32_t T, const int64_t* part_off, const int32_t* 
     return LA_OK;
 }
 
+// ---- RCCL, loaded at run time (la_allgather_results) ------------------------------------------------------------------
+// Only the five entry points the all-gather needs; prototypes as in rccl.h (ncclResult_t is an int enum, 0 = success;
+// ncclInt32 = 2).  A copy of the library that the process has already loaded wins: a process that carries its own ROCm
+// runtime (PyTorch does) must not get a second one through /opt/rocm's librccl.
+struct RcclApi {
+    void* handle = nullptr;
+    int (*CommInitAll)(void** comms, int ndev, const int* devlist) = nullptr;
+    int (*CommDestroy)(void* comm) = nullptr;
+    int (*AllGather)(const void* send, void* recv, size_t count, int datatype, void* comm, hipStream_t stream) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+    std::string why;
+};
+
+RcclApi& rccl_api() {
+    static RcclApi api;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        const char* names[] = {"librccl.so", "librccl.so.1"};
+        for (const char* n : names)
+            if (!api.handle) api.handle = dlopen(n, RTLD_NOW | RTLD_NOLOAD);       // already in the process?
+        for (const char* n : names)
+            if (!api.handle) api.handle = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+        if (!api.handle) { api.why = std::string("librccl not found: ") + (dlerror() ? dlerror() : "?"); return; }
+        auto sym = [&](const char* name) { return dlsym(api.handle, name); };
+        api.CommInitAll = (decltype(api.CommInitAll))sym("ncclCommInitAll");
+        api.CommDestroy = (decltype(api.CommDestroy))sym("ncclCommDestroy");
+        api.AllGather = (decltype(api.AllGather))sym("ncclAllGather");
+        api.GroupStart = (decltype(api.GroupStart))sym("ncclGroupStart");
+        api.GroupEnd = (decltype(api.GroupEnd))sym("ncclGroupEnd");
+        api.GetErrorString = (decltype(api.GetErrorString))sym("ncclGetErrorString");
+        if (!api.CommInitAll || !api.CommDestroy || !api.AllGather || !api.GroupStart || !api.GroupEnd) {
+            api.why = "librccl lacks ncclCommInitAll / ncclAllGather / ncclGroupStart";
+            api.handle = nullptr;
+        }
+    });
+    return api;
+}
+
 int create_lane(Lane& ln) {
     hipError_t e;
     if ((e = hipStreamCreateWithFlags(&ln.stream, hipStreamNonBlocking)) != hipSuccess ||
@@ -1208,6 +1252,16 @@ LA_API int la_create(la_ctx** out, int device_id, unsigned flags) { return la_cr
 
 LA_API void la_destroy(la_ctx* ctx) {
     if (!ctx) return;
+    if (!ctx->comms.empty()) {
+        for (Shard& sh : ctx->shards) {                                   // nothing of an all-gather stays in flight
+            (void)hipSetDevice(sh.device);
+            if (!sh.lanes.empty() && sh.lanes[0].stream) (void)hipStreamSynchronize(sh.lanes[0].stream);
+        }
+        RcclApi& r = rccl_api();
+        for (void* c : ctx->comms)
+            if (c && r.CommDestroy) (void)r.CommDestroy(c);
+        ctx->comms.clear();
+    }
     for (Shard& sh : ctx->shards) {
         (void)hipSetDevice(sh.device);
         for (Lane& ln : sh.lanes) destroy_lane(ln);
@@ -1258,6 +1312,49 @@ LA_API int la_last_shard_bounds(const la_ctx* ctx, int32_t* bounds, int32_t capa
     if (bounds)
         for (int i = 0; i <= S && i < capacity; ++i) bounds[i] = ctx->last_bounds[i];
     return S;
+}
+
+LA_API int la_allgather_results(la_ctx* ctx, int64_t count, const int32_t* const* d_send, int32_t* const* d_recv) {
+    if (!ctx) return LA_EINVAL;
+    try {
+        const int S = (int)ctx->shards.size();
+        if (count < 0 || !d_send || !d_recv) return fail(ctx, LA_EINVAL, "null buffer list or negative count");
+        for (int i = 0; i < S; ++i)
+            if (count > 0 && (!d_send[i] || !d_recv[i])) return fail(ctx, LA_EINVAL, "null buffer of shard %d", i);
+        for (int i = 0; i < S; ++i)
+            for (int j = 0; j < i; ++j)
+                if (ctx->shards[(size_t)i].device == ctx->shards[(size_t)j].device)
+                    return fail(ctx, LA_EINVAL, "shards %d and %d share device %d: RCCL needs one distinct device per rank", j, i,
+                                ctx->shards[(size_t)i].device);
+        if (count == 0) return LA_OK;
+        RcclApi& r = rccl_api();
+        if (!r.handle) return fail(ctx, LA_ENODEV, "%s", r.why.c_str());
+        auto text = [&](int rc) { return r.GetErrorString ? r.GetErrorString(rc) : "rccl error"; };
+        if (ctx->comms.empty()) {
+            std::vector<int> devs;
+            for (const Shard& sh : ctx->shards) devs.push_back(sh.device);
+            std::vector<void*> comms((size_t)S, nullptr);
+            const int rc = r.CommInitAll(comms.data(), S, devs.data());
+            if (rc != 0) return fail(ctx, LA_EHIP, "ncclCommInitAll over %d device(s): %s", S, text(rc));
+            ctx->comms = comms;
+        }
+        int rc = r.GroupStart();
+        if (rc != 0) return fail(ctx, LA_EHIP, "ncclGroupStart: %s", text(rc));
+        int first_bad = 0;
+        for (int i = 0; i < S; ++i) {
+            Shard& sh = ctx->shards[(size_t)i];
+            if (hipSetDevice(sh.device) != hipSuccess) { first_bad = -1; break; }
+            rc = r.AllGather(d_send[i], d_recv[i], (size_t)count, /* ncclInt32 */ 2, ctx->comms[(size_t)i], sh.lanes[0].stream);
+            if (rc != 0 && first_bad == 0) first_bad = rc;
+        }
+        rc = r.GroupEnd();
+        if (first_bad == -1) return fail(ctx, LA_EHIP, "hipSetDevice failed while enqueueing the all-gather");
+        if (first_bad != 0) return fail(ctx, LA_EHIP, "ncclAllGather: %s", text(first_bad));
+        if (rc != 0) return fail(ctx, LA_EHIP, "ncclGroupEnd: %s", text(rc));
+        return LA_OK;
+    } catch (...) {
+        return fail(ctx, LA_ENOMEM, "exception in la_allgather_results");
+    }
 }
 
 LA_API int la_last_pipeline(const la_ctx* ctx) { return ctx ? ctx->last_pipeline : LA_EINVAL; }

@@ -174,6 +174,52 @@ def test_device_entry_points_on_every_shard(ctx4):
     assert ei.value.code == N.LA_EINVAL
 
 
+def test_native_rccl_allgather_of_the_results(ctx4):
+    """la_allgather_results: the north star's single RCCL all-gather as a native call site (ncclCommInitAll + one
+    ncclAllGather per shard in a group), for a process that drives all the node's GPUs itself.  A one-GPU box can run it
+    at one rank -- RCCL init, the collective on the shard's stream behind the kernels, la_sync_on -- and with every GPU
+    of a bigger box (distinct devices); several shards on one device are refused with a clear error, as RCCL would."""
+    import torch
+    n_dev = N.device_count()
+    c = N.Context(list(range(n_dev)))                              # one shard per physical device
+    try:
+        S = c.shard_count
+        w = synth.config("cfg4", 0.05)
+        lag = oracle.compute_lags(w.begin, w.end, w.committed, False)
+        exp = oracle.assign_flat(w.part_off, w.partition_id, lag, w.cons_off, w.cons_rank)
+        bounds = N.plan_shards(w.part_off, S)
+        counts = [int(w.part_off[bounds[i + 1]] - w.part_off[bounds[i]]) for i in range(S)]
+        cap = max(counts)
+        shards, packed, recv = [], [], []
+        for i in range(S):
+            dev = torch.device("cuda", c.shard_device(i))
+            sh = _device_shard(torch, w, int(bounds[i]), int(bounds[i + 1]), dev)
+            buf = torch.zeros(2 * cap, device=dev, dtype=torch.int32)          # [2, cap]: partition order | member rank
+            sh["b"].d_out_partition = buf.data_ptr()
+            sh["b"].d_out_member_rank = buf.data_ptr() + 4 * cap
+            shards.append(sh); packed.append(buf)
+            recv.append(torch.full((S * 2 * cap,), -9, device=dev, dtype=torch.int32))
+        torch.cuda.synchronize()
+        for i in range(S):
+            c.assign_batch_device(shards[i]["b"], c.shard_stream(i), shard=i)
+        c.allgather_results(2 * cap, [p.data_ptr() for p in packed], [r.data_ptr() for r in recv])   # behind the kernels
+        for i in range(S):
+            c.sync(c.shard_stream(i), shard=i)
+        for i in range(S):                                          # every device holds the global assignment
+            g = recv[i].cpu().numpy().reshape(S, 2, cap)
+            pid = np.concatenate([g[r, 0, :counts[r]] for r in range(S)])
+            rank = np.concatenate([g[r, 1, :counts[r]] for r in range(S)])
+            np.testing.assert_array_equal(pid, exp[0], err_msg="gathered partition order on device %d" % i)
+            np.testing.assert_array_equal(rank, exp[1], err_msg="gathered member ranks on device %d" % i)
+    finally:
+        c.close()
+    # several shards on ONE device: refused
+    d = torch.zeros(8, device="cuda:0", dtype=torch.int32)
+    with pytest.raises(N.LagAssignError) as ei:
+        ctx4.allgather_results(2, [d.data_ptr()] * 4, [d.data_ptr()] * 4)
+    assert ei.value.code == N.LA_EINVAL and "distinct device" in str(ei.value)
+
+
 def test_compute_lag_and_group_by_member_across_shards(ctx4, ctx1):
     """la_compute_lag and la_group_by_member split large inputs over the shards (element ranges / topic ranges); the
     results equal the one-device ones."""
