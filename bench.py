@@ -91,6 +91,8 @@ def parse_args():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg (rank 0, N=1)")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the oracle legs (parity check, cpu_baseline, host_boundary)")
     ap.add_argument("--no-sort-phase", action="store_true", help="skip the sort_phase leg of the default line")
+    ap.add_argument("--no-live-traffic", action="store_true",
+                    help="roofline.traffic from the committed PMC summary instead of two rocprofv3 child passes in this run")
     return ap.parse_args()
 
 
@@ -221,6 +223,77 @@ def measured_traffic(T, P, C, mode, algo):
     return None
 
 
+def _pmc_passes(probe_args, seconds=150):
+    """Two child processes under rocprofv3 (--pmc FETCH_SIZE, then --pmc WRITE_SIZE: separate passes, as
+    MI355X_MICROARCH.md's HBM section prescribes) over tools/pmc_probe.py -- a calibration kernel with known bytes, then
+    the launches to measure -- summarised and calibrated by tools/pmc_parse.py.  rocprofv3 cannot wrap the process it is
+    called from, hence the children.  None when rocprofv3 is missing or a pass fails or times out."""
+    import shutil
+    import subprocess
+    import tempfile
+    prof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(prof):
+        return None
+    out = tempfile.mkdtemp(prefix="la_pmc_")
+    env = dict(os.environ, TMPDIR="/tmp")
+    probe = [sys.executable, os.path.join(ROOT, "tools", "pmc_probe.py")] + probe_args
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            r = subprocess.run([prof, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d",
+                                os.path.join(out, counter), "--"] + probe, cwd="/tmp", env=env, capture_output=True,
+                               text=True, timeout=seconds)
+            if r.returncode != 0:
+                return None
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pmc_parse.py"), os.path.join(out, "FETCH_SIZE"),
+                            os.path.join(out, "WRITE_SIZE")], capture_output=True, text=True, timeout=60)
+        d = json.loads(r.stdout)
+        d["how"] = ("measured in this run: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate child processes over "
+                    "tools/pmc_probe.py on this box), calibrated on lag_kernel_vec2's known bytes (fetch x%.1f B/count, "
+                    "write x%.1f B/count)" % (d["calibration"]["fetch_bytes_per_count"], d["calibration"]["write_bytes_per_count"]))
+        return d
+    except Exception:  # noqa: BLE001 -- a reported extra: the committed summary stands in
+        return None
+    finally:
+        shutil.rmtree(out, ignore_errors=True)
+
+
+def live_traffic(reset_mode, algo):
+    """HBM bytes per launch of the target batch's kernels, measured now on this box (see _pmc_passes)."""
+    d = _pmc_passes(["--reset-mode", reset_mode, "--algo", algo, "--launches", "3"])
+    if not d:
+        return None
+    rd = wr = 0.0
+    for k, e in d["kernels"].items():
+        if "wave_tile_packed_kernel" in k or "wave_tile_wide_kernel" in k:
+            rd += e.get("fetch_bytes_calibrated", 0.0)
+            wr += e.get("write_bytes_calibrated", 0.0)
+    if rd <= 0 or wr <= 0:
+        return None
+    return {"hbm_bytes_per_launch": round(rd + wr), "read_bytes": round(rd), "written_bytes": round(wr), "source": d["how"]}
+
+
+def live_sort_traffic(n, form):
+    """HBM bytes of the radix-sort phase of one n-partition topic, measured now: every pass kernel's mean bytes per
+    launch times the 12 launches of a sort (the skipped passes' launches move next to nothing and are in the mean)."""
+    if form == "multi":
+        os.environ["LA_SORT_MULTIKERNEL"] = "1"
+    try:
+        d = _pmc_passes(["--topics", "0", "--large-partitions", str(n), "--large-consumers", "0"], seconds=240)
+    finally:
+        os.environ.pop("LA_SORT_MULTIKERNEL", None)
+    if not d:
+        return None
+    names = ("onesweep_pass_kernel",) if form == "single" else ("tile_count_kernel", "scan_group_sums_kernel", "scan_offsets_kernel", "tile_scatter_kernel")
+    rd = wr = 0.0
+    for k, e in d["kernels"].items():
+        if any(x in k for x in names):
+            rd += 12 * e.get("fetch_bytes_calibrated", 0.0)
+            wr += 12 * e.get("write_bytes_calibrated", 0.0)
+    if rd <= 0 or wr <= 0:
+        return None
+    return {"hbm_bytes_per_launch": round(rd + wr), "read_bytes": round(rd), "written_bytes": round(wr), "source": d["how"]}
+
+
 def kernel_name(max_p, max_c):
     if max_p <= 1024 and max_c <= 64:
         return "wave_tile_packed_kernel (+ the wide-record kernel over its deferred-tile list, empty here)"
@@ -229,7 +302,7 @@ def kernel_name(max_p, max_c):
     return "large-topic path (all kernels)"
 
 
-def run_sort_phase(torch, N, ctx, dev, n, reps, stream, form="single"):
+def run_sort_phase(torch, N, ctx, dev, n, reps, stream, form="single", live=False):
     """The radix-sort phase of the large path on one topic of n partitions (no consumers: keys, sort, ids).  Times come
     from HIP events the library records around its phases (LA_FLAG_PROFILE / la_last_phase_times)."""
     w = sort_phase_workload(n, torch, dev)
@@ -259,7 +332,7 @@ def run_sort_phase(torch, N, ctx, dev, n, reps, stream, form="single"):
     perm_lag = lag_dev[inv[pid]]
     ok = bool(((perm_lag[:-1] > perm_lag[1:]) | ((perm_lag[:-1] == perm_lag[1:]) & (pid[:-1] < pid[1:]))).all()) if n > 1 else True
     del pid, lag_dev, perm_lag, inv
-    tr = measured_sort_traffic(n, form)
+    tr = (live_sort_traffic(n, form) if live else None) or measured_sort_traffic(n, form)
     return {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": tr["hbm_bytes_per_launch"] if tr else None,
             "traffic_source": tr["source"] if tr else None,
@@ -325,7 +398,7 @@ def main():
     if args.phase == "sort":
         n = args.partitions or SORT_PHASE_PARTITIONS
         reps = max(1, min(args.steps, 20))
-        sp = run_sort_phase(torch, N, ctx, dev, n, reps, stream, args.sort_form)
+        sp = run_sort_phase(torch, N, ctx, dev, n, reps, stream, args.sort_form, live=not args.no_live_traffic)
         if rank == 0:
             print(json.dumps({
                 "metric": "radix-sort phase of the large path, partitions sorted/sec", "value": round(n / (sp["kernel_ms"] * 1e-3), 1),
@@ -473,7 +546,13 @@ def main():
     uniform = bool(lens_p.size and (lens_p == P).all() and (lens_c == C).all())
     bpp = BYTES_PER_PARTITION[args.reset_mode]
     achieved = bpp * n_part / (kern_ms * 1e-3) / 1e9
-    tr = measured_traffic(b.n_topics, P, C, args.reset_mode, args.algo) if uniform else None
+    tr = None
+    if uniform and world == 1 and wname == "target" and not args.no_live_traffic and not args.no_cpu_baseline:
+        tr = live_traffic(args.reset_mode, args.algo)              # measured in this run (child processes, this box)
+    if tr is None:
+        tr = measured_traffic(b.n_topics, P, C, args.reset_mode, args.algo) if uniform else None
+        if tr:
+            tr = dict(tr, source="%s (committed summary of the same workload: the live PMC passes were skipped or failed)" % tr.get("source"))
     roofline = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "traffic": tr["hbm_bytes_per_launch"] if tr else None,
@@ -489,7 +568,8 @@ def main():
         roofline["per_rank_kernel_ms"] = [round(float(x), 4) for x in per_rank[:world]]
         roofline["per_rank_gather_ms"] = [round(float(x), 4) for x in per_rank[world:]]
     if tr:
-        roofline["traffic_source"] = "%s (PMC passes cannot run inside this process; committed summary of the same workload)" % tr.get("source")
+        roofline["traffic_source"] = tr.get("source")
+        roofline["traffic_read_bytes"], roofline["traffic_written_bytes"] = tr.get("read_bytes"), tr.get("written_bytes")
 
     # ---- quality metric of BASELINE.json: max/min per-consumer total lag per topic (min clamped to 1) ----
     lag_ratio = None
@@ -599,10 +679,11 @@ def main():
         try:
             del sh.d                                             # the batch is done with: make room
             torch.cuda.empty_cache()
-            sp = run_sort_phase(torch, N, ctx, dev, SORT_PHASE_PARTITIONS, 5, stream, args.sort_form)
+            sp = run_sort_phase(torch, N, ctx, dev, SORT_PHASE_PARTITIONS, 5, stream, args.sort_form,
+                                live=world == 1 and not args.no_live_traffic and not args.no_cpu_baseline)
             sort_phase = {k: sp[k] for k in ("frac", "achieved", "unit", "kernel", "form", "rank", "kernel_ms", "partitions", "id_passes",
                                              "algorithmic_bytes",
-                                             "key_passes", "algorithmic_bytes_per_launch", "traffic", "sorted_ok", "source")}
+                                             "key_passes", "algorithmic_bytes_per_launch", "traffic", "traffic_source", "sorted_ok", "source")}
         except Exception as exc:  # noqa: BLE001 -- a reported extra
             sort_phase = {"error": str(exc)}
 
