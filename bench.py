@@ -223,7 +223,7 @@ def measured_traffic(T, P, C, mode, algo):
     return None
 
 
-def _pmc_passes(probe_args, seconds=150):
+def _pmc_passes(probe_args, seconds=60):
     """Two child processes under rocprofv3 (--pmc FETCH_SIZE, then --pmc WRITE_SIZE: separate passes, as
     MI355X_MICROARCH.md's HBM section prescribes) over tools/pmc_probe.py -- a calibration kernel with known bytes, then
     the launches to measure -- summarised and calibrated by tools/pmc_parse.py.  rocprofv3 cannot wrap the process it is
@@ -278,7 +278,7 @@ def live_sort_traffic(n, form):
     if form == "multi":
         os.environ["LA_SORT_MULTIKERNEL"] = "1"
     try:
-        d = _pmc_passes(["--topics", "0", "--large-partitions", str(n), "--large-consumers", "0"], seconds=240)
+        d = _pmc_passes(["--topics", "0", "--large-partitions", str(n), "--large-consumers", "0"], seconds=90)
     finally:
         os.environ.pop("LA_SORT_MULTIKERNEL", None)
     if not d:
