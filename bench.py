@@ -234,6 +234,9 @@ def _pmc_passes(probe_args, seconds=60):
     prof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(prof):
         return None
+    # already under a profiler (rocprofv3 -- python bench.py ...)?  Its environment would follow the children: stand down
+    if any(k.startswith(("ROCPROF", "ROCP_", "ROCPROFILER")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", ""):
+        return None
     out = tempfile.mkdtemp(prefix="la_pmc_")
     env = dict(os.environ, TMPDIR="/tmp")
     probe = [sys.executable, os.path.join(ROOT, "tools", "pmc_probe.py")] + probe_args
