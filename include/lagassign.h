@@ -20,7 +20,10 @@
  *   la_create_multi         the per-topic loop, sharded over the GPUs of a node Main.java:177-184
  *   la_assign_batch_device_on  the same loop for a caller whose data already lives on every GPU
  *   la_plan_shards          (which topics of that loop each shard takes)
+ *   la_allgather_results    nothing in the reference (it has one thread and one heap): the reassembly of the global
+ *                           assignment on every GPU, one RCCL all-gather over xGMI
  *   la_last_phase_times     nothing: measurement hook (radix-sort phase against the HBM roofline)
+ *   la_device_features, la_last_pipeline   nothing: diagnostics (what the library found / did)
  *
  * Data model (SoA; TopicPartitionLag, Main.java:431-455, flattened):
  *   topic t owns partitions [part_off[t], part_off[t+1]) of the per-partition arrays and
