@@ -416,6 +416,22 @@ def test_cfg5_full_size_latest(ctx):
         np.testing.assert_array_equal(g, e, err_msg="oracle: " + what)
 
 
+def test_cfg5_full_size_other_forms(ctx):
+    """cfg5 at full size through the device entry point in the forms the default call does not take: greedy rounds that
+    never merge their runs, four-kernel radix passes, both, and the full bitonic network in every round -- each equal to the
+    round form of the oracle (which test_cfg5_full_size checks against the literal per-step min)."""
+    w = synth.config("cfg5")
+    lag = oracle.compute_lags(w.begin, w.end, w.committed, False)
+    exp = _round_form(w.part_off, w.partition_id, lag, w.cons_off, w.cons_rank)
+    for flags, what in ((0, "default"), (N.LA_FLAG_NO_RUN_MERGE, "runs sorted, not merged"),
+                        (N.LA_FLAG_SORT_MULTIKERNEL, "four-kernel radix passes"),
+                        (N.LA_FLAG_NO_RUN_MERGE | N.LA_FLAG_SORT_MULTIKERNEL | N.LA_FLAG_SAMPLE_TIGHT, "all three hooks"),
+                        (N.LA_FLAG_NO_SAMPLE_SORT | N.LA_FLAG_NO_RUN_MERGE, "full network every round")):
+        got = _run_device(ctx, w, N.LA_ALGO_AUTO, use_lag=False, latest=False, flags=flags)
+        for g, e, name in zip(got, exp, ("partition order", "member", "totals")):
+            np.testing.assert_array_equal(g, e, err_msg="cfg5, %s: %s" % (what, name))
+
+
 # ---- device-resident entry point; round form == literal wavefront argmin ------------------------------
 def _run_device(ctx, w, algo, use_lag=False, latest=True, flags=0, host_offsets=True):
     import ctypes
