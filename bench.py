@@ -616,7 +616,6 @@ def main():
                 done_total += e - done
                 done = e
             spent += local
-        checked_partitions = None
         parity = {"checked_topics": done_total, "bit_exact": ok,
                   "against": "oracle/lag_oracle.c (literal per-step min)%s" % (
                       "; the all-gathered global arrays, a slice of every rank's shard" if strong else "")}
