@@ -472,9 +472,10 @@ def main():
         step()
 
     # ---- timed region: exactly K steps, bracketed by barrier + synchronize on both sides --------------------
-    # HIP events around about 200 of the steps (every step when K <= 200): an event record is a marker packet
-    # in the queue, and three per step would be a measurable part of a 160 us step
-    stride = max(1, args.steps // 200)
+    # HIP events around a sample of the steps: an event record is a marker packet in the queue, ~1.5 us each, and a pair
+    # around every one of the driver's 20 steps took 2 % off `value` (the wall clock over the K steps).  About 200 of the
+    # steps of a long run, every other step of a short one (at least 10 samples).
+    stride = max(1, args.steps // 200) if args.steps > 40 else (2 if args.steps >= 20 else 1)
     ev = {s: tuple(torch.cuda.Event(enable_timing=True) for _ in range(3)) for s in range(0, args.steps, stride)}
     barrier()
     t0c = time.perf_counter()
