@@ -218,6 +218,21 @@ def test_native_rccl_allgather_of_the_results(ctx4):
     with pytest.raises(N.LagAssignError) as ei:
         ctx4.allgather_results(2, [d.data_ptr()] * 4, [d.data_ptr()] * 4)
     assert ei.value.code == N.LA_EINVAL and "distinct device" in str(ei.value)
+    # argument errors of the per-shard entry points: codes, not crashes
+    import ctypes
+    lib = ctx4._lib
+    assert lib.la_sync_on(ctx4._h, 7, None) == N.LA_EINVAL
+    assert lib.la_allgather_results(ctx4._h, -1, None, None) == N.LA_EINVAL
+    assert lib.la_allgather_results(None, 1, None, None) == N.LA_EINVAL
+    assert lib.la_shard_stream(ctx4._h, 9) is None and lib.la_device_features(ctx4._h, -1) == N.LA_EINVAL
+    assert lib.la_last_pipeline(None) == N.LA_EINVAL
+    one = N.Context(0)
+    try:
+        null = (ctypes.c_void_p * 1)(None)
+        assert lib.la_allgather_results(one._h, 4, null, null) == N.LA_EINVAL        # a shard's buffer is NULL
+        assert lib.la_allgather_results(one._h, 0, null, null) == N.LA_OK            # nothing to gather
+    finally:
+        one.close()
 
 
 def test_compute_lag_and_group_by_member_across_shards(ctx4, ctx1):
