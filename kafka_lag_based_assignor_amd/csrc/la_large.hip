@@ -10,13 +10,16 @@
 //                            over the whole topic is skipped on the device (plan kernel), so
 //                            lags < 2^40 with ids < 2^24 cost 8 passes, not 12; input that is
 //                            already in id order skips the 4 id passes.
-//                            per pass: tile digit counts -> per-digit scan over tiles -> stable
-//                            scatter (wave-level match ranking, no atomics on the data path).
+//                            per pass ONE kernel: stable scatter with decoupled look-back (every tile
+//                            publishes its digit counts as {tag, count} granules and walks back over its
+//                            predecessors'); ranks from returning LDS atomics.  The four-kernel form (tile
+//                            digit counts -> per-digit scan over tiles -> scatter) stays as a test hook.
 //   kernel 3  greedy         ONE workgroup (the chain of rounds is serial): consumer bins live in
 //                            registers, E per thread; each round bitonic-sorts the bins by
 //                            (total lag, member) -- in registers, across lanes with DPP, across
 //                            waves through LDS -- and hands the round's C partitions out in
-//                            that order.  ceil(P/C) rounds instead of P argmins.
+//                            that order.  ceil(P/C) rounds instead of P argmins.  A round whose bins are a
+//                            few ascending runs (flat tails of lags) merges the runs instead of sorting.
 //                            LA_ALGO_ARGMIN keeps the literal form: bins (count, total) in LDS,
 //                            one wavefront-argmin + LDS combine per partition.
 #include "la_kernels.h"
