@@ -30,6 +30,22 @@ namespace la {
 
 namespace {
 
+#ifdef LA_BLOCK_CLOCKS   // development build: thread 0 of workgroup 0 accumulates the time of every stage (tools/block_probe.py --clocks)
+__device__ unsigned long long g_block_clocks[8];
+#define LA_BCLK(i)                                                         \
+    do {                                                                   \
+        if (threadIdx.x == 0 && blockIdx.x == 0) {                         \
+            const unsigned long long now_ = wall_clock64();                \
+            g_block_clocks[i] += now_ - bclk_;                             \
+            bclk_ = now_;                                                  \
+        }                                                                  \
+    } while (0)
+#define LA_BCLK_START unsigned long long bclk_ = wall_clock64()
+#else
+#define LA_BCLK(i) do {} while (0)
+#define LA_BCLK_START do {} while (0)
+#endif
+
 constexpr int kSpan = 128;      // slots a wavefront owns: 64 pairs
 
 // n: power of two >= live.  cmpx(i, p) with i < p leaves the smaller record at i.
@@ -304,6 +320,76 @@ __device__ __forceinline__ void greedy_one_wave_packed(const BlockArgs& a, const
     }
 }
 
+// LDS byte address of a __shared__ object (what ds_* instructions take)
+__device__ __forceinline__ uint32_t lds_address(const void* p) {
+    return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)p;
+}
+__device__ __forceinline__ uint64_t lds_read64(uint32_t addr) {
+    return *(const __attribute__((address_space(3))) uint64_t*)(uintptr_t)addr;
+}
+__device__ __forceinline__ void lds_write32(uint32_t addr, uint32_t v) {
+    *(__attribute__((address_space(3))) uint32_t*)(uintptr_t)addr = v;
+}
+
+// Greedy rounds for up to 64 consumers with packed bins, one bin per lane, the chain of rounds cut down to its
+// instruction count (la_sort64.h (d)).  `slot` holds, per sorted position, the partition's lag << idx_bits (written by
+// the whole workgroup) and slot[P] = 0; a round reads its slots, and writes the winner's consumer position back into
+// the low word of the slot.  Member ranks and global stores are the workgroup's business after the last round.
+template <int L>
+__device__ __forceinline__ void greedy_one_wave_slots(const BlockArgs& a, uint64_t* slot, int64_t c0, int P, int C,
+                                                      int idx_bits, int lane) {
+    const uint32_t idx_mask = (1u << idx_bits) - 1;
+    const bool own = lane < C;
+    const uint32_t base = lds_address(slot);
+    const uint32_t zb = (uint32_t)__builtin_amdgcn_readfirstlane((int)(base + (uint32_t)P * 8u));
+    const uint32_t stride = (uint32_t)__builtin_amdgcn_readfirstlane(C * 8);
+    const int rounds = __builtin_amdgcn_readfirstlane((P + C - 1) / C);
+    const uint32_t lane_mask = own ? idx_mask : 0u;       // idle lanes write zero into the zero slot
+    P64 bin = p64_from(own ? (uint64_t)lane : kRoundSentinel);
+    uint32_t kv[4];
+    round_keep_vectors(lane, kv);
+    uint32_t sb = own ? base + (uint32_t)lane * 8u : 0x40000000u;   // idle lanes: always clamped
+    uint32_t ab_a = sb < zb ? sb : zb, ab_b;
+    uint64_t cur_a = lds_read64(ab_a), cur_b;
+    // round 0: the bins are in order as they stand (totals 0, positions ascending)
+    sb += stride;
+    ab_b = sb < zb ? sb : zb;
+    cur_b = lds_read64(ab_b);
+    {
+        const uint64_t nb = p64_value(bin) + cur_a;                                        // Main.java:265
+        bin = p64_from(nb);
+        lds_write32(ab_a, (uint32_t)nb & lane_mask);
+    }
+    if constexpr (L >= 2 && L <= 16) {
+        asm volatile("s_nop 1" : "+v"(bin.lo), "+v"(bin.hi));          // compiler-written bins -> a DPP read
+        int q = 1;
+        for (; q + 1 < rounds; q += 2) {
+            greedy_round_p64<L>(bin, sb, ab_b, ab_a, cur_b, cur_a, stride, zb, lane_mask, kv);
+            greedy_round_p64<L>(bin, sb, ab_a, ab_b, cur_a, cur_b, stride, zb, lane_mask, kv);
+        }
+        if (q < rounds) greedy_round_p64<L>(bin, sb, ab_b, ab_a, cur_b, cur_a, stride, zb, lane_mask, kv);
+    } else {
+        for (int q = 1; q < rounds; ++q) {
+            sb += stride;
+            ab_a = sb < zb ? sb : zb;
+            cur_a = lds_read64(ab_a);
+            if constexpr (L > 1) {
+                asm volatile("s_nop 1" : "+v"(bin.lo), "+v"(bin.hi));
+                bitonic_sort_lanes_p64<L>(bin);
+            }
+            const uint64_t nb = p64_value(bin) + cur_b;
+            bin = p64_from(nb);
+            lds_write32(ab_b, (uint32_t)nb & lane_mask);
+            ab_b = ab_a;
+            cur_b = cur_a;
+        }
+    }
+    if (a.out_total && own) {
+        const uint64_t v = p64_value(bin);
+        a.out_total[c0 + ((uint32_t)v & idx_mask)] = (int64_t)(v >> idx_bits);
+    }
+}
+
 // Greedy rounds for 257 .. 2 048 consumers with packed bins: the bins stay in registers, EC per thread over
 // n_c / EC threads (slot = tid*EC + r); a round's sort runs inside each wavefront through the networks of
 // la_sort64.h and across wavefronts through LDS exchanges (x: n_c words, register-major) -- the scheme of the
@@ -411,6 +497,7 @@ __global__ __launch_bounds__(1024) void block_topic_kernel(BlockArgs a) {
     }
     const int P = (int)Pl, C = (int)Cl;
     const bool latest = a.reset_latest != 0;
+    LA_BCLK_START;
 
     // ---- records: coalesced loads straight into the sort's registers (the sort does not care where a record
     // starts), lag fused in --------------------------------------------------------------------------------
@@ -469,6 +556,7 @@ __global__ __launch_bounds__(1024) void block_topic_kernel(BlockArgs a) {
             id_or |= (uint32_t)pid[r];
         }
     }
+    LA_BCLK(0);                                                         // record loads issued and consumed
     // do the topic's records fit one 64-bit word?  (workgroup-wide OR of the lags and the ids)
     uint32_t* s_or = reinterpret_cast<uint32_t*>(s_rank + a.nc_cap);   // [3] (4 allotted) workgroup-wide ORs
     if (tid < 3) s_or[tid] = 0;
@@ -487,7 +575,14 @@ __global__ __launch_bounds__(1024) void block_topic_kernel(BlockArgs a) {
     const int lbw = all_lag ? 64 - __builtin_clzll((unsigned long long)all_lag) : 0;    // 64: a negative lag
     const int sh = all_id ? 32 - __builtin_clz(all_id) : 0;                             // 32: a negative id
     const bool fits = sh < 32 && lbw + sh <= 63;                                        // workgroup-uniform
+    // Up to 64 consumers and bins that pack (no negative lag: lbw < 64; no total near 2^62: the top bit of the OR of the
+    // lags IS the top bit of the largest lag): the sorted positions become the slots of greedy_one_wave_slots.
+    const int n_c = pow2ceil_dev(C);
+    const int idx_bits = 31 - __builtin_clz((unsigned)(n_c | 1));
+    const bool slots = C > 0 && P > 0 && n_c <= kWave && lbw < 64 &&
+                       lbw + (32 - __builtin_clz((unsigned)((P + C - 1) / C) | 1u)) + idx_bits <= 62;
 
+    LA_BCLK(1);
     // ---- sort by (lag desc, partition asc); the ids leave from the registers, the keys go to LDS by position --
     if (fits) {
         const uint64_t lag_max = lbw ? (~0ull >> (64 - lbw)) : 0;
@@ -499,12 +594,14 @@ __global__ __launch_bounds__(1024) void block_topic_kernel(BlockArgs a) {
             rec[r] = p64_from(valid ? (((lag_max - (uint64_t)lag[r]) << sh) | (uint32_t)pid[r]) : ~0ull);
         }
         block_sort_packed<E>(rec, n_eff, tid, nt, x_key);
+        LA_BCLK(2);
 #pragma unroll
         for (int r = 0; r < E; ++r) {
             const int i = tid * E + r;
             if (i < P) {
                 const uint64_t v = p64_value(rec[r]);
-                s_key[i] = (lag_max - (v >> sh)) ^ kLagKeyFlip;
+                const uint64_t lv = lag_max - (v >> sh);
+                s_key[i] = slots ? (lv << idx_bits) : (lv ^ kLagKeyFlip);
                 a.out_pid[p0 + i] = (int32_t)((uint32_t)v & id_mask);
                 if (C == 0) a.out_rank[p0 + i] = -1;                    // Main.java:211-214: nobody to assign to
             }
@@ -524,7 +621,8 @@ __global__ __launch_bounds__(1024) void block_topic_kernel(BlockArgs a) {
         for (int r = 0; r < E; ++r) {
             const int i = tid * E + r;
             if (i < P) {
-                s_key[i] = ((uint64_t)rec[r].hi << 32) | rec[r].lo;
+                const uint64_t key = ((uint64_t)rec[r].hi << 32) | rec[r].lo;
+                s_key[i] = slots ? ((key ^ kLagKeyFlip) << idx_bits) : key;
                 a.out_pid[p0 + i] = (int32_t)(rec[r].tb ^ kPidBias);
                 if (C == 0) a.out_rank[p0 + i] = -1;                    // Main.java:211-214: nobody to assign to
             }
@@ -535,20 +633,40 @@ __global__ __launch_bounds__(1024) void block_topic_kernel(BlockArgs a) {
         s_idx[i] = (uint32_t)i;
         s_rank[i] = a.cons_rank[c0 + i];
     }
+    if (slots && tid == 0) s_key[P] = 0;                                // the slot idle lanes and rounds past P read
     __syncthreads();
+    LA_BCLK(3);
     if (C == 0) return;
 
     // ---- greedy rounds --------------------------------------------------------------------------------
+    if (slots) {
+        if (tid < kWave) {
+            switch (n_c) {
+                case 1: greedy_one_wave_slots<1>(a, s_key, c0, P, C, idx_bits, tid); break;
+                case 2: greedy_one_wave_slots<2>(a, s_key, c0, P, C, idx_bits, tid); break;
+                case 4: greedy_one_wave_slots<4>(a, s_key, c0, P, C, idx_bits, tid); break;
+                case 8: greedy_one_wave_slots<8>(a, s_key, c0, P, C, idx_bits, tid); break;
+                case 16: greedy_one_wave_slots<16>(a, s_key, c0, P, C, idx_bits, tid); break;
+                case 32: greedy_one_wave_slots<32>(a, s_key, c0, P, C, idx_bits, tid); break;
+                default: greedy_one_wave_slots<64>(a, s_key, c0, P, C, idx_bits, tid); break;
+            }
+        }
+        __syncthreads();
+        LA_BCLK(4);
+        // the winners (consumer positions, low word of each slot) -> member ranks, every wavefront, coalesced
+        const uint32_t* won = reinterpret_cast<const uint32_t*>(s_key);
+        for (int i = tid; i < P; i += nt) a.out_rank[p0 + i] = s_rank[won[2 * i]];
+        LA_BCLK(5);
+        return;
+    }
     // Slots 2*idx and 2*idx+1 are updated by the thread that owns pair idx in the network's in-span steps,
     // so the update and the next round's sort are separated by a wavefront fence only.
-    const int n_c = pow2ceil_dev(C);
     if (n_c <= 4 * kWave) {
         if (tid < kWave) {
             // packed bins when nothing can overflow: the keys are sorted, the first carries the largest lag and
             // the last the smallest
             const int64_t lmax = P > 0 ? (int64_t)(s_key[0] ^ kLagKeyFlip) : 0;
             const int64_t lmin = P > 0 ? (int64_t)(s_key[P - 1] ^ kLagKeyFlip) : 0;
-            const int idx_bits = 31 - __builtin_clz((unsigned)n_c);
             const int lag_bits = lmax > 0 ? 64 - __builtin_clzll((unsigned long long)lmax) : 0;
             const int round_bits = 32 - __builtin_clz((unsigned)((P + C - 1) / C) | 1u);
             const bool packed = lmin >= 0 && lag_bits + round_bits + idx_bits <= 62;
@@ -575,7 +693,6 @@ __global__ __launch_bounds__(1024) void block_topic_kernel(BlockArgs a) {
     {
         const int64_t lmax = P > 0 ? (int64_t)(s_key[0] ^ kLagKeyFlip) : 0;
         const int64_t lmin = P > 0 ? (int64_t)(s_key[P - 1] ^ kLagKeyFlip) : 0;
-        const int idx_bits = 31 - __builtin_clz((unsigned)n_c);
         const int lag_bits = lmax > 0 ? 64 - __builtin_clzll((unsigned long long)lmax) : 0;
         const int round_bits = 32 - __builtin_clz((unsigned)((P + C - 1) / C) | 1u);
         if (lmin >= 0 && lag_bits + round_bits + idx_bits <= 62) {       // workgroup-uniform
@@ -624,6 +741,17 @@ __global__ __launch_bounds__(1024) void block_topic_kernel(BlockArgs a) {
 }
 
 }  // namespace
+
+#ifdef LA_BLOCK_CLOCKS
+extern "C" __attribute__((visibility("default"))) int la_debug_block_clocks(unsigned long long* out, int reset) {
+    hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(g_block_clocks), sizeof(g_block_clocks));
+    if (e == hipSuccess && reset) {
+        unsigned long long zero[8] = {};
+        e = hipMemcpyToSymbol(HIP_SYMBOL(g_block_clocks), zero, sizeof zero);
+    }
+    return e == hipSuccess ? 0 : -3;
+}
+#endif
 
 hipError_t block_launch(BlockArgs a, int cls, hipStream_t stream) {
     // workgroup size = np_cap / records per thread; the small classes leave room for many workgroups per CU

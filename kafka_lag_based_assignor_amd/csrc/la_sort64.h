@@ -329,4 +329,91 @@ __device__ __forceinline__ void bitonic_sort_lanes_p64(P64& rec) {
     rec = r1[0];
 }
 
+// ---- (d) one greedy round of a one-wavefront topic, as ONE statement ---------------------------------------------------
+// The block path's greedy for up to 64 consumers is a chain of ceil(P / C) dependent rounds run by ONE wavefront on a CU that
+// has nothing else to issue.  Measured on 200 topics x 8 000 partitions x 16 consumers (tools/block_probe.py with a
+// -DLA_BLOCK_CLOCKS build): a wavefront issues one instruction every 4 cycles whatever its kind (s_nop and SALU
+// included), a VALU result feeds the next VALU instruction without a bubble -- and a VALU -> SALU -> VALU hop through
+// VCC (the s_xor_b64 of the steps above) stalls ~17 cycles.  The round took ~530 cycles: 10 steps x (6 issue slots + that
+// stall) + ~55 slots of compiler-scheduled addressing, predication and loop control.  Here a whole round is one asm
+// statement: bins += (the round's lags << idx_bits) after the sort of the bins, and
+//   * the direction of a step stays in the VALU: bins and sentinels are below 2^63, so the borrow of partner - mine is the
+//     sign of the difference's high word; that word XOR a per-lane constant (all-ones on keep-min lanes), compared with
+//     zero, is the "keep my own record" mask -- two VALU instead of one SALU, and no hop;
+//   * the wait states a DPP read needs after the previous step's v_cndmask do the round's own bookkeeping instead of
+//     s_nop where there is any (next slot address, its clamp, the LDS read of the next round's add values);
+//   * the add values come from LDS pre-shifted (8 B per sorted position, written by the whole workgroup), and the winner's
+//     consumer position goes back into the low word of the slot just consumed -- member ranks and the global stores are
+//     done by all wavefronts after the last round, coalesced;
+//   * lanes without a live bin and slots past the topic are not predicated: their slot address clamps to a slot that
+//     holds zero (v_min_u32), their winner word is masked to zero.
+// Slots: byte addresses in LDS.  `sb` = this lane's slot for the NEXT round (advanced by `stride` here), `ab_cur` = the
+// clamped slot of THIS round (winner goes there), `ab_next` <- the clamped slot of the next round, `nxt` <- its add value
+// (complete when the statement ends: s_waitcnt inside), `cur` = this round's add value.  kv[0..3]: all-ones on the lanes
+// whose lane-id bit 1 / 2 / 4 / 8 is clear (round_keep_vectors).
+#define LA_R_STEP(CTRL, KEEP)                                                         \
+    "v_sub_co_u32_dpp %[t], vcc, %[lo], %[lo] " CTRL LA_DPP_TAIL "\n\t"               \
+    "v_subb_co_u32_dpp %[t], vcc, %[hi], %[hi], vcc " CTRL LA_DPP_TAIL "\n\t"         \
+    "v_xor_b32 %[t], %[" KEEP "], %[t]\n\t"                                          \
+    "v_cmp_gt_i32 vcc, 0, %[t]\n\t"                                                  \
+    "v_cndmask_b32_dpp %[lo], %[lo], %[lo], vcc " CTRL LA_DPP_TAIL "\n\t"             \
+    "v_cndmask_b32_dpp %[hi], %[hi], %[hi], vcc " CTRL LA_DPP_TAIL "\n\t"
+#define LA_R_STEP_X4(KEEP)                                                                     \
+    "v_mov_b32_dpp %[u], %[lo] row_half_mirror" LA_DPP_TAIL "\n\t"                               \
+    "v_mov_b32_dpp %[w], %[hi] row_half_mirror" LA_DPP_TAIL "\n\t"                               \
+    "s_nop 0\n\t"                                                                              \
+    "v_sub_co_u32_dpp %[t], vcc, %[u], %[lo] quad_perm:[3,2,1,0]" LA_DPP_TAIL "\n\t"             \
+    "v_subb_co_u32_dpp %[t], vcc, %[w], %[hi], vcc quad_perm:[3,2,1,0]" LA_DPP_TAIL "\n\t"       \
+    "v_xor_b32 %[t], %[" KEEP "], %[t]\n\t"                                                   \
+    "v_cmp_gt_i32 vcc, 0, %[t]\n\t"                                                           \
+    "v_cndmask_b32_dpp %[lo], %[u], %[lo], vcc quad_perm:[3,2,1,0]" LA_DPP_TAIL "\n\t"           \
+    "v_cndmask_b32_dpp %[hi], %[w], %[hi], vcc quad_perm:[3,2,1,0]" LA_DPP_TAIL "\n\t"
+#define LA_R_X1 "quad_perm:[1,0,3,2]"
+#define LA_R_X2 "quad_perm:[2,3,0,1]"
+#define LA_R_M4 "quad_perm:[3,2,1,0]"
+#define LA_R_NOP "s_nop 0\n\t"
+// the bookkeeping that fills the first three wait-state slots
+#define LA_R_ADV "v_add_u32 %[sb], %[stride], %[sb]\n\t"
+#define LA_R_CLAMP "v_min_u32 %[abn], %[zb], %[sb]\n\t"
+#define LA_R_READ "ds_read_b64 %[nxt], %[abn]\n\t"
+#define LA_R_TAIL                                            \
+    "s_waitcnt lgkmcnt(0)\n\t"                               \
+    "v_add_co_u32 %[lo], vcc, %[clo], %[lo]\n\t"             \
+    "v_addc_co_u32 %[hi], vcc, %[chi], %[hi], vcc\n\t"       \
+    "v_and_b32 %[won], %[mk], %[lo]\n\t"                     \
+    "ds_write_b32 %[abc], %[won]"
+// the sorting networks of merge_p64<L, 1, ...>, step by step (direction-free bitonic: mirror, then lane ^ j)
+#define LA_R_NET2 LA_R_STEP(LA_R_X1, "k1")
+#define LA_R_NET4_REST LA_R_STEP(LA_R_M4, "k2") LA_R_CLAMP LA_R_STEP(LA_R_X1, "k1")
+#define LA_R_NET8_REST LA_R_STEP("row_half_mirror", "k4") LA_R_NOP LA_R_STEP(LA_R_X2, "k2") LA_R_NOP LA_R_STEP(LA_R_X1, "k1")
+#define LA_R_NET16_REST \
+    LA_R_STEP("row_mirror", "k8") LA_R_NOP LA_R_STEP_X4("k4") LA_R_NOP LA_R_STEP(LA_R_X2, "k2") LA_R_NOP LA_R_STEP(LA_R_X1, "k1")
+#define LA_ROUND_ASM(BODY)                                                                                             \
+    asm volatile(BODY LA_R_TAIL                                                                                        \
+                 : [lo] "+v"(bin.lo), [hi] "+v"(bin.hi), [sb] "+v"(sb), [abn] "=&v"(ab_next), [nxt] "=&v"(nxt),         \
+                   [t] "=&v"(t), [u] "=&v"(u), [w] "=&v"(w), [won] "=&v"(won)                                           \
+                 : [abc] "v"(ab_cur), [clo] "v"((uint32_t)cur), [chi] "v"((uint32_t)(cur >> 32)), [stride] "s"(stride), \
+                   [zb] "s"(zb), [mk] "v"(lane_mask), [k1] "v"(kv[0]), [k2] "v"(kv[1]), [k4] "v"(kv[2]), [k8] "v"(kv[3]) \
+                 : "vcc", "memory")
+
+constexpr uint64_t kRoundSentinel = 0x7FFFFFFFFFFFFFFFull;   // an idle lane's bin: above every real bin, below 2^63
+
+__device__ __forceinline__ void round_keep_vectors(int lane, uint32_t (&kv)[4]) {
+#pragma unroll
+    for (int b = 0; b < 4; ++b) kv[b] = (lane & (1 << b)) ? 0u : 0xFFFFFFFFu;
+}
+
+template <int L>
+__device__ __forceinline__ void greedy_round_p64(P64& bin, uint32_t& sb, uint32_t ab_cur, uint32_t& ab_next, uint64_t cur,
+                                                 uint64_t& nxt, uint32_t stride, uint32_t zb, uint32_t lane_mask,
+                                                 const uint32_t (&kv)[4]) {
+    static_assert(L == 2 || L == 4 || L == 8 || L == 16, "one statement per width up to a DPP row");
+    uint32_t t, u, w, won;
+    // wait states: a step ends on v_cndmask lo, v_cndmask hi; the next one DPP-reads lo first -> one more instruction between
+    if constexpr (L == 2) LA_ROUND_ASM(LA_R_ADV LA_R_CLAMP LA_R_READ LA_R_NET2);
+    else if constexpr (L == 4) LA_ROUND_ASM(LA_R_ADV LA_R_NET2 LA_R_CLAMP LA_R_STEP(LA_R_M4, "k2") LA_R_READ LA_R_STEP(LA_R_X1, "k1"));
+    else if constexpr (L == 8) LA_ROUND_ASM(LA_R_NET2 LA_R_ADV LA_R_NET4_REST LA_R_READ LA_R_NET8_REST);
+    else LA_ROUND_ASM(LA_R_NET2 LA_R_ADV LA_R_NET4_REST LA_R_READ LA_R_NET8_REST LA_R_NOP LA_R_NET16_REST);
+}
+
 }  // namespace la

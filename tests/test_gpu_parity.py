@@ -825,6 +825,60 @@ def test_block_single_topic(ctx, p, c, kind):
         np.testing.assert_array_equal(g, e, err_msg=what)
 
 
+# up to 64 consumers and more than 1 024 partitions: the one-wavefront greedy whose round is one asm statement
+# (la_sort64.h (d): widths 2 / 4 / 8 / 16) or the generic form (1 / 32 / 64); every consumer count around the widths,
+# partition counts that end a round early, lags that pack ("u40", "ties", "zero", "u22" = near the 2^62 total limit for
+# few rounds) and lags that do not ("u63", "full" with negatives: the 96-bit path)
+@pytest.mark.parametrize("c", [1, 2, 3, 4, 5, 7, 8, 9, 12, 15, 16, 17, 24, 31, 32, 33, 48, 63, 64])
+def test_block_one_wave_rounds_every_width(ctx, c):
+    rng = np.random.default_rng(4200 + c)
+    for p, kind in [(1025, "u40"), (1024 + c, "ties"), (1023 + 2 * c, "u40"), (2048, "zero"), (3000 + c, "u40"),
+                    (8192, "ties"), (8191, "u40"), (8192 - c + 1, "u63"), (5000, "full"), (int(rng.integers(1025, 8193)), "u40"),
+                    (16384 if c <= 32 else 8192, "u40")]:
+        po, pid, lag, co, ranks = _single_topic(97 * p + c, p, c, kind, shuffled=bool(rng.integers(0, 2)),
+                                                negative=(kind == "full"))
+        exp = oracle.assign_flat(po, pid, lag, co, ranks)
+        got = ctx.assign_batch_lags(po, pid, lag, co, ranks)
+        for g, e, what in zip(got, exp, ("partition order", "member", "totals")):
+            np.testing.assert_array_equal(g, e, err_msg="%s p=%d c=%d %s" % (what, p, c, kind))
+
+
+def test_block_one_wave_rounds_at_the_packing_limit(ctx):
+    # lag bits + round bits + index bits = 62 packs, 63 does not: both sides of the switch give the oracle's answer
+    for c, p in [(16, 4096), (4, 2000), (64, 8192), (3, 1500)]:
+        n_c = 1 << (c - 1).bit_length()
+        idx_bits = max(n_c.bit_length() - 1, 0)
+        round_bits = (-(-p // c)).bit_length()
+        for lag_bits in (62 - round_bits - idx_bits, 63 - round_bits - idx_bits):
+            rng = np.random.default_rng(lag_bits * 131 + c)
+            lag = rng.integers(0, 1 << lag_bits, p).astype(np.int64)
+            lag[0] = (1 << lag_bits) - 1
+            pid = rng.permutation(p).astype(np.int32)
+            ranks = np.arange(c, dtype=np.int32)
+            exp = oracle.assign_flat([0, p], pid, lag, [0, c], ranks)
+            got = ctx.assign_batch_lags([0, p], pid, lag, [0, c], ranks)
+            for g, e, what in zip(got, exp, ("partition order", "member", "totals")):
+                np.testing.assert_array_equal(g, e, err_msg="%s p=%d c=%d lag_bits=%d" % (what, p, c, lag_bits))
+
+
+def test_block_one_wave_rounds_many_topics(ctx):
+    # 300 topics of different widths side by side (more workgroups than CUs), partitions not a multiple of the consumers
+    rng = np.random.default_rng(99)
+    t = 300
+    ps = rng.integers(1025, 3000, t)
+    cs = rng.integers(1, 65, t)
+    part_off = np.concatenate([[0], np.cumsum(ps)]).astype(np.int64)
+    cons_off = np.concatenate([[0], np.cumsum(cs)]).astype(np.int64)
+    pid = np.concatenate([rng.permutation(int(x)) for x in ps]).astype(np.int32)
+    lag = rng.integers(0, 1 << 30, int(part_off[-1])).astype(np.int64)
+    lag[rng.random(lag.size) < 0.3] = 0                                   # caught-up partitions: ties at the tail
+    ranks = np.concatenate([np.sort(rng.choice(200, int(x), replace=False)) for x in cs]).astype(np.int32)
+    exp = oracle.assign_flat(part_off, pid, lag, cons_off, ranks)
+    got = ctx.assign_batch_lags(part_off, pid, lag, cons_off, ranks)
+    for g, e, what in zip(got, exp, ("partition order", "member", "totals")):
+        np.testing.assert_array_equal(g, e, err_msg=what)
+
+
 @pytest.mark.parametrize("seed,max_p,max_c", [(1, 3000, 300), (2, 9000, 70), (3, 1500, 2500), (4, 600, 100),
                                               (5, 8192, 2048)])
 def test_block_batches_mixed_with_tile_and_large_topics(ctx, seed, max_p, max_c):

@@ -47,6 +47,18 @@ def run(t, p, c, algo=N.LA_ALGO_AUTO, reps=5, lag_bits=34, offsets=False):
         best = min(best, time.perf_counter() - t0)
     return best
 
+if hasattr(ctx._lib, "la_debug_block_clocks"):          # development build (-DLA_BLOCK_CLOCKS): stage times of workgroup 0
+    names = ["loads", "decide", "sort", "slots + out_partition", "greedy rounds", "member ranks out", "-", "-"]
+    for (t, p, c) in [(200, 8000, 16), (200, 8000, 64), (200, 8000, 4), (1000, 2000, 16)]:
+        clk = (ctypes.c_ulonglong * 8)()
+        run(t, p, c, reps=1)
+        ctx._lib.la_debug_block_clocks(clk, 1)
+        ms = run(t, p, c, reps=9) * 1e3                 # 1 warm-up + 9 timed calls
+        ctx._lib.la_debug_block_clocks(clk, 1)
+        print("T=%d P=%d C=%d: %.3f ms per call; workgroup 0, us per stage (100 MHz clock): " % (t, p, c, ms) +
+              ", ".join("%s %.1f" % (n, v / 10 / 100.0) for n, v in zip(names, clk) if n != "-"))
+    sys.exit(0)
+
 for (t, p, c) in [(1000, 2000, 100), (5000, 200, 100), (200, 8000, 16), (2000, 1000, 500), (64, 8192, 2048),
                   (1, 2000, 100), (1, 8192, 2048), (20000, 100, 65), (300, 5000, 3), (1, 100, 65), (1, 1025, 8), (20000, 300, 10)]:
     ms = run(t, p, c) * 1e3
