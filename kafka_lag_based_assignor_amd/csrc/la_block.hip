@@ -273,7 +273,7 @@ __device__ __forceinline__ void greedy_one_wave_packed(const BlockArgs& a, const
 #pragma unroll
     for (int r = 0; r < EC; ++r) {
         const int e = lane * EC + r;
-        bin[r] = p64_from(e < C ? (uint64_t)e : ~0ull);
+        bin[r] = p64_from(e < C ? (uint64_t)e : kRoundSentinel);    // below 2^63: the steps' VALU form (la_sort64.h)
         lag[r] = s_key[e < P ? e : last];
         won[r] = 0;
         had[r] = false;
@@ -292,7 +292,7 @@ __device__ __forceinline__ void greedy_one_wave_packed(const BlockArgs& a, const
             // the networks read these registers through DPP: 2 wait states after their last compiler-generated write
 #pragma unroll
             for (int r = 0; r < EC; ++r) asm volatile("s_nop 1" : "+v"(bin[r].lo), "+v"(bin[r].hi));
-            bitonic_sort_tile_p64<L, EC>(bin);
+            bitonic_sort_tile_p64<L, EC, true>(bin);
         }
 #pragma unroll
         for (int r = 0; r < EC; ++r) {
@@ -315,7 +315,7 @@ __device__ __forceinline__ void greedy_one_wave_packed(const BlockArgs& a, const
 #pragma unroll
         for (int r = 0; r < EC; ++r) {
             const uint64_t v = p64_value(bin[r]);
-            if (v != ~0ull) a.out_total[c0 + ((uint32_t)v & idx_mask)] = (int64_t)(v >> idx_bits);
+            if (v != kRoundSentinel) a.out_total[c0 + ((uint32_t)v & idx_mask)] = (int64_t)(v >> idx_bits);
         }
     }
 }
@@ -375,7 +375,7 @@ __device__ __forceinline__ void greedy_one_wave_slots(const BlockArgs& a, uint64
             cur_a = lds_read64(ab_a);
             if constexpr (L > 1) {
                 asm volatile("s_nop 1" : "+v"(bin.lo), "+v"(bin.hi));
-                bitonic_sort_lanes_p64<L>(bin);
+                bitonic_sort_lanes_p64<L, true>(bin);      // one wavefront alone: the steps without the SALU hop
             }
             const uint64_t nb = p64_value(bin) + cur_b;
             bin = p64_from(nb);
@@ -399,6 +399,7 @@ __device__ __forceinline__ void greedy_multi_wave_packed(const BlockArgs& a, con
                                                          uint64_t* x, int64_t p0, int64_t c0, int P, int C, int n_c,
                                                          int idx_bits, int tid) {
     constexpr int kSpanSlots = kWave * EC;
+    constexpr bool kVo = true;                                           // the steps' VALU form (few wavefronts per SIMD)
     const int ntu = n_c / EC;                                            // threads that hold bins (multiple of 64)
     const bool active = tid < ntu;                                       // wavefront-uniform
     const uint32_t idx_mask = (1u << idx_bits) - 1;
@@ -407,7 +408,7 @@ __device__ __forceinline__ void greedy_multi_wave_packed(const BlockArgs& a, con
 #pragma unroll
     for (int r = 0; r < EC; ++r) {
         const int e = tid * EC + r;
-        bin[r] = p64_from((active && e < C) ? (uint64_t)e : ~0ull);
+        bin[r] = p64_from((active && e < C) ? (uint64_t)e : kRoundSentinel);
         lag[r] = (active && e < C && e < P) ? (s_key[e] ^ kLagKeyFlip) : 0;
     }
     const int rounds = (P + C - 1) / C;
@@ -423,7 +424,7 @@ __device__ __forceinline__ void greedy_multi_wave_packed(const BlockArgs& a, con
             if (active) {
 #pragma unroll
                 for (int r = 0; r < EC; ++r) asm volatile("s_nop 1" : "+v"(bin[r].lo), "+v"(bin[r].hi));
-                bitonic_sort_tile_p64<kWave, EC>(bin);
+                bitonic_sort_tile_p64<kWave, EC, kVo>(bin);
             }
             for (int K = 2 * kSpanSlots; K <= n_c; K <<= 1) {
                 for (int j = K >> 1; j >= kSpanSlots; j >>= 1) {
@@ -449,7 +450,7 @@ __device__ __forceinline__ void greedy_multi_wave_packed(const BlockArgs& a, con
                 if (active) {
 #pragma unroll
                     for (int r = 0; r < EC; ++r) asm volatile("s_nop 1" : "+v"(bin[r].lo), "+v"(bin[r].hi));
-                    clean_p64<kWave, EC, kSpanSlots / 2, false>(bin);
+                    clean_p64<kWave, EC, kSpanSlots / 2, false, kVo>(bin);
                 }
             }
         }
@@ -469,7 +470,7 @@ __device__ __forceinline__ void greedy_multi_wave_packed(const BlockArgs& a, con
 #pragma unroll
         for (int r = 0; r < EC; ++r) {
             const uint64_t v = p64_value(bin[r]);
-            if (v != ~0ull) a.out_total[c0 + ((uint32_t)v & idx_mask)] = (int64_t)(v >> idx_bits);
+            if (v != kRoundSentinel) a.out_total[c0 + ((uint32_t)v & idx_mask)] = (int64_t)(v >> idx_bits);
         }
     }
 }

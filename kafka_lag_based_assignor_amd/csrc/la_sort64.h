@@ -52,47 +52,74 @@ struct KeepMin {
 };
 
 #define LA_DPP_TAIL " row_mask:0xf bank_mask:0xf"
+// "keep my own record" from the borrow of partner - mine, two ways:
+//   SALU form  s_xor_b64 vcc, vcc, KEEP_MIN (one issue slot).  Right for kernels with several wavefronts per SIMD (the
+//              wave-tile kernels, the workgroup sorts): the ~17 cycles a VALU -> SALU -> VALU hop through VCC stalls its
+//              wavefront are filled by the others.
+//   VALU form  (VO = true) for a chain ONE wavefront runs alone (the block path's greedy rounds): records below 2^63, so
+//              the borrow is the sign of the difference's high word T; T ^= (all-ones on keep-min lanes); vcc = T < 0.
+//              Two slots, no hop (measured: 200 x 8 000 x 16, 99 -> 74 us of greedy rounds).
+#define LA_FIX_S(K) "s_xor_b64 vcc, vcc, " K "\n\t"
+#define LA_FIX_V(T, K) "v_xor_b32 " T ", " K ", " T "\n\t" "v_cmp_gt_i32 vcc, 0, " T "\n\t"
+
+// all-ones on the lanes whose lane-id bit J is clear (the keep-min lanes of KeepMin<J>), as a VGPR
+template <int J>
+__device__ __forceinline__ uint32_t keep_vec() {
+    const uint32_t lane = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    return (lane & (uint32_t)J) ? 0u : 0xFFFFFFFFu;
+}
+
 #define LA_PAD0 ""
 #define LA_PAD1 "s_nop 0\n\t"
 #define LA_PAD2 "s_nop 1\n\t"
 
 // ---- (a) rec <-> the same register of lane^(pattern), single-DPP patterns -------------------------------
-#define LA_SAME_ASM(PADSTR, CTRL)                                                          \
+#define LA_SAME_ASM(PADSTR, CTRL, FIX, KC, KV)                                             \
     asm volatile(PADSTR                                                                    \
                  "v_sub_co_u32_dpp %2, vcc, %0, %0 " CTRL LA_DPP_TAIL "\n\t"                 \
                  "v_subb_co_u32_dpp %2, vcc, %1, %1, vcc " CTRL LA_DPP_TAIL "\n\t"           \
-                 "s_xor_b64 vcc, vcc, %3\n\t"                                              \
+                 FIX                                                                       \
                  "v_cndmask_b32_dpp %0, %0, %0, vcc " CTRL LA_DPP_TAIL "\n\t"                \
                  "v_cndmask_b32_dpp %1, %1, %1, vcc " CTRL LA_DPP_TAIL                       \
                  : "+v"(r.lo), "+v"(r.hi), "=&v"(t)                                         \
-                 : "s"(keep)                                                               \
+                 : KC(KV)                                                                  \
                  : "vcc", "scc")
+#define LA_SAME_VO(PADSTR, CTRL)                                                           \
+    do {                                                                                   \
+        if constexpr (VO) LA_SAME_ASM(PADSTR, CTRL, LA_FIX_V("%2", "%3"), "v", kvec);      \
+        else LA_SAME_ASM(PADSTR, CTRL, LA_FIX_S("%3"), "s", keep);                         \
+    } while (0)
 
 #define LA_SAME_PADS(CTRL)                                  \
     do {                                                    \
-        if constexpr (PAD == 0) LA_SAME_ASM(LA_PAD0, CTRL);  \
-        else if constexpr (PAD == 1) LA_SAME_ASM(LA_PAD1, CTRL); \
-        else LA_SAME_ASM(LA_PAD2, CTRL);                     \
+        if constexpr (PAD == 0) LA_SAME_VO(LA_PAD0, CTRL);   \
+        else if constexpr (PAD == 1) LA_SAME_VO(LA_PAD1, CTRL); \
+        else LA_SAME_VO(LA_PAD2, CTRL);                      \
     } while (0)
 
 // lane ^ 4: no single DPP control; half-mirror into temporaries, then quad reverse as the DPP source
-#define LA_SAME_X4_ASM(PADSTR)                                                                 \
+#define LA_SAME_X4_ASM(PADSTR, FIX, KC, KV)                                                    \
     asm volatile(PADSTR                                                                        \
                  "v_mov_b32_dpp %2, %0 row_half_mirror" LA_DPP_TAIL "\n\t"                       \
                  "v_mov_b32_dpp %3, %1 row_half_mirror" LA_DPP_TAIL "\n\t"                       \
                  "s_nop 0\n\t"                                                                 \
                  "v_sub_co_u32_dpp %4, vcc, %2, %0 quad_perm:[3,2,1,0]" LA_DPP_TAIL "\n\t"       \
                  "v_subb_co_u32_dpp %4, vcc, %3, %1, vcc quad_perm:[3,2,1,0]" LA_DPP_TAIL "\n\t" \
-                 "s_xor_b64 vcc, vcc, %5\n\t"                                                  \
+                 FIX                                                                           \
                  "v_cndmask_b32_dpp %0, %2, %0, vcc quad_perm:[3,2,1,0]" LA_DPP_TAIL "\n\t"      \
                  "v_cndmask_b32_dpp %1, %3, %1, vcc quad_perm:[3,2,1,0]" LA_DPP_TAIL             \
                  : "+v"(r.lo), "+v"(r.hi), "=&v"(t), "=&v"(u), "=&v"(w)                          \
-                 : "s"(keep)                                                                   \
+                 : KC(KV)                                                                      \
                  : "vcc", "scc")
+#define LA_SAME_X4_VO(PADSTR)                                                              \
+    do {                                                                                   \
+        if constexpr (VO) LA_SAME_X4_ASM(PADSTR, LA_FIX_V("%4", "%5"), "v", kvec);         \
+        else LA_SAME_X4_ASM(PADSTR, LA_FIX_S("%5"), "s", keep);                            \
+    } while (0)
 
 // lane ^ 16 / lane ^ 32: v_permlane*_swap gives both lanes of a pair (A, B) = (lower's, upper's)
 // record; each keeps A or B.  keep-min lanes keep A iff A < B.
-#define LA_SAME_SWAP_ASM(PADSTR, SWAP)                       \
+#define LA_SAME_SWAP_ASM(PADSTR, SWAP, FIX, KC, KV)          \
     asm volatile(PADSTR                                      \
                  "v_mov_b32 %2, %0\n\t"                      \
                  "v_mov_b32 %3, %1\n\t"                      \
@@ -101,43 +128,72 @@ struct KeepMin {
                  SWAP " %1, %3\n\t"                          \
                  "v_sub_co_u32 %4, vcc, %0, %2\n\t"          \
                  "v_subb_co_u32 %4, vcc, %1, %3, vcc\n\t"    \
-                 "s_xor_b64 vcc, vcc, %5\n\t"                \
+                 FIX                                         \
                  "v_cndmask_b32 %0, %0, %2, vcc\n\t"         \
                  "v_cndmask_b32 %1, %1, %3, vcc"             \
                  : "+v"(r.lo), "+v"(r.hi), "=&v"(t), "=&v"(u), "=&v"(w) \
-                 : "s"(keep)                                 \
+                 : KC(KV)                                    \
                  : "vcc", "scc")
+#define LA_SAME_SWAP_VO(PADSTR, SWAP)                                                      \
+    do {                                                                                   \
+        if constexpr (VO) LA_SAME_SWAP_ASM(PADSTR, SWAP, LA_FIX_V("%4", "%5"), "v", kvec); \
+        else LA_SAME_SWAP_ASM(PADSTR, SWAP, LA_FIX_S("%5"), "s", keep);                    \
+    } while (0)
 
 // rec <- min or max of (rec, record of lane ^ J), min where bit J of the lane id is clear
-template <int J, int PAD>
+template <int J, int PAD, bool VO = false>
 __device__ __forceinline__ void cmpx_same_xor(P64& r) {
-    const uint64_t keep = KeepMin<J>::value;
+    [[maybe_unused]] const uint64_t keep = KeepMin<J>::value;
+    [[maybe_unused]] const uint32_t kvec = keep_vec<J>();
     uint32_t t;
     if constexpr (J == 1) LA_SAME_PADS("quad_perm:[1,0,3,2]");
     else if constexpr (J == 2) LA_SAME_PADS("quad_perm:[2,3,0,1]");
     else if constexpr (J == 8) LA_SAME_PADS("row_ror:8");
     else if constexpr (J == 4) {
         uint32_t u, w;
-        if constexpr (PAD == 0) LA_SAME_X4_ASM(LA_PAD0);
-        else if constexpr (PAD == 1) LA_SAME_X4_ASM(LA_PAD1);
-        else LA_SAME_X4_ASM(LA_PAD2);
+        if constexpr (PAD == 0) LA_SAME_X4_VO(LA_PAD0);
+        else if constexpr (PAD == 1) LA_SAME_X4_VO(LA_PAD1);
+        else LA_SAME_X4_VO(LA_PAD2);
     } else {
         uint32_t u, w;
         // after the swaps: %0/%1 = A (lower lane's record), %2/%3 = B; vcc = (A<B) ^ keepmin; 1 -> B
-        if constexpr (J == 16) LA_SAME_SWAP_ASM(LA_PAD2, "v_permlane16_swap_b32");
-        else LA_SAME_SWAP_ASM(LA_PAD2, "v_permlane32_swap_b32");
+        if constexpr (J == 16) LA_SAME_SWAP_VO(LA_PAD2, "v_permlane16_swap_b32");
+        else LA_SAME_SWAP_VO(LA_PAD2, "v_permlane32_swap_b32");
+    }
+}
+
+// plain (already moved) select: r <- keep-min lanes (lane-id bit J clear) min(r, o), others max(r, o)
+#define LA_SELECT_ASM(FIX, KC, KV)                               \
+    asm volatile("v_sub_co_u32 %2, vcc, %3, %0\n\t"              \
+                 "v_subb_co_u32 %2, vcc, %4, %1, vcc\n\t"        \
+                 FIX                                             \
+                 "v_cndmask_b32 %0, %3, %0, vcc\n\t"             \
+                 "v_cndmask_b32 %1, %4, %1, vcc"                 \
+                 : "+v"(r.lo), "+v"(r.hi), "=&v"(t)              \
+                 : "v"(o.lo), "v"(o.hi), KC(KV)                  \
+                 : "vcc", "scc")
+template <int J, bool VO = false>
+__device__ __forceinline__ void select_minmax(P64& r, const P64& o) {
+    uint32_t t;
+    if constexpr (VO) {
+        const uint32_t kvec = keep_vec<J>();
+        LA_SELECT_ASM(LA_FIX_V("%2", "%5"), "v", kvec);
+    } else {
+        const uint64_t keep = KeepMin<J>::value;
+        LA_SELECT_ASM(LA_FIX_S("%5"), "s", keep);
     }
 }
 
 // rec <- min or max of (rec, record of lane ^ (M-1)), min where bit M/2 of the lane id is clear.
 // Single-register form (one record per lane: the consumer bins).
-template <int M, int PAD>
+template <int M, int PAD, bool VO = false>
 __device__ __forceinline__ void cmpx_same_mirror(P64& r) {
     static_assert(M == 2 || M == 4 || M == 8 || M == 16 || M == 32 || M == 64, "bad mirror width");
     if constexpr (M == 2) {
-        cmpx_same_xor<1, PAD>(r);
+        cmpx_same_xor<1, PAD, VO>(r);
     } else if constexpr (M == 4 || M == 8 || M == 16) {
-        const uint64_t keep = KeepMin<M / 2>::value;
+        [[maybe_unused]] const uint64_t keep = KeepMin<M / 2>::value;
+        [[maybe_unused]] const uint32_t kvec = keep_vec<M / 2>();
         uint32_t t;
         if constexpr (M == 4) LA_SAME_PADS("quad_perm:[3,2,1,0]");
         else if constexpr (M == 8) LA_SAME_PADS("row_half_mirror");
@@ -151,60 +207,44 @@ __device__ __forceinline__ void cmpx_same_mirror(P64& r) {
         P64 o;
         o.lo = shfl_mirror<M>(r.lo);
         o.hi = shfl_mirror<M>(r.hi);
-        const uint64_t keep = KeepMin<M / 2>::value;
-        uint32_t t;
-        asm volatile("v_sub_co_u32 %2, vcc, %3, %0\n\t"
-                     "v_subb_co_u32 %2, vcc, %4, %1, vcc\n\t"
-                     "s_xor_b64 vcc, vcc, %5\n\t"
-                     "v_cndmask_b32 %0, %3, %0, vcc\n\t"
-                     "v_cndmask_b32 %1, %4, %1, vcc"
-                     : "+v"(r.lo), "+v"(r.hi), "=&v"(t)
-                     : "v"(o.lo), "v"(o.hi), "s"(keep)
-                     : "vcc", "scc");
+        select_minmax<M / 2, VO>(r, o);
     }
 }
 
 // ---- (b) mirror step between registers: my r <-> partner's q and my q <-> partner's r ---------------------
-#define LA_CROSS_ASM(PADSTR, CTRL)                                                          \
+#define LA_CROSS_ASM(PADSTR, CTRL, FIX, KC, KV)                                             \
     asm volatile(PADSTR                                                                     \
                  "v_sub_co_u32_dpp %2, vcc, %0, %5 " CTRL LA_DPP_TAIL "\n\t"                  \
                  "v_subb_co_u32_dpp %2, vcc, %1, %6, vcc " CTRL LA_DPP_TAIL "\n\t"            \
-                 "s_xor_b64 vcc, vcc, %7\n\t"                                               \
+                 FIX                                                                        \
                  "v_cndmask_b32_dpp %3, %0, %5, vcc " CTRL LA_DPP_TAIL "\n\t"                 \
                  "v_cndmask_b32_dpp %4, %1, %6, vcc " CTRL LA_DPP_TAIL "\n\t"                 \
                  "v_sub_co_u32_dpp %2, vcc, %5, %0 " CTRL LA_DPP_TAIL "\n\t"                  \
                  "v_subb_co_u32_dpp %2, vcc, %6, %1, vcc " CTRL LA_DPP_TAIL "\n\t"            \
-                 "s_xor_b64 vcc, vcc, %7\n\t"                                               \
+                 FIX                                                                        \
                  "v_cndmask_b32_dpp %0, %5, %0, vcc " CTRL LA_DPP_TAIL "\n\t"                 \
                  "v_cndmask_b32_dpp %1, %6, %1, vcc " CTRL LA_DPP_TAIL                        \
                  : "+v"(q.lo), "+v"(q.hi), "=&v"(t), "=&v"(n.lo), "=&v"(n.hi)                       \
-                 : "v"(r.lo), "v"(r.hi), "s"(keep)                                          \
+                 : "v"(r.lo), "v"(r.hi), KC(KV)                                             \
                  : "vcc", "scc")
+#define LA_CROSS_VO(PADSTR, CTRL)                                                          \
+    do {                                                                                   \
+        if constexpr (VO) LA_CROSS_ASM(PADSTR, CTRL, LA_FIX_V("%2", "%7"), "v", kvec);     \
+        else LA_CROSS_ASM(PADSTR, CTRL, LA_FIX_S("%7"), "s", keep);                        \
+    } while (0)
 
 #define LA_CROSS_PADS(CTRL)                                   \
     do {                                                      \
-        if constexpr (PAD == 0) LA_CROSS_ASM(LA_PAD0, CTRL);   \
-        else if constexpr (PAD == 1) LA_CROSS_ASM(LA_PAD1, CTRL); \
-        else LA_CROSS_ASM(LA_PAD2, CTRL);                      \
+        if constexpr (PAD == 0) LA_CROSS_VO(LA_PAD0, CTRL);    \
+        else if constexpr (PAD == 1) LA_CROSS_VO(LA_PAD1, CTRL); \
+        else LA_CROSS_VO(LA_PAD2, CTRL);                       \
     } while (0)
 
-// plain (already moved) select: r <- keep-min lanes min(r, o), others max(r, o)
-__device__ __forceinline__ void select_minmax(P64& r, const P64& o, uint64_t keep) {
-    uint32_t t;
-    asm volatile("v_sub_co_u32 %2, vcc, %3, %0\n\t"
-                 "v_subb_co_u32 %2, vcc, %4, %1, vcc\n\t"
-                 "s_xor_b64 vcc, vcc, %5\n\t"
-                 "v_cndmask_b32 %0, %3, %0, vcc\n\t"
-                 "v_cndmask_b32 %1, %4, %1, vcc"
-                 : "+v"(r.lo), "+v"(r.hi), "=&v"(t)
-                 : "v"(o.lo), "v"(o.hi), "s"(keep)
-                 : "vcc", "scc");
-}
-
-template <int M, int PAD>
+template <int M, int PAD, bool VO = false>
 __device__ __forceinline__ void cmpx_cross_mirror(P64& r, P64& q) {
     static_assert(M == 2 || M == 4 || M == 8 || M == 16 || M == 32 || M == 64, "bad mirror width");
-    const uint64_t keep = KeepMin<M / 2>::value;
+    [[maybe_unused]] const uint64_t keep = KeepMin<M / 2>::value;
+    [[maybe_unused]] const uint32_t kvec = keep_vec<M / 2>();
     if constexpr (M <= 16) {
         uint32_t t;
         P64 n;
@@ -218,8 +258,8 @@ __device__ __forceinline__ void cmpx_cross_mirror(P64& r, P64& q) {
         P64 oq, orr;
         oq.lo = shfl_mirror<M>(q.lo); oq.hi = shfl_mirror<M>(q.hi);
         orr.lo = shfl_mirror<M>(r.lo); orr.hi = shfl_mirror<M>(r.hi);
-        select_minmax(r, oq, keep);
-        select_minmax(q, orr, keep);
+        select_minmax<M / 2, VO>(r, oq);
+        select_minmax<M / 2, VO>(q, orr);
     }
 }
 
@@ -248,23 +288,23 @@ __device__ __forceinline__ void cmpx_regs_p64(P64& a, P64& b) {
 // wrote: the mirror walks pairs from the middle outwards ((E/2-1, E/2) first), and the in-register stage
 // finishes on (E-2, E-1).  E <= 2 cannot be ordered that way and pads every DPP block.
 
-template <int L, int E, int J, bool FIRST>
+template <int L, int E, int J, bool FIRST, bool VO = false>
 __device__ __forceinline__ void clean_p64(P64 (&rec)[E]) {
     if constexpr (J >= 1) {
         if constexpr (J >= E) {
             constexpr int PADN = (E <= 2) ? 1 : 0;
 #pragma unroll
-            for (int r = 0; r < E; ++r) cmpx_same_xor<J / E, PADN>(rec[r]);
+            for (int r = 0; r < E; ++r) cmpx_same_xor<J / E, PADN, VO>(rec[r]);
         } else {
 #pragma unroll
             for (int r = 0; r < E; ++r)
                 if ((r & J) == 0) cmpx_regs_p64(rec[r], rec[r | J]);
         }
-        clean_p64<L, E, J / 2, false>(rec);
+        clean_p64<L, E, J / 2, false, VO>(rec);
     }
 }
 
-template <int L, int E, int K, bool FIRST>
+template <int L, int E, int K, bool FIRST, bool VO = false>
 __device__ __forceinline__ void merge_p64(P64 (&rec)[E]) {
     if constexpr (K <= L * E) {
         if constexpr (K <= E) {
@@ -274,23 +314,23 @@ __device__ __forceinline__ void merge_p64(P64 (&rec)[E]) {
         } else {
             constexpr int M = K / E;
             if constexpr (E == 1) {
-                cmpx_same_mirror<M, FIRST ? 2 : 1>(rec[0]);
+                cmpx_same_mirror<M, FIRST ? 2 : 1, VO>(rec[0]);
             } else {
                 constexpr int PADN = FIRST ? 2 : ((E <= 2) ? 1 : 0);
 #pragma unroll
-                for (int r = E / 2 - 1; r >= 0; --r) cmpx_cross_mirror<M, PADN>(rec[r], rec[E - 1 - r]);
+                for (int r = E / 2 - 1; r >= 0; --r) cmpx_cross_mirror<M, PADN, VO>(rec[r], rec[E - 1 - r]);
             }
         }
-        clean_p64<L, E, K / 4, false>(rec);
-        merge_p64<L, E, K * 2, false>(rec);
+        clean_p64<L, E, K / 4, false, VO>(rec);
+        merge_p64<L, E, K * 2, false, VO>(rec);
     }
 }
 
-template <int L, int E>
+template <int L, int E, bool VO = false>
 __device__ __forceinline__ void bitonic_sort_tile_p64(P64 (&rec)[E]) {
     // the first DPP block may directly follow compiler-generated writes of its sources: PAD 2
-    if constexpr (E == 1) merge_p64<L, E, 2, true>(rec);
-    else merge_p64<L, E, 2, false>(rec);
+    if constexpr (E == 1) merge_p64<L, E, 2, true, VO>(rec);
+    else merge_p64<L, E, 2, false, VO>(rec);
 }
 
 // ---- bins that are in order already ------------------------------------------------------------------------------
@@ -322,10 +362,10 @@ __device__ __forceinline__ bool lanes_in_order_p64(const P64& r, int gl) {
 }
 
 // One record per lane (consumer bins), ascending over each group of L lanes.
-template <int L>
+template <int L, bool VO = false>
 __device__ __forceinline__ void bitonic_sort_lanes_p64(P64& rec) {
     P64 r1[1] = {rec};
-    merge_p64<L, 1, 2, true>(r1);
+    merge_p64<L, 1, 2, true, VO>(r1);
     rec = r1[0];
 }
 
