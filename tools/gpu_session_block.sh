@@ -12,6 +12,7 @@ for cfg in "1000 2000 100" "5000 200 100" "200 8000 16" "2000 1000 500" "20000 1
 done
 cd /tmp; export TMPDIR=/tmp
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python $R/bench.py --topics 1000 --partitions 2000 --consumers 100 --steps 50 --warmup 10 --no-cpu-baseline > $O/stats.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_8000x16 -- python $R/bench.py --topics 200 --partitions 8000 --consumers 16 --steps 50 --warmup 10 --no-cpu-baseline > $O/stats_8000x16.log 2>&1
 cd $R
 find $O -name "*.db" -delete 2>/dev/null
 find $O -name "*kernel_trace.csv" -size +2M -delete 2>/dev/null
@@ -19,3 +20,4 @@ for f in $O/bench_*.json; do python3 -c "
 import json,sys
 d=json.loads(open('$f').read()); print(d['config']['workload'][:60], '%.3e'%d['value'], d['ms_per_step'], d['roofline']['frac'], d['parity'])"; done
 find $O/stats -name "*kernel_stats.csv" | head -1 | xargs head -4 | cut -c1-150
+find $O/stats_8000x16 -name "*kernel_stats.csv" | head -1 | xargs head -4 | cut -c1-150
