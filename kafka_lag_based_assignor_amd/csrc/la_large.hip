@@ -515,6 +515,21 @@ __global__ __launch_bounds__(kSortThreads) void tile_scatter_kernel(SortBufs b, 
 #ifdef LA_LOOKBACK_STATS   // development build: how far the walks go (tools/lookback_probe.py)
 __device__ unsigned long long g_lookback_stats[8];      // walks, hops, polls that found nothing, longest walk, cycles in walks
 #endif
+#ifdef LA_SWEEP_CLOCKS     // development build: thread 0 of every tile adds the time of each phase (tools/lookback_probe.py)
+__device__ unsigned long long g_sweep_clocks[12];
+#define LA_SCLK(i)                                                                      \
+    do {                                                                                \
+        if (threadIdx.x == 0) {                                                         \
+            const unsigned long long now_ = wall_clock64();                             \
+            atomicAdd(&g_sweep_clocks[i], now_ - sclk_);                                \
+            sclk_ = now_;                                                               \
+        }                                                                               \
+    } while (0)
+#define LA_SCLK_START unsigned long long sclk_ = wall_clock64(); if (threadIdx.x == 0) atomicAdd(&g_sweep_clocks[11], 1ull)
+#else
+#define LA_SCLK(i) do {} while (0)
+#define LA_SCLK_START do {} while (0)
+#endif
 constexpr uint32_t kStateAggregate = 1u, kStateInclusive = 2u;
 constexpr int kLookWindow = LA_LOOK_WINDOW;           // predecessors a walk polls at once
 constexpr uint32_t kLookbackSpinLimit = 1u << 22;     // polls of one granule (~1 us each with the sleep) before giving up
@@ -532,6 +547,7 @@ __global__ __launch_bounds__(THREADS, 4) void onesweep_pass_kernel(SortBufs b, i
     __shared__ uint64_t s_stage[TILE];                // the tile reordered by digit: one array at a time
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const bool digit_thread = threadIdx.x < kRadix;   // (whole wavefronts: 0 .. 3)
+    LA_SCLK_START;
     if (threadIdx.x == 0) s_ticket = atomicAdd(&b.ticket[pass], 1u);
     for (int i = threadIdx.x; i < WAVES * kRadix; i += THREADS) (&cnt[0][0])[i] = 0;
     __syncthreads();
@@ -557,8 +573,11 @@ __global__ __launch_bounds__(THREADS, 4) void onesweep_pass_kernel(SortBufs b, i
         key[it] = valid ? kin[i] : 0;
         val[it] = valid ? vin[i] : 0;
     }
+    LA_SCLK(0);                                       // ticket, counters, loads issued
     rank_in_wave<ATOMIC_RANK>(key, val, loc, cnt[wave], pass, w0, b.n, lane);
+    LA_SCLK(1);                                       // loads landed + ranks (this wavefront)
     __syncthreads();
+    LA_SCLK(2);                                       // ... of the slowest wavefront
     // thread d: digit d's count in this tile; published at once, so that later tiles never wait for this tile's walk
     uint32_t count = 0, incl = 0;
     unsigned long long win[kLookWindow];
@@ -607,6 +626,7 @@ __global__ __launch_bounds__(THREADS, 4) void onesweep_pass_kernel(SortBufs b, i
         for (int it = 0; it < kItems; ++it)
             if (w0 + it * kWave + lane < b.n) s_stage[loc[it]] = key[it];
     }
+    LA_SCLK(3);                                       // counts published, bin starts, first array staged
     if (digit_thread)
     {   // The walk: thread d adds up digit d's counts of the tiles before this one, nearest first, until it meets an
         // inclusive prefix.  A hop costs a trip to the fabric (the granules are write-through, the per-XCD L2s are not
@@ -665,7 +685,9 @@ __global__ __launch_bounds__(THREADS, 4) void onesweep_pass_kernel(SortBufs b, i
         }
         bin_base[d] = b.gbase[pass * kRadix + d] + excl - bin_start[d];
     }
+    LA_SCLK(4);                                       // this wavefront's walk
     __syncthreads();
+    LA_SCLK(5);                                       // ... the slowest walk
     // the global position of tile-local position j is bin_base[digit of the element at j] + j
     uint32_t gpos[kItems];
     if (pass < 4) {
@@ -709,6 +731,7 @@ __global__ __launch_bounds__(THREADS, 4) void onesweep_pass_kernel(SortBufs b, i
             if (j < n_here) vout[gpos[it]] = s_val[j];
         }
     }
+    LA_SCLK(6);                                       // both scatters issued (stores still in flight)
 }
 
 // ---- outputs that do not depend on the greedy ----------------------------------------------------
@@ -1702,6 +1725,17 @@ hipError_t group_by_member_launch(LargeScratch& scratch, int64_t n, int32_t n_me
                        out_partition, member_off, grouped_topic, grouped_partition, grouped_entry);
     return hipGetLastError();
 }
+
+#ifdef LA_SWEEP_CLOCKS
+extern "C" __attribute__((visibility("default"))) int la_debug_sweep_clocks(unsigned long long* out, int reset) {
+    hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(g_sweep_clocks), sizeof(g_sweep_clocks));
+    if (e == hipSuccess && reset) {
+        unsigned long long zero[12] = {};
+        e = hipMemcpyToSymbol(HIP_SYMBOL(g_sweep_clocks), zero, sizeof zero);
+    }
+    return e == hipSuccess ? 0 : -3;
+}
+#endif
 
 #ifdef LA_LOOKBACK_STATS
 extern "C" __attribute__((visibility("default"))) int la_debug_lookback_stats(unsigned long long* out, int reset) {
