@@ -52,32 +52,47 @@ def test_no_dpp_read_within_two_wait_states_of_a_valu_write(isa, capsys):
     assert checked > 10000          # the networks really are in these units
 
 
+def _asm_statements(src):
+    """Every asm volatile( ... ) of a source text, by parenthesis matching (string literals skipped), with its line."""
+    for m in re.finditer(r"asm\s+volatile\s*\(", src):
+        i, depth = m.end(), 1
+        while depth:
+            c = src[i]
+            if c == '"':
+                i += 1
+                while src[i] != '"':
+                    i += 2 if src[i] == "\\" else 1
+            elif c == "(":
+                depth += 1
+            elif c == ")":
+                depth -= 1
+            i += 1
+        yield src.count("\n", 0, m.start()) + 1, src[m.end():i - 1]
+
+
 def test_asm_statements_with_salu_logic_declare_scc():
     # s_and / s_or / s_xor / s_andn2 ... write SCC; an asm statement that contains one must say so, or the
-    # compiler keeps a live SCC across it (the bug: a loop condition's s_cmp result straddling a network block)
+    # compiler keeps a live SCC across it (the bug: a loop condition's s_cmp result straddling a network block).
+    # The compare-exchange statements take their "keep my own record" fix-up as a macro parameter (FIX: LA_FIX_S is
+    # the s_xor_b64 form, LA_FIX_V the VALU form), so a statement with a FIX slot counts as one that may hold SALU logic.
     pat = re.compile(r"\bs_(and|or|xor|andn2|orn2|nand|nor|xnor|not|add|sub|cmp|bfe|lshl|lshr)[a-z0-9_]*\b")
     offenders = []
     seen = 0
-    for name in os.listdir(CSRC):
+    for name in sorted(os.listdir(CSRC)):
         if not name.endswith((".h", ".hip")):
             continue
         src = open(os.path.join(CSRC, name)).read()
-        # macro-built asm bodies: look at every asm volatile( ... ); statement, macros expanded textually enough
-        for m in re.finditer(r"asm\s+volatile\s*\((.*?)\)\s*;", src, re.S):
-            body = m.group(1)
-            uses_macro = re.search(r"\bLA_[A-Z0-9_]*ASM\b|\bLA_[A-Z_]*PADS?\b", body)
-            text = body
-            if uses_macro:
-                # pull in the macro definitions of the same file
-                for mm in re.finditer(r"#define\s+(LA_[A-Z0-9_]+)\b(?:\([^)]*\))?((?:.*\\\n)*.*)", src):
-                    if mm.group(1) in body:
-                        text += mm.group(2)
-            if pat.search(text):
+        fix_macros = {m.group(1) for m in re.finditer(r"#define\s+(LA_FIX_[A-Z0-9_]+)\b[^\n]*", src) if pat.search(m.group(0))}
+        for line, body in _asm_statements(src):
+            may_hold_salu = bool(pat.search(body)) or bool(re.search(r"\bFIX\b", body)) or any(f in body for f in fix_macros)
+            if may_hold_salu:
                 seen += 1
                 if '"scc"' not in body:
-                    offenders.append("%s: %s" % (name, " ".join(body.split())[:100]))
+                    offenders.append("%s:%d: %s" % (name, line, " ".join(body.split())[:100]))
     assert seen >= 3            # the check is looking at the right statements
     assert not offenders, offenders
+    # and the SALU fix-up macro exists where the statements expect it
+    assert "s_xor_b64 vcc" in open(os.path.join(CSRC, "la_sort64.h")).read()
 
 
 def test_lds_exchanges_stay_lds_instructions(isa):
