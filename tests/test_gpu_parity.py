@@ -793,6 +793,18 @@ print("ok")
         assert out.returncode == 0 and "ok" in out.stdout, (env_rank, out.stdout[-1500:], out.stderr[-1500:])
 
 
+def test_large_topic_with_more_tiles_than_resident_workgroups(ctx):
+    """5 M partitions = 306 tiles of 16 384 elements against the 256 workgroups of 1 024 threads a MI355X keeps resident:
+    the single-kernel radix passes then run in more than one wave of workgroups (arrival tickets decide which tile a
+    workgroup takes, so the look-back never waits for a tile that has not started)."""
+    p, c = 5_000_000, 3
+    po, pid, lag, co, ranks = _single_topic(99, p, c, "u40")
+    exp = oracle.assign_flat(po, pid, lag, co, ranks)
+    got = ctx.assign_batch_lags(po, pid, lag, co, ranks)
+    for g, e, name in zip(got, exp, ("partition order", "member", "totals")):
+        np.testing.assert_array_equal(g, e, err_msg=name)
+
+
 def test_large_phase_times(ctx):
     fresh = N.Context(0)
     with pytest.raises(N.LagAssignError) as ei:                                            # nothing profiled yet
