@@ -125,17 +125,22 @@ __device__ __forceinline__ V load_at(const T* base, IDX idx) {
         return *reinterpret_cast<const V*>(base + idx);
 }
 
-// element index of a lane's v-th pair, clamped so that a 2-element load stays inside [0, n_total)
-template <int L, int E, typename D>
+// element index of a lane's v-th pair, clamped so that a 2-element load stays inside [0, n_total).
+// FULL (here and below): every topic of the wavefront fills its tile exactly (P == L * E) -- every slot holds a
+// partition, no index leaves its topic, and the clamps, validity selects and empty-slot sentinels of the general
+// form are dead code.  The kernel decides per wavefront (one ballot on the descriptors) and runs one of the two forms;
+// partition counts that are a power of two from 8 to 1 024 -- the usual choice -- are full tiles of some shape.
+template <int L, int E, bool FULL = false, typename D>
 __device__ __forceinline__ auto clamped_index(const TileArgs& a, const D& d, int v, int gl) {
     using IDX = decltype(d.p0);
     const IDX g = d.p0 + (IDX)load_index<L, E>(v, gl);
+    if constexpr (FULL) return g;
     const IDX hi = (IDX)(a.n_total - (E >= 2 ? 2 : 1));
     return g < hi ? g : hi;
 }
 
 // stage 1: everything that does not depend on data.  Committed offsets first: stage 2 needs only them.
-template <int L, int E, typename D>
+template <int L, int E, bool FULL = false, typename D>
 __device__ __forceinline__ void issue_loads(const TileArgs& a, const D& d, int gl, Raw<E>& raw) {
     if constexpr (kAblate == 2) return;
     constexpr int NP = (E + 1) / 2;
@@ -143,7 +148,7 @@ __device__ __forceinline__ void issue_loads(const TileArgs& a, const D& d, int g
     if (!a.lag) {
 #pragma unroll
         for (int k = 0; k < NP; ++k) {
-            const auto g = clamped_index<L, E>(a, d, 2 * k, gl);
+            const auto g = clamped_index<L, E, FULL>(a, d, 2 * k, gl);
             if constexpr (E >= 2) raw.cm[k] = load_at<I64x2>(a.committed, g);
             else { raw.cm[k].x = load_at<int64_t>(a.committed, g); raw.cm[k].y = 0; }
         }
@@ -153,7 +158,7 @@ __device__ __forceinline__ void issue_loads(const TileArgs& a, const D& d, int g
     }
 #pragma unroll
     for (int k = 0; k < NP; ++k) {
-        const auto g = clamped_index<L, E>(a, d, 2 * k, gl);
+        const auto g = clamped_index<L, E, FULL>(a, d, 2 * k, gl);
         if constexpr (E >= 2) {
             raw.en[k] = load_at<I64x2>(src_en, g);
             raw.id[k] = load_at<I32x2>(a.pid, g);
@@ -173,14 +178,14 @@ __device__ __forceinline__ bool second_stage_needed(const TileArgs& a) {
     return !a.lag && !a.reset_latest && a.begin;                        // wave-uniform
 }
 
-template <int L, int E, typename D>
+template <int L, int E, bool FULL = false, typename D>
 __device__ __forceinline__ void issue_begin_loads(const TileArgs& a, const D& d, int gl, Raw<E>& raw) {
     if constexpr (kAblate == 2) return;
     constexpr int NP = (E + 1) / 2;
     if (!second_stage_needed<L, E>(a)) return;
 #pragma unroll
     for (int k = 0; k < NP; ++k) {
-        const auto g = clamped_index<L, E>(a, d, 2 * k, gl);
+        const auto g = clamped_index<L, E, FULL>(a, d, 2 * k, gl);
         // a lane whose element has a committed offset needs nothing: all such lanes read ONE fixed word (a single
         // cache line per wavefront instead of a second pass over their own lines through L2) and keep their value
         using G = decltype(g);
@@ -196,7 +201,7 @@ __device__ __forceinline__ void issue_begin_loads(const TileArgs& a, const D& d,
 }
 
 // computePartitionLag (Main.java:376-404) on what the two stages fetched
-template <int L, int E, typename D>
+template <int L, int E, bool FULL = false, typename D>
 __device__ __forceinline__ void finish_lags(const TileArgs& a, const D& d, int gl, const Raw<E>& raw,
                                             int64_t (&lag)[E], int32_t (&pid)[E]) {
     const bool latest = a.reset_latest != 0;
@@ -223,7 +228,7 @@ __device__ __forceinline__ void finish_lags(const TileArgs& a, const D& d, int g
         const int e = load_index<L, E>(2 * k, gl);
         // a pair clamped back by one element holds this lane's first element in .y (only the very last
         // element of the batch can be in that position)
-        const bool shifted = (E >= 2) && (d.p0 + (decltype(d.p0))e == (decltype(d.p0))(a.n_total - 1));
+        const bool shifted = !FULL && (E >= 2) && (d.p0 + (decltype(d.p0))e == (decltype(d.p0))(a.n_total - 1));
         const int64_t en_x = shifted ? raw.en[k].y : raw.en[k].x;
         const int64_t cm_x = shifted ? raw.cm[k].y : raw.cm[k].x;
         pid[2 * k] = shifted ? raw.id[k].y : raw.id[k].x;
@@ -234,6 +239,7 @@ __device__ __forceinline__ void finish_lags(const TileArgs& a, const D& d, int g
         }
     }
     // slots past the topic's partitions: lag 0, id 0 (they must not influence the format decision)
+    if constexpr (FULL) return;
 #pragma unroll
     for (int v = 0; v < E; ++v) {
         const bool valid = load_index<L, E>(v, gl) < d.P;
@@ -244,13 +250,13 @@ __device__ __forceinline__ void finish_lags(const TileArgs& a, const D& d, int g
 
 // ---- packed path ------------------------------------------------------------------------------------
 // records of the packed format:  ((2^lbw - 1 - lag) << sh) | id,  empty slots all ones (sort last)
-template <int L, int E>
+template <int L, int E, bool FULL = false>
 __device__ __forceinline__ void pack_records(int P, int gl, const int64_t (&lag)[E], const int32_t (&pid)[E], int sh,
                                              uint64_t lag_max, P64 (&rec)[E]) {
 #pragma unroll
     for (int v = 0; v < E; ++v) {
         const int e = load_index<L, E>(v, gl);
-        rec[v] = p64_from((e < P) ? (((lag_max - (uint64_t)lag[v]) << sh) | (uint32_t)pid[v]) : ~0ull);
+        rec[v] = p64_from((FULL || e < P) ? (((lag_max - (uint64_t)lag[v]) << sh) | (uint32_t)pid[v]) : ~0ull);
     }
 }
 
@@ -265,7 +271,7 @@ __device__ __forceinline__ void pack_records(int P, int gl, const int64_t (&lag)
 //   otherwise:  key = (top bits of the record) << idx_bits | slot, record stored at its load slot.
 // Dropped low bits (and duplicate ids, which would collide in a slot) can only make the check fail, never
 // pass wrongly: the check is on the full records.
-template <int L, int E>
+template <int L, int E, bool FULL = false>
 __device__ __forceinline__ void sort_into_slice(uint64_t* slice, int gl, P64 (&rec)[E], int lbw, int sh) {
     using Cfg = TileCfg<L, E>;
     if constexpr (kAblate == 1 || kAblate == 4) {
@@ -289,17 +295,17 @@ __device__ __forceinline__ void sort_into_slice(uint64_t* slice, int gl, P64 (&r
     if (by_id && drop == sh) {
         // nothing dropped: the key IS the record (it is shorter than 31 bits); no fetch, no check
 #pragma unroll
-        for (int v = 0; v < E; ++v) key[v] = rec[v].hi == 0xFFFFFFFFu ? 0xFFFFFFFFu : rec[v].lo;
+        for (int v = 0; v < E; ++v) key[v] = (!FULL && rec[v].hi == 0xFFFFFFFFu) ? 0xFFFFFFFFu : rec[v].lo;
         bitonic_sort_tile_u32<L, E>(key);
 #pragma unroll
         for (int r = 0; r < E; ++r)
-            slice[slot_of(gl * E + r)] = key[r] == 0xFFFFFFFFu ? ~0ull : (uint64_t)key[r];
+            slice[slot_of(gl * E + r)] = (!FULL && key[r] == 0xFFFFFFFFu) ? ~0ull : (uint64_t)key[r];
         return;
     }
 #pragma unroll
     for (int v = 0; v < E; ++v) {
         const uint64_t r = p64_value(rec[v]);
-        const bool valid = r != ~0ull;
+        const bool valid = FULL || r != ~0ull;
         const uint32_t idx = by_id ? ((uint32_t)r & idx_mask) : (uint32_t)load_index<L, E>(v, gl);
         if (valid) slice[slot_of((int)idx)] = r;
         key[v] = valid ? (((uint32_t)(r >> drop) << idx_bits) | idx) : 0xFFFFFFFFu;
@@ -311,19 +317,19 @@ __device__ __forceinline__ void sort_into_slice(uint64_t* slice, int gl, P64 (&r
 #pragma unroll
     for (int r = 0; r < E; ++r) {
         const uint64_t x = slice[slot_of((int)(key[r] & idx_mask))];
-        got[r] = p64_from(key[r] == 0xFFFFFFFFu ? ~0ull : x);
+        got[r] = p64_from((!FULL && key[r] == 0xFFFFFFFFu) ? ~0ull : x);
     }
     // strictly ascending?  position s = gl*E + r; all-ones records (empty slots) are all at the end
     bool bad = false;
 #pragma unroll
     for (int r = 0; r + 1 < E; ++r) {
         const uint64_t x = p64_value(got[r]), y = p64_value(got[r + 1]);
-        bad |= (x >= y) && (y != ~0ull);
+        bad |= (x >= y) && (FULL || y != ~0ull);
     }
     {
         const uint64_t x = p64_value(got[E - 1]);
         const uint64_t y = ((uint64_t)(uint32_t)__shfl_down((int)got[0].hi, 1) << 32) | (uint32_t)__shfl_down((int)got[0].lo, 1);
-        bad |= (gl != L - 1) && (x >= y) && (y != ~0ull);
+        bad |= (gl != L - 1) && (x >= y) && (FULL || y != ~0ull);
     }
     wave_lds_fence();
     if (__builtin_amdgcn_ballot_w64(bad) != 0) {
@@ -380,7 +386,7 @@ __device__ __forceinline__ void greedy_rounds_tile(P64& bin, uint64_t* slice, in
 }
 
 // ---- 3..5: greedy rounds over the sorted slice, outputs ------------------------------------------------------
-template <int L, int E, typename IDX>
+template <int L, int E, bool FULL = false, typename IDX>
 __device__ __forceinline__ void assign_packed(const TileArgs& a, uint64_t* slice, int32_t* rank_tab, IDX p0,
                                               IDX c0, int P, int C, int gl, int sh, uint64_t lag_max,
                                               int32_t my_rank) {
@@ -419,7 +425,7 @@ __device__ __forceinline__ void assign_packed(const TileArgs& a, uint64_t* slice
                 om[i] = (C > 0) ? rank_tab[(uint32_t)(w >> 32) & 63u] : -1;
             }
             if (kAblate == 2 && (op[0] ^ om[1] ^ op[2] ^ om[3]) != 0x7FFFFFF1) continue;
-            if (s0 + 3 < P) {
+            if (FULL || s0 + 3 < P) {
                 // element-aligned 16-byte stores, non-temporal: the results are not read again by this launch
                 // (measured: -1 % on the target batch; the same hint on the loads changes nothing)
                 typedef int I32x4 __attribute__((ext_vector_type(4), aligned(4)));
@@ -583,6 +589,56 @@ __device__ __forceinline__ TopicDescT<IDX> load_desc(const TileArgs& a, int64_t 
     return make_desc<L, E, IDX>(a, fetch_desc<L, E>(a, t, n_tiles, grp), gl);
 }
 
+// One tile of kernel 1, from the descriptor on (see the kernel below).
+template <int L, int E, typename IDX, bool INLINE_WIDE, bool FULL>
+__device__ __forceinline__ void packed_tile(const TileArgs& a, const TopicDescT<IDX>& cur, uint64_t* slice, int32_t* rank_tab,
+                                            int64_t tile, int gl, int lane) {
+    using Cfg = TileCfg<L, E>;
+    Raw<E> raw;
+    issue_loads<L, E, FULL>(a, cur, gl, raw);
+    // consumer ranks of the topic, used only at the very end: fetched with everything else
+    int32_t my_rank = 0;
+    if constexpr (kAblate != 2) {
+        const IDX want = cur.c0 + (IDX)gl, last = (IDX)(a.k_total > 0 ? a.k_total - 1 : 0);
+        if (a.k_total > 0) my_rank = load_at<int32_t>(a.cons_rank, want < last ? want : last);
+    }
+    issue_begin_loads<L, E, FULL>(a, cur, gl, raw);
+
+    P64 rec[E];
+    int sh, lbw;
+    bool fits;
+    uint64_t lag_max;
+    int64_t lag[E];
+    int32_t pid[E];
+    {
+        finish_lags<L, E, FULL>(a, cur, gl, raw, lag, pid);
+        // can this wavefront's records be packed into 64 bits?  (empty slots hold lag 0, id 0)
+        uint32_t id_or = 0;
+        uint64_t lag_or = 0;
+#pragma unroll
+        for (int v = 0; v < E; ++v) { id_or |= (uint32_t)pid[v]; lag_or |= (uint64_t)lag[v]; }
+        id_or = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave_or_u32(id_or));
+        sh = 32 - __builtin_clz(id_or | 1u);                             // 1..32 (32: a negative id)
+        // bits of the wavefront's largest lag (64: a negative lag)
+        const uint32_t hi = (uint32_t)(lag_or >> 32), lo = (uint32_t)lag_or;
+        const int my_bits = hi ? 64 - __builtin_clz(hi) : (lo ? 32 - __builtin_clz(lo) : 0);
+        lbw = __builtin_amdgcn_readfirstlane(wave_max_i32(my_bits));
+        int lim = 63 - sh;
+        if (lim > 57 - Cfg::kLog2Cap) lim = 57 - Cfg::kLog2Cap;
+        fits = sh < 32 && lbw <= lim;                                    // wave-uniform
+        lag_max = lbw >= 64 ? ~0ull : (((uint64_t)1 << lbw) - 1);
+        if (fits) pack_records<L, E, FULL>(cur.P, gl, lag, pid, sh, lag_max, rec);
+    }
+    if (fits) {
+        sort_into_slice<L, E, FULL>(slice, gl, rec, lbw, sh);
+        assign_packed<L, E, FULL>(a, slice, rank_tab, cur.p0, cur.c0, cur.P, cur.C, gl, sh, lag_max, my_rank);
+    } else if constexpr (INLINE_WIDE) {
+        assign_wide<L, E, false>(a, slice, (int64_t)cur.p0, (int64_t)cur.c0, cur.P, cur.C, gl, lag, pid);
+    } else if (lane == 0) {
+        a.defer_list[atomicAdd(a.defer_count, 1)] = (int32_t)tile;
+    }
+}
+
 // ---- kernel 1: packed records -------------------------------------------------------------------------
 // One tile per wavefront.  Loads (all issued back to back) -> lags -> format decision -> 32-bit key sort ->
 // greedy rounds -> stores.  A tile whose records do not fit the packed format is appended to the deferred
@@ -617,52 +673,17 @@ __global__ __launch_bounds__(256) LA_WPE_ATTR void wave_tile_packed_kernel(TileA
     // whatever an earlier one left there and re-run a stale list.  Idle by stream order, like in the wide kernel.
     if constexpr (INLINE_WIDE) if (blockIdx.x == 0 && threadIdx.x == 0) *a.defer_count_next = 0;
     if (tile >= n_tiles) return;
-    {
-        const TopicDescT<IDX> cur = load_desc<L, E, IDX>(a, tile, n_tiles, grp, gl);
-        Raw<E> raw;
-        issue_loads<L, E>(a, cur, gl, raw);
-        // consumer ranks of the topic, used only at the very end: fetched with everything else
-        int32_t my_rank = 0;
-        if constexpr (kAblate != 2) {
-            const IDX want = cur.c0 + (IDX)gl, last = (IDX)(a.k_total > 0 ? a.k_total - 1 : 0);
-            if (a.k_total > 0) my_rank = load_at<int32_t>(a.cons_rank, want < last ? want : last);
-        }
-        issue_begin_loads<L, E>(a, cur, gl, raw);
-
-        P64 rec[E];
-        int sh, lbw;
-        bool fits;
-        uint64_t lag_max;
-        int64_t lag[E];
-        int32_t pid[E];
-        {
-            finish_lags<L, E>(a, cur, gl, raw, lag, pid);
-            // can this wavefront's records be packed into 64 bits?  (empty slots hold lag 0, id 0)
-            uint32_t id_or = 0;
-            uint64_t lag_or = 0;
-#pragma unroll
-            for (int v = 0; v < E; ++v) { id_or |= (uint32_t)pid[v]; lag_or |= (uint64_t)lag[v]; }
-            id_or = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave_or_u32(id_or));
-            sh = 32 - __builtin_clz(id_or | 1u);                             // 1..32 (32: a negative id)
-            // bits of the wavefront's largest lag (64: a negative lag)
-            const uint32_t hi = (uint32_t)(lag_or >> 32), lo = (uint32_t)lag_or;
-            const int my_bits = hi ? 64 - __builtin_clz(hi) : (lo ? 32 - __builtin_clz(lo) : 0);
-            lbw = __builtin_amdgcn_readfirstlane(wave_max_i32(my_bits));
-            int lim = 63 - sh;
-            if (lim > 57 - Cfg::kLog2Cap) lim = 57 - Cfg::kLog2Cap;
-            fits = sh < 32 && lbw <= lim;                                    // wave-uniform
-            lag_max = lbw >= 64 ? ~0ull : (((uint64_t)1 << lbw) - 1);
-            if (fits) pack_records<L, E>(cur.P, gl, lag, pid, sh, lag_max, rec);
-        }
-        if (fits) {
-            sort_into_slice<L, E>(slice, gl, rec, lbw, sh);
-            assign_packed<L, E>(a, slice, rank_tab, cur.p0, cur.c0, cur.P, cur.C, gl, sh, lag_max, my_rank);
-        } else if constexpr (INLINE_WIDE) {
-            assign_wide<L, E, false>(a, slice, (int64_t)cur.p0, (int64_t)cur.c0, cur.P, cur.C, gl, lag, pid);
-        } else if (lane == 0) {
-            a.defer_list[atomicAdd(a.defer_count, 1)] = (int32_t)tile;
+    const TopicDescT<IDX> cur = load_desc<L, E, IDX>(a, tile, n_tiles, grp, gl);
+    // every topic of this wavefront fills its tile exactly: the form without clamps, validity selects and sentinels
+    // (the single-launch form of small batches keeps to the general one: it carries the wide code already)
+    if constexpr (!INLINE_WIDE) {
+        // (and lies inside the batch: the general form's clamps are also what keeps a bogus descriptor's loads in bounds)
+        if (__builtin_amdgcn_ballot_w64(cur.P != Cfg::kCap || (int64_t)cur.p0 + Cfg::kCap > a.n_total) == 0) {
+            packed_tile<L, E, IDX, false, true>(a, cur, slice, rank_tab, tile, gl, lane);
+            return;
         }
     }
+    packed_tile<L, E, IDX, INLINE_WIDE, false>(a, cur, slice, rank_tab, tile, gl, lane);
 }
 
 // ---- kernel 2: wide records (and the literal argmin form) ------------------------------------------------------

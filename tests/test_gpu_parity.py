@@ -112,6 +112,66 @@ def test_tile_hard_distributions(ctx, dist):
     _check_lags(ctx, w, dist)
 
 
+# ---- full tiles: the form without clamps, validity selects and sentinels (chosen per wavefront) -----------------
+def _full_tile_batch(seed, t, p, c, kind):
+    """T topics of exactly P partitions each (P = lanes x records of some tile shape) -- except every 5th topic in the
+    "mixed" kinds, which is one partition short, so wavefronts of both forms and wavefronts holding one topic of each
+    sit in the same launch."""
+    rng = np.random.default_rng(seed)
+    sizes = np.full(t, p, dtype=np.int64)
+    if kind.startswith("mixed"):
+        sizes[::5] = max(p - 1, 1)
+    part_off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    n = int(part_off[-1])
+    pid = np.empty(n, dtype=np.int32)
+    lag = np.empty(n, dtype=np.int64)
+    for i in range(t):
+        q = int(sizes[i])
+        ids = rng.permutation(q).astype(np.int64)
+        if kind == "sparse":
+            ids = ids * 7 + 5                                    # ids beyond the tile: keys carry the load slot
+        elif kind == "dup" and q > 1:
+            ids[rng.integers(0, q)] = ids[rng.integers(0, q)]    # a duplicate id: two records in one slot, the check must fail
+        pid[part_off[i]:part_off[i + 1]] = ids
+        if kind == "ties":
+            l = rng.integers(0, 3, q) * 1000
+        elif kind == "zero":
+            l = np.zeros(q, dtype=np.int64)
+        elif kind == "u63":
+            l = rng.integers(0, (1 << 63) - 1, q)                # does not pack: the wide kernel's list
+        elif kind == "negative":
+            l = rng.integers(0, 1 << 30, q)
+            l[rng.integers(0, q)] = -5
+        elif kind == "tiny":
+            l = rng.integers(0, 100, q)                          # the key is the whole record: no fetch, no check
+        else:
+            l = rng.integers(0, 1 << 40, q)
+        lag[part_off[i]:part_off[i + 1]] = l
+    cons_off = np.arange(t + 1, dtype=np.int64) * c
+    ranks = np.tile(np.arange(c, dtype=np.int32) * 2 + 1, t)
+    com = rng.integers(0, 1 << 20, n).astype(np.int64)
+    end = com + np.maximum(lag, 0)
+    com = np.where(rng.random(n) < 0.03, np.int64(-1), com)
+    begin = rng.integers(0, 1 << 10, n).astype(np.int64)
+    return synth.Workload("full", t, part_off, pid, begin, end, com, lag, cons_off, ranks, p, c)
+
+
+@pytest.mark.parametrize("p,c", [(8, 8), (16, 3), (32, 32), (64, 8), (128, 16), (128, 64), (256, 32), (512, 33), (1024, 64)])
+@pytest.mark.parametrize("kind", ["u40", "mixed", "sparse", "dup", "ties", "zero", "tiny", "u63", "negative"])
+def test_tile_full_tiles(ctx, p, c, kind):
+    w = _full_tile_batch(7 * p + c, 37, p, c, kind)               # 37: the last wavefront of a launch is partly empty
+    _check_lags(ctx, w, "full tiles %d x %d %s" % (p, c, kind))
+
+
+@pytest.mark.parametrize("p,c", [(64, 8), (256, 32), (1024, 20)])
+@pytest.mark.parametrize("mode", [N.LA_RESET_LATEST, N.LA_RESET_EARLIEST])
+def test_tile_full_tiles_offsets(ctx, p, c, mode):
+    for kind in ("u40", "mixed"):
+        w = _full_tile_batch(p + c + mode, 41, p, c, kind)
+        w.lag = None                                              # offsets in: the lag is computed in the kernel
+        _check_offsets(ctx, w, mode, "full tiles %d x %d %s" % (p, c, kind))
+
+
 # ---- packed 64-bit record format (chosen per wavefront) vs the wide format -----------------------------
 def _uniform_batch(seed, t, p, c, lag_hi, pid_hi, lag_lo=0):
     """T topics x P partitions x C consumers; lags uniform on [lag_lo, lag_hi], ids distinct in [0, pid_hi]."""

@@ -1,9 +1,19 @@
 #!/bin/bash
-# A second liblagassign.so with another la_large.o (development flags, or an older source), for same-box A/B via LA_LIB_PATH.
-# Usage: tools/build_lab_lib.sh OUT.so LA_LARGE_SOURCE [hipcc flags...]
-OUT=$1; SRC=$2; shift 2
+# A second liblagassign.so for same-box A/B via LA_LIB_PATH: some translation units rebuilt with other flags or from other
+# sources, the rest taken from the in-tree build (csrc/build/*.o).
+# Usage: tools/build_lab_lib.sh OUT.so "UNIT[=SOURCE] ..." [hipcc flags...]
+#   tools/build_lab_lib.sh tools/_lab/a.so "la_large=/tmp/old_la_large.hip" -DLA_SWEEP_CLOCKS
+#   tools/build_lab_lib.sh tools/_lab/b.so "la_wave_tile_l8 la_wave_tile_l16 la_wave_tile_l32 la_wave_tile_l64" -DLA_WPE=7
+OUT=$1; UNITS=$2; shift 2
 R=$(cd $(dirname $0)/.. && pwd); C=$R/kafka_lag_based_assignor_amd/csrc
 T=$(mktemp -d)
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -I$C -I$R/include "$@" -c $SRC -o $T/la_large.o || exit 1
-OBJS=$(ls $C/build/*.o | grep -v la_large.o)
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -Wl,--no-undefined -o $OUT $OBJS $T/la_large.o -ldl && rm -rf $T && echo built $OUT
+SKIP=""
+for u in $UNITS; do
+  name=${u%%=*}; src=$C/$name.hip; [ "$u" != "$name" ] && src=${u#*=}
+  ( /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -fvisibility=hidden -I$C -I$R/include "$@" -c $src -o $T/$name.o || touch $T/failed ) &
+  SKIP="$SKIP -e /$name.o"
+done
+wait
+[ -e $T/failed ] && { echo "compile failed"; exit 1; }
+OBJS=$(ls $C/build/*.o | grep -v $SKIP)
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -Wl,--no-undefined -o $OUT $OBJS $T/*.o -ldl && rm -rf $T && echo built $OUT
