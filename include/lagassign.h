@@ -242,7 +242,7 @@ typedef struct la_device_batch {
     const int64_t *d_lag;            /* [N] or NULL: precomputed lags instead of offsets */
     const int64_t *d_cons_off;       /* [T+1]                                            */
     const int32_t *d_cons_rank;      /* [K]                                              */
-    int32_t *d_out_partition;        /* [N]                                              */
+    int32_t *d_out_partition;        /* [N]  (not looked at when N == 0)                 */
     int32_t *d_out_member_rank;      /* [N]                                              */
     int64_t *d_out_total_lag;        /* [K] or NULL                                      */
     /* host copies of the two offset arrays; required only when the shape hint exceeds

@@ -387,8 +387,9 @@ int enqueue_batch(la_ctx* ctx, Lane& ln, const la_device_batch* b, hipStream_t s
     if (b->n_topics < 0 || b->n_partitions < 0 || b->n_consumers < 0)
         return fail(ctx, LA_EINVAL, "negative size");
     if (b->n_topics == 0) return LA_OK;
-    if (!b->d_part_off || !b->d_cons_off || !b->d_out_partition || !b->d_out_member_rank)
-        return fail(ctx, LA_EINVAL, "null offsets or outputs");
+    if (!b->d_part_off || !b->d_cons_off) return fail(ctx, LA_EINVAL, "null offsets");
+    // (a batch whose topics have no partitions at all has nothing to write: its [0]-sized outputs may be anything)
+    if (b->n_partitions > 0 && (!b->d_out_partition || !b->d_out_member_rank)) return fail(ctx, LA_EINVAL, "null outputs");
     if (b->n_partitions > 0 && (!b->d_partition_id || (!b->d_lag && (!b->d_end_off || !b->d_committed_off))))
         return fail(ctx, LA_EINVAL, "null per-partition input");
     if (b->n_consumers > 0 && !b->d_cons_rank) return fail(ctx, LA_EINVAL, "null cons_rank");

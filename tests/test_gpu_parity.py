@@ -699,6 +699,16 @@ def test_group_by_member_many_members(ctx):
     np.testing.assert_array_equal(g_p, e_p)
 
 
+def test_device_entry_batch_without_partitions(ctx):
+    """Topics with consumers and no partition metadata at all (Main.java:182 hands assignTopic an empty list): nothing
+    to write, so the zero-length result arrays -- a null data pointer in torch -- are not an argument error; every
+    consumer still reports a total of 0."""
+    w = synth.ragged(3, 5, 0, 4)
+    assert w.n_partitions == 0 and w.cons_rank.size > 0
+    p, m, t = _run_device(ctx, w, N.LA_ALGO_AUTO, use_lag=True)
+    assert p.size == 0 and m.size == 0 and t.tolist() == [0] * w.cons_rank.size
+
+
 # ---- randomized sweep: shapes x distributions x entry points ----------------------------------------------
 @pytest.mark.parametrize("seed", range(24))
 def test_fuzz_tile_batches(ctx, seed):

@@ -22,6 +22,25 @@ def main():
             tgp.test_fuzz_tile_batches.__wrapped__(ctx, seed) if hasattr(tgp.test_fuzz_tile_batches, "__wrapped__") else tgp.test_fuzz_tile_batches(ctx, seed)
         except AssertionError as e:
             bad += 1; print("TILE seed", seed, "FAILED:", str(e)[:200])
+    # full tiles (every topic P == lanes x records of some tile shape): the tile kernel's form without clamps / sentinels,
+    # alone and mixed with topics one partition short, every kind of ids and lags, lags in and offsets in
+    nf = 0
+    for seed in range(100, 100 + nt):
+        rng = np.random.default_rng(seed)
+        p = int(rng.choice([8, 16, 32, 64, 128, 256, 512, 1024]))
+        c = int(rng.integers(1, min(64, p) + 1))
+        t = int(rng.integers(1, 120))
+        kind = str(rng.choice(["u40", "mixed", "sparse", "dup", "ties", "zero", "tiny", "u63", "negative"]))
+        w = tgp._full_tile_batch(seed, t, p, c, kind)
+        try:
+            tgp._check_lags(ctx, w, "full %d x %d x %d %s" % (t, p, c, kind))
+            if kind in ("u40", "mixed", "ties", "zero", "tiny"):
+                w.lag = None
+                tgp._check_offsets(ctx, w, N.LA_RESET_LATEST if seed & 1 else N.LA_RESET_EARLIEST, "full, offsets")
+            nf += 1
+        except AssertionError as e:
+            bad += 1; print("FULL seed", seed, "FAILED:", str(e)[:200])
+    print("full-tile batches checked:", nf)
     for seed in range(100, 100 + nl):
         try:
             tgp.test_fuzz_large_topics(ctx, seed)
