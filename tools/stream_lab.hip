@@ -67,6 +67,51 @@ __global__ __launch_bounds__(256) void read_kernel(const L2* a, const L2* b, con
     if (acc == 0x123456789) *sink = acc;
 }
 
+
+// ---- the radix pass's traffic shape without its work: every workgroup streams one tile of TILE elements in and writes it
+// out as TILE / RUN runs of RUN elements, run d of tile t at  d * (n / bins) + slot(t, d) * RUN  -- what a pass does when
+// every digit is equally likely (slot() spreads a digit's runs over the tiles so that the bins do not alias onto one set of
+// memory channels, as the real digit counts do).  Two arrays (8 B keys, 4 B ids) or ONE array of REC-byte records.
+template <int RUN>
+__global__ __launch_bounds__(1024) void scatter_two_arrays(const uint64_t* kin, const uint32_t* vin, uint64_t* kout, uint32_t* vout,
+                                                           int64_t n, int n_tiles) {
+    constexpr int TILE = 16384, BINS = TILE / RUN;
+    const int t = blockIdx.x;
+    const int64_t per_bin = n / BINS;
+    uint64_t k[16]; uint32_t v[16];
+#pragma unroll
+    for (int it = 0; it < 16; ++it) { const int64_t i = (int64_t)t * TILE + it * 1024 + threadIdx.x; k[it] = kin[i]; v[it] = vin[i]; }
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+        const int j = it * 1024 + threadIdx.x, d = j / RUN, r = j % RUN;
+        const int64_t dst = (int64_t)d * per_bin + (int64_t)((t + d * 37) % n_tiles) * RUN + r;
+        kout[dst] = k[it];
+    }
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+        const int j = it * 1024 + threadIdx.x, d = j / RUN, r = j % RUN;
+        const int64_t dst = (int64_t)d * per_bin + (int64_t)((t + d * 37) % n_tiles) * RUN + r;
+        vout[dst] = v[it];
+    }
+}
+
+struct __attribute__((aligned(4))) Rec12 { uint32_t a, b, c; };
+struct __attribute__((aligned(16))) Rec16 { uint32_t a, b, c, d; };
+template <typename REC, int RUN, int ITEMS>
+__global__ __launch_bounds__(1024) void scatter_one_array(const REC* in, REC* out, int64_t n, int n_tiles) {
+    constexpr int TILE = 1024 * ITEMS, BINS = TILE / RUN;
+    const int t = blockIdx.x;
+    const int64_t per_bin = n / BINS;
+    REC x[ITEMS];
+#pragma unroll
+    for (int it = 0; it < ITEMS; ++it) x[it] = in[(int64_t)t * TILE + it * 1024 + threadIdx.x];
+#pragma unroll
+    for (int it = 0; it < ITEMS; ++it) {
+        const int j = it * 1024 + threadIdx.x, d = j / RUN, r = j % RUN;
+        out[(int64_t)d * per_bin + (int64_t)((t + d * 37) % n_tiles) * RUN + r] = x[it];
+    }
+}
+
 int main() {
     const int64_t n = 25600000, n2 = n / 2;
     void *a, *b, *c, *o1, *o2; int64_t* sink;
@@ -93,5 +138,21 @@ int main() {
     }
     time("tile shape (one 512-partition tile per wave)", bytes_mix, [&] { hipLaunchKernelGGL(tile_shape_kernel, dim3(12500), dim3(256), 0, nullptr, (const L2*)a, (const L2*)b, (const I2*)c, (I4*)o1, (I4*)o2, (int64_t)50000); });
     time("read only 20 B/partition, grid 8192", bytes_rd, [&] { hipLaunchKernelGGL(read_kernel, dim3(8192), dim3(256), 0, nullptr, (const L2*)a, (const L2*)b, (const I2*)c, n2, sink); });
+
+    {   // radix-pass shapes on 33.5 M elements (402 MB in + 402 MB out per pass: past the Infinity Cache)
+        const int64_t m = (int64_t)1 << 25;
+        const int tiles = (int)(m / 16384);
+        void *ki, *vi, *ko, *vo;
+        CK(hipMalloc(&ki, m * 16)); CK(hipMalloc(&vi, m * 4)); CK(hipMalloc(&ko, m * 16)); CK(hipMalloc(&vo, m * 4));
+        CK(hipMemset(ki, 1, m * 16)); CK(hipMemset(vi, 2, m * 4));
+        const double bytes24 = (double)m * 24, bytes32 = (double)m * 32;
+        time("scatter, keys 8 B + ids 4 B, runs of 32", bytes24, [&] { hipLaunchKernelGGL(scatter_two_arrays<32>, dim3(tiles), dim3(1024), 0, nullptr, (const uint64_t*)ki, (const uint32_t*)vi, (uint64_t*)ko, (uint32_t*)vo, m, tiles); });
+        time("scatter, keys 8 B + ids 4 B, runs of 64 (ours)", bytes24, [&] { hipLaunchKernelGGL(scatter_two_arrays<64>, dim3(tiles), dim3(1024), 0, nullptr, (const uint64_t*)ki, (const uint32_t*)vi, (uint64_t*)ko, (uint32_t*)vo, m, tiles); });
+        time("scatter, keys 8 B + ids 4 B, runs of 128", bytes24, [&] { hipLaunchKernelGGL(scatter_two_arrays<128>, dim3(tiles), dim3(1024), 0, nullptr, (const uint64_t*)ki, (const uint32_t*)vi, (uint64_t*)ko, (uint32_t*)vo, m, tiles); });
+        time("scatter, keys 8 B + ids 4 B, runs of 1024", bytes24, [&] { hipLaunchKernelGGL(scatter_two_arrays<1024>, dim3(tiles), dim3(1024), 0, nullptr, (const uint64_t*)ki, (const uint32_t*)vi, (uint64_t*)ko, (uint32_t*)vo, m, tiles); });
+        const int tiles12 = (int)(m / 12288);
+        time("scatter, ONE array of 12 B records, runs of 48", bytes24, [&] { hipLaunchKernelGGL((scatter_one_array<Rec12, 48, 12>), dim3(tiles12), dim3(1024), 0, nullptr, (const Rec12*)ki, (Rec12*)ko, (int64_t)tiles12 * 12288, tiles12); });
+        time("scatter, ONE array of 16 B records, runs of 64", bytes32, [&] { hipLaunchKernelGGL((scatter_one_array<Rec16, 64, 16>), dim3(tiles), dim3(1024), 0, nullptr, (const Rec16*)ki, (Rec16*)ko, m, tiles); });
+    }
     return 0;
 }
