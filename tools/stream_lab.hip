@@ -72,7 +72,7 @@ __global__ __launch_bounds__(256) void read_kernel(const L2* a, const L2* b, con
 // out as TILE / RUN runs of RUN elements, run d of tile t at  d * (n / bins) + slot(t, d) * RUN  -- what a pass does when
 // every digit is equally likely (slot() spreads a digit's runs over the tiles so that the bins do not alias onto one set of
 // memory channels, as the real digit counts do).  Two arrays (8 B keys, 4 B ids) or ONE array of REC-byte records.
-template <int RUN>
+template <int RUN, int OFF = 0>
 __global__ __launch_bounds__(1024) void scatter_two_arrays(const uint64_t* kin, const uint32_t* vin, uint64_t* kout, uint32_t* vout,
                                                            int64_t n, int n_tiles) {
     constexpr int TILE = 16384, BINS = TILE / RUN;
@@ -84,13 +84,13 @@ __global__ __launch_bounds__(1024) void scatter_two_arrays(const uint64_t* kin, 
 #pragma unroll
     for (int it = 0; it < 16; ++it) {
         const int j = it * 1024 + threadIdx.x, d = j / RUN, r = j % RUN;
-        const int64_t dst = (int64_t)d * per_bin + (int64_t)((t + d * 37) % n_tiles) * RUN + r;
+        const int64_t dst = (int64_t)d * per_bin + (int64_t)((t + d * 37) % n_tiles) * RUN + r + (OFF ? (d * 13 + OFF) % RUN : 0);
         kout[dst] = k[it];
     }
 #pragma unroll
     for (int it = 0; it < 16; ++it) {
         const int j = it * 1024 + threadIdx.x, d = j / RUN, r = j % RUN;
-        const int64_t dst = (int64_t)d * per_bin + (int64_t)((t + d * 37) % n_tiles) * RUN + r;
+        const int64_t dst = (int64_t)d * per_bin + (int64_t)((t + d * 37) % n_tiles) * RUN + r + (OFF ? (d * 13 + OFF) % RUN : 0);
         vout[dst] = v[it];
     }
 }
@@ -148,6 +148,7 @@ int main() {
         const double bytes24 = (double)m * 24, bytes32 = (double)m * 32;
         time("scatter, keys 8 B + ids 4 B, runs of 32", bytes24, [&] { hipLaunchKernelGGL(scatter_two_arrays<32>, dim3(tiles), dim3(1024), 0, nullptr, (const uint64_t*)ki, (const uint32_t*)vi, (uint64_t*)ko, (uint32_t*)vo, m, tiles); });
         time("scatter, keys 8 B + ids 4 B, runs of 64 (ours)", bytes24, [&] { hipLaunchKernelGGL(scatter_two_arrays<64>, dim3(tiles), dim3(1024), 0, nullptr, (const uint64_t*)ki, (const uint32_t*)vi, (uint64_t*)ko, (uint32_t*)vo, m, tiles); });
+        time("scatter, runs of 64 starting off the cache lines", bytes24, [&] { hipLaunchKernelGGL((scatter_two_arrays<64, 7>), dim3(tiles), dim3(1024), 0, nullptr, (const uint64_t*)ki, (const uint32_t*)vi, (uint64_t*)ko + 64, (uint32_t*)vo + 64, m - 128, tiles - 1); });
         time("scatter, keys 8 B + ids 4 B, runs of 128", bytes24, [&] { hipLaunchKernelGGL(scatter_two_arrays<128>, dim3(tiles), dim3(1024), 0, nullptr, (const uint64_t*)ki, (const uint32_t*)vi, (uint64_t*)ko, (uint32_t*)vo, m, tiles); });
         time("scatter, keys 8 B + ids 4 B, runs of 1024", bytes24, [&] { hipLaunchKernelGGL(scatter_two_arrays<1024>, dim3(tiles), dim3(1024), 0, nullptr, (const uint64_t*)ki, (const uint32_t*)vi, (uint64_t*)ko, (uint32_t*)vo, m, tiles); });
         const int tiles12 = (int)(m / 12288);
