@@ -659,9 +659,32 @@ def main():
                 pdt = min(ptimes[1:])
                 pinned_ok = bool(np.array_equal(pp, ref_p) and np.array_equal(pm, ref_m)) and \
                     ctx.last_pipeline() == N.LA_PIPELINE_STREAMS
+                # what the Java host really does with a batch: the ungrouped result stays on the device, every member's
+                # list comes back grouped (la_group_last_by_member: a stable device sort by member rank, then the D2H)
+                n_members = int(w.cons_rank.max()) + 1 if w.cons_rank.size else 0
+                gout = (ctx.host_alloc((n_members + 1,), np.int64), ctx.host_alloc((w.n_partitions,), np.int32),
+                        ctx.host_alloc((w.n_partitions,), np.int32))
+                gtimes = []
+                for _ in range(3):
+                    c0 = time.perf_counter()
+                    ctx.assign_batch(*pa, keep_on_device=True, want_totals=False)
+                    g_off, g_t, g_p = ctx.group_last_by_member(w.n_partitions, n_members, out=gout)
+                    gtimes.append(time.perf_counter() - c0)
+                gdt = min(gtimes[1:])
+                # the reference's order: member by member, inside a member topic by topic in assignment order = a stable
+                # sort of the ungrouped arrays by member rank (checked on the first two million entries of every member range)
+                order = np.argsort(ref_m, kind="stable")
+                first = int(np.searchsorted(ref_m[order], 0))          # entries of topics without consumers come first
+                grouped_ok = bool(g_off[0] == first and g_off[-1] == w.n_partitions and
+                                  np.array_equal(g_p, ref_p[order]) and
+                                  np.array_equal(g_t, (np.searchsorted(w.part_off, order, side="right") - 1).astype(np.int32)))
                 host_leg = {"ms": round(dt * 1e3, 2), "value": round(w.n_partitions / dt, 1), "unit": "partition-assignments/sec",
                             "pinned_ms": round(pdt * 1e3, 2), "pinned_value": round(w.n_partitions / pdt, 1),
                             "pinned_ms_all": [round(x * 1e3, 2) for x in ptimes], "pinned_bit_exact_and_three_streams": pinned_ok,
+                            "grouped_ms": round(gdt * 1e3, 2), "grouped_value": round(w.n_partitions / gdt, 1),
+                            "grouped_what": "pinned arrays in, the ungrouped result stays on the device, every member's list back "
+                                            "(la_assign_batch + la_group_last_by_member): the Java host's flow; best of the last 2 of 3",
+                            "grouped_lists_equal_stable_sort_by_member": grouped_ok,
                             "h2d_floor_ms": round(w.n_partitions * (bpp - 8) / 57.2e9 * 1e3, 2),
                             "h2d_floor": "the input bytes of the call at the 57.2 GB/s one pinned hipMemcpy sustains on this "
                                          "link (tools/pcie_probe.py, profiles/r03_pcie_probe.txt): no host-buffer call can be faster",

@@ -346,12 +346,22 @@ class Context:
                                                  _p32(out_member_rank), n_members, _p64(off), _p32(g_t), _p32(g_p)))
         return off, g_t, g_p
 
-    def group_last_by_member(self, n_partitions: int, n_members: int) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+    def group_last_by_member(self, n_partitions: int, n_members: int, out=None
+                             ) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
         """group_by_member on the results the last assign_batch / assign_batch_lags call left on the device
-        (give that call keep_on_device=True to skip the download of the ungrouped arrays)."""
-        off = np.zeros(n_members + 1, dtype=np.int64)
-        g_t = np.empty(n_partitions, dtype=np.int32)
-        g_p = np.empty(n_partitions, dtype=np.int32)
+        (give that call keep_on_device=True to skip the download of the ungrouped arrays).
+        `out` = (member_off int64[M+1], grouped_topic int32[N], grouped_partition int32[N]): caller-owned arrays to
+        reuse across calls (pinned ones from host_alloc, for instance), as for assign_batch."""
+        if out is not None:
+            off, g_t, g_p = out
+            if (off.dtype != np.int64 or off.size != n_members + 1 or g_t.dtype != np.int32 or g_p.dtype != np.int32 or
+                    g_t.size != n_partitions or g_p.size != n_partitions or
+                    not (off.flags.c_contiguous and g_t.flags.c_contiguous and g_p.flags.c_contiguous)):
+                raise ValueError("out buffers must be contiguous int64[M+1], int32[N], int32[N]")
+        else:
+            off = np.zeros(n_members + 1, dtype=np.int64)
+            g_t = np.empty(n_partitions, dtype=np.int32)
+            g_p = np.empty(n_partitions, dtype=np.int32)
         self._check(self._lib.la_group_last_by_member(self._h, n_members, _p64(off), _p32(g_t), _p32(g_p)))
         return off, g_t, g_p
 
