@@ -13,9 +13,9 @@
 //                issued back to back; `begin` only where there is no committed offset; lag in registers.
 //   2. format    per wavefront: packed 64-bit records if ids and lags are narrow enough (kernel 1), else
 //                the tile is deferred to the wide-record kernel (kernel 2).
-//   3. sort      32-bit keys (top bits of the record, id as tie-break) through a bitonic network of DPP
-//                min/max; records fetched from the LDS slice by the key's index and CHECKED to be strictly
-//                ascending; the full 64-bit network only if the check fails.  No HBM.
+//   3. sort      32-bit keys (top bits of the record, id as tie-break) through a bitonic network whose steps across
+//                lanes are a DPP move + v_med3_u32 (la_sort32.h); records fetched from the LDS slice by the key's
+//                index and CHECKED to be strictly ascending; the full 64-bit network only if the check fails.  No HBM.
 //   4. greedy    ROUND-STRUCTURED: the count is the comparator's first key (Main.java:246-250),
 //                so assignment proceeds in rounds of C partitions; in a round the k-th
 //                partition goes to the k-th consumer in (total lag, memberId) order as of
@@ -35,6 +35,9 @@
 //   wide     (key64, tie-break32) records, biased so that unsigned order == Java's signed
 //            order; totals wrap like Java's long.  Any int64 lag, any int32 id.
 //            LA_ALGO_ROUNDS_WIDE forces it (tests run both on the same inputs).
+//
+// Steps 1-5 exist in two forms: a wavefront whose topics all fill their tile exactly (P == L*E) runs the one without index
+// clamps, validity selects and empty-slot sentinels (template flag FULL, decided by one ballot on the descriptors).
 //
 // HBM traffic is at most the algorithmic 36 B/partition (+ ~2% descriptors): every input byte is read at
 // most once (`begin` usually not at all), every output byte written once, nothing spills in between.
