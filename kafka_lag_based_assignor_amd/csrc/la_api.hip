@@ -878,6 +878,7 @@ int run_workers(la_ctx* ctx, int n, F&& fn) {
 // for a three-partition batch.  Here the inputs are packed into one pinned staging buffer (a memcpy of kilobytes), go up
 // in ONE copy together with a zeroed status word, and status + results come back in ONE copy.
 constexpr size_t kSmallBytes = 2u << 20;
+constexpr size_t kSmallHostCheck = 16384;      // consumer entries up to which the small path validates the ranks on the host
 
 struct SmallLayout {
     size_t po, co, pid, end, com, beg, cr, status, ot, op, orank, total;
@@ -921,13 +922,23 @@ int assign_small(la_ctx* ctx, const HostCall& c, Shard& sh, const SmallLayout& L
         if (c.use_begin) memcpy(h + L.beg, c.begin, n * 8);
     }
     if (k) memcpy(h + L.cr, c.cons_rank, k * 4);
+    if (k && k <= kSmallHostCheck) {
+        // a topic's member ranks must be strictly ascending (the kernels compare ranks, never strings).  A few thousand
+        // entries are checked here in less time than the ~5 us a dependent launch of the check kernel puts in front of
+        // the assignment kernels -- and a real rebalance is this size.
+        for (size_t t = 0; t < T; ++t)
+            for (int64_t j = c.cons_off[t] + 1; j < c.cons_off[t + 1]; ++j)
+                if (c.cons_rank[j - 1] >= c.cons_rank[j])
+                    return fail(ctx, LA_EINVAL, "a topic's cons_rank segment is not strictly ascending");
+    }
     memset(h + L.status, 0, 256);
     LA_HIP(ctx, hipMemcpyAsync(d, h, L.status + 256, hipMemcpyHostToDevice, st));
     ln.status_word = (uint32_t*)(d + L.status);
     struct Restore { Lane& l; ~Restore() { l.status_word = nullptr; } } restore{ln};
-    if (k)
+    if (k > kSmallHostCheck) {
         LA_HIP(ctx, la::check_consumers_launch(c.T, (const int64_t*)(d + L.co), (const int32_t*)(d + L.cr),
                                                ln.status_word, st));
+    }
     la_device_batch b{};
     b.n_topics = c.T;
     b.reset_mode = c.reset_mode == LA_RESET_LATEST ? LA_RESET_LATEST : LA_RESET_EARLIEST;
