@@ -1703,6 +1703,74 @@ hipError_t large_topic_launch(LargeScratch& scratch, const LargeArgs& a, bool ar
     }
 }
 
+// ---- the same grouping for what a real rebalance is: a few hundred entries -------------------------------------------------
+// member_keys + plan + one or two radix passes + emit are five dependent launches (~25 us) for a job one workgroup does in a
+// few microseconds: count the entries of every group (group = member rank + 1; 0 = topics without consumers), scan, and place
+// entry i behind the entries of its group that come before it -- a stable counting sort, the order of member_emit_kernel.
+constexpr int kSmallGroupN = 1024;       // entries: one per thread; the placement walks the entries before its own (n^2 / 2 compares in all)
+constexpr int kSmallGroupM = 4096;       // groups (members + 1)
+
+__global__ __launch_bounds__(1024) void group_small_kernel(int n, int32_t n_members, int64_t n_topics, const int64_t* part_off,
+                                                           const int32_t* out_partition, const int32_t* member_rank,
+                                                           int64_t* member_off, int32_t* grouped_topic,
+                                                           int32_t* grouped_partition, int32_t* grouped_entry) {
+    __shared__ __attribute__((aligned(16))) uint32_t g[kSmallGroupN];
+    __shared__ uint32_t start[kSmallGroupM];          // counts, then exclusive starts
+    __shared__ uint32_t wsum[1024 / kWave];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int G = n_members + 1;
+    for (int k = tid; k < kSmallGroupM; k += 1024) start[k] = 0;
+    __syncthreads();
+    for (int i = tid; i < n; i += 1024) {
+        uint32_t gi = (uint32_t)(member_rank[i] + 1);
+        gi = gi < (uint32_t)G ? gi : (uint32_t)G;                     // a rank >= n_members (out of contract) sorts behind every member, as in
+                                                                       // member_emit_kernel: member_off[n_members] is then where such entries start
+        g[i] = gi;
+        atomicAdd(&start[gi], 1u);
+    }
+    __syncthreads();
+    // exclusive scan over the kSmallGroupM counts: four per thread, a wavefront scan, the wavefronts' sums
+    uint32_t c[4], run = 0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { c[r] = start[4 * tid + r]; run += c[r]; }
+    uint32_t incl = run;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t y = __shfl_up(incl, o);
+        if (lane >= o) incl += y;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    uint32_t base = incl - run;
+    for (int w = 0; w < wave; ++w) base += wsum[w];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { start[4 * tid + r] = base; base += c[r]; }
+    __syncthreads();
+    // member r's list starts where the groups 0 .. r end; positions before member_off[0] belong to topics without consumers
+    for (int k = tid; k <= n_members; k += 1024) member_off[k] = (int64_t)start[k + 1];
+    for (int i = tid; i < n; i += 1024) {
+        const uint32_t gi = g[i];
+        uint32_t before = 0;
+        int j = 0;                                                     // (all lanes of a wavefront read the same words: broadcasts)
+        for (; j + 4 <= i; j += 4) {
+            const uint4 q = *reinterpret_cast<const uint4*>(&g[j]);
+            before += (q.x == gi ? 1u : 0u) + (q.y == gi ? 1u : 0u) + (q.z == gi ? 1u : 0u) + (q.w == gi ? 1u : 0u);
+        }
+        for (; j < i; ++j) before += g[j] == gi ? 1u : 0u;
+        const uint32_t pos = start[gi] + before;
+        if (grouped_entry) grouped_entry[pos] = i;
+        if (grouped_partition) grouped_partition[pos] = out_partition[i];
+        if (grouped_topic) {
+            int64_t lo = 0, hi = n_topics;                             // largest t with part_off[t] <= i
+            while (hi - lo > 1) {
+                const int64_t mid = (lo + hi) >> 1;
+                if (part_off[mid] <= (int64_t)i) lo = mid; else hi = mid;
+            }
+            grouped_topic[pos] = (int32_t)lo;
+        }
+    }
+}
+
 hipError_t group_by_member_launch(LargeScratch& scratch, int64_t n, int32_t n_members, int64_t n_topics,
                                   const int64_t* part_off, const int32_t* out_partition, const int32_t* member_rank,
                                   int64_t* member_off, int32_t* grouped_topic, int32_t* grouped_partition,
@@ -1710,6 +1778,11 @@ hipError_t group_by_member_launch(LargeScratch& scratch, int64_t n, int32_t n_me
     if (n < 0 || n > 0x7FFFFFFF || n_members < 0) return hipErrorInvalidValue;
     hipError_t e;
     if (n == 0) return hipMemsetAsync(member_off, 0, sizeof(int64_t) * ((size_t)n_members + 1), stream);
+    if (n <= kSmallGroupN && (int64_t)n_members + 2 <= kSmallGroupM && !getenv("LA_NO_SMALL_GROUP")) {
+        hipLaunchKernelGGL(group_small_kernel, dim3(1), dim3(1024), 0, stream, (int)n, n_members, n_topics, part_off, out_partition,
+                           member_rank, member_off, grouped_topic, grouped_partition, grouped_entry);
+        return hipGetLastError();
+    }
     SortBufs b{};
     if ((e = sort_prepare(scratch, n, stream, &b)) != hipSuccess) return e;
     int grid = (int)((n + 255) / 256);

@@ -686,6 +686,27 @@ def test_group_last_by_member_equals_group_by_member(ctx):
     assert rc == N.LA_EINVAL
 
 
+@pytest.mark.parametrize("n,m", [(1, 1), (3, 2), (100, 3), (777, 40), (1024, 1), (1023, 900), (1024, 4094), (1024, 64),
+                                 (1025, 5), (1000, 4095)])
+def test_group_by_member_small_form(ctx, n, m):
+    """Up to 1 024 entries and 4 094 members one workgroup groups the entries by a stable counting sort (one launch instead
+    of five); past either limit the radix passes do.  Same answer on both sides of the limits, entries of topics without
+    consumers (rank -1) in front, empty members, empty topics."""
+    rng = np.random.default_rng(n * 31 + m)
+    out_m = rng.integers(-1, m, n).astype(np.int32)
+    if n > 10:
+        out_m[rng.integers(0, n, n // 7)] = m - 1              # a crowded last member
+        out_m[out_m == m // 2] = -1                             # an empty member in the middle (when m > 1)
+    out_p = rng.integers(0, 1 << 20, n).astype(np.int32)
+    cuts = np.sort(rng.integers(0, n + 1, 6))
+    part_off = np.concatenate([[0], cuts, [n]]).astype(np.int64)   # 7 topics, some of them empty
+    off, g_t, g_p = ctx.group_by_member(part_off, out_p, out_m, m)
+    e_off, e_t, e_p = _expected_groups(part_off, out_p, out_m, m)
+    np.testing.assert_array_equal(off, e_off)
+    np.testing.assert_array_equal(g_t, e_t)
+    np.testing.assert_array_equal(g_p, e_p)
+
+
 def test_group_by_member_many_members(ctx):
     rng = np.random.default_rng(5)
     n, m = 200000, 70000
