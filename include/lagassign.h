@@ -320,6 +320,19 @@ int la_group_by_member(la_ctx *ctx, int32_t n_topics, const int64_t *part_off,
 int la_group_last_by_member(la_ctx *ctx, int32_t n_members,
                             int64_t *member_off, int32_t *grouped_topic, int32_t *grouped_partition);
 
+/* Both steps in one call -- what the reference's assign(Cluster, GroupSubscription) does between reading the offsets
+ * and wrapping the lists (Main.java:147-156): la_assign_batch with the ungrouped result left on the device, then
+ * la_group_last_by_member.  For the call a real rebalance is (its arrays fit the library's 2 MB staging buffer) the lists
+ * are built behind the assignment kernels on the same stream and come back in the call's ONE download with the status and
+ * the totals: one upload, one download, one wait.  Larger batches run the two steps one after the other.  The results stay
+ * on the device as after la_assign_batch (la_group_last_by_member may be called again).  grouped_topic and out_total_lag
+ * may be NULL. */
+int la_assign_batch_grouped(la_ctx *ctx, int32_t n_topics, const int64_t *part_off, const int32_t *partition_id,
+                            const int64_t *begin_off, const int64_t *end_off, const int64_t *committed_off,
+                            int32_t reset_mode, const int64_t *cons_off, const int32_t *cons_rank, int32_t n_members,
+                            int64_t *member_off, int32_t *grouped_topic, int32_t *grouped_partition,
+                            int64_t *out_total_lag);
+
 /* Same on device buffers (N = n_partitions entries); enqueues on `stream` and returns. */
 int la_group_by_member_device(la_ctx *ctx, int32_t n_topics, int64_t n_partitions,
                               const int64_t *d_part_off, const int32_t *d_out_partition,

@@ -214,13 +214,24 @@ public class GpuLagBasedPartitionAssignor implements ConsumerPartitionAssignor, 
         final int reset = resetMode.equalsIgnoreCase("latest") ? LagAssignNative.RESET_LATEST
                                                                : LagAssignNative.RESET_EARLIEST;
         final boolean trace = LOGGER.isTraceEnabled();
-        engine.check(LagAssignNative.assignBatch(engine.ctx, nTopics, engine.partOff.bytes, engine.partitionId.bytes,
-            engine.begin.bytes, engine.end.bytes, engine.committed.bytes, reset, engine.consOff.bytes,
-            engine.consRank.bytes,
-            trace ? engine.outPartition.bytes : null,         // normally the ungrouped result stays on the device
-            trace ? engine.outMemberRank.bytes : null,
-            engine.outTotal.bytes));
-        final Map<String, List<TopicPartition>> lists = engine.memberLists(plan, n);
+        final Map<String, List<TopicPartition>> lists;
+        if (trace) {
+            // the trace lines need the ungrouped arrays as well: two native calls
+            engine.check(LagAssignNative.assignBatch(engine.ctx, nTopics, engine.partOff.bytes, engine.partitionId.bytes,
+                engine.begin.bytes, engine.end.bytes, engine.committed.bytes, reset, engine.consOff.bytes,
+                engine.consRank.bytes, engine.outPartition.bytes, engine.outMemberRank.bytes, engine.outTotal.bytes));
+            lists = engine.memberLists(plan, n);
+        } else {
+            // normally the ungrouped result never leaves the device, and assignment + every member's list are ONE native
+            // call: for a rebalance of ordinary size one upload, one download, one wait (la_assign_batch_grouped)
+            final int nMembers = plan.byRank.length;
+            engine.memberOff.ensure(engine, 8L * (nMembers + 1));
+            engine.check(LagAssignNative.assignBatchGrouped(engine.ctx, nTopics, engine.partOff.bytes,
+                engine.partitionId.bytes, engine.begin.bytes, engine.end.bytes, engine.committed.bytes, reset,
+                engine.consOff.bytes, engine.consRank.bytes, nMembers, engine.memberOff.bytes,
+                engine.groupedTopic.bytes, engine.groupedPartition.bytes, engine.outTotal.bytes));
+            lists = engine.wrapLists(plan);
+        }
         if (trace) {
             // per-partition lags for the trace lines, from the device as well (la_compute_lag on the same buffers)
             engine.check(LagAssignNative.computeLag(engine.ctx, n, engine.begin.bytes, engine.end.bytes,
@@ -495,6 +506,12 @@ public class GpuLagBasedPartitionAssignor implements ConsumerPartitionAssignor, 
             memberOff.ensure(this, 8L * (nMembers + 1));
             check(LagAssignNative.groupLastByMember(ctx, nMembers, memberOff.bytes, groupedTopic.bytes,
                 groupedPartition.bytes));
+            return wrapLists(plan);
+        }
+
+        /** The grouped arrays (memberOff / groupedTopic / groupedPartition, filled by the native side) as member -> list. */
+        Map<String, List<TopicPartition>> wrapLists(Plan plan) {
+            final int nMembers = plan.byRank.length;
             // topic -> (partition -> the entry's own topic string) is only needed by the static seam, where an entry
             // may carry a topic string that differs from its map key
             final Map<String, List<TopicPartition>> lists = new HashMap<>();

@@ -63,6 +63,16 @@ final class LagAssignNative {
                                   ByteBuffer consOff, ByteBuffer consRank, ByteBuffer outPartition,
                                   ByteBuffer outMemberRank, ByteBuffer outTotalLag);
 
+    /**
+     * la_assign_batch_grouped: assignBatch with the ungrouped result left on the device + groupLastByMember in ONE native
+     * call -- for a rebalance of ordinary size one upload, one download, one wait.  Buffers as for those two calls;
+     * groupedTopic and outTotalLag may be null.
+     */
+    static native int assignBatchGrouped(long ctx, int nTopics, ByteBuffer partOff, ByteBuffer partitionId,
+                                         ByteBuffer begin, ByteBuffer end, ByteBuffer committed, int resetMode,
+                                         ByteBuffer consOff, ByteBuffer consRank, int nMembers, ByteBuffer memberOff,
+                                         ByteBuffer groupedTopic, ByteBuffer groupedPartition, ByteBuffer outTotalLag);
+
     /** la_assign_batch_lags: the static assign(Map,Map) seam, on precomputed lags (any int64). */
     static native int assignBatchLags(long ctx, int nTopics, ByteBuffer partOff, ByteBuffer partitionId,
                                       ByteBuffer lag, ByteBuffer consOff, ByteBuffer consRank,

@@ -33,7 +33,7 @@ EXPORTED_SYMBOLS = (
     "la_device_count", "la_create_multi", "la_shard_count", "la_shard_device", "la_plan_shards",
     "la_last_shard_bounds", "la_host_alloc", "la_host_free", "la_last_phase_times", "la_device_features",
     "la_shard_stream", "la_assign_batch_device_on", "la_sync_on", "la_group_by_member_device_on", "la_last_pipeline",
-    "la_allgather_results",
+    "la_allgather_results", "la_assign_batch_grouped",
 )
 
 _i64p = ctypes.POINTER(ctypes.c_int64)
@@ -123,6 +123,9 @@ def load() -> ctypes.CDLL:
     L.la_assign_batch.argtypes = [ctypes.c_void_p, ctypes.c_int32, _i64p, _i32p, _i64p, _i64p, _i64p,
                                   ctypes.c_int32, _i64p, _i32p, _i32p, _i32p, _i64p]
     L.la_assign_batch_lags.restype = ctypes.c_int
+    L.la_assign_batch_grouped.argtypes = [ctypes.c_void_p, ctypes.c_int32, _i64p, _i32p, _i64p, _i64p, _i64p,
+                                          ctypes.c_int32, _i64p, _i32p, ctypes.c_int32, _i64p, _i32p, _i32p, _i64p]
+    L.la_assign_batch_grouped.restype = ctypes.c_int
     L.la_assign_batch_lags.argtypes = [ctypes.c_void_p, ctypes.c_int32, _i64p, _i32p, _i64p, _i64p, _i32p,
                                        _i32p, _i32p, _i64p]
     L.la_assign_batch_device.restype = ctypes.c_int
@@ -332,6 +335,25 @@ class Context:
                                                    _p32(partition_id), _p64(lag), _p64(cons_off),
                                                    _p32(cons_rank), _p32(out_p), _p32(out_m), _p64(out_t)))
         return out_p, out_m, out_t
+
+    def assign_batch_grouped(self, part_off, partition_id, begin, end, committed, reset_mode: int, cons_off, cons_rank,
+                             n_members: int, want_totals: bool = True, want_topic: bool = True
+                             ) -> Tuple[np.ndarray, Optional[np.ndarray], np.ndarray, Optional[np.ndarray]]:
+        """la_assign_batch_grouped: assign and every member's list in ONE call (for a small batch: one upload, one
+        download).  Returns (member_off [M+1], grouped_topic [N] or None, grouped_partition [N], totals [K] or None)."""
+        part_off, cons_off = _a64(part_off), _a64(cons_off)
+        partition_id, cons_rank = _a32(partition_id), _a32(cons_rank)
+        end, committed = _a64(end), _a64(committed)
+        begin = None if begin is None else _a64(begin)
+        off = np.zeros(n_members + 1, dtype=np.int64)
+        g_t = np.empty(partition_id.size, dtype=np.int32) if want_topic else None
+        g_p = np.empty(partition_id.size, dtype=np.int32)
+        out_t = np.zeros(cons_rank.size, dtype=np.int64) if want_totals else None
+        self._check(self._lib.la_assign_batch_grouped(self._h, part_off.size - 1, _p64(part_off), _p32(partition_id),
+                                                      _p64(begin), _p64(end), _p64(committed), reset_mode,
+                                                      _p64(cons_off), _p32(cons_rank), n_members, _p64(off), _p32(g_t),
+                                                      _p32(g_p), _p64(out_t)))
+        return off, g_t, g_p, out_t
 
     def group_by_member(self, part_off, out_partition, out_member_rank, n_members: int
                         ) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:

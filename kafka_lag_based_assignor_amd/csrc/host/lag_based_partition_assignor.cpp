@@ -152,16 +152,18 @@ Assignment run_native(const Plan& plan, const std::vector<const TopicData*>& dat
     if (!plan.topics.empty()) {
         std::lock_guard<std::mutex> lock(g_ctx_mutex);       // one lock over both calls: the second reads the first's results
         la_ctx* ctx = shared_ctx_locked();
-        int rc;
-        if (offsets_mode)
-            rc = la_assign_batch(ctx, (int32_t)plan.topics.size(), f.part_off.data(), f.pid.data(), f.begin.data(),
-                                 f.end.data(), f.committed.data(), reset_mode, f.cons_off.data(), f.cons_rank.data(),
-                                 nullptr, nullptr, out_total.data());
-        else
-            rc = la_assign_batch_lags(ctx, (int32_t)plan.topics.size(), f.part_off.data(), f.pid.data(), f.lag.data(),
-                                      f.cons_off.data(), f.cons_rank.data(), nullptr, nullptr, out_total.data());
-        check(ctx, rc);
-        check(ctx, la_group_last_by_member(ctx, n_members, member_off.data(), grouped_topic.data(), grouped_pid.data()));
+        if (offsets_mode) {
+            // assign(Cluster, GroupSubscription): both steps in ONE native call -- for a rebalance of ordinary size one
+            // upload, one download, one wait (la_assign_batch_grouped)
+            check(ctx, la_assign_batch_grouped(ctx, (int32_t)plan.topics.size(), f.part_off.data(), f.pid.data(),
+                                               f.begin.data(), f.end.data(), f.committed.data(), reset_mode,
+                                               f.cons_off.data(), f.cons_rank.data(), n_members, member_off.data(),
+                                               grouped_topic.data(), grouped_pid.data(), out_total.data()));
+        } else {
+            check(ctx, la_assign_batch_lags(ctx, (int32_t)plan.topics.size(), f.part_off.data(), f.pid.data(), f.lag.data(),
+                                            f.cons_off.data(), f.cons_rank.data(), nullptr, nullptr, out_total.data()));
+            check(ctx, la_group_last_by_member(ctx, n_members, member_off.data(), grouped_topic.data(), grouped_pid.data()));
+        }
     }
     // partition id -> the element's own topic string (normally the map key), per topic
     std::vector<std::unordered_map<int32_t, const std::string*>> topic_of(plan.topics.size());

@@ -562,6 +562,12 @@ struct HostCall {
     int64_t* out_total = nullptr;
     bool use_begin = false;
     Shape shape;
+    // la_assign_batch_grouped: every member's list is wanted instead of the ungrouped arrays.  A small call builds it in the same
+    // staging buffer and brings it back in its one D2H (grouped_done = true); any other call leaves it to group_last_impl.
+    int32_t g_members = -1;
+    int64_t* g_off = nullptr;
+    int32_t *g_topic = nullptr, *g_part = nullptr;
+    bool* grouped_done = nullptr;
 };
 
 struct ShardPlan {
@@ -881,7 +887,7 @@ constexpr size_t kSmallBytes = 2u << 20;
 constexpr size_t kSmallHostCheck = 16384;      // consumer entries up to which the small path validates the ranks on the host
 
 struct SmallLayout {
-    size_t po, co, pid, end, com, beg, cr, status, ot, op, orank, total;
+    size_t po, co, pid, end, com, beg, cr, status, ot, goff, gt, gp, op, orank, total;
 };
 
 SmallLayout small_layout(const HostCall& c) {
@@ -898,6 +904,10 @@ SmallLayout small_layout(const HostCall& c) {
     L.cr = carve(k * 4);
     L.status = carve(256);                                    // last word of the upload, first of the download
     L.ot = carve(k * 8);
+    const bool grouped = c.g_members >= 0;                    // la_assign_batch_grouped: the CSR rides in the same download
+    L.goff = carve(grouped ? ((size_t)c.g_members + 1) * 8 : 0);
+    L.gt = carve(grouped && c.g_topic ? n * 4 : 0);
+    L.gp = carve(grouped ? n * 4 : 0);
     L.op = carve(n * 4);
     L.orank = carve(n * 4);
     L.total = off;
@@ -965,7 +975,18 @@ int assign_small(la_ctx* ctx, const HostCall& c, Shard& sh, const SmallLayout& L
         (void)hipStreamSynchronize(st);
         return rc;
     }
-    // status | totals | partition order | member ranks: as far as the caller wants them
+    if (c.g_members >= 0) {
+        // every member's list, built where the results are: one more launch on the same stream, no second round trip
+        const hipError_t e = la::group_by_member_launch(ln.large, c.shape.n, c.g_members, c.T, (const int64_t*)(d + L.po),
+                                                        (const int32_t*)(d + L.op), (const int32_t*)(d + L.orank),
+                                                        (int64_t*)(d + L.goff), c.g_topic ? (int32_t*)(d + L.gt) : nullptr,
+                                                        (int32_t*)(d + L.gp), nullptr, ln.status_word, st);
+        if (e != hipSuccess) {
+            (void)hipStreamSynchronize(st);
+            return fail(ctx, e == hipErrorOutOfMemory ? LA_ENOMEM : LA_EHIP, "group_by_member: %s", hipGetErrorString(e));
+        }
+    }
+    // status | totals | (member_off | grouped topic | grouped partition) | partition order | member ranks: as far as the caller wants them
     const size_t upto = c.out_pid ? L.total : L.op;
     LA_HIP(ctx, hipMemcpyAsync(h + L.status, d + L.status, upto - L.status, hipMemcpyDeviceToHost, st));
     LA_HIP(ctx, hipStreamSynchronize(st));
@@ -982,6 +1003,14 @@ int assign_small(la_ctx* ctx, const HostCall& c, Shard& sh, const SmallLayout& L
         memcpy(c.out_pid, h + L.op, n * 4);
         memcpy(c.out_rank, h + L.orank, n * 4);
     }
+    if (c.g_members >= 0) {
+        memcpy(c.g_off, h + L.goff, ((size_t)c.g_members + 1) * 8);
+        if (n) {
+            memcpy(c.g_part, h + L.gp, n * 4);
+            if (c.g_topic) memcpy(c.g_topic, h + L.gt, n * 4);
+        }
+        if (c.grouped_done) *c.grouped_done = true;
+    }
     sh.last_part_off = (const int64_t*)(d + L.po);
     sh.last_out_pid = (const int32_t*)(d + L.op);
     sh.last_out_rank = (const int32_t*)(d + L.orank);
@@ -991,7 +1020,7 @@ int assign_small(la_ctx* ctx, const HostCall& c, Shard& sh, const SmallLayout& L
 int assign_host(la_ctx* ctx, int32_t T, const int64_t* part_off, const int32_t* pid, const int64_t* begin,
                 const int64_t* end, const int64_t* committed, const int64_t* lag, int32_t reset_mode,
                 const int64_t* cons_off, const int32_t* cons_rank, int32_t* out_pid, int32_t* out_rank,
-                int64_t* out_total) {
+                int64_t* out_total, const HostCall* grouped = nullptr) {
     if (!ctx) return LA_EINVAL;
     ctx->last_valid = false;
     if (T < 0) return fail(ctx, LA_EINVAL, "n_topics < 0");
@@ -1011,6 +1040,10 @@ int assign_host(la_ctx* ctx, int32_t T, const int64_t* part_off, const int32_t* 
     c.reset_mode = reset_mode; c.cons_off = cons_off; c.cons_rank = cons_rank;
     c.out_pid = out_pid; c.out_rank = out_rank; c.out_total = out_total;
     c.use_begin = !lag && begin && reset_mode != LA_RESET_LATEST;
+    if (grouped) {
+        c.g_members = grouped->g_members; c.g_off = grouped->g_off; c.g_topic = grouped->g_topic; c.g_part = grouped->g_part;
+        c.grouped_done = grouped->grouped_done;
+    }
 
     // shards: all devices for a batch worth splitting, fewer (down to one) for a small one
     int S = (int)ctx->shards.size();
@@ -1022,7 +1055,11 @@ int assign_host(la_ctx* ctx, int32_t T, const int64_t* part_off, const int32_t* 
     plan_ranges(part_off, 0, T, S, ctx->last_bounds);
     ctx->last_shards = S;
     if (S == 1 && !ctx->split_always && s.n > 0) {
-        const SmallLayout L = small_layout(c);
+        SmallLayout L = small_layout(c);
+        if (L.total > kSmallBytes && c.g_members >= 0) {     // too large with the lists aboard: they take their own round trip
+            c.g_members = -1;
+            L = small_layout(c);
+        }
         if (L.total <= kSmallBytes) {
             Shard& sh = ctx->shards[0];
             sh.last_t0 = 0; sh.last_topics = T; sh.last_p0 = 0; sh.last_n = s.n;
@@ -1724,6 +1761,41 @@ LA_API int la_group_last_by_member(la_ctx* ctx, int32_t n_members, int64_t* memb
         return group_last_impl(ctx, n_members, member_off, grouped_topic, grouped_partition);
     } catch (...) {
         return fail(ctx, LA_ENOMEM, "exception in la_group_last_by_member");
+    }
+}
+
+LA_API int la_assign_batch_grouped(la_ctx* ctx, int32_t n_topics, const int64_t* part_off, const int32_t* partition_id,
+                                   const int64_t* begin_off, const int64_t* end_off, const int64_t* committed_off,
+                                   int32_t reset_mode, const int64_t* cons_off, const int32_t* cons_rank, int32_t n_members,
+                                   int64_t* member_off, int32_t* grouped_topic, int32_t* grouped_partition,
+                                   int64_t* out_total_lag) {
+    if (!ctx) return LA_EINVAL;
+    try {
+        if (n_members < 0) return fail(ctx, LA_EINVAL, "negative size");
+        if (!member_off) return fail(ctx, LA_EINVAL, "member_off is NULL");
+        if (n_topics > 0 && part_off && part_off[n_topics] > 0 && !grouped_partition)
+            return fail(ctx, LA_EINVAL, "grouped_partition is NULL");
+        if (n_topics <= 0) {                                        // nothing assigned: every member's list is empty
+            if (n_topics < 0) return fail(ctx, LA_EINVAL, "n_topics < 0");
+            ctx->last_valid = false;
+            for (int32_t r = 0; r <= n_members; ++r) member_off[r] = 0;
+            return LA_OK;
+        }
+        bool done = false;
+        HostCall g;
+        g.g_members = n_members; g.g_off = member_off; g.g_topic = grouped_topic; g.g_part = grouped_partition;
+        g.grouped_done = &done;
+        if (int rc = assign_host(ctx, n_topics, part_off, partition_id, begin_off, end_off, committed_off, nullptr, reset_mode,
+                                 cons_off, cons_rank, nullptr, nullptr, out_total_lag, &g))
+            return rc;
+        if (done) return LA_OK;                                      // a small call: the lists came back with the totals
+        if (!ctx->last_valid) {                                      // (no partitions at all)
+            for (int32_t r = 0; r <= n_members; ++r) member_off[r] = 0;
+            return LA_OK;
+        }
+        return group_last_impl(ctx, n_members, member_off, grouped_topic, grouped_partition);
+    } catch (...) {
+        return fail(ctx, LA_ENOMEM, "exception in la_assign_batch_grouped");
     }
 }
 

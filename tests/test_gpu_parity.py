@@ -707,6 +707,53 @@ def test_group_by_member_small_form(ctx, n, m):
     np.testing.assert_array_equal(g_p, e_p)
 
 
+@pytest.mark.parametrize("shape", [(1, 3, 2), (10, 10, 3), (60, 64, 8), (300, 256, 32), (3, 5000, 300), (4000, 200, 20)])
+def test_assign_batch_grouped_equals_the_two_calls(ctx, shape):
+    """la_assign_batch_grouped = la_assign_batch with the result left on the device + la_group_last_by_member: in one
+    download for a call that fits the small path's staging buffer, one step after the other past it (the last shape)."""
+    t, max_p, max_c = shape
+    w = synth.ragged(11 * t + max_p, t, max_p, max_c, dist="small")
+    n_members = int(w.cons_rank.max()) + 1 if w.cons_rank.size else 0
+    for mode in (N.LA_RESET_LATEST, N.LA_RESET_EARLIEST):
+        a = (w.part_off, w.partition_id, None if mode == N.LA_RESET_LATEST else w.begin, w.end, w.committed, mode,
+             w.cons_off, w.cons_rank)
+        _, _, tot = ctx.assign_batch(*a, keep_on_device=True)
+        want = ctx.group_last_by_member(w.n_partitions, n_members)
+        off, g_t, g_p, tot1 = ctx.assign_batch_grouped(*a, n_members)
+        np.testing.assert_array_equal(off, want[0])
+        np.testing.assert_array_equal(g_t, want[1])
+        np.testing.assert_array_equal(g_p, want[2])
+        np.testing.assert_array_equal(tot1, tot)
+        again = ctx.group_last_by_member(w.n_partitions, n_members)          # the results are still held
+        np.testing.assert_array_equal(again[2], want[2])
+        off2, none_t, g_p2, none_tot = ctx.assign_batch_grouped(*a, n_members, want_totals=False, want_topic=False)
+        assert none_t is None and none_tot is None
+        np.testing.assert_array_equal(off2, want[0])
+        np.testing.assert_array_equal(g_p2, want[2])
+    # the lists against the oracle's assignment, grouped by a stable sort
+    lag = oracle.compute_lags(w.begin, w.end, w.committed, False)
+    e_p, e_m, _ = oracle.assign_flat(w.part_off, w.partition_id, lag, w.cons_off, w.cons_rank)
+    e_off, e_t, e_gp = _expected_groups(np.asarray(w.part_off), e_p, e_m, n_members)
+    np.testing.assert_array_equal(off, e_off)
+    np.testing.assert_array_equal(g_t, e_t)
+    np.testing.assert_array_equal(g_p, e_gp)
+
+
+def test_assign_batch_grouped_argument_errors(ctx):
+    w = synth.ragged(5, 4, 10, 3)
+    a = (w.part_off, w.partition_id, w.begin, w.end, w.committed, N.LA_RESET_EARLIEST, w.cons_off, w.cons_rank)
+    with pytest.raises(N.LagAssignError) as ei:
+        ctx.assign_batch_grouped(*a, -1)
+    assert ei.value.code == N.LA_EINVAL
+    bad = w.cons_rank.copy()
+    k0 = next(int(w.cons_off[t]) for t in range(w.n_topics) if w.cons_off[t + 1] - w.cons_off[t] >= 2)
+    bad[k0], bad[k0 + 1] = bad[k0 + 1], bad[k0]                              # one topic's ranks out of order
+    with pytest.raises(N.LagAssignError) as ei:
+        ctx.assign_batch_grouped(w.part_off, w.partition_id, w.begin, w.end, w.committed, N.LA_RESET_EARLIEST,
+                                 w.cons_off, bad, int(bad.max()) + 1)
+    assert ei.value.code == N.LA_EINVAL
+
+
 def test_group_by_member_many_members(ctx):
     rng = np.random.default_rng(5)
     n, m = 200000, 70000

@@ -31,9 +31,19 @@ def main():
             ctx.group_last_by_member(w.n_partitions, c)
             tg.append(time.perf_counter() - t0)
         tg = np.array(tg) * 1e6
+        # ... and as ONE call (la_assign_batch_grouped: the lists ride in the small call's one download)
+        t1 = []
+        ref = ctx.group_last_by_member(w.n_partitions, c)
+        for _ in range(100):
+            t0 = time.perf_counter()
+            got = ctx.assign_batch_grouped(*a, c)
+            t1.append(time.perf_counter() - t0)
+        t1 = np.array(t1) * 1e6
+        same = all(np.array_equal(x, y) for x, y in zip(got[:3], ref))
         print("%6d topics x %4d partitions x %3d consumers (%8d partitions): assign median %.1f us (p10 %.1f, p90 %.1f); "
-              "assign + group_last %.1f us" % (t, p, c, w.n_partitions, np.median(ts), np.percentile(ts, 10),
-                                              np.percentile(ts, 90), np.median(tg)))
+              "assign + group_last %.1f us; assign_batch_grouped %.1f us (same lists: %s)"
+              % (t, p, c, w.n_partitions, np.median(ts), np.percentile(ts, 10), np.percentile(ts, 90), np.median(tg),
+                 np.median(t1), same))
     ctx.close()
 
 
