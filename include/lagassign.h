@@ -17,6 +17,8 @@
  *   la_assign_batch_lags    static assign(Map,Map) on precomputed lags      Main.java:166-188
  *   la_assign_batch_device  the same two, on buffers already resident in HBM
  *   la_group_by_member      building every member's List<TopicPartition>      Main.java:171-174, :264
+ *   la_assign_batch_grouped la_assign_batch + la_group_last_by_member in one call: the body of
+ *                           assign(Cluster, GroupSubscription) between the offset RPCs and the wrapping  Main.java:147-156
  *   la_create_multi         the per-topic loop, sharded over the GPUs of a node Main.java:177-184
  *   la_assign_batch_device_on  the same loop for a caller whose data already lives on every GPU
  *   la_plan_shards          (which topics of that loop each shard takes)
