@@ -27,8 +27,13 @@ data-path collective.
                    100 000-topic target, or BASELINE config 4 with `--workload cfg4` -- is split
                    over the ranks by the library's own planner (la_plan_shards of the C ABI), every
                    rank runs the hot path on its shard, and the global assignment is reassembled on
-                   every rank by ONE RCCL all-gather per step inside the timed region: a rank's two
-                   result arrays are the two halves of one [2, cap] int32 buffer.
+                   every rank by ONE RCCL all-gather per step inside the timed region.  What is gathered
+                   is the narrow wire format of include/lagassign.h (la_pack_results_on): one element of
+                   2 bytes per assigned partition at the target and cfg4 -- ((member rank + 1) << id_bits)
+                   | partition id -- instead of two int32 arrays (`--wire int32`: the round-3 form, one
+                   [2, cap] int32 buffer); every rank then expands the gathered map back into the two
+                   int32 arrays (la_unpack_results_on; `--no-unpack` leaves it packed), so the product
+                   of a step is the same as at one rank.
   --scaling weak   (default at one rank) every rank owns a full copy of the workload; `--gather`
                    adds the same single all-gather.
 
@@ -83,6 +88,12 @@ def parse_args():
                          "the north star's multi-GPU workload), weak at one rank")
     ap.add_argument("--gather", action="store_true",
                     help="weak scaling: also all-gather the packed result buffer (RCCL) in the timed region; strong scaling always does")
+    ap.add_argument("--wire", choices=["packed", "int32"], default="packed",
+                    help="what the all-gather moves: packed = the narrow wire format (2 B per partition at the target), "
+                         "int32 = the two int32 result arrays as one [2, cap] buffer (8 B per partition)")
+    ap.add_argument("--no-unpack", action="store_true",
+                    help="packed wire: leave the gathered map in the wire format (no la_unpack_results_on in the step)")
+    ap.add_argument("--no-configs", action="store_true", help="skip the per-BASELINE-config block of the default line")
     ap.add_argument("--phase", choices=["assign", "sort"], default="assign",
                     help="sort: time the radix-sort phase of the large path on one topic of --partitions partitions "
                          "(default 33 554 432, no consumers) and report it against the HBM roofline")
@@ -115,7 +126,7 @@ def make_workload(args):
     return w, "custom", {"zipf": "Zipf(1.1)", "uniform40": "uniform [0, 2^40)", "pareto": "Pareto(1.5)"}[d]
 
 
-def sort_phase_workload(n, torch=None, dev=None):
+def sort_phase_workload(n, torch=None, dev=None, ids=None):
     """One topic of n partitions, no consumers, lags uniform on [0, 2^40) from the SplitMix64 generator; ids are a random
     permutation of [0, n): the stable argsort of a second SplitMix64 stream (sorted on the device when one is given: an
     argsort of 33.5 M keys costs ten seconds of one host core).
@@ -126,7 +137,7 @@ def sort_phase_workload(n, torch=None, dev=None):
     (profiles/r03_large_timeline.txt); partition ids of a real topic do not arrive as an arithmetic progression."""
     from kafka_lag_based_assignor_amd import synth
     lag = (synth.splitmix64(0x9E3779B97F4A7C15 ^ 12, n, 1) >> np.uint64(24)).astype(np.int64)
-    if os.environ.get("LA_SORT_IDS") == "affine":
+    if (ids or os.environ.get("LA_SORT_IDS")) == "affine":
         m = 1
         while m < n:
             m <<= 1
@@ -167,17 +178,23 @@ class DeviceShard:
         self.out_pid = self.out2[:cap]
         self.out_rank = self.out2[cap:]
         self.out_total = torch.zeros(max(self.k, 1), device=dev, dtype=torch.int64)
-        lens_p = np.diff(po)
-        lens_c = np.diff(co)
+        self.max_p = int(np.diff(po).max()) if po.size > 1 else 0
+        self.max_c = int(np.diff(co).max()) if co.size > 1 else 0
+        self._N = N
+        self.batch = self.make_batch(latest, algo, flags)
+
+    def make_batch(self, latest, algo="auto", flags=0):
+        """A la_device_batch over this shard's resident arrays (`latest`: auto.offset.reset=latest, `begin` not even passed)."""
+        N = self._N
         b = N.DeviceBatch()
-        b.n_topics = t1 - t0
+        b.n_topics = self.t1 - self.t0
         b.reset_mode = N.LA_RESET_LATEST if latest else N.LA_RESET_EARLIEST
         b.algo = {"auto": N.LA_ALGO_AUTO, "wide": N.LA_ALGO_ROUNDS_WIDE, "argmin": N.LA_ALGO_ARGMIN}[algo]
         b.flags = flags
         b.n_partitions = self.n
         b.n_consumers = self.k
-        b.max_partitions_per_topic = int(lens_p.max()) if lens_p.size else 0
-        b.max_consumers_per_topic = int(lens_c.max()) if lens_c.size else 0
+        b.max_partitions_per_topic = self.max_p
+        b.max_consumers_per_topic = self.max_c
         b.d_part_off = self.d["part_off"].data_ptr()
         b.d_partition_id = self.d["pid"].data_ptr()
         b.d_begin_off = None if latest else self.d["begin"].data_ptr()
@@ -192,7 +209,7 @@ class DeviceShard:
         if b.max_partitions_per_topic > 1024 or b.max_consumers_per_topic > 64:
             b.h_part_off = self.h_part_off.ctypes.data_as(ctypes.POINTER(ctypes.c_int64))
             b.h_cons_off = self.h_cons_off.ctypes.data_as(ctypes.POINTER(ctypes.c_int64))
-        self.batch = b
+        return b
 
 
 def measured_sort_traffic(n, form="single"):
@@ -300,15 +317,138 @@ def live_sort_traffic(n, form):
 def kernel_name(max_p, max_c):
     if max_p <= 1024 and max_c <= 64:
         return "wave_tile_packed_kernel (+ the wide-record kernel over its deferred-tile list, empty here)"
-    if max_p <= 8192 and max_c <= 2048:
-        return "block_topic_kernel (one workgroup per topic; + the list copy)"
-    return "large-topic path (all kernels)"
+    if (max_p <= 8192 and max_c <= 2048) or (max_p <= 16384 and max_c <= 1024):
+        return "block_topic_kernel<%d> (one workgroup per topic)" % (16 if max_p > 8192 else 8)
+    return "large path: greedy_rounds_kernel (one workgroup per topic) behind build_keys + onesweep_pass_kernel x passes"
 
 
-def run_sort_phase(torch, N, ctx, dev, n, reps, stream, form="single", live=False):
+FROZEN_FULL = os.path.join(ROOT, "tests", "golden", "oracle_frozen_full.json")   # tests/golden/make_golden.py --full
+
+
+def timed_calls(torch, ctx, batch, stream, settle_ms, min_calls=10, max_calls=400, window_ms=60.0):
+    """ms per la_assign_batch_device call at steady state: an untimed settle phase sized in time, then ONE pair of HIP events
+    around a back-to-back block of calls on the stream they run on."""
+    ctx.assign_batch_device(batch, stream)
+    ctx.sync(stream)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    ctx.assign_batch_device(batch, stream)
+    e1.record()
+    ctx.sync(stream)
+    est = max(float(e0.elapsed_time(e1)), 1e-3)
+    t0 = time.perf_counter()
+    while (time.perf_counter() - t0) * 1e3 < settle_ms:
+        for _ in range(max(1, min(50, int(5.0 / est)))):
+            ctx.assign_batch_device(batch, stream)
+        ctx.sync(stream)
+    calls = int(max(min_calls, min(max_calls, window_ms / est)))
+    e0.record()
+    for _ in range(calls):
+        ctx.assign_batch_device(batch, stream)
+    e1.record()
+    ctx.sync(stream)
+    return float(e0.elapsed_time(e1)) / calls, calls
+
+
+def run_configs(torch, N, ctx, dev, stream):
+    """Every BASELINE.json configuration that runs on one GPU (configs[1..4]; configs[0] is the README triple on the CPU path),
+    at full size, device-resident, auto.offset.reset=earliest: settled ms per call by HIP events, the 36 B/partition roofline
+    reading, the dominant kernel, and bit-exactness of the LAST timed call's results -- cfg2b / cfg3 / cfg4 against the literal
+    oracle run here, cfg5 (15 s of literal oracle) against oracle/round_form.py; all four also against the sha256 the literal
+    oracle froze into tests/golden/oracle_frozen_full.json."""
+    import hashlib
+    from kafka_lag_based_assignor_amd import synth
+    from oracle import oracle
+    from oracle.round_form import round_form
+    try:
+        with open(FROZEN_FULL) as fh:
+            frozen = json.load(fh)
+    except (OSError, ValueError):
+        frozen = {}
+    out = {}
+    for name in ("cfg2b", "cfg3", "cfg4", "cfg5"):
+        try:
+            w = synth.config(name)
+            sh = DeviceShard(torch, N, dev, w, 0, w.n_topics, False, "auto")
+            ms, calls = timed_calls(torch, ctx, sh.batch, stream, settle_ms=40.0)
+            n = sh.n
+            g_pid, g_rank = sh.out_pid[:n].cpu().numpy(), sh.out_rank[:n].cpu().numpy()
+            g_tot = sh.out_total[: sh.k].cpu().numpy()
+            lag = oracle.compute_lags(w.begin, w.end, w.committed, False)
+            t0 = time.perf_counter()
+            if name == "cfg5":
+                e_pid, e_rank, e_tot = round_form(w.part_off, w.partition_id, lag, w.cons_off, w.cons_rank)
+                against = "oracle/round_form.py (independent numpy round form)"
+            else:
+                e_pid, e_rank, e_tot = oracle.assign_flat(w.part_off, w.partition_id, lag, w.cons_off, w.cons_rank)
+                against = "oracle/lag_oracle.c (literal per-step min)"
+            cpu_s = time.perf_counter() - t0
+            ok = bool(np.array_equal(g_pid, e_pid) and np.array_equal(g_rank, e_rank) and np.array_equal(g_tot, e_tot))
+            h = hashlib.sha256()
+            for a in (g_pid.astype("<i4"), g_rank.astype("<i4"), g_tot.astype("<i8")):
+                h.update(np.ascontiguousarray(a).tobytes())
+            fz = frozen.get("%s@1/earliest" % name, {}).get("sha256")
+            ratio = synth.lag_ratio(g_tot, w.cons_off)
+            out[name] = {
+                "workload": "%d topic(s) x %d partitions x %d consumers" % (w.n_topics, w.max_partitions, w.max_consumers),
+                "partitions": int(n), "ms_per_call": round(ms, 5), "calls_timed": calls,
+                "value": round(n / (ms * 1e-3), 1), "frac": round(36.0 * n / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                "kernel": kernel_name(w.max_partitions, w.max_consumers),
+                "bit_exact": ok, "against": against, "checker_seconds": round(cpu_s, 2),
+                "sha256_matches_frozen_literal_oracle": (h.hexdigest() == fz) if fz else None,
+                "lag_ratio_mean": round(float(ratio.mean()), 4),
+            }
+            del sh
+            torch.cuda.empty_cache()
+        except Exception as exc:  # noqa: BLE001 -- a reported extra
+            out[name] = {"error": str(exc)}
+    out["what"] = ("every single-GPU BASELINE.json config at full size, device-resident, earliest mode: ms per "
+                   "la_assign_batch_device call from one HIP-event pair around a settled back-to-back block of calls; frac = "
+                   "36 B x partitions / time / 8 TB/s (cfg2b / cfg5 are ONE topic -- a dependent chain on one workgroup -- and "
+                   "cfg3 is 1 000 small topics: launch / latency bound, the fraction says so)")
+    return out
+
+
+def run_small_calls(N, ctx):
+    """What ONE real rebalance costs: la_assign_batch_grouped (assignment + every member's list, host buffers in, host buffers
+    out) against the C oracle on the SAME call on one host core, so the crossover is on the record (VERDICT r3 weak #7)."""
+    from kafka_lag_based_assignor_amd import synth
+    from oracle import oracle
+    rows = []
+    for (t, p, c) in [(10, 10, 3), (40, 50, 5), (100, 100, 8), (1000, 50, 5), (1000, 256, 32)]:
+        w = synth.make_uniform("lat", 20, t, p, c, "uniform40")
+        a = (w.part_off, w.partition_id, w.begin, w.end, w.committed, N.LA_RESET_EARLIEST, w.cons_off, w.cons_rank)
+        for _ in range(20):
+            got = ctx.assign_batch_grouped(*a, c)
+        reps = 200 if w.n_partitions <= 10000 else 40
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            got = ctx.assign_batch_grouped(*a, c)
+            ts.append(time.perf_counter() - t0)
+        tc = []
+        for _ in range(max(5, reps // 8)):
+            t0 = time.perf_counter()
+            lag = oracle.compute_lags(w.begin, w.end, w.committed, False)
+            e_pid, e_rank, e_tot = oracle.assign_flat(w.part_off, w.partition_id, lag, w.cons_off, w.cons_rank)
+            order = np.argsort(e_rank, kind="stable")              # the per-member lists (what the grouped call returns)
+            tc.append(time.perf_counter() - t0)
+        ok = bool(np.array_equal(got[2], e_pid[order]) and np.array_equal(got[3], e_tot))
+        rows.append({"topics": t, "partitions_per_topic": p, "consumers": c, "partitions": int(w.n_partitions),
+                     "gpu_call_us": round(float(np.median(ts)) * 1e6, 1), "cpu_oracle_us": round(float(np.median(tc)) * 1e6, 1),
+                     "bit_exact": ok})
+    cross = next((r["partitions"] for r in rows if r["gpu_call_us"] < r["cpu_oracle_us"]), None)
+    return {"rows": rows, "gpu_faster_from_partitions": cross,
+            "what": "median wall time of ONE la_assign_batch_grouped call (pageable host buffers in, every member's list out: "
+                    "one upload, the kernels, one download) against the C oracle + a stable sort by member for the same call on "
+                    "one host core (ctypes call overhead included on both sides).  Below the crossover a rebalance is cheaper "
+                    "on the CPU: the GPU path's floor is the ~30 us of two PCIe copies and two launches"}
+
+
+def run_sort_phase(torch, N, ctx, dev, n, reps, stream, form="single", live=False, ids=None):
     """The radix-sort phase of the large path on one topic of n partitions (no consumers: keys, sort, ids).  Times come
     from HIP events the library records around its phases (LA_FLAG_PROFILE / la_last_phase_times)."""
-    w = sort_phase_workload(n, torch, dev)
+    w = sort_phase_workload(n, torch, dev, ids)
     torch.cuda.empty_cache()
     sh = DeviceShard(torch, N, dev, w, 0, 1, False, "auto",
                      flags=N.LA_FLAG_PROFILE | (N.LA_FLAG_SORT_MULTIKERNEL if form == "multi" else 0))
@@ -343,6 +483,9 @@ def run_sort_phase(torch, N, ctx, dev, n, reps, stream, form="single", live=Fals
                        if form == "single" else "tile_count+scan_group_sums+scan_offsets+tile_scatter (every active 8-bit pass)"),
             "form": form, "rank": "ds_add_rtn" if ctx.device_features(0) & N.LA_FEATURE_ATOMIC_RANK else "wave match",
             "kernel_ms": round(ms, 4), "partitions": n, "id_passes": int(t.id_passes), "key_passes": int(t.key_passes),
+            "ids": ids or os.environ.get("LA_SORT_IDS") or "random", "bytes_per_partition": round(algo_bytes / n, 1),
+            "traffic_bytes_per_partition": round(tr["hbm_bytes_per_launch"] / n, 1) if tr else None,
+            "frac_moved": round(tr["hbm_bytes_per_launch"] / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if tr else None,
             "algorithmic_bytes_per_launch": int(algo_bytes),
             "algorithmic_bytes": "%d B per id pass + %d B per key pass, per partition" % (bytes_id, bytes_key),
             "keys_ms": round(float(np.mean(keys_ms)), 4), "ids_ms": round(float(np.mean(ids_ms)), 4),
@@ -423,6 +566,7 @@ def main():
     if strong:
         # la_plan_shards (what la_create_multi uses itself); ncclAllGather needs equal counts: buffers padded to `cap`
         ranges, counts, cap = sharding.strong_plan(w.part_off, world)
+        cap = (cap + 7) // 8 * 8              # every rank's block of the gathered buffer starts 16-byte aligned
         bounds = [r[0] for r in ranges] + [ranges[-1][1]]
         t0, t1 = ranges[rank]
         sh = DeviceShard(torch, N, dev, w, t0, t1, latest, args.algo, out_cap=cap)
@@ -435,15 +579,55 @@ def main():
         gather = bool(args.gather and use_dist)
     cap = sh.cap
     do_gather = gather and use_dist
-    if do_gather:
-        gathered = torch.empty(world * 2 * cap, device=dev, dtype=torch.int32)     # [world][2][cap]
     n_part = sh.n
     b = sh.batch
+    # What the ONE all-gather of a step moves.  packed (default): the wire format of include/lagassign.h -- one unsigned
+    # element per assigned partition, ((member rank + 1) << id_bits) | partition id, 2 bytes at the target and at cfg4 (the
+    # library picks the width from the largest id and the member count: la_wire_format_for); int32: the two result arrays as
+    # one [2, cap] int32 buffer (8 B per partition, round 3's form).
+    packed = do_gather and args.wire == "packed"
+    unpack = packed and not args.no_unpack
+    fmt = None
+    if do_gather:
+        max_id = int(w.partition_id.max()) if w.partition_id.size and int(w.partition_id.min()) >= 0 else -1
+        n_members = int(w.cons_rank.max()) + 1 if w.cons_rank.size else 0
+        fmt = N.wire_format_for(max_id, n_members)
+        if packed:
+            # raw bytes: RCCL (like NCCL) has no 16-bit integer type, and an all-gather does no arithmetic
+            wire_send = torch.zeros(cap * fmt.elem_bytes, device=dev, dtype=torch.uint8)          # the tail beyond n_part stays padding
+            wire_recv = torch.empty(world * cap * fmt.elem_bytes, device=dev, dtype=torch.uint8)  # [world][cap] elements
+            if unpack:
+                gathered = torch.empty(2 * world * cap, device=dev, dtype=torch.int32)  # [2][world][cap]: ids | ranks
+        else:
+            gathered = torch.empty(world * 2 * cap, device=dev, dtype=torch.int32)     # [world][2][cap]
+    gather_bytes_per_rank = (cap * fmt.elem_bytes if packed else 2 * cap * 4) if do_gather else 0
+
+    def gather_step(trio=None):
+        """pack -> THE collective of a step -> unpack; trio[2..4] are recorded behind each phase when given."""
+        if packed:
+            ctx.pack_results(n_part, sh.out_pid.data_ptr(), sh.out_rank.data_ptr(), fmt, wire_send.data_ptr(), stream)
+            if trio:
+                trio[2].record()
+            all_gather(wire_recv, wire_send)
+            if trio:
+                trio[3].record()
+            if unpack:
+                ctx.unpack_results(world * cap, wire_recv.data_ptr(), fmt, gathered.data_ptr(),
+                                   gathered.data_ptr() + 4 * world * cap, stream)
+            if trio:
+                trio[4].record()
+        else:
+            if trio:
+                trio[2].record()
+            all_gather(gathered, sh.out2)
+            if trio:
+                trio[3].record()
+                trio[4].record()
 
     def step():
         ctx.assign_batch_device(b, stream)
         if do_gather:
-            all_gather(gathered, sh.out2)                           # THE collective of a step: both result arrays at once
+            gather_step()
 
     def barrier():
         torch.cuda.synchronize()
@@ -476,7 +660,7 @@ def main():
     # around every one of the driver's 20 steps took 2 % off `value` (the wall clock over the K steps).  About 200 of the
     # steps of a long run, every other step of a short one (at least 10 samples).
     stride = max(1, args.steps // 200) if args.steps > 40 else (2 if args.steps >= 20 else 1)
-    ev = {s: tuple(torch.cuda.Event(enable_timing=True) for _ in range(3)) for s in range(0, args.steps, stride)}
+    ev = {s: tuple(torch.cuda.Event(enable_timing=True) for _ in range(5)) for s in range(0, args.steps, stride)}
     barrier()
     t0c = time.perf_counter()
     for s in range(args.steps):
@@ -488,18 +672,20 @@ def main():
             ctx.assign_batch_device(b, stream)
             trio[1].record()
             if do_gather:
-                all_gather(gathered, sh.out2)
-                trio[2].record()
+                gather_step(trio)
     barrier()
     elapsed = time.perf_counter() - t0c
     ctx.sync(stream)
 
-    # HIP-event durations on the stream the work runs on: the assign launch (the kernels of one step), and the gather
+    # HIP-event durations on the stream the work runs on: the assign launch (the kernels of one step), then pack, the
+    # collective, unpack
     kern_ms = float(np.mean([e[0].elapsed_time(e[1]) for e in ev.values()]))
-    gather_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in ev.values()])) if do_gather else 0.0
+    pack_ms = float(np.mean([e[1].elapsed_time(e[2]) for e in ev.values()])) if do_gather else 0.0
+    gather_ms = float(np.mean([e[2].elapsed_time(e[3]) for e in ev.values()])) if do_gather else 0.0
+    unpack_ms = float(np.mean([e[3].elapsed_time(e[4]) for e in ev.values()])) if do_gather else 0.0
 
     cdev = "cpu" if backend == "gloo" else dev
-    t = torch.tensor([elapsed, kern_ms, gather_ms], device=cdev, dtype=torch.float64)
+    t = torch.tensor([elapsed, kern_ms, gather_ms, pack_ms, unpack_ms], device=cdev, dtype=torch.float64)
     per_rank = torch.zeros(2 * world, device=cdev, dtype=torch.float64)
     per_rank[rank] = kern_ms
     per_rank[world + rank] = gather_ms
@@ -507,12 +693,23 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.all_reduce(per_rank, op=dist.ReduceOp.SUM)
     elapsed, kern_ms_max, gather_ms_max = float(t[0].item()), float(t[1].item()), float(t[2].item())
+    pack_ms_max, unpack_ms_max = float(t[3].item()), float(t[4].item())
     per_rank = per_rank.cpu().numpy()
 
     # strong scaling: the gathered buffer, stripped of its padding, is the global assignment -- checked below
     gathered_host = None
     if strong and rank == 0:
-        if do_gather:
+        if do_gather and packed and not unpack:
+            # the map was left in the wire format: expand it here, after the timed region, with the library's own decoder
+            tmp = torch.empty(2 * world * cap, device=dev, dtype=torch.int32)
+            ctx.unpack_results(world * cap, wire_recv.data_ptr(), fmt, tmp.data_ptr(), tmp.data_ptr() + 4 * world * cap, stream)
+            ctx.sync(stream)
+            g = tmp.cpu().numpy().reshape(2, world * cap)
+            gathered_host = (sharding.strip_padding(g[0], counts, cap), sharding.strip_padding(g[1], counts, cap))
+        elif do_gather and packed:
+            g = gathered.cpu().numpy().reshape(2, world * cap)
+            gathered_host = (sharding.strip_padding(g[0], counts, cap), sharding.strip_padding(g[1], counts, cap))
+        elif do_gather:
             g = gathered.cpu().numpy().reshape(world, 2, cap)
             gathered_host = (sharding.strip_padding(np.ascontiguousarray(g[:, 0, :]).reshape(-1), counts, cap),
                              sharding.strip_padding(np.ascontiguousarray(g[:, 1, :]).reshape(-1), counts, cap))
@@ -574,6 +771,20 @@ def main():
     if tr:
         roofline["traffic_source"] = tr.get("source")
         roofline["traffic_read_bytes"], roofline["traffic_written_bytes"] = tr.get("read_bytes"), tr.get("written_bytes")
+        # the SAME kernel time over the bytes that really crossed the fabric (PMC): the numerator of `frac` charges `begin`
+        # for every partition (SURVEY 8d fixes 36 B) while the kernels read it only where there is no committed offset
+        roofline["frac_moved"] = round(tr["hbm_bytes_per_launch"] / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+        roofline["moved_bytes_per_partition"] = round(tr["hbm_bytes_per_launch"] / max(n_part, 1), 2)
+    # ... and the `latest` form of the same batch (28 B contract: no `begin` array exists at all), same settled regime
+    if world == 1 and not latest and not args.no_cpu_baseline:
+        try:
+            lms, lcalls = timed_calls(torch, ctx, sh.make_batch(True, args.algo), stream, settle_ms=60.0)
+            roofline["latest_mode"] = {"kernel_ms": round(lms, 4), "calls_timed": lcalls, "algorithmic_bytes_per_partition": 28,
+                                       "frac": round(28.0 * n_part / (lms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                       "value": round(n_part / (lms * 1e-3), 1),
+                                       "what": "auto.offset.reset=latest on the same resident batch: d_begin_off = NULL"}
+        except Exception as exc:  # noqa: BLE001
+            roofline["latest_mode"] = {"error": str(exc)}
 
     # ---- quality metric of BASELINE.json: max/min per-consumer total lag per topic (min clamped to 1) ----
     lag_ratio = None
@@ -659,6 +870,22 @@ def main():
                 pdt = min(ptimes[1:])
                 pinned_ok = bool(np.array_equal(pp, ref_p) and np.array_equal(pm, ref_m)) and \
                     ctx.last_pipeline() == N.LA_PIPELINE_STREAMS
+                # the same call with `begin` handed over only where there is no committed offset (la_assign_batch_sparse): 20 B
+                # instead of 28 B per partition cross the link
+                sparse_ms = sparse_ok = None
+                if not latest:
+                    s_idx, s_val = N.sparse_begin(w.begin, w.committed)
+                    p_idx, p_val = ctx.host_alloc(s_idx.shape, np.int64), ctx.host_alloc(s_val.shape, np.int64)
+                    p_idx[...] = s_idx
+                    p_val[...] = s_val
+                    stimes = []
+                    for _ in range(4):
+                        c0 = time.perf_counter()
+                        sp_, sm_, st_ = ctx.assign_batch_sparse(pa[0], pa[1], pa[3], pa[4], mode, p_idx, p_val, pa[6], pa[7], out=pout)
+                        stimes.append(time.perf_counter() - c0)
+                    sparse_ms = min(stimes[1:])
+                    sparse_ok = bool(np.array_equal(sp_, ref_p) and np.array_equal(sm_, ref_m)) and \
+                        ctx.last_pipeline() == N.LA_PIPELINE_STREAMS
                 # what the Java host really does with a batch: the ungrouped result stays on the device, every member's
                 # list comes back grouped (la_group_last_by_member: a stable device sort by member rank, then the D2H)
                 n_members = int(w.cons_rank.max()) + 1 if w.cons_rank.size else 0
@@ -681,6 +908,14 @@ def main():
                 host_leg = {"ms": round(dt * 1e3, 2), "value": round(w.n_partitions / dt, 1), "unit": "partition-assignments/sec",
                             "pinned_ms": round(pdt * 1e3, 2), "pinned_value": round(w.n_partitions / pdt, 1),
                             "pinned_ms_all": [round(x * 1e3, 2) for x in ptimes], "pinned_bit_exact_and_three_streams": pinned_ok,
+                            "sparse_begin_ms": round(sparse_ms * 1e3, 2) if sparse_ms else None,
+                            "sparse_begin_value": round(w.n_partitions / sparse_ms, 1) if sparse_ms else None,
+                            "sparse_begin_bit_exact_and_three_streams": sparse_ok,
+                            "sparse_begin_what": "la_assign_batch_sparse on pinned arrays: begin offsets only for the partitions "
+                                                 "without a committed offset (%d of %d): 20 B + 16 B x 1 %% per partition over PCIe, "
+                                                 "floor %.2f ms at 57.2 GB/s" % (
+                                                     int((w.committed < 0).sum()), w.n_partitions,
+                                                     (w.n_partitions * 20 + int((w.committed < 0).sum()) * 16) / 57.2e9 * 1e3),
                             "grouped_ms": round(gdt * 1e3, 2), "grouped_value": round(w.n_partitions / gdt, 1),
                             "grouped_what": "pinned arrays in, the ungrouped result stays on the device, every member's list back "
                                             "(la_assign_batch + la_group_last_by_member): the Java host's flow; best of the last 2 of 3",
@@ -699,6 +934,21 @@ def main():
         if not ok:
             print("PARITY FAILURE against the oracle", file=sys.stderr)
 
+    # ---- every other BASELINE config, and what one small rebalance costs (rank 0, N = 1) ----------------------------
+    configs = small_call = None
+    if world == 1 and not args.no_cpu_baseline and not args.no_configs and wname == "target":
+        try:
+            small_call = run_small_calls(N, ctx)
+        except Exception as exc:  # noqa: BLE001 -- a reported extra
+            small_call = {"error": str(exc)}
+        configs = run_configs(torch, N, ctx, dev, stream)
+        P_t, C_t = int(np.diff(w.part_off).max()), int(np.diff(w.cons_off).max())
+        configs["target"] = {"workload": "%d topics x %d partitions x %d consumers" % (T, P_t, C_t), "partitions": int(n_part),
+                             "ms_per_call": round(kern_ms, 5), "value": round(n_part / (kern_ms * 1e-3), 1),
+                             "frac": roofline["frac"], "kernel": roofline["kernel"],
+                             "bit_exact": parity["bit_exact"] if parity else None,
+                             "against": "oracle/lag_oracle.c on the first %d topics (the cpu_baseline leg's budget)" % parity["checked_topics"] if parity else None}
+
     # ---- the north star's other figure: the radix-sort phase against the HBM roofline, measured in this run --------
     sort_phase = None
     if not args.no_sort_phase:                                  # rank 0 (the other ranks wait at the closing barrier)
@@ -707,9 +957,15 @@ def main():
             torch.cuda.empty_cache()
             sp = run_sort_phase(torch, N, ctx, dev, SORT_PHASE_PARTITIONS, 5, stream, args.sort_form,
                                 live=world == 1 and not args.no_live_traffic and not args.no_cpu_baseline)
-            sort_phase = {k: sp[k] for k in ("frac", "achieved", "unit", "kernel", "form", "rank", "kernel_ms", "partitions", "id_passes",
-                                             "algorithmic_bytes",
+            sort_phase = {k: sp[k] for k in ("frac", "frac_moved", "achieved", "unit", "kernel", "form", "rank", "kernel_ms", "partitions",
+                                             "id_passes", "ids", "algorithmic_bytes", "bytes_per_partition", "traffic_bytes_per_partition",
                                              "key_passes", "algorithmic_bytes_per_launch", "traffic", "traffic_source", "sorted_ok", "source")}
+            # the round-1/2 workload beside it: ids as the affine permutation i -> (a*i + c) mod 2^k, whose id
+            # passes alias their 256 output runs onto one set of memory channels
+            if world == 1 and not args.no_cpu_baseline:
+                torch.cuda.empty_cache()
+                sa = run_sort_phase(torch, N, ctx, dev, SORT_PHASE_PARTITIONS, 3, stream, args.sort_form, live=False, ids="affine")
+                sort_phase["affine_ids"] = {k: sa[k] for k in ("kernel_ms", "frac", "id_passes", "key_passes", "sorted_ok")}
         except Exception as exc:  # noqa: BLE001 -- a reported extra
             sort_phase = {"error": str(exc)}
 
@@ -733,9 +989,19 @@ def main():
                    "topics": T, "partitions_per_topic": P, "consumers_per_topic": C,
                    "topics_on_rank0": int(b.n_topics), "gather": bool(do_gather), "algo": args.algo,
                    "collectives_per_step": 1 if do_gather else 0,
-                   "collective": ("ONE all_gather_into_tensor of the [2, %d] int32 result buffer (partition order | member "
-                                  "rank) per step, inside the timed region: %.4f ms by HIP events (max over ranks)"
-                                  % (cap, gather_ms_max)) if do_gather else None,
+                   "collective": (("ONE all_gather_into_tensor of %d wire elements of %d bytes per rank (((member rank + 1) << %d) | "
+                                   "partition id; la_pack_results_on before it%s), inside the timed region: %.4f ms by HIP events "
+                                   "(max over ranks)" % (cap, fmt.elem_bytes, fmt.id_bits,
+                                                         ", la_unpack_results_on over the gathered map after it" if unpack else
+                                                         "; the gathered map stays in the wire format", gather_ms_max))
+                                  if packed else
+                                  ("ONE all_gather_into_tensor of the [2, %d] int32 result buffer (partition order | member "
+                                   "rank) per step, inside the timed region: %.4f ms by HIP events (max over ranks)"
+                                   % (cap, gather_ms_max))) if do_gather else None,
+                   "wire": ({"format": args.wire, "elem_bytes": int(fmt.elem_bytes) if packed else 8, "id_bits": int(fmt.id_bits) if packed else None,
+                             "gather_bytes_per_rank": int(gather_bytes_per_rank), "unpacked_in_step": bool(unpack),
+                             "pack_ms": round(pack_ms_max, 4), "gather_ms": round(gather_ms_max, 4), "unpack_ms": round(unpack_ms_max, 4),
+                             "kernels_ms": round(kern_ms_max, 4)} if do_gather else None),
                    "backend": ("rccl" if backend == "nccl" else "gloo, ranks sharing devices (test hook: not a performance number)") if use_dist else None,
                    "settle_ms": args.settle_ms, "settle_steps": settle_steps},
         "roofline": roofline,
@@ -746,6 +1012,8 @@ def main():
         "cpu_baseline": cpu,
         "parity": parity,
         "host_boundary": host_leg,
+        "configs": configs,
+        "small_call": small_call,
     }
     print(json.dumps(line), flush=True)
     if use_dist:

@@ -14,6 +14,7 @@
  *   la_assign_batch         readTopicPartitionLags' per-partition lag call  Main.java:344-356
  *                           + the per-topic loop of assign(Map,Map)         Main.java:177-184
  *                           + assignTopic (sort + greedy + update)          Main.java:204-266
+ *   la_assign_batch_sparse  the same with beginning offsets only where they are read   Main.java:384-396
  *   la_assign_batch_lags    static assign(Map,Map) on precomputed lags      Main.java:166-188
  *   la_assign_batch_device  the same two, on buffers already resident in HBM
  *   la_group_by_member      building every member's List<TopicPartition>      Main.java:171-174, :264
@@ -24,6 +25,8 @@
  *   la_plan_shards          (which topics of that loop each shard takes)
  *   la_allgather_results    nothing in the reference (it has one thread and one heap): the reassembly of the global
  *                           assignment on every GPU, one RCCL all-gather over xGMI
+ *   la_pack_results_on, la_unpack_results_on, la_allgather_packed, la_wire_format_for
+ *                           the same gather in 2 (or 4) bytes per assigned partition instead of 8
  *   la_last_phase_times     nothing: measurement hook (radix-sort phase against the HBM roofline)
  *   la_device_features, la_last_pipeline   nothing: diagnostics (what the library found / did)
  *
@@ -186,7 +189,13 @@ void la_host_free(la_ctx *ctx, void *p);
 /* Text of the last error on this context ("" if none).  ctx may be NULL: returns the
  * text of the last la_create failure on the calling thread. */
 const char *la_last_error(const la_ctx *ctx);
-/* ABI version: major*10000 + minor*100 + patch. */
+/* ABI version: major*10000 + minor*100 + patch.  LA_VERSION is the header's, la_version() the loaded library's: a shim
+ * (JNI, ctypes) compares the two before it binds entry points that older libraries lack.
+ *   0.2.1 (201)  rounds 2-3: multi-device contexts, grouped calls, *_on device entry points, la_allgather_results
+ *   0.3.0 (300)  round 4: la_wire_format_for / la_pack_results_on / la_unpack_results_on / la_allgather_packed (narrow wire
+ *                format of the all-gather), la_assign_batch_sparse / la_assign_batch_grouped_sparse (begin offsets only
+ *                where there is no committed offset); every entry point restores the caller's current HIP device */
+#define LA_VERSION 300
 int la_version(void);
 
 /* computePartitionLag over n partitions (host buffers).  begin_off may be NULL when
@@ -213,6 +222,24 @@ int la_assign_batch(la_ctx *ctx, int32_t n_topics,
                     int32_t *out_partition,        /* [N]  (both NULL: results stay on   */
                     int32_t *out_member_rank,      /* [N]   the device, see la_group_last_by_member) */
                     int64_t *out_total_lag);       /* [K]  or NULL                       */
+
+/* la_assign_batch with `begin` handed over SPARSELY.  computePartitionLag reads the beginning offset only where a partition
+ * has no committed offset and auto.offset.reset is not "latest" (Main.java:384-396) -- typically ~1 % of a group's
+ * partitions -- while a dense begin_off array is 8 of the 28 input bytes per partition that cross PCIe, the link that bounds
+ * every host-buffer call.  Here the caller lists only those partitions:
+ *   none_index[j]  position (index into the per-partition arrays, 0 .. N-1) of a partition without a committed offset,
+ *                  ASCENDING (the marshaller meets them in order: GpuLagBasedPartitionAssignor.java, `md == null`)
+ *   none_begin[j]  its beginning offset
+ * A partition with committed_off < 0 that is NOT listed has begin 0 -- the reference's getOrDefault(tp, 0L) for a missing
+ * beginning offset (Main.java:350-351).  Entries whose partition HAS a committed offset are harmless (never read).
+ * In LA_RESET_LATEST mode the list is ignored (may be NULL).  A list that is not ascending or leaves [0, N): LA_EINVAL.
+ * Results are those of la_assign_batch on the equivalent dense array, bit for bit. */
+int la_assign_batch_sparse(la_ctx *ctx, int32_t n_topics,
+                           const int64_t *part_off, const int32_t *partition_id,
+                           const int64_t *end_off, const int64_t *committed_off, int32_t reset_mode,
+                           int64_t n_none, const int64_t *none_index, const int64_t *none_begin,
+                           const int64_t *cons_off, const int32_t *cons_rank,
+                           int32_t *out_partition, int32_t *out_member_rank, int64_t *out_total_lag);
 
 /* Same, on precomputed lags: the static assign(Map,Map) seam the reference's own tests
  * use (Test.java:127-128).  lag[] may hold any int64, negatives included. */
@@ -335,6 +362,14 @@ int la_assign_batch_grouped(la_ctx *ctx, int32_t n_topics, const int64_t *part_o
                             int64_t *member_off, int32_t *grouped_topic, int32_t *grouped_partition,
                             int64_t *out_total_lag);
 
+/* la_assign_batch_grouped with the sparse `begin` of la_assign_batch_sparse: what the Java host calls. */
+int la_assign_batch_grouped_sparse(la_ctx *ctx, int32_t n_topics, const int64_t *part_off, const int32_t *partition_id,
+                                   const int64_t *end_off, const int64_t *committed_off, int32_t reset_mode,
+                                   int64_t n_none, const int64_t *none_index, const int64_t *none_begin,
+                                   const int64_t *cons_off, const int32_t *cons_rank, int32_t n_members,
+                                   int64_t *member_off, int32_t *grouped_topic, int32_t *grouped_partition,
+                                   int64_t *out_total_lag);
+
 /* Same on device buffers (N = n_partitions entries); enqueues on `stream` and returns. */
 int la_group_by_member_device(la_ctx *ctx, int32_t n_topics, int64_t n_partitions,
                               const int64_t *d_part_off, const int32_t *d_out_partition,
@@ -354,6 +389,31 @@ int la_group_by_member_device(la_ctx *ctx, int32_t n_topics, int64_t n_partition
  * not there.  RCCL wants one DISTINCT device per rank: LA_EINVAL for a context with several shards on one device.
  * (One process per GPU -- bench.py, torch.distributed -- calls RCCL through its own framework instead.) */
 int la_allgather_results(la_ctx *ctx, int64_t count, const int32_t *const *d_send, int32_t *const *d_recv);
+
+/* ---- the narrow wire format of that all-gather ------------------------------------------------------------------------
+ * What the gather moves per assigned partition is a (partition id, member) pair in assignment order (Main.java:264): 8 B as
+ * two int32 arrays, but 8 + 6 bits of information at the 100 000 x 256 x 32 target.  xGMI is the slow station of the
+ * multi-GPU step (7 links x ~77 GB/s per direction against ~5 TB/s of HBM), so the gather's bytes are the step's time.
+ * One wire element =
+ *       ((member rank + 1) << id_bits) | partition id        (rank + 1 == 0: the topic had no consumer, Main.java:211-213)
+ * as an unsigned integer of elem_bytes = 2, 4 or 8 bytes; the 8-byte form (id_bits = 32) carries ANY int32 pair.
+ *   la_wire_format_for   the narrowest format for ids in [0, max_partition_id] and ranks in [-1, n_members); pass
+ *                        max_partition_id < 0 when ids may be negative or are not known (-> the 8-byte form).  Pure host code.
+ *   la_pack_results_on   n results of shard `shard` (device arrays, e.g. what la_assign_batch_device_on wrote) -> n wire
+ *                        elements; enqueued on `stream`.  A pair that does not fit `fmt` is reported by la_sync_on as LA_EINVAL.
+ *   la_unpack_results_on the reverse, on any shard's device (e.g. over the whole gathered buffer, padding included).
+ *   la_allgather_packed  la_allgather_results for `count` elements of elem_bytes each.
+ * Pointers 16-byte aligned take the 16-byte-access kernels; any alignment of elem_bytes works. */
+typedef struct la_wire_format {
+    int32_t elem_bytes;    /* 2, 4 or 8 */
+    int32_t id_bits;       /* low bits of an element that hold the partition id (32 in the 8-byte form) */
+} la_wire_format;
+int la_wire_format_for(int64_t max_partition_id, int64_t n_members, la_wire_format *out);
+int la_pack_results_on(la_ctx *ctx, int shard, int64_t n, const int32_t *d_out_partition,
+                       const int32_t *d_out_member_rank, const la_wire_format *fmt, void *d_packed, void *stream);
+int la_unpack_results_on(la_ctx *ctx, int shard, int64_t n, const void *d_packed, const la_wire_format *fmt,
+                         int32_t *d_out_partition, int32_t *d_out_member_rank, void *stream);
+int la_allgather_packed(la_ctx *ctx, int64_t count, int32_t elem_bytes, const void *const *d_send, void *const *d_recv);
 
 /* la_group_by_member_device on shard `shard` (buffers on that shard's device). */
 int la_group_by_member_device_on(la_ctx *ctx, int shard, int32_t n_topics, int64_t n_partitions,

@@ -34,6 +34,8 @@ EXPORTED_SYMBOLS = (
     "la_last_shard_bounds", "la_host_alloc", "la_host_free", "la_last_phase_times", "la_device_features",
     "la_shard_stream", "la_assign_batch_device_on", "la_sync_on", "la_group_by_member_device_on", "la_last_pipeline",
     "la_allgather_results", "la_assign_batch_grouped",
+    "la_wire_format_for", "la_pack_results_on", "la_unpack_results_on", "la_allgather_packed",
+    "la_assign_batch_sparse", "la_assign_batch_grouped_sparse",
 )
 
 _i64p = ctypes.POINTER(ctypes.c_int64)
@@ -61,6 +63,15 @@ class DeviceBatch(ctypes.Structure):
         ("d_out_total_lag", ctypes.c_void_p),
         ("h_part_off", _i64p), ("h_cons_off", _i64p),
     ]
+
+
+class WireFormat(ctypes.Structure):
+    """struct la_wire_format: one element = ((member rank + 1) << id_bits) | partition id, in elem_bytes bytes"""
+    _fields_ = [("elem_bytes", ctypes.c_int32), ("id_bits", ctypes.c_int32)]
+
+    @property
+    def dtype(self):
+        return {2: np.uint16, 4: np.uint32, 8: np.uint64}[int(self.elem_bytes)]
 
 
 class PhaseTimes(ctypes.Structure):
@@ -150,6 +161,24 @@ def load() -> ctypes.CDLL:
                                        ctypes.POINTER(ctypes.c_void_p)]
     L.la_last_pipeline.restype = ctypes.c_int
     L.la_last_pipeline.argtypes = [ctypes.c_void_p]
+    L.la_wire_format_for.restype = ctypes.c_int
+    L.la_wire_format_for.argtypes = [ctypes.c_int64, ctypes.c_int64, ctypes.POINTER(WireFormat)]
+    L.la_pack_results_on.restype = ctypes.c_int
+    L.la_pack_results_on.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p,
+                                     ctypes.POINTER(WireFormat), ctypes.c_void_p, ctypes.c_void_p]
+    L.la_unpack_results_on.restype = ctypes.c_int
+    L.la_unpack_results_on.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_void_p,
+                                       ctypes.POINTER(WireFormat), ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+    L.la_allgather_packed.restype = ctypes.c_int
+    L.la_allgather_packed.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.POINTER(ctypes.c_void_p),
+                                      ctypes.POINTER(ctypes.c_void_p)]
+    L.la_assign_batch_sparse.restype = ctypes.c_int
+    L.la_assign_batch_sparse.argtypes = [ctypes.c_void_p, ctypes.c_int32, _i64p, _i32p, _i64p, _i64p, ctypes.c_int32,
+                                         ctypes.c_int64, _i64p, _i64p, _i64p, _i32p, _i32p, _i32p, _i64p]
+    L.la_assign_batch_grouped_sparse.restype = ctypes.c_int
+    L.la_assign_batch_grouped_sparse.argtypes = [ctypes.c_void_p, ctypes.c_int32, _i64p, _i32p, _i64p, _i64p, ctypes.c_int32,
+                                                 ctypes.c_int64, _i64p, _i64p, _i64p, _i32p, ctypes.c_int32, _i64p, _i32p,
+                                                 _i32p, _i64p]
     L.la_shard_stream.restype = ctypes.c_void_p
     L.la_shard_stream.argtypes = [ctypes.c_void_p, ctypes.c_int]
     L.la_assign_batch_device_on.restype = ctypes.c_int
@@ -189,6 +218,23 @@ def plan_shards(part_off, n_shards: int) -> np.ndarray:
     if rc != LA_OK:
         raise LagAssignError(rc, "la_plan_shards: bad arguments")
     return bounds
+
+
+def wire_format_for(max_partition_id: int, n_members: int) -> WireFormat:
+    """la_wire_format_for (pure host code): the narrowest wire element for ids in [0, max_partition_id] (negative: any
+    int32) and member ranks in [-1, n_members)."""
+    f = WireFormat()
+    rc = load().la_wire_format_for(int(max_partition_id), int(n_members), ctypes.byref(f))
+    if rc != LA_OK:
+        raise LagAssignError(rc, "la_wire_format_for")
+    return f
+
+
+def sparse_begin(begin, committed):
+    """(none_index int64[m], none_begin int64[m]) of a dense `begin` array: the positions without a committed offset, ascending
+    -- what a marshaller that knows `md == null` hands to la_assign_batch_sparse instead of the dense array."""
+    idx = np.flatnonzero(np.asarray(committed) < 0).astype(np.int64)
+    return idx, np.ascontiguousarray(np.asarray(begin, dtype=np.int64)[idx])
 
 
 def device_count() -> int:
@@ -315,6 +361,50 @@ class Context:
                                               _p64(out_t)))
         return out_p, out_m, out_t
 
+    def assign_batch_sparse(self, part_off, partition_id, end, committed, reset_mode: int, none_index, none_begin,
+                            cons_off, cons_rank, want_totals: bool = True, out=None, keep_on_device: bool = False):
+        """la_assign_batch_sparse: `begin` only for the partitions listed in none_index (ascending positions)."""
+        part_off, cons_off = _a64(part_off), _a64(cons_off)
+        partition_id, cons_rank = _a32(partition_id), _a32(cons_rank)
+        end, committed = _a64(end), _a64(committed)
+        none_index = None if none_index is None else _a64(none_index)
+        none_begin = None if none_begin is None else _a64(none_begin)
+        n_none = 0 if none_index is None else none_index.size
+        if keep_on_device:
+            out_p = out_m = None
+            out_t = np.zeros(cons_rank.size, dtype=np.int64) if want_totals else None
+        elif out is not None:
+            out_p, out_m, out_t = out
+        else:
+            out_p = np.empty(partition_id.size, dtype=np.int32)
+            out_m = np.empty(partition_id.size, dtype=np.int32)
+            out_t = np.zeros(cons_rank.size, dtype=np.int64) if want_totals else None
+        self._check(self._lib.la_assign_batch_sparse(self._h, part_off.size - 1, _p64(part_off), _p32(partition_id),
+                                                     _p64(end), _p64(committed), reset_mode, n_none, _p64(none_index),
+                                                     _p64(none_begin), _p64(cons_off), _p32(cons_rank), _p32(out_p),
+                                                     _p32(out_m), _p64(out_t)))
+        return out_p, out_m, out_t
+
+    def assign_batch_grouped_sparse(self, part_off, partition_id, end, committed, reset_mode: int, none_index, none_begin,
+                                    cons_off, cons_rank, n_members: int, want_totals: bool = True, want_topic: bool = True):
+        """la_assign_batch_grouped_sparse -> (member_off, grouped_topic or None, grouped_partition, totals or None)."""
+        part_off, cons_off = _a64(part_off), _a64(cons_off)
+        partition_id, cons_rank = _a32(partition_id), _a32(cons_rank)
+        end, committed = _a64(end), _a64(committed)
+        none_index = None if none_index is None else _a64(none_index)
+        none_begin = None if none_begin is None else _a64(none_begin)
+        n_none = 0 if none_index is None else none_index.size
+        off = np.zeros(n_members + 1, dtype=np.int64)
+        g_t = np.empty(partition_id.size, dtype=np.int32) if want_topic else None
+        g_p = np.empty(partition_id.size, dtype=np.int32)
+        out_t = np.zeros(cons_rank.size, dtype=np.int64) if want_totals else None
+        self._check(self._lib.la_assign_batch_grouped_sparse(self._h, part_off.size - 1, _p64(part_off), _p32(partition_id),
+                                                             _p64(end), _p64(committed), reset_mode, n_none,
+                                                             _p64(none_index), _p64(none_begin), _p64(cons_off),
+                                                             _p32(cons_rank), n_members, _p64(off), _p32(g_t), _p32(g_p),
+                                                             _p64(out_t)))
+        return off, g_t, g_p, out_t
+
     def assign_batch_lags(self, part_off, partition_id, lag, cons_off, cons_rank, want_totals: bool = True,
                           keep_on_device: bool = False, out=None
                           ) -> Tuple[Optional[np.ndarray], Optional[np.ndarray], Optional[np.ndarray]]:
@@ -409,6 +499,27 @@ class Context:
         send = (ctypes.c_void_p * n)(*[ctypes.c_void_p(int(x)) for x in d_send])
         recv = (ctypes.c_void_p * n)(*[ctypes.c_void_p(int(x)) for x in d_recv])
         self._check(self._lib.la_allgather_results(self._h, count, send, recv))
+
+    def pack_results(self, n: int, d_out_partition: int, d_out_member_rank: int, fmt: WireFormat, d_packed: int,
+                     stream: int = 0, shard: int = 0) -> None:
+        """la_pack_results_on: n (partition id, member rank) pairs -> n wire elements (device pointers as ints)."""
+        self._check(self._lib.la_pack_results_on(self._h, shard, n, ctypes.c_void_p(d_out_partition),
+                                                 ctypes.c_void_p(d_out_member_rank), ctypes.byref(fmt),
+                                                 ctypes.c_void_p(d_packed), ctypes.c_void_p(stream)))
+
+    def unpack_results(self, n: int, d_packed: int, fmt: WireFormat, d_out_partition: int, d_out_member_rank: int,
+                       stream: int = 0, shard: int = 0) -> None:
+        """la_unpack_results_on: the reverse."""
+        self._check(self._lib.la_unpack_results_on(self._h, shard, n, ctypes.c_void_p(d_packed), ctypes.byref(fmt),
+                                                   ctypes.c_void_p(d_out_partition), ctypes.c_void_p(d_out_member_rank),
+                                                   ctypes.c_void_p(stream)))
+
+    def allgather_packed(self, count: int, elem_bytes: int, d_send, d_recv) -> None:
+        """la_allgather_packed: d_send / d_recv are lists of device pointers (ints), one per shard."""
+        n = self.shard_count
+        send = (ctypes.c_void_p * n)(*[ctypes.c_void_p(int(x)) for x in d_send])
+        recv = (ctypes.c_void_p * n)(*[ctypes.c_void_p(int(x)) for x in d_recv])
+        self._check(self._lib.la_allgather_packed(self._h, count, elem_bytes, send, recv))
 
     def last_pipeline(self) -> int:
         """LA_PIPELINE_* of the last host-buffer assign call."""

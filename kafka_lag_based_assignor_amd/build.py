@@ -22,7 +22,7 @@ OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(HERE, "liblagassign.so")
 HOST = os.path.join(HERE, "_host" + (sysconfig.get_config_var("EXT_SUFFIX") or ".so"))
 SOURCES = ["la_api.hip", "la_lag.hip", "la_wave_tile.hip", "la_wave_tile_l8.hip", "la_wave_tile_l16.hip",
-           "la_wave_tile_l32.hip", "la_wave_tile_l64.hip", "la_large.hip", "la_block.hip"]
+           "la_wave_tile_l32.hip", "la_wave_tile_l64.hip", "la_large.hip", "la_block.hip", "la_wire.hip"]
 HOST_SOURCES = ["host/lag_based_partition_assignor.cpp", "host/pybind_host.cpp"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden",
          "-Wall", "-Wextra", "-Wno-unused-parameter"] + os.environ.get("LA_EXTRA_HIPCC_FLAGS", "").split()

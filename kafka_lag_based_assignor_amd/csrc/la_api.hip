@@ -36,6 +36,16 @@ struct DevBuf {
     size_t cap = 0;
 };
 
+// Every entry point that switches devices leaves the calling thread's current HIP device as it found it (a caller that
+// drives its own kernels next to the library must not find its device changed by a call on a multi-device context).
+struct DeviceGuard {
+    int dev = -1;
+    DeviceGuard() { if (hipGetDevice(&dev) != hipSuccess) { dev = -1; (void)hipGetLastError(); } }
+    ~DeviceGuard() { if (dev >= 0) (void)hipSetDevice(dev); }
+    DeviceGuard(const DeviceGuard&) = delete;
+    DeviceGuard& operator=(const DeviceGuard&) = delete;
+};
+
 }  // namespace
 
 // Everything ONE in-flight batch needs besides the bulk arrays: a stream, the device status word + deferred-tile
@@ -77,6 +87,7 @@ struct HostBuf {                         // pinned, grow-only
 struct Shard {
     int device = 0;
     DevBuf part_off, pid, begin, end, committed, cons_off, cons_rank, out_pid, out_rank, out_total;
+    DevBuf none_idx, none_val;           // la_assign_batch_sparse: the shard's slice of the (position, begin) list
     std::vector<Lane> lanes;
     hipEvent_t ready = nullptr;          // the shard's offsets are on the device (lane 0's stream)
     std::vector<int64_t> local_part_off, local_cons_off;   // offsets rebased to the shard's first topic (shards > 0)
@@ -509,6 +520,21 @@ int enqueue_batch(la_ctx* ctx, Lane& ln, const la_device_batch* b, hipStream_t s
     return LA_OK;
 }
 
+// The device status word as an error of the call (most severe first).
+int status_error(la_ctx* ctx, uint32_t st) {
+    if (st & la::kStatusInternal)
+        return fail(ctx, LA_EHIP, "internal error: a radix-sort look-back gave up waiting for an earlier tile");
+    if (st & la::kStatusOrder)
+        return fail(ctx, LA_EHIP, "internal error: a device radix sort left its result out of order");
+    if (st & la::kStatusUnsorted)
+        return fail(ctx, LA_EINVAL, "a topic's cons_rank segment is not strictly ascending");
+    if (st & la::kStatusSparse)
+        return fail(ctx, LA_EINVAL, "none_index must hold ascending positions inside the batch");
+    if (st & la::kStatusWire)
+        return fail(ctx, LA_EINVAL, "a partition id or member rank does not fit the wire format given to la_pack_results_on");
+    return fail(ctx, LA_ESHAPE, "a topic exceeds the batch's shape hint");
+}
+
 // Waits for `stream` and reports what the kernels flagged on this lane (one copy + one sync).
 int sync_status(la_ctx* ctx, Lane& ln, hipStream_t stream) {
     LA_HIP(ctx, hipMemcpyAsync(ln.h_status, ln.d_status, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
@@ -517,11 +543,7 @@ int sync_status(la_ctx* ctx, Lane& ln, hipStream_t stream) {
     if (st) {
         LA_HIP(ctx, hipMemsetAsync(ln.d_status, 0, sizeof st, stream));
         LA_HIP(ctx, hipStreamSynchronize(stream));
-        if (st & la::kStatusInternal)
-            return fail(ctx, LA_EHIP, "internal error: a radix-sort look-back gave up waiting for an earlier tile");
-        if (st & la::kStatusUnsorted)
-            return fail(ctx, LA_EINVAL, "a topic's cons_rank segment is not strictly ascending");
-        return fail(ctx, LA_ESHAPE, "a topic exceeds the batch's shape hint");
+        return status_error(ctx, st);
     }
     return LA_OK;
 }
@@ -561,6 +583,11 @@ struct HostCall {
     int32_t *out_pid = nullptr, *out_rank = nullptr;
     int64_t* out_total = nullptr;
     bool use_begin = false;
+    // la_assign_batch_sparse: `begin` arrives as (position, value) pairs for the partitions without a committed offset; the
+    // dense array the kernels read is rebuilt on the device (zero + scatter), chunk by chunk
+    bool sparse = false;
+    int64_t n_none = 0;
+    const int64_t *none_index = nullptr, *none_begin = nullptr;
     Shape shape;
     // la_assign_batch_grouped: every member's list is wanted instead of the ungrouped arrays.  A small call builds it in the same
     // staging buffer and brings it back in its one D2H (grouped_done = true); any other call leaves it to group_last_impl.
@@ -575,6 +602,7 @@ struct ShardPlan {
     int64_t P0 = 0, K0 = 0, n = 0, k = 0;   // its partitions / consumer entries: first position, count
     const int64_t *lpo = nullptr, *lco = nullptr;   // offsets rebased to the shard (host)
     std::vector<int32_t> chunk;             // chunk boundaries, shard-local topic indices
+    std::vector<int64_t> none_at;           // sparse begin: first list entry of every chunk (+ the end), caller's numbering
     std::atomic<int> next{0};
 };
 
@@ -629,6 +657,44 @@ int prepare_shard(la_ctx* ctx, const HostCall& c, Shard& sh, ShardPlan& sp) {
     sp.chunk.resize((size_t)n_chunks + 1);
     plan_ranges(sp.lpo, 0, Ts, n_chunks, sp.chunk.data());
     sp.next.store(0);
+    if (c.sparse) {
+        // the list is ascending by contract, so a chunk's entries are one slice of it.  The first chunk of the call starts at
+        // entry 0 and the last ends at n_none whatever the values say: every entry is then looked at by exactly one chunk, and
+        // one that is not inside its chunk's positions (an unsorted or out-of-range list) is caught by the scatter kernel.
+        sp.none_at.resize((size_t)n_chunks + 1);
+        const int64_t* nb = c.none_index;
+        const int64_t* ne = c.none_index + c.n_none;
+        for (int ci = 0; ci <= n_chunks; ++ci) {
+            const int64_t pos = sp.P0 + sp.lpo[sp.chunk[(size_t)ci]];
+            sp.none_at[(size_t)ci] = std::lower_bound(nb, ne, pos) - nb;
+        }
+        if (sp.P0 == 0) sp.none_at[0] = 0;
+        if (sp.P0 + sp.n == c.shape.n) sp.none_at[(size_t)n_chunks] = c.n_none;
+        const size_t m = (size_t)(sp.none_at[(size_t)n_chunks] - sp.none_at[0]);
+        if ((rc = reserve(ctx, sh.none_idx, m * 8 + 16)) || (rc = reserve(ctx, sh.none_val, m * 8 + 16))) return rc;
+    }
+    return LA_OK;
+}
+
+// Sparse begin offsets of chunk ci: `copy` (non-null) uploads the chunk's slice of the (position, begin) list, `kern`
+// (non-null) zeroes the chunk's part of the dense array and scatters the slice into it.  One stream may play both roles.
+int sparse_begin_chunk(la_ctx* ctx, const HostCall& c, Shard& sh, const ShardPlan& sp, int ci, Lane& ln, hipStream_t copy,
+                       hipStream_t kern) {
+    const int64_t j0 = sp.none_at[(size_t)ci], j1 = sp.none_at[(size_t)ci + 1], at = j0 - sp.none_at[0];
+    const size_t m = (size_t)(j1 - j0);
+    const int32_t a = sp.chunk[(size_t)ci], z = sp.chunk[(size_t)ci + 1];
+    const int64_t p0 = sp.lpo[a], p1 = sp.lpo[z];
+    int64_t* d_idx = (int64_t*)sh.none_idx.p + at;
+    int64_t* d_val = (int64_t*)sh.none_val.p + at;
+    if (copy && m) {
+        LA_HIP(ctx, hipMemcpyAsync(d_idx, c.none_index + j0, m * 8, hipMemcpyHostToDevice, copy));
+        LA_HIP(ctx, hipMemcpyAsync(d_val, c.none_begin + j0, m * 8, hipMemcpyHostToDevice, copy));
+    }
+    if (kern) {
+        if (p1 > p0) LA_HIP(ctx, hipMemsetAsync((int64_t*)sh.begin.p + p0, 0, (size_t)(p1 - p0) * 8, kern));
+        LA_HIP(ctx, la::sparse_begin_launch((int64_t)m, d_idx, d_val, sp.P0, sp.P0 + p0, sp.P0 + p1, (int64_t*)sh.begin.p,
+                                            ln.d_status, kern));
+    }
     return LA_OK;
 }
 
@@ -654,10 +720,14 @@ int run_lane(la_ctx* ctx, const HostCall& c, Shard& sh, ShardPlan& sp, int lane_
                 LA_HIP(ctx, hipMemcpyAsync((int64_t*)sh.end.p + p0, c.end + gp, np * 8, hipMemcpyHostToDevice, st));
                 LA_HIP(ctx, hipMemcpyAsync((int64_t*)sh.committed.p + p0, c.committed + gp, np * 8,
                                            hipMemcpyHostToDevice, st));
-                if (c.use_begin)
+                if (c.use_begin && !c.sparse)
                     LA_HIP(ctx, hipMemcpyAsync((int64_t*)sh.begin.p + p0, c.begin + gp, np * 8, hipMemcpyHostToDevice, st));
+                if (c.sparse)
+                    if (int rc = sparse_begin_chunk(ctx, c, sh, sp, ci, ln, st, st)) return rc;
             }
         }
+        if (c.sparse && !np && sp.none_at[(size_t)ci + 1] > sp.none_at[(size_t)ci])      // entries where there are no partitions:
+            if (int rc = sparse_begin_chunk(ctx, c, sh, sp, ci, ln, st, st)) return rc;       // the kernel reports them
         if (nk) {
             LA_HIP(ctx, hipMemcpyAsync((int32_t*)sh.cons_rank.p + k0, c.cons_rank + gk, nk * 4, hipMemcpyHostToDevice, st));
             // the ascending-rank contract of cons_rank is checked on the device (one pass over K entries there
@@ -719,18 +789,29 @@ int run_lane(la_ctx* ctx, const HostCall& c, Shard& sh, ShardPlan& sp, int lane_
 // to and from it are plain DMA and hipMemcpyAsync returns at once.  NULL / zero bytes count as pinned.
 bool is_pinned(const void* p, size_t bytes) {
     if (!p || bytes == 0) return true;
-    hipPointerAttribute_t at{};
-    if (hipPointerGetAttributes(&at, p) != hipSuccess) {
+    // first AND last byte: a buffer registered only in part (hipHostRegister of a sub-range), or one that runs past its
+    // allocation into another, must not take the thread-less pipeline, which assumes plain DMA over the whole range
+    hipPointerAttribute_t at{}, az{};
+    if (hipPointerGetAttributes(&at, p) != hipSuccess ||
+        hipPointerGetAttributes(&az, (const char*)p + (bytes - 1)) != hipSuccess) {
         (void)hipGetLastError();                          // an ordinary malloc'ed pointer: not an error of ours
         return false;
     }
-    return at.type == hipMemoryTypeHost;
+    if (at.type != hipMemoryTypeHost || az.type != hipMemoryTypeHost) return false;
+    // the same registration: where the runtime reports the host / device views, they advance together from first to last byte
+    const ptrdiff_t span = (ptrdiff_t)(bytes - 1);
+    if (at.hostPointer && az.hostPointer && (const char*)az.hostPointer - (const char*)at.hostPointer != span) return false;
+    if ((at.devicePointer == nullptr) != (az.devicePointer == nullptr)) return false;
+    if (at.devicePointer && (const char*)az.devicePointer - (const char*)at.devicePointer != span) return false;
+    return true;
 }
 
 bool call_is_pinned(const HostCall& c) {
     const size_t n = (size_t)c.shape.n, k = (size_t)c.shape.k;
     return is_pinned(c.pid, n * 4) && is_pinned(c.end, n * 8) && is_pinned(c.committed, n * 8) && is_pinned(c.lag, n * 8) &&
-           (!c.use_begin || is_pinned(c.begin, n * 8)) && is_pinned(c.cons_rank, k * 4) && is_pinned(c.out_pid, n * 4) &&
+           (!c.use_begin || c.sparse || is_pinned(c.begin, n * 8)) &&
+           (!c.sparse || (is_pinned(c.none_index, (size_t)c.n_none * 8) && is_pinned(c.none_begin, (size_t)c.n_none * 8))) &&
+           is_pinned(c.cons_rank, k * 4) && is_pinned(c.out_pid, n * 4) &&
            is_pinned(c.out_rank, n * 4) && is_pinned(c.out_total, k * 8);
 }
 
@@ -774,12 +855,20 @@ int run_shard_async(la_ctx* ctx, const HostCall& c, Shard& sh, ShardPlan& sp) {
             } else {
                 LA_HIP(ctx, hipMemcpyAsync((int64_t*)sh.end.p + p0, c.end + gp, np * 8, hipMemcpyHostToDevice, si));
                 LA_HIP(ctx, hipMemcpyAsync((int64_t*)sh.committed.p + p0, c.committed + gp, np * 8, hipMemcpyHostToDevice, si));
-                if (c.use_begin)
+                if (c.use_begin && !c.sparse)
                     LA_HIP(ctx, hipMemcpyAsync((int64_t*)sh.begin.p + p0, c.begin + gp, np * 8, hipMemcpyHostToDevice, si));
+            }
+            if (c.sparse) {
+                // the list's slice rides the input stream with the chunk's other arrays; zero + scatter run on the kernel stream
+                if (int rc = sparse_begin_chunk(ctx, c, sh, sp, ci, ln, si, nullptr)) return rc;
             }
             LA_HIP(ctx, hipEventRecord(ev_in, si));
             LA_HIP(ctx, hipStreamWaitEvent(sk, ev_in, 0));
+            if (c.sparse)
+                if (int rc = sparse_begin_chunk(ctx, c, sh, sp, ci, ln, nullptr, sk)) return rc;
         }
+        if (c.sparse && !np && sp.none_at[(size_t)ci + 1] > sp.none_at[(size_t)ci])      // entries where there are no partitions:
+            if (int rc = sparse_begin_chunk(ctx, c, sh, sp, ci, ln, sk, sk)) return rc;       // the kernel reports them
         if (nk)
             LA_HIP(ctx, la::check_consumers_launch(z - a, (const int64_t*)sh.cons_off.p + a, (const int32_t*)sh.cons_rank.p,
                                                    ln.d_status, sk));
@@ -929,7 +1018,20 @@ int assign_small(la_ctx* ctx, const HostCall& c, Shard& sh, const SmallLayout& L
         memcpy(h + L.pid, c.pid, n * 4);
         memcpy(h + L.end, c.lag ? c.lag : c.end, n * 8);
         if (!c.lag) memcpy(h + L.com, c.committed, n * 8);
-        if (c.use_begin) memcpy(h + L.beg, c.begin, n * 8);
+        if (c.use_begin && !c.sparse) memcpy(h + L.beg, c.begin, n * 8);
+        if (c.sparse) {
+            // a small call rebuilds the dense array right here in the staging buffer: unlisted partitions have begin 0
+            int64_t* hb = (int64_t*)(h + L.beg);
+            memset(hb, 0, n * 8);
+            int64_t prev = -1;
+            for (int64_t j = 0; j < c.n_none; ++j) {
+                const int64_t g = c.none_index[j];
+                if (g <= prev || g >= (int64_t)n)
+                    return fail(ctx, LA_EINVAL, "none_index must hold ascending positions inside the batch");
+                hb[g] = c.none_begin[j];
+                prev = g;
+            }
+        }
     }
     if (k) memcpy(h + L.cr, c.cons_rank, k * 4);
     if (k && k <= kSmallHostCheck) {
@@ -991,13 +1093,7 @@ int assign_small(la_ctx* ctx, const HostCall& c, Shard& sh, const SmallLayout& L
     LA_HIP(ctx, hipMemcpyAsync(h + L.status, d + L.status, upto - L.status, hipMemcpyDeviceToHost, st));
     LA_HIP(ctx, hipStreamSynchronize(st));
     const uint32_t status = *(const uint32_t*)(h + L.status);
-    if (status) {
-        if (status & la::kStatusInternal)
-            return fail(ctx, LA_EHIP, "internal error: a radix-sort look-back gave up waiting for an earlier tile");
-        if (status & la::kStatusUnsorted)
-            return fail(ctx, LA_EINVAL, "a topic's cons_rank segment is not strictly ascending");
-        return fail(ctx, LA_ESHAPE, "a topic exceeds the batch's shape hint");
-    }
+    if (status) return status_error(ctx, status);
     if (c.out_total && k) memcpy(c.out_total, h + L.ot, k * 8);
     if (c.out_pid && n) {
         memcpy(c.out_pid, h + L.op, n * 4);
@@ -1020,7 +1116,7 @@ int assign_small(la_ctx* ctx, const HostCall& c, Shard& sh, const SmallLayout& L
 int assign_host(la_ctx* ctx, int32_t T, const int64_t* part_off, const int32_t* pid, const int64_t* begin,
                 const int64_t* end, const int64_t* committed, const int64_t* lag, int32_t reset_mode,
                 const int64_t* cons_off, const int32_t* cons_rank, int32_t* out_pid, int32_t* out_rank,
-                int64_t* out_total, const HostCall* grouped = nullptr) {
+                int64_t* out_total, const HostCall* grouped = nullptr, const HostCall* sparse = nullptr) {
     if (!ctx) return LA_EINVAL;
     ctx->last_valid = false;
     if (T < 0) return fail(ctx, LA_EINVAL, "n_topics < 0");
@@ -1034,12 +1130,19 @@ int assign_host(la_ctx* ctx, int32_t T, const int64_t* part_off, const int32_t* 
     if ((out_pid == nullptr) != (out_rank == nullptr))
         return fail(ctx, LA_EINVAL, "out_partition and out_member_rank must both be given or both be NULL");
     if (s.k > 0 && !cons_rank) return fail(ctx, LA_EINVAL, "null cons_rank");
-    if (!lag && reset_mode != LA_RESET_LATEST && !begin && s.n > 0)
+    const bool is_sparse = sparse && !lag && reset_mode != LA_RESET_LATEST;      // (`latest` never reads begin: the list is ignored)
+    if (is_sparse && (sparse->n_none < 0 || (sparse->n_none > 0 && (!sparse->none_index || !sparse->none_begin))))
+        return fail(ctx, LA_EINVAL, "n_none < 0 or a null sparse-begin array");
+    if (!lag && reset_mode != LA_RESET_LATEST && !begin && !is_sparse && s.n > 0)
         return fail(ctx, LA_EINVAL, "begin_off is required unless reset_mode is LA_RESET_LATEST");
     c.T = T; c.part_off = part_off; c.pid = pid; c.begin = begin; c.end = end; c.committed = committed; c.lag = lag;
     c.reset_mode = reset_mode; c.cons_off = cons_off; c.cons_rank = cons_rank;
     c.out_pid = out_pid; c.out_rank = out_rank; c.out_total = out_total;
-    c.use_begin = !lag && begin && reset_mode != LA_RESET_LATEST;
+    c.use_begin = !lag && (begin || is_sparse) && reset_mode != LA_RESET_LATEST;
+    if (is_sparse) {
+        c.sparse = true; c.begin = nullptr;
+        c.n_none = sparse->n_none; c.none_index = sparse->none_index; c.none_begin = sparse->none_begin;
+    }
     if (grouped) {
         c.g_members = grouped->g_members; c.g_off = grouped->g_off; c.g_topic = grouped->g_topic; c.g_part = grouped->g_part;
         c.grouped_done = grouped->grouped_done;
@@ -1227,7 +1330,7 @@ int group_shard_device(la_ctx* ctx, Shard& sh, int32_t n_members, bool want_topi
 }  // namespace
 
 // ---- C ABI --------------------------------------------------------------------------------------
-LA_API int la_version(void) { return 201; }   // 0.2.1
+LA_API int la_version(void) { return LA_VERSION; }
 
 LA_API const char* la_last_error(const la_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
 
@@ -1239,6 +1342,7 @@ LA_API int la_device_count(void) {
 }
 
 LA_API int la_create_multi(la_ctx** out, int n_devices, const int* device_ids, unsigned flags) {
+    DeviceGuard restore_device;
     if (!out) return fail(nullptr, LA_EINVAL, "out is NULL");
     *out = nullptr;
     try {
@@ -1300,6 +1404,7 @@ LA_API int la_create_multi(la_ctx** out, int n_devices, const int* device_ids, u
 LA_API int la_create(la_ctx** out, int device_id, unsigned flags) { return la_create_multi(out, 1, &device_id, flags); }
 
 LA_API void la_destroy(la_ctx* ctx) {
+    DeviceGuard restore_device;
     if (!ctx) return;
     if (!ctx->comms.empty()) {
         for (Shard& sh : ctx->shards) {                                   // nothing of an all-gather stays in flight
@@ -1315,7 +1420,7 @@ LA_API void la_destroy(la_ctx* ctx) {
         (void)hipSetDevice(sh.device);
         for (Lane& ln : sh.lanes) destroy_lane(ln);
         for (DevBuf* b : {&sh.part_off, &sh.pid, &sh.begin, &sh.end, &sh.committed, &sh.cons_off, &sh.cons_rank,
-                          &sh.out_pid, &sh.out_rank, &sh.out_total, &sh.small_d, &sh.small_g})
+                          &sh.out_pid, &sh.out_rank, &sh.out_total, &sh.small_d, &sh.small_g, &sh.none_idx, &sh.none_val})
             release(*b);
         for (HostBuf* h : {&sh.g_off, &sh.g_topic, &sh.g_part, &sh.small_h, &sh.small_gh})
             if (h->p) (void)hipHostFree(h->p);
@@ -1336,6 +1441,7 @@ LA_API int la_shard_device(const la_ctx* ctx, int shard) {
 }
 
 LA_API int la_device_features(const la_ctx* ctx, int shard) {
+    DeviceGuard restore_device;
     if (!ctx || shard < 0 || shard >= (int)ctx->shards.size()) return LA_EINVAL;
     if (hipSetDevice(ctx->shards[(size_t)shard].device) != hipSuccess) return LA_EHIP;
     return la::large_atomic_rank_supported() ? LA_FEATURE_ATOMIC_RANK : 0;
@@ -1363,52 +1469,120 @@ LA_API int la_last_shard_bounds(const la_ctx* ctx, int32_t* bounds, int32_t capa
     return S;
 }
 
+// One ncclAllGather per shard inside one group, `bytes` bytes each (ncclUint8: an all-gather does no arithmetic, the type only
+// sizes the elements), on the shards' own streams.
+static int allgather_bytes(la_ctx* ctx, size_t bytes, const void* const* d_send, void* const* d_recv) {
+    const int S = (int)ctx->shards.size();
+    if (!d_send || !d_recv) return fail(ctx, LA_EINVAL, "null buffer list");
+    for (int i = 0; i < S; ++i)
+        if (bytes > 0 && (!d_send[i] || !d_recv[i])) return fail(ctx, LA_EINVAL, "null buffer of shard %d", i);
+    for (int i = 0; i < S; ++i)
+        for (int j = 0; j < i; ++j)
+            if (ctx->shards[(size_t)i].device == ctx->shards[(size_t)j].device)
+                return fail(ctx, LA_EINVAL, "shards %d and %d share device %d: RCCL needs one distinct device per rank", j, i,
+                            ctx->shards[(size_t)i].device);
+    if (bytes == 0) return LA_OK;
+    RcclApi& r = rccl_api();
+    if (!r.handle) return fail(ctx, LA_ENODEV, "%s", r.why.c_str());
+    auto text = [&](int rc) { return r.GetErrorString ? r.GetErrorString(rc) : "rccl error"; };
+    if (ctx->comms.empty()) {
+        std::vector<int> devs;
+        for (const Shard& sh : ctx->shards) devs.push_back(sh.device);
+        std::vector<void*> comms((size_t)S, nullptr);
+        const int rc = r.CommInitAll(comms.data(), S, devs.data());
+        if (rc != 0) return fail(ctx, LA_EHIP, "ncclCommInitAll over %d device(s): %s", S, text(rc));
+        ctx->comms = comms;
+    }
+    int rc = r.GroupStart();
+    if (rc != 0) return fail(ctx, LA_EHIP, "ncclGroupStart: %s", text(rc));
+    int first_bad = 0;
+    for (int i = 0; i < S; ++i) {
+        Shard& sh = ctx->shards[(size_t)i];
+        if (hipSetDevice(sh.device) != hipSuccess) { first_bad = -1; break; }
+        rc = r.AllGather(d_send[i], d_recv[i], bytes, /* ncclUint8 */ 1, ctx->comms[(size_t)i], sh.lanes[0].stream);
+        if (rc != 0 && first_bad == 0) first_bad = rc;
+    }
+    rc = r.GroupEnd();
+    if (first_bad == -1) return fail(ctx, LA_EHIP, "hipSetDevice failed while enqueueing the all-gather");
+    if (first_bad != 0) return fail(ctx, LA_EHIP, "ncclAllGather: %s", text(first_bad));
+    if (rc != 0) return fail(ctx, LA_EHIP, "ncclGroupEnd: %s", text(rc));
+    return LA_OK;
+}
+
 LA_API int la_allgather_results(la_ctx* ctx, int64_t count, const int32_t* const* d_send, int32_t* const* d_recv) {
+    DeviceGuard restore_device;
     if (!ctx) return LA_EINVAL;
     try {
-        const int S = (int)ctx->shards.size();
-        if (count < 0 || !d_send || !d_recv) return fail(ctx, LA_EINVAL, "null buffer list or negative count");
-        for (int i = 0; i < S; ++i)
-            if (count > 0 && (!d_send[i] || !d_recv[i])) return fail(ctx, LA_EINVAL, "null buffer of shard %d", i);
-        for (int i = 0; i < S; ++i)
-            for (int j = 0; j < i; ++j)
-                if (ctx->shards[(size_t)i].device == ctx->shards[(size_t)j].device)
-                    return fail(ctx, LA_EINVAL, "shards %d and %d share device %d: RCCL needs one distinct device per rank", j, i,
-                                ctx->shards[(size_t)i].device);
-        if (count == 0) return LA_OK;
-        RcclApi& r = rccl_api();
-        if (!r.handle) return fail(ctx, LA_ENODEV, "%s", r.why.c_str());
-        auto text = [&](int rc) { return r.GetErrorString ? r.GetErrorString(rc) : "rccl error"; };
-        if (ctx->comms.empty()) {
-            std::vector<int> devs;
-            for (const Shard& sh : ctx->shards) devs.push_back(sh.device);
-            std::vector<void*> comms((size_t)S, nullptr);
-            const int rc = r.CommInitAll(comms.data(), S, devs.data());
-            if (rc != 0) return fail(ctx, LA_EHIP, "ncclCommInitAll over %d device(s): %s", S, text(rc));
-            ctx->comms = comms;
-        }
-        int rc = r.GroupStart();
-        if (rc != 0) return fail(ctx, LA_EHIP, "ncclGroupStart: %s", text(rc));
-        int first_bad = 0;
-        for (int i = 0; i < S; ++i) {
-            Shard& sh = ctx->shards[(size_t)i];
-            if (hipSetDevice(sh.device) != hipSuccess) { first_bad = -1; break; }
-            rc = r.AllGather(d_send[i], d_recv[i], (size_t)count, /* ncclInt32 */ 2, ctx->comms[(size_t)i], sh.lanes[0].stream);
-            if (rc != 0 && first_bad == 0) first_bad = rc;
-        }
-        rc = r.GroupEnd();
-        if (first_bad == -1) return fail(ctx, LA_EHIP, "hipSetDevice failed while enqueueing the all-gather");
-        if (first_bad != 0) return fail(ctx, LA_EHIP, "ncclAllGather: %s", text(first_bad));
-        if (rc != 0) return fail(ctx, LA_EHIP, "ncclGroupEnd: %s", text(rc));
-        return LA_OK;
+        if (count < 0) return fail(ctx, LA_EINVAL, "negative count");
+        return allgather_bytes(ctx, (size_t)count * 4, (const void* const*)d_send, (void* const*)d_recv);
     } catch (...) {
         return fail(ctx, LA_ENOMEM, "exception in la_allgather_results");
+    }
+}
+
+LA_API int la_allgather_packed(la_ctx* ctx, int64_t count, int32_t elem_bytes, const void* const* d_send, void* const* d_recv) {
+    DeviceGuard restore_device;
+    if (!ctx) return LA_EINVAL;
+    try {
+        if (count < 0) return fail(ctx, LA_EINVAL, "negative count");
+        if (elem_bytes != 2 && elem_bytes != 4 && elem_bytes != 8) return fail(ctx, LA_EINVAL, "elem_bytes must be 2, 4 or 8");
+        return allgather_bytes(ctx, (size_t)count * (size_t)elem_bytes, d_send, d_recv);
+    } catch (...) {
+        return fail(ctx, LA_ENOMEM, "exception in la_allgather_packed");
+    }
+}
+
+LA_API int la_wire_format_for(int64_t max_partition_id, int64_t n_members, la_wire_format* out) {
+    if (!out) return LA_EINVAL;
+    int eb = 8, ib = 32;
+    la::wire_format_for(max_partition_id, n_members, &eb, &ib);
+    out->elem_bytes = eb;
+    out->id_bits = ib;
+    return LA_OK;
+}
+
+LA_API int la_pack_results_on(la_ctx* ctx, int shard, int64_t n, const int32_t* d_out_partition, const int32_t* d_out_member_rank,
+                              const la_wire_format* fmt, void* d_packed, void* stream) {
+    DeviceGuard restore_device;
+    if (!ctx) return LA_EINVAL;
+    try {
+        if (shard < 0 || shard >= (int)ctx->shards.size()) return fail(ctx, LA_EINVAL, "shard %d of %d", shard, (int)ctx->shards.size());
+        if (n < 0) return fail(ctx, LA_EINVAL, "negative size");
+        if (!fmt || !la::wire_format_valid(fmt->elem_bytes, fmt->id_bits)) return fail(ctx, LA_EINVAL, "bad wire format");
+        if (n > 0 && (!d_out_partition || !d_out_member_rank || !d_packed)) return fail(ctx, LA_EINVAL, "null buffer");
+        Shard& sh = ctx->shards[(size_t)shard];
+        LA_HIP(ctx, hipSetDevice(sh.device));
+        LA_HIP(ctx, la::wire_pack_launch(n, d_out_partition, d_out_member_rank, fmt->elem_bytes, fmt->id_bits, d_packed,
+                                         sh.lanes[0].d_status, (hipStream_t)stream));
+        return LA_OK;
+    } catch (...) {
+        return fail(ctx, LA_ENOMEM, "exception in la_pack_results_on");
+    }
+}
+
+LA_API int la_unpack_results_on(la_ctx* ctx, int shard, int64_t n, const void* d_packed, const la_wire_format* fmt,
+                                int32_t* d_out_partition, int32_t* d_out_member_rank, void* stream) {
+    DeviceGuard restore_device;
+    if (!ctx) return LA_EINVAL;
+    try {
+        if (shard < 0 || shard >= (int)ctx->shards.size()) return fail(ctx, LA_EINVAL, "shard %d of %d", shard, (int)ctx->shards.size());
+        if (n < 0) return fail(ctx, LA_EINVAL, "negative size");
+        if (!fmt || !la::wire_format_valid(fmt->elem_bytes, fmt->id_bits)) return fail(ctx, LA_EINVAL, "bad wire format");
+        if (n > 0 && (!d_out_partition || !d_out_member_rank || !d_packed)) return fail(ctx, LA_EINVAL, "null buffer");
+        Shard& sh = ctx->shards[(size_t)shard];
+        LA_HIP(ctx, hipSetDevice(sh.device));
+        LA_HIP(ctx, la::wire_unpack_launch(n, d_packed, fmt->elem_bytes, fmt->id_bits, d_out_partition, d_out_member_rank,
+                                           (hipStream_t)stream));
+        return LA_OK;
+    } catch (...) {
+        return fail(ctx, LA_ENOMEM, "exception in la_unpack_results_on");
     }
 }
 
 LA_API int la_last_pipeline(const la_ctx* ctx) { return ctx ? ctx->last_pipeline : LA_EINVAL; }
 
 LA_API void* la_host_alloc(la_ctx* ctx, size_t bytes) {
+    DeviceGuard restore_device;
     if (!ctx || ctx->shards.empty()) return nullptr;
     void* p = nullptr;
     if (hipSetDevice(ctx->shards[0].device) != hipSuccess) return nullptr;
@@ -1427,6 +1601,7 @@ LA_API void la_host_free(la_ctx* ctx, void* p) {
 
 LA_API int la_compute_lag(la_ctx* ctx, int64_t n, const int64_t* begin_off, const int64_t* end_off,
                           const int64_t* committed_off, int32_t reset_mode, int64_t* out_lag) {
+    DeviceGuard restore_device;
     if (!ctx) return LA_EINVAL;
     try {
         if (n < 0) return fail(ctx, LA_EINVAL, "n < 0");
@@ -1475,6 +1650,7 @@ LA_API int la_assign_batch(la_ctx* ctx, int32_t n_topics, const int64_t* part_of
                            const int64_t* begin_off, const int64_t* end_off, const int64_t* committed_off,
                            int32_t reset_mode, const int64_t* cons_off, const int32_t* cons_rank,
                            int32_t* out_partition, int32_t* out_member_rank, int64_t* out_total_lag) {
+    DeviceGuard restore_device;
     try {
         return assign_host(ctx, n_topics, part_off, partition_id, begin_off, end_off, committed_off, nullptr,
                            reset_mode, cons_off, cons_rank, out_partition, out_member_rank, out_total_lag);
@@ -1486,6 +1662,7 @@ LA_API int la_assign_batch(la_ctx* ctx, int32_t n_topics, const int64_t* part_of
 LA_API int la_assign_batch_lags(la_ctx* ctx, int32_t n_topics, const int64_t* part_off, const int32_t* partition_id,
                                 const int64_t* lag, const int64_t* cons_off, const int32_t* cons_rank,
                                 int32_t* out_partition, int32_t* out_member_rank, int64_t* out_total_lag) {
+    DeviceGuard restore_device;
     try {
         if (ctx && !lag && n_topics > 0 && part_off && part_off[n_topics] > 0)
             return fail(ctx, LA_EINVAL, "lag is NULL");
@@ -1498,6 +1675,7 @@ LA_API int la_assign_batch_lags(la_ctx* ctx, int32_t n_topics, const int64_t* pa
 }
 
 LA_API int la_assign_batch_device_on(la_ctx* ctx, int shard, const la_device_batch* batch, void* stream) {
+    DeviceGuard restore_device;
     if (!ctx) return LA_EINVAL;
     try {
         if (shard < 0 || shard >= (int)ctx->shards.size()) return fail(ctx, LA_EINVAL, "shard %d of %d", shard, (int)ctx->shards.size());
@@ -1533,6 +1711,7 @@ LA_API int la_group_by_member_device_on(la_ctx* ctx, int shard, int32_t n_topics
                                         const int64_t* d_part_off, const int32_t* d_out_partition,
                                         const int32_t* d_out_member_rank, int32_t n_members, int64_t* d_member_off,
                                         int32_t* d_grouped_topic, int32_t* d_grouped_partition, void* stream) {
+    DeviceGuard restore_device;
     if (!ctx) return LA_EINVAL;
     try {
         if (shard < 0 || shard >= (int)ctx->shards.size()) return fail(ctx, LA_EINVAL, "shard %d of %d", shard, (int)ctx->shards.size());
@@ -1583,7 +1762,7 @@ static int group_last_impl(la_ctx* ctx, int32_t n_members, int64_t* member_off, 
                                          (int32_t*)(d + o_topic), (int32_t*)(d + o_part))))
                 return rc;
             LA_HIP(ctx, hipMemcpyAsync(h, d, g_total, hipMemcpyDeviceToHost, st));
-            LA_HIP(ctx, hipStreamSynchronize(st));
+            if ((rc = sync_status(ctx, sh.lanes[0], st))) return rc;    // the grouping's sort reports through the lane's status word
             memcpy(member_off, h, mb);
             if (n) {
                 memcpy(grouped_partition, h + o_part, nb4);
@@ -1597,8 +1776,7 @@ static int group_last_impl(la_ctx* ctx, int32_t n_members, int64_t* member_off, 
             LA_HIP(ctx, hipMemcpyAsync(grouped_partition, sh.pid.p, nb4, hipMemcpyDeviceToHost, st));
             if (grouped_topic) LA_HIP(ctx, hipMemcpyAsync(grouped_topic, sh.cons_rank.p, nb4, hipMemcpyDeviceToHost, st));
         }
-        LA_HIP(ctx, hipStreamSynchronize(st));
-        return LA_OK;
+        return sync_status(ctx, sh.lanes[0], st);
     }
     // Several shards.  A member's list is its per-topic appends in topic order (Main.java:177-184, :264), and the
     // shards are contiguous topic ranges: the list is the concatenation, in shard order, of the shards' lists.
@@ -1621,8 +1799,7 @@ static int group_last_impl(la_ctx* ctx, int32_t n_members, int64_t* member_off, 
             LA_HIP(ctx, hipMemcpyAsync(sh.g_part.p, sh.pid.p, nb4, hipMemcpyDeviceToHost, st));
             if (grouped_topic) LA_HIP(ctx, hipMemcpyAsync(sh.g_topic.p, sh.cons_rank.p, nb4, hipMemcpyDeviceToHost, st));
         }
-        LA_HIP(ctx, hipStreamSynchronize(st));
-        return LA_OK;
+        return sync_status(ctx, sh.lanes[0], st);
     });
     if (rc) return rc;
     // group g = 0 is "no consumer" (rank -1: the entries before member_off[0]), g = r + 1 is member r
@@ -1668,6 +1845,7 @@ static int group_last_impl(la_ctx* ctx, int32_t n_members, int64_t* member_off, 
 LA_API int la_group_by_member(la_ctx* ctx, int32_t n_topics, const int64_t* part_off, const int32_t* out_partition,
                               const int32_t* out_member_rank, int32_t n_members, int64_t* member_off,
                               int32_t* grouped_topic, int32_t* grouped_partition) {
+    DeviceGuard restore_device;
     if (!ctx) return LA_EINVAL;
     try {
         ctx->last_valid = false;                       // this call reuses the scratch the last results live in
@@ -1744,8 +1922,7 @@ LA_API int la_group_by_member(la_ctx* ctx, int32_t n_topics, const int64_t* part
             LA_HIP(ctx, hipMemcpyAsync(grouped_partition, sh.pid.p, nb4, hipMemcpyDeviceToHost, st));
             if (grouped_topic) LA_HIP(ctx, hipMemcpyAsync(grouped_topic, sh.cons_rank.p, nb4, hipMemcpyDeviceToHost, st));
         }
-        LA_HIP(ctx, hipStreamSynchronize(st));
-        return LA_OK;
+        return sync_status(ctx, sh.lanes[0], st);
     } catch (...) {
         return fail(ctx, LA_ENOMEM, "exception in la_group_by_member");
     }
@@ -1753,6 +1930,7 @@ LA_API int la_group_by_member(la_ctx* ctx, int32_t n_topics, const int64_t* part
 
 LA_API int la_group_last_by_member(la_ctx* ctx, int32_t n_members, int64_t* member_off, int32_t* grouped_topic,
                                    int32_t* grouped_partition) {
+    DeviceGuard restore_device;
     if (!ctx) return LA_EINVAL;
     try {
         if (!ctx->last_valid)
@@ -1764,42 +1942,86 @@ LA_API int la_group_last_by_member(la_ctx* ctx, int32_t n_members, int64_t* memb
     }
 }
 
+static int assign_grouped(la_ctx* ctx, int32_t n_topics, const int64_t* part_off, const int32_t* partition_id,
+                          const int64_t* begin_off, const int64_t* end_off, const int64_t* committed_off, int32_t reset_mode,
+                          const int64_t* cons_off, const int32_t* cons_rank, int32_t n_members, int64_t* member_off,
+                          int32_t* grouped_topic, int32_t* grouped_partition, int64_t* out_total_lag, const HostCall* sparse) {
+    if (n_members < 0) return fail(ctx, LA_EINVAL, "negative size");
+    if (!member_off) return fail(ctx, LA_EINVAL, "member_off is NULL");
+    if (n_topics > 0 && part_off && part_off[n_topics] > 0 && !grouped_partition)
+        return fail(ctx, LA_EINVAL, "grouped_partition is NULL");
+    if (n_topics <= 0) {                                        // nothing assigned: every member's list is empty
+        if (n_topics < 0) return fail(ctx, LA_EINVAL, "n_topics < 0");
+        ctx->last_valid = false;
+        for (int32_t r = 0; r <= n_members; ++r) member_off[r] = 0;
+        return LA_OK;
+    }
+    bool done = false;
+    HostCall g;
+    g.g_members = n_members; g.g_off = member_off; g.g_topic = grouped_topic; g.g_part = grouped_partition;
+    g.grouped_done = &done;
+    if (int rc = assign_host(ctx, n_topics, part_off, partition_id, begin_off, end_off, committed_off, nullptr, reset_mode,
+                             cons_off, cons_rank, nullptr, nullptr, out_total_lag, &g, sparse))
+        return rc;
+    if (done) return LA_OK;                                      // a small call: the lists came back with the totals
+    if (!ctx->last_valid) {                                      // (no partitions at all)
+        for (int32_t r = 0; r <= n_members; ++r) member_off[r] = 0;
+        return LA_OK;
+    }
+    return group_last_impl(ctx, n_members, member_off, grouped_topic, grouped_partition);
+}
+
 LA_API int la_assign_batch_grouped(la_ctx* ctx, int32_t n_topics, const int64_t* part_off, const int32_t* partition_id,
                                    const int64_t* begin_off, const int64_t* end_off, const int64_t* committed_off,
                                    int32_t reset_mode, const int64_t* cons_off, const int32_t* cons_rank, int32_t n_members,
                                    int64_t* member_off, int32_t* grouped_topic, int32_t* grouped_partition,
                                    int64_t* out_total_lag) {
+    DeviceGuard restore_device;
     if (!ctx) return LA_EINVAL;
     try {
-        if (n_members < 0) return fail(ctx, LA_EINVAL, "negative size");
-        if (!member_off) return fail(ctx, LA_EINVAL, "member_off is NULL");
-        if (n_topics > 0 && part_off && part_off[n_topics] > 0 && !grouped_partition)
-            return fail(ctx, LA_EINVAL, "grouped_partition is NULL");
-        if (n_topics <= 0) {                                        // nothing assigned: every member's list is empty
-            if (n_topics < 0) return fail(ctx, LA_EINVAL, "n_topics < 0");
-            ctx->last_valid = false;
-            for (int32_t r = 0; r <= n_members; ++r) member_off[r] = 0;
-            return LA_OK;
-        }
-        bool done = false;
-        HostCall g;
-        g.g_members = n_members; g.g_off = member_off; g.g_topic = grouped_topic; g.g_part = grouped_partition;
-        g.grouped_done = &done;
-        if (int rc = assign_host(ctx, n_topics, part_off, partition_id, begin_off, end_off, committed_off, nullptr, reset_mode,
-                                 cons_off, cons_rank, nullptr, nullptr, out_total_lag, &g))
-            return rc;
-        if (done) return LA_OK;                                      // a small call: the lists came back with the totals
-        if (!ctx->last_valid) {                                      // (no partitions at all)
-            for (int32_t r = 0; r <= n_members; ++r) member_off[r] = 0;
-            return LA_OK;
-        }
-        return group_last_impl(ctx, n_members, member_off, grouped_topic, grouped_partition);
+        return assign_grouped(ctx, n_topics, part_off, partition_id, begin_off, end_off, committed_off, reset_mode, cons_off,
+                              cons_rank, n_members, member_off, grouped_topic, grouped_partition, out_total_lag, nullptr);
     } catch (...) {
         return fail(ctx, LA_ENOMEM, "exception in la_assign_batch_grouped");
     }
 }
 
+LA_API int la_assign_batch_sparse(la_ctx* ctx, int32_t n_topics, const int64_t* part_off, const int32_t* partition_id,
+                                  const int64_t* end_off, const int64_t* committed_off, int32_t reset_mode, int64_t n_none,
+                                  const int64_t* none_index, const int64_t* none_begin, const int64_t* cons_off,
+                                  const int32_t* cons_rank, int32_t* out_partition, int32_t* out_member_rank,
+                                  int64_t* out_total_lag) {
+    DeviceGuard restore_device;
+    try {
+        HostCall sp;
+        sp.n_none = n_none; sp.none_index = none_index; sp.none_begin = none_begin;
+        return assign_host(ctx, n_topics, part_off, partition_id, nullptr, end_off, committed_off, nullptr, reset_mode, cons_off,
+                           cons_rank, out_partition, out_member_rank, out_total_lag, nullptr, &sp);
+    } catch (...) {
+        return ctx ? fail(ctx, LA_ENOMEM, "exception in la_assign_batch_sparse") : LA_EINVAL;
+    }
+}
+
+LA_API int la_assign_batch_grouped_sparse(la_ctx* ctx, int32_t n_topics, const int64_t* part_off, const int32_t* partition_id,
+                                          const int64_t* end_off, const int64_t* committed_off, int32_t reset_mode,
+                                          int64_t n_none, const int64_t* none_index, const int64_t* none_begin,
+                                          const int64_t* cons_off, const int32_t* cons_rank, int32_t n_members,
+                                          int64_t* member_off, int32_t* grouped_topic, int32_t* grouped_partition,
+                                          int64_t* out_total_lag) {
+    DeviceGuard restore_device;
+    if (!ctx) return LA_EINVAL;
+    try {
+        HostCall sp;
+        sp.n_none = n_none; sp.none_index = none_index; sp.none_begin = none_begin;
+        return assign_grouped(ctx, n_topics, part_off, partition_id, nullptr, end_off, committed_off, reset_mode, cons_off, cons_rank,
+                              n_members, member_off, grouped_topic, grouped_partition, out_total_lag, &sp);
+    } catch (...) {
+        return fail(ctx, LA_ENOMEM, "exception in la_assign_batch_grouped_sparse");
+    }
+}
+
 LA_API int la_last_phase_times(la_ctx* ctx, la_phase_times* out) {
+    DeviceGuard restore_device;
     if (!ctx) return LA_EINVAL;
     try {
         if (!out) return fail(ctx, LA_EINVAL, "out is NULL");
@@ -1825,6 +2047,7 @@ LA_API int la_last_phase_times(la_ctx* ctx, la_phase_times* out) {
 }
 
 LA_API int la_sync_on(la_ctx* ctx, int shard, void* stream) {
+    DeviceGuard restore_device;
     if (!ctx) return LA_EINVAL;
     try {
         if (shard < 0 || shard >= (int)ctx->shards.size()) return fail(ctx, LA_EINVAL, "shard %d of %d", shard, (int)ctx->shards.size());

@@ -81,6 +81,7 @@ __device__ __forceinline__ int pow2ceil_dev(int x) {
 // registers, distances inside a wavefront go through DPP / permlane moves, only distances >= 64*E cross
 // wavefronts through LDS (10 of the 91 steps at 8 192 slots).  Wavefronts wholly beyond n_eff only keep the
 // barriers company.
+constexpr int kZeroSlotBytes = 16;    // region A's tail: the explicit zero slot s_key[np_cap] (see block_topic_kernel)
 constexpr int kXchg = 8;              // records per thread that cross wavefronts in one LDS exchange
 
 template <int JL, int E>
@@ -480,7 +481,10 @@ __device__ __forceinline__ void greedy_multi_wave_packed(const BlockArgs& a, con
 template <int E>
 __global__ __launch_bounds__(1024) void block_topic_kernel(BlockArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint64_t smem64[];
-    const int region_a = (E * 8 > kXchg * 12 ? E * 8 : kXchg * 12) * (int)blockDim.x;   // bytes
+    // bytes; + one 16-byte slot behind the np_cap keys: s_key[P] is the zero slot of the one-wavefront slots greedy, and with
+    // P == np_cap (E = 16: region A is exactly np_cap words) it would otherwise be s_tot[0]
+    const int region_a = (E * 8 > kXchg * 12 ? E * 8 : kXchg * 12) * (int)blockDim.x + kZeroSlotBytes;
+    static_assert(kZeroSlotBytes % 16 == 0 && kZeroSlotBytes >= 8, "the bins behind region A stay 16-byte aligned");
     uint64_t* s_key = smem64;                                         // sorted partition keys by position
     uint64_t* x_key = smem64;                                         // exchange area of the sort
     uint32_t* x_id = reinterpret_cast<uint32_t*>(x_key + kXchg * blockDim.x);
@@ -764,7 +768,7 @@ hipError_t block_launch(BlockArgs a, int cls, hipStream_t stream) {
     const int nt = kThreads[cls], e = kRecs[cls];
     a.np_cap = nt * e;
     a.nc_cap = kNc[cls];
-    const size_t region_a = (size_t)(e * 8 > kXchg * 12 ? e * 8 : kXchg * 12) * nt;
+    const size_t region_a = (size_t)(e * 8 > kXchg * 12 ? e * 8 : kXchg * 12) * nt + kZeroSlotBytes;
     const size_t lds = region_a + (size_t)16 * a.nc_cap + 16;
     static PerDeviceOnce lds_opt_in;
     hipError_t err = lds_opt_in.run([] {

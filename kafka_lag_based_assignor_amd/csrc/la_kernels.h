@@ -31,6 +31,14 @@ constexpr uint32_t kStatusUnsorted = 2u;   // a topic's cons_rank segment is not
 constexpr uint32_t kStatusInternal = 4u;   // a look-back walk of the radix sort gave up waiting (never expected: a bounded spin
                                            // exists so that a scheduling surprise ends as an error, not as a hung device)
 
+constexpr uint32_t kStatusOrder = 8u;      // the radix sort's result is not in order (emit_ids_kernel / member_emit_kernel compare neighbours
+                                           // on their way through): the lane-order property the atomic ranking relies on did not
+                                           // hold under load.  Never expected; a checked error instead of a silently wrong assignment
+
+constexpr uint32_t kStatusWire = 16u;      // la_pack_results_on: a partition id or member rank does not fit the wire format it was given
+
+constexpr uint32_t kStatusSparse = 32u;    // la_assign_batch_sparse: none_index is not ascending, or points outside the batch
+
 constexpr int32_t kTileSkipOversize = 4;  // TileArgs::flags: topics beyond the tile belong to another path, no error
 
 constexpr int64_t kTileMaxPartitions = 1024;   // 64 lanes x 16 records
@@ -78,6 +86,10 @@ hipError_t wave_tile_launch(TileArgs a, int64_t max_p, int64_t max_c, int mode, 
 // Elementwise lag: out_lag[i] = computePartitionLag(...)   (Main.java:376-404)
 hipError_t lag_launch(int64_t n, const int64_t* begin, const int64_t* end, const int64_t* committed,
                       bool reset_latest, int64_t* out_lag, hipStream_t stream);
+
+// begin[idx[j] - base] = val[j] for the m entries of a sparse begin list cut for positions [lo, hi); sets kStatusSparse.
+hipError_t sparse_begin_launch(int64_t m, const int64_t* idx, const int64_t* val, int64_t base, int64_t lo, int64_t hi,
+                               int64_t* begin, uint32_t* status, hipStream_t stream);
 
 // Checks that every topic's cons_rank segment is strictly ascending; sets kStatusUnsorted.
 hipError_t check_consumers_launch(int64_t n_topics, const int64_t* cons_off, const int32_t* cons_rank,
@@ -170,5 +182,13 @@ hipError_t group_by_member_launch(LargeScratch& scratch, int64_t n, int32_t n_me
                                   const int64_t* part_off, const int32_t* out_partition, const int32_t* member_rank,
                                   int64_t* member_off, int32_t* grouped_topic, int32_t* grouped_partition,
                                   int32_t* grouped_entry, uint32_t* status, hipStream_t stream);
+
+// ---- narrow wire format of the all-gather (la_wire.hip) -----------------------------------------------------------
+void wire_format_for(int64_t max_partition_id, int64_t n_members, int* elem_bytes, int* id_bits);     // pure host code
+bool wire_format_valid(int elem_bytes, int id_bits);
+hipError_t wire_pack_launch(int64_t n, const int32_t* pid, const int32_t* rank, int elem_bytes, int id_bits, void* out,
+                            uint32_t* status, hipStream_t stream);
+hipError_t wire_unpack_launch(int64_t n, const void* in, int elem_bytes, int id_bits, int32_t* pid, int32_t* rank,
+                              hipStream_t stream);
 
 }  // namespace la

@@ -90,4 +90,30 @@ hipError_t check_consumers_launch(int64_t n_topics, const int64_t* cons_off, con
     return hipGetLastError();
 }
 
+// ---- sparse begin offsets (la_assign_batch_sparse) ---------------------------------------------------------
+// The earliest-offset fallback reads `begin` only where a partition has no committed offset (Main.java:384-396) -- ~1 % of
+// a batch -- so the boundary can hand over (position, begin) pairs for just those instead of a dense 8 B/partition array.
+// The dense array the kernels read is rebuilt here: zeroed by the caller (an unlisted partition has begin 0, the reference's
+// getOrDefault(tp, 0L), Main.java:350-351), then entry j lands at begin[idx[j] - base].  [lo, hi) is the range of positions
+// the sub-list was cut for: an entry outside it means the list was not ascending (or out of the batch) -> kStatusSparse.
+__global__ __launch_bounds__(256) void sparse_begin_kernel(int64_t m, const int64_t* __restrict__ idx, const int64_t* __restrict__ val,
+                                                           int64_t base, int64_t lo, int64_t hi, int64_t* __restrict__ begin,
+                                                           uint32_t* status) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    bool bad = false;
+    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < m; j += stride) {
+        const int64_t g = idx[j];
+        if (g < lo || g >= hi) bad = true;
+        else begin[g - base] = val[j];
+    }
+    if (bad) atomicOr(status, kStatusSparse);
+}
+
+hipError_t sparse_begin_launch(int64_t m, const int64_t* idx, const int64_t* val, int64_t base, int64_t lo, int64_t hi,
+                               int64_t* begin, uint32_t* status, hipStream_t stream) {
+    if (m <= 0) return hipSuccess;
+    hipLaunchKernelGGL(sparse_begin_kernel, dim3(grid_for(m)), dim3(256), 0, stream, m, idx, val, base, lo, hi, begin, status);
+    return hipGetLastError();
+}
+
 }  // namespace la

@@ -735,13 +735,27 @@ __global__ __launch_bounds__(THREADS, 4) void onesweep_pass_kernel(SortBufs b, i
 }
 
 // ---- outputs that do not depend on the greedy ----------------------------------------------------
+// It also CHECKS the sort: neighbours must be in (key, id) order.  Every LSD pass has to be stable, and the default ranking of a pass
+// (one returning LDS atomic per element) is stable only because colliding lanes are served in lane order -- a property of
+// the hardware checked once at la_create on an idle device, not a promise of the ISA.  A violation under load would scramble
+// the order silently; here it raises kStatusOrder (LA_EHIP at the next sync) for 8 B more read per element.
 __global__ __launch_bounds__(256) void emit_ids_kernel(LargeArgs a, SortBufs b, int fill_rank_minus1) {
-    const uint32_t* val = b.val[b.ctl->cur[kDigits]];
+    const uint32_t fin = b.ctl->cur[kDigits];
+    const uint32_t* val = b.val[fin];
+    const uint64_t* key = b.key[fin];
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    bool bad = false;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < b.n; i += stride) {
-        a.out_pid[a.p0 + i] = (int32_t)(val[i] ^ kPidBias);
+        const uint32_t v = val[i];
+        const uint64_t k = key[i];
+        if (i > 0) {
+            const uint64_t kp = key[i - 1];
+            bad |= kp > k || (kp == k && val[i - 1] > v);
+        }
+        a.out_pid[a.p0 + i] = (int32_t)(v ^ kPidBias);
         if (fill_rank_minus1) a.out_rank[a.p0 + i] = -1;
     }
+    if (__any(bad) && (threadIdx.x & (kWave - 1)) == 0) atomicOr(a.status, kStatusOrder);
 }
 
 // ---- kernel 3, packed form: bins are one 64-bit word -----------------------------------------------------
@@ -1485,7 +1499,7 @@ __global__ __launch_bounds__(256) void member_keys_kernel(const int32_t* member_
 __global__ __launch_bounds__(256) void member_emit_kernel(SortBufs b, int32_t n_members, int64_t n_topics,
                                                           const int64_t* part_off, const int32_t* out_partition,
                                                           int64_t* member_off, int32_t* grouped_topic,
-                                                          int32_t* grouped_partition, int32_t* grouped_entry) {
+                                                          int32_t* grouped_partition, int32_t* grouped_entry, uint32_t* status) {
     const uint32_t fin = b.ctl->cur[kDigits];
     const uint64_t* key = b.key[fin];
     const uint32_t* val = b.val[fin];
@@ -1494,6 +1508,9 @@ __global__ __launch_bounds__(256) void member_emit_kernel(SortBufs b, int32_t n_
         // boundaries: key k (= rank + 1) starts at the first i with key[i] >= k
         const int64_t k_prev = i > 0 ? (int64_t)key[i - 1] : 0;
         const int64_t k_here = i < b.n ? (int64_t)key[i] : (int64_t)n_members + 1;
+        // the sort's result, checked on the way (see emit_ids_kernel): groups ascending, entry indices ascending inside a group
+        if (i > 0 && i < b.n && status && (k_prev > k_here || (k_prev == k_here && val[i - 1] >= val[i])))
+            atomicOr(status, kStatusOrder);
         for (int64_t k = k_prev + 1; k <= k_here; ++k)
             if (k >= 1 && k <= (int64_t)n_members + 1) member_off[k - 1] = i;
         if (i < b.n) {
@@ -1795,7 +1812,7 @@ hipError_t group_by_member_launch(LargeScratch& scratch, int64_t n, int32_t n_me
     for (int d = 0; d < 8 && ((uint64_t)n_members >> (8 * d)) != 0; ++d) mask |= 1u << (4 + d);
     sort_run_passes(b, stream, status, nullptr, mask);
     hipLaunchKernelGGL(member_emit_kernel, dim3(grid), dim3(256), 0, stream, b, n_members, n_topics, part_off,
-                       out_partition, member_off, grouped_topic, grouped_partition, grouped_entry);
+                       out_partition, member_off, grouped_topic, grouped_partition, grouped_entry, status);
     return hipGetLastError();
 }
 

@@ -73,6 +73,65 @@ def strip_padding(gathered, counts: List[int], cap: int):
     return torch.cat([gathered[r * cap: r * cap + counts[r]] for r in range(len(counts))])
 
 
+def wire_format_numpy(max_partition_id: int, n_members: int) -> Tuple[int, int]:
+    """la_wire_format_for restated (elem_bytes, id_bits): the narrowest unsigned element that holds
+    ((member rank + 1) << id_bits) | partition id for ids in [0, max_partition_id] and ranks in [-1, n_members);
+    (8, 32) carries any int32 pair.  tests/test_sharding_gloo.py asserts that the library agrees."""
+    if max_partition_id < 0 or max_partition_id > 0x7FFFFFFF or n_members < 0 or n_members > 0x7FFFFFFF:
+        return 8, 32
+    ib, rb = int(max_partition_id).bit_length(), int(n_members).bit_length()
+    if ib + rb <= 16:
+        return 2, ib
+    if ib + rb <= 32:
+        return 4, ib
+    return 8, 32
+
+
+_WIRE_DTYPE = {2: np.uint16, 4: np.uint32, 8: np.uint64}
+
+
+def pack_results_numpy(pid: np.ndarray, rank: np.ndarray, elem_bytes: int, id_bits: int) -> np.ndarray:
+    """The wire format on the host (what la_pack_results_on does on the device): raises if a pair does not fit."""
+    p = np.asarray(pid, dtype=np.int32).view(np.uint32).astype(np.uint64)
+    r1 = (np.asarray(rank, dtype=np.int64) + 1)
+    if (r1 < 0).any():
+        raise ValueError("member ranks must be >= -1")
+    r1 = r1.astype(np.uint64)
+    if elem_bytes != 8:
+        if (p >> np.uint64(id_bits)).any() or (r1 >> np.uint64(8 * elem_bytes - id_bits)).any():
+            raise ValueError("a partition id or member rank does not fit the wire format")
+    return ((r1 << np.uint64(id_bits)) | p).astype(_WIRE_DTYPE[elem_bytes])
+
+
+def unpack_results_numpy(packed: np.ndarray, elem_bytes: int, id_bits: int):
+    w = np.asarray(packed).astype(np.uint64)
+    mask = np.uint64(0xFFFFFFFF if id_bits >= 32 else (1 << id_bits) - 1)
+    pid = (w & mask).astype(np.uint32).view(np.int32)
+    rank = ((w >> np.uint64(id_bits)).astype(np.int64) - 1).astype(np.int32)
+    return pid, rank
+
+
+def gather_results_packed(local_pid, local_rank, counts: List[int], max_partition_id: int, n_members: int, group=None):
+    """gather_results through the narrow wire format: ONE all_gather_into_tensor of `cap` elements of 2 / 4 / 8 bytes per
+    rank instead of two int32 arrays (8 B per partition).  Host tensors (gloo; the CPU test): packed with the numpy
+    restatement; device tensors go through la_pack_results_on / la_unpack_results_on in bench.py."""
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group)
+    cap = max(counts) if counts else 0
+    eb, ib = wire_format_numpy(max_partition_id, n_members)
+    dt = {2: torch.int16, 4: torch.int32, 8: torch.int64}[eb]           # same width; gloo has no unsigned 16 / 32
+    send = torch.zeros(cap, dtype=dt)
+    packed = pack_results_numpy(local_pid.numpy(), local_rank.numpy(), eb, ib)
+    send[: packed.size] = torch.from_numpy(packed.view({2: np.int16, 4: np.int32, 8: np.int64}[eb]))
+    recv = torch.empty(world * cap, dtype=dt)
+    dist.all_gather_into_tensor(recv, send, group=group)
+    g = strip_padding(recv.numpy().view(_WIRE_DTYPE[eb]), counts, cap)
+    pid, rank = unpack_results_numpy(g, eb, ib)
+    return torch.from_numpy(pid), torch.from_numpy(rank), eb * cap
+
+
 def gather_results(local_pid, local_rank, counts: List[int], group=None):
     """All-gathers the per-rank result arrays into the global arrays (topic order = rank
     order, because shards are contiguous).  ``counts[r]`` = partitions owned by rank r.

@@ -46,6 +46,10 @@ def test_default_at_two_ranks_is_the_north_star_workload():
     assert d["parity"]["bit_exact"] is True and d["parity"]["checked_topics"] > 0
     assert len(d["roofline"]["per_rank_kernel_ms"]) == 2 and min(d["roofline"]["per_rank_kernel_ms"]) > 0
     assert d["cold_call_ms"] > 0                                 # rank 0's extras survive at N > 1
+    # the default wire format: 2 bytes per assigned partition (ids < 256, 32 members), expanded again on every rank
+    wire = d["config"]["wire"]
+    assert wire["format"] == "packed" and wire["elem_bytes"] == 2 and wire["id_bits"] == 8 and wire["unpacked_in_step"] is True
+    assert wire["gather_bytes_per_rank"] == 2 * 12800000
 
 
 @pytest.mark.timeout(1200)
@@ -63,6 +67,18 @@ def test_strong_scaling_four_ranks_cfg4():
     assert d["n_gpus"] == 4 and d["scaling"] == "strong" and d["config"]["topics_on_rank0"] == 25000
     assert d["parity"]["bit_exact"] is True and d["parity"]["checked_topics"] == 100000
     assert len(d["roofline"]["per_rank_gather_ms"]) == 4
+    assert d["config"]["wire"]["elem_bytes"] == 2 and d["config"]["wire"]["gather_bytes_per_rank"] == 2 * 1600000
+
+
+@pytest.mark.timeout(1200)
+def test_strong_scaling_three_ranks_other_wire_forms():
+    """The round-3 form ([2, cap] int32) and the packed form left packed: same global arrays (checked by rank 0's oracle)."""
+    d = _run(3, ["--workload", "cfg4", "--wire", "int32"], GLOO)
+    assert d["config"]["wire"]["format"] == "int32" and d["config"]["wire"]["elem_bytes"] == 8
+    assert d["parity"]["bit_exact"] is True and d["parity"]["checked_topics"] == 100000 and d["config"]["collectives_per_step"] == 1
+    d = _run(3, ["--workload", "cfg4", "--no-unpack"], GLOO)
+    assert d["config"]["wire"]["unpacked_in_step"] is False and d["config"]["wire"]["elem_bytes"] == 2
+    assert d["parity"]["bit_exact"] is True and d["parity"]["checked_topics"] == 100000
 
 
 @pytest.mark.timeout(1200)
@@ -81,3 +97,4 @@ def test_rccl_leg_one_rank_strong_cfg4():
     assert d["config"]["collectives_per_step"] == 1 and d["scaling"] == "strong"
     assert d["parity"]["bit_exact"] is True and d["parity"]["checked_topics"] == 100000
     assert d["roofline"]["per_rank_gather_ms"][0] > 0
+    assert d["config"]["wire"]["format"] == "packed" and d["config"]["wire"]["elem_bytes"] == 2     # bytes through RCCL (ncclUint8)

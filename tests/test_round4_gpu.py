@@ -1,0 +1,262 @@
+"""Round-4 additions, through the C ABI, bit-exact against the oracle:
+
+* the narrow wire format of the all-gather (la_pack_results_on / la_unpack_results_on, include/lagassign.h): equal to the numpy
+  restatement in sharding.py at every width, any alignment, a misfit is an error, round trip over real results;
+* la_assign_batch_sparse / la_assign_batch_grouped_sparse: `begin` only where there is no committed offset (Main.java:384-396)
+  -- 0 %, 1 %, 100 % uncommitted, `latest`, the one-copy, lanes and three-stream pipelines, several shards, bad lists;
+* the block path with P == np_cap (explicit zero slot), group paths report device status, the caller's current
+  device survives every call, la_version follows the header.
+"""
+import os
+import re
+
+import numpy as np
+import pytest
+
+from kafka_lag_based_assignor_amd import _native as N
+from kafka_lag_based_assignor_amd import sharding, synth
+from oracle import oracle
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = N.Context(0)
+    yield c
+    c.close()
+
+
+@pytest.fixture(scope="module")
+def torch_dev():
+    import torch
+    return torch, torch.device("cuda", 0)
+
+
+# ---- wire format ----------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("max_id,n_members,n,shift", [
+    (255, 32, 100003, 0), (63, 8, 8 * 1024, 0), (255, 32, 1000, 3), (70000, 3, 50001, 0), (70000, 3, 777, 1),
+    (-1, 100, 40000, 0), (2 ** 20 - 1, 8192, 12345, 2), (0, 0, 17, 0), (255, 255, 4096, 0), (255, 256, 4096, 5)])
+def test_wire_pack_unpack_equal_the_numpy_restatement(ctx, torch_dev, max_id, n_members, n, shift):
+    torch, dev = torch_dev
+    rng = np.random.default_rng(n + shift)
+    fmt = N.wire_format_for(max_id, n_members)
+    assert (fmt.elem_bytes, fmt.id_bits) == sharding.wire_format_numpy(max_id, n_members)
+    if max_id < 0:
+        pid = rng.integers(-2 ** 31, 2 ** 31 - 1, n).astype(np.int32)
+    else:
+        pid = rng.integers(0, max_id + 1, n).astype(np.int32)
+        pid[: min(n, 4)] = max_id
+    rank = rng.integers(-1, max(n_members, 1), n).astype(np.int32) if n_members else np.full(n, -1, np.int32)
+    if n_members:
+        rank[-1] = n_members - 1
+    # `shift` elements of offset: pointers that are NOT 16-byte aligned take the scalar kernels
+    d_pid = torch.zeros(n + 8, dtype=torch.int32, device=dev)
+    d_rank = torch.zeros(n + 8, dtype=torch.int32, device=dev)
+    d_pid[shift:shift + n] = torch.from_numpy(pid).to(dev)
+    d_rank[shift:shift + n] = torch.from_numpy(rank).to(dev)
+    eb = fmt.elem_bytes
+    d_wire = torch.zeros((n + 8) * eb, dtype=torch.uint8, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+    ctx.pack_results(n, d_pid.data_ptr() + 4 * shift, d_rank.data_ptr() + 4 * shift, fmt, d_wire.data_ptr() + eb * shift, stream)
+    ctx.sync(stream)
+    got = d_wire.cpu().numpy()[eb * shift: eb * (shift + n)].view(fmt.dtype)
+    exp = sharding.pack_results_numpy(pid, rank, eb, fmt.id_bits)
+    np.testing.assert_array_equal(got, exp)
+    o_pid = torch.full((n + 8,), 7, dtype=torch.int32, device=dev)
+    o_rank = torch.full((n + 8,), 7, dtype=torch.int32, device=dev)
+    ctx.unpack_results(n, d_wire.data_ptr() + eb * shift, fmt, o_pid.data_ptr() + 4 * shift, o_rank.data_ptr() + 4 * shift, stream)
+    ctx.sync(stream)
+    np.testing.assert_array_equal(o_pid.cpu().numpy()[shift:shift + n], pid)
+    np.testing.assert_array_equal(o_rank.cpu().numpy()[shift:shift + n], rank)
+    assert int(o_pid[shift + n]) == 7 and (shift == 0 or int(o_pid[shift - 1]) == 7)      # nothing outside the run is touched
+
+
+def test_wire_misfit_is_an_error_not_a_truncation(ctx, torch_dev):
+    torch, dev = torch_dev
+    stream = torch.cuda.current_stream().cuda_stream
+    fmt = N.wire_format_for(255, 32)                                                      # 2 bytes, 8 id bits
+    for pid, rank in ((np.array([1, 256, 3], np.int32), np.array([0, 1, 2], np.int32)),   # an id beyond the format
+                      (np.array([1, 2, 3], np.int32), np.array([0, 255, 2], np.int32)),   # a rank beyond it
+                      (np.array([1, -2, 3], np.int32), np.array([0, 1, 2], np.int32))):   # a negative id
+        d_pid, d_rank = torch.from_numpy(pid).to(dev), torch.from_numpy(rank).to(dev)
+        d_wire = torch.zeros(16, dtype=torch.uint8, device=dev)
+        ctx.pack_results(3, d_pid.data_ptr(), d_rank.data_ptr(), fmt, d_wire.data_ptr(), stream)
+        with pytest.raises(N.LagAssignError) as e:
+            ctx.sync(stream)
+        assert e.value.code == N.LA_EINVAL and "wire format" in str(e.value)
+    ctx.sync(stream)                                                                      # the status word was cleared
+    bad = N.WireFormat()
+    bad.elem_bytes, bad.id_bits = 3, 8
+    with pytest.raises(N.LagAssignError):
+        ctx.pack_results(3, 1, 1, bad, 1, stream)
+
+
+def test_wire_round_trip_of_real_results_cfg4(ctx, torch_dev):
+    """A shard's results -> wire -> back: exactly what a rank sends and what every rank rebuilds."""
+    torch, dev = torch_dev
+    w = synth.config("cfg4", 0.05)
+    p, m, _ = ctx.assign_batch(w.part_off, w.partition_id, w.begin, w.end, w.committed, N.LA_RESET_EARLIEST, w.cons_off, w.cons_rank)
+    fmt = N.wire_format_for(int(w.partition_id.max()), int(w.cons_rank.max()) + 1)
+    assert fmt.elem_bytes == 2
+    n = p.size
+    stream = torch.cuda.current_stream().cuda_stream
+    d_p, d_m = torch.from_numpy(p).to(dev), torch.from_numpy(m).to(dev)
+    d_w = torch.empty(n * 2, dtype=torch.uint8, device=dev)
+    o = torch.empty(2 * n, dtype=torch.int32, device=dev)
+    ctx.pack_results(n, d_p.data_ptr(), d_m.data_ptr(), fmt, d_w.data_ptr(), stream)
+    ctx.unpack_results(n, d_w.data_ptr(), fmt, o.data_ptr(), o.data_ptr() + 4 * n, stream)
+    ctx.sync(stream)
+    np.testing.assert_array_equal(o[:n].cpu().numpy(), p)
+    np.testing.assert_array_equal(o[n:].cpu().numpy(), m)
+
+
+# ---- sparse begin -----------------------------------------------------------------------------------------------------
+def _expected(w, latest, begin=None):
+    lag = oracle.compute_lags(w.begin if begin is None else begin, w.end, w.committed, latest)
+    return oracle.assign_flat(w.part_off, w.partition_id, lag, w.cons_off, w.cons_rank)
+
+
+def _workload(seed, frac_none, topics=300, big=False):
+    w = synth.ragged(seed, topics, 3000 if big else 300, 40)
+    rng = np.random.default_rng(seed)
+    n = w.n_partitions
+    com = rng.integers(0, 1 << 20, n).astype(np.int64)
+    com[rng.random(n) < frac_none] = -1
+    w.committed = com
+    w.begin = rng.integers(0, 1 << 19, n).astype(np.int64)                  # non-zero: a dropped entry would show
+    with np.errstate(over="ignore"):
+        w.end = np.maximum(com, w.begin) + np.maximum(w.lag, 0)
+    return w
+
+
+@pytest.mark.parametrize("frac_none", [0.0, 0.01, 0.3, 1.0])
+@pytest.mark.parametrize("kind", ["one_copy", "lanes", "streams", "shards"])
+def test_sparse_begin_equals_the_dense_call(frac_none, kind):
+    big = kind != "one_copy"
+    w = _workload(int(frac_none * 100) + len(kind), frac_none, topics=400 if big else 60, big=big)
+    idx, val = N.sparse_begin(w.begin, w.committed)
+    assert idx.size == int((w.committed < 0).sum())
+    flags = {"one_copy": 0, "lanes": N.LA_CREATE_SPLIT_ALWAYS | 3, "streams": 0, "shards": N.LA_CREATE_SPLIT_ALWAYS}[kind]
+    dev = [0, 0, 0] if kind == "shards" else 0
+    with N.Context(dev, flags=flags) as c:
+        if kind == "streams":
+            os.environ["LA_CHUNK_PARTITIONS"] = "20000"
+        try:
+            exp = _expected(w, False)
+            args = (w.part_off, w.partition_id, w.end, w.committed, N.LA_RESET_EARLIEST)
+            if kind == "streams":
+                # every array pinned: the thread-less three-stream pipeline
+                with N.Context(0) as cp:                                          # (a context created under the chunk override)
+                    pin = lambda a: _pinned(cp, a)                                # noqa: E731
+                    out = (cp.host_alloc((w.n_partitions,), np.int32), cp.host_alloc((w.n_partitions,), np.int32),
+                           cp.host_alloc((w.cons_rank.size,), np.int64))
+                    got = cp.assign_batch_sparse(pin(w.part_off), pin(w.partition_id), pin(w.end), pin(w.committed),
+                                                 N.LA_RESET_EARLIEST, pin(idx), pin(val), pin(w.cons_off), pin(w.cons_rank), out=out)
+                    assert cp.last_pipeline() == N.LA_PIPELINE_STREAMS
+            else:
+                got = c.assign_batch_sparse(*args, idx, val, w.cons_off, w.cons_rank)
+                assert c.last_pipeline() == (N.LA_PIPELINE_ONE_COPY if kind == "one_copy" else N.LA_PIPELINE_LANES)
+            for g, e, what in zip(got, exp, ("order", "member", "totals")):
+                np.testing.assert_array_equal(g, e, err_msg=what)
+            # and the dense call on the same context agrees (same bits either way)
+            dense = c.assign_batch(w.part_off, w.partition_id, w.begin, w.end, w.committed, N.LA_RESET_EARLIEST, w.cons_off, w.cons_rank)
+            for g, e in zip(dense, exp):
+                np.testing.assert_array_equal(g, e)
+        finally:
+            os.environ.pop("LA_CHUNK_PARTITIONS", None)
+
+
+def _pinned(c, a):
+    a = np.ascontiguousarray(a)
+    p = c.host_alloc(a.shape, a.dtype)
+    p[...] = a
+    return p
+
+
+def test_sparse_begin_semantics(ctx):
+    w = _workload(5, 0.2, topics=50)
+    idx, val = N.sparse_begin(w.begin, w.committed)
+    a = (w.part_off, w.partition_id, w.end, w.committed)
+    # `latest` never reads begin: the list is ignored, may be absent
+    exp = _expected(w, True)
+    for lst in ((idx, val), (None, None)):
+        got = ctx.assign_batch_sparse(*a, N.LA_RESET_LATEST, lst[0], lst[1], w.cons_off, w.cons_rank)
+        np.testing.assert_array_equal(got[1], exp[1])
+    # an unlisted partition without a committed offset has begin 0 (getOrDefault(tp, 0L), Main.java:350-351)
+    keep = np.arange(idx.size) % 2 == 0
+    begin0 = np.zeros_like(w.begin)
+    begin0[idx[keep]] = val[keep]
+    exp = _expected(w, False, begin0)
+    got = ctx.assign_batch_sparse(*a, N.LA_RESET_EARLIEST, idx[keep], val[keep], w.cons_off, w.cons_rank)
+    for g, e in zip(got, exp):
+        np.testing.assert_array_equal(g, e)
+    # entries for partitions that HAVE a committed offset are harmless
+    extra_idx = np.arange(w.n_partitions, dtype=np.int64)
+    got = ctx.assign_batch_sparse(*a, N.LA_RESET_EARLIEST, extra_idx, w.begin, w.cons_off, w.cons_rank)
+    for g, e in zip(got, _expected(w, False)):
+        np.testing.assert_array_equal(g, e)
+    # the grouped form: the same lists as the dense grouped call
+    n_members = int(w.cons_rank.max()) + 1
+    g_dense = ctx.assign_batch_grouped(w.part_off, w.partition_id, w.begin, w.end, w.committed, N.LA_RESET_EARLIEST, w.cons_off,
+                                       w.cons_rank, n_members)
+    g_sparse = ctx.assign_batch_grouped_sparse(*a, N.LA_RESET_EARLIEST, idx, val, w.cons_off, w.cons_rank, n_members)
+    for x, y in zip(g_dense, g_sparse):
+        np.testing.assert_array_equal(x, y)
+
+
+@pytest.mark.parametrize("flags", [0, N.LA_CREATE_SPLIT_ALWAYS | 3])
+def test_sparse_begin_bad_lists_are_errors(flags):
+    w = _workload(9, 0.1, topics=200, big=flags != 0)
+    idx, val = N.sparse_begin(w.begin, w.committed)
+    a = (w.part_off, w.partition_id, w.end, w.committed, N.LA_RESET_EARLIEST)
+    with N.Context(0, flags=flags) as c:
+        swapped = idx.copy()
+        swapped[[0, -1]] = swapped[[-1, 0]]                                        # not ascending (across chunks)
+        beyond = idx.copy()
+        beyond[-1] = w.n_partitions                                                # outside the batch
+        negative = idx.copy()
+        negative[0] = -1
+        for bad in (swapped, beyond, negative):
+            with pytest.raises(N.LagAssignError) as e:
+                c.assign_batch_sparse(*a, bad, val, w.cons_off, w.cons_rank)
+            assert e.value.code == N.LA_EINVAL and "none_index" in str(e.value)
+        good = c.assign_batch_sparse(*a, idx, val, w.cons_off, w.cons_rank)        # the context is usable afterwards
+        np.testing.assert_array_equal(good[1], _expected(w, False)[1])
+        with pytest.raises(N.LagAssignError):
+            c.assign_batch_sparse(*a, idx, None, w.cons_off, w.cons_rank)          # a null array with n_none > 0
+
+
+# ---- ADVICE r3 ----------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("c", [1, 7, 64])
+def test_block_path_with_exactly_np_cap_partitions(ctx, c):
+    """16 384 partitions x <= 64 consumers: the E = 16 class filled to the last slot; the one-wavefront slots greedy reads
+    s_key[P] as its zero slot, which has its own 16 bytes now (it used to alias s_tot[0])."""
+    rng = np.random.default_rng(c)
+    p = 16384
+    part_off = np.array([0, p, 2 * p], np.int64)
+    cons_off = np.array([0, c, 2 * c], np.int64)
+    pid = np.concatenate([rng.permutation(p), rng.permutation(p)]).astype(np.int32)
+    lag = rng.integers(0, 1 << 30, 2 * p).astype(np.int64)
+    lag[p:] = rng.integers(0, 3, p)                                                # heavy ties in the second topic
+    ranks = np.concatenate([np.sort(rng.choice(500, c, replace=False)) for _ in range(2)]).astype(np.int32)
+    got = ctx.assign_batch_lags(part_off, pid, lag, cons_off, ranks)
+    exp = oracle.assign_flat(part_off, pid, lag, cons_off, ranks)
+    for g, e, what in zip(got, exp, ("order", "member", "totals")):
+        np.testing.assert_array_equal(g, e, err_msg=what)
+
+
+def test_version_follows_the_header():
+    header = open(os.path.join(ROOT, "include", "lagassign.h")).read()
+    v = int(re.search(r"#define\s+LA_VERSION\s+(\d+)", header).group(1))
+    assert N.load().la_version() == v >= 300
+
+
+def test_calls_leave_the_current_device_alone(ctx, torch_dev):
+    torch, dev = torch_dev
+    before = torch.cuda.current_device()                                              # torch owns the HIP runtime: ask torch
+    w = synth.config("cfg3", 0.01)
+    ctx.assign_batch(w.part_off, w.partition_id, w.begin, w.end, w.committed, N.LA_RESET_EARLIEST, w.cons_off, w.cons_rank)
+    ctx.device_features(0)
+    assert torch.cuda.current_device() == before

@@ -53,6 +53,11 @@ def _worker(rank, world, port, ret):
     recv = torch.empty(world * cap, dtype=torch.int32)
     dist.all_gather_into_tensor(recv, send)
     ok = ok and np.array_equal(sharding.strip_padding(recv.numpy(), counts, cap), e_pid)
+    # the narrow wire format: ONE all-gather of 2-byte elements (ids < 64, ranks < 27 here) rebuilds the same arrays
+    p_pid, p_rank, sent = sharding.gather_results_packed(torch.from_numpy(pid), torch.from_numpy(rk), counts,
+                                                         int(w.partition_id.max()), int(w.cons_rank.max()) + 1)
+    ok = ok and np.array_equal(p_pid.numpy(), e_pid) and np.array_equal(p_rank.numpy(), e_rank)
+    ok = ok and sent == sharding.wire_format_numpy(int(w.partition_id.max()), int(w.cons_rank.max()) + 1)[0] * cap
     ret[rank] = bool(ok)
     dist.barrier()
     dist.destroy_process_group()
@@ -105,3 +110,25 @@ def test_plan_shards_properties_through_the_c_abi():
         N.plan_shards(np.array([0, 5, 3], dtype=np.int64), 2)                 # offsets decrease
     with pytest.raises(N.LagAssignError):
         N.plan_shards(np.array([0, 5], dtype=np.int64), 0)
+
+
+def test_wire_format_library_and_restatement_agree():
+    """la_wire_format_for is pure host code: the numpy restatement (what the gloo path packs with) picks the same element."""
+    from kafka_lag_based_assignor_amd import _native as N
+    rng = np.random.default_rng(3)
+    cases = [(255, 32), (63, 8), (0, 0), (-1, 5), (65535, 1), (65535, 0), (2 ** 31 - 1, 1), (255, 255), (255, 256), (1 << 20, 8192)]
+    cases += [(int(rng.integers(0, 1 << int(rng.integers(1, 32)))), int(rng.integers(0, 1 << int(rng.integers(1, 32))))) for _ in range(300)]
+    for max_id, members in cases:
+        f = N.wire_format_for(max_id, members)
+        assert (f.elem_bytes, f.id_bits) == sharding.wire_format_numpy(max_id, members), (max_id, members)
+        if max_id >= 0:
+            pid = np.array([0, max_id], np.int32)
+            rank = np.array([-1, members - 1], np.int32)
+            w = sharding.pack_results_numpy(pid, rank, f.elem_bytes, f.id_bits)
+            assert w.dtype.itemsize == f.elem_bytes
+            p2, r2 = sharding.unpack_results_numpy(w, f.elem_bytes, f.id_bits)
+            assert np.array_equal(p2, pid) and np.array_equal(r2, rank)
+    # target and cfg4: two bytes
+    assert sharding.wire_format_numpy(255, 32) == (2, 8) and sharding.wire_format_numpy(63, 8) == (2, 6)
+    with pytest.raises(ValueError):
+        sharding.pack_results_numpy(np.array([256], np.int32), np.array([0], np.int32), 2, 8)
