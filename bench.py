@@ -779,6 +779,8 @@ def main():
     if world == 1 and not latest and not args.no_cpu_baseline:
         try:
             lms, lcalls = timed_calls(torch, ctx, sh.make_batch(True, args.algo), stream, settle_ms=60.0)
+            ctx.assign_batch_device(b, stream)                      # the result buffers hold the EARLIEST assignment again:
+            ctx.sync(stream)                                        # lag_ratio, parity and the host legs below read them
             roofline["latest_mode"] = {"kernel_ms": round(lms, 4), "calls_timed": lcalls, "algorithmic_bytes_per_partition": 28,
                                        "frac": round(28.0 * n_part / (lms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                                        "value": round(n_part / (lms * 1e-3), 1),

@@ -118,6 +118,9 @@ extern "C" {
 #define LA_FLAG_NO_RUN_MERGE 256 /* large path: greedy rounds whose bins form a few ascending runs sort them like any other   *
                                  * round instead of merging the runs (test hook / A-B)                                  */
 
+#define LA_FLAG_SERIAL_LARGE 512 /* large path: the batch's large topics one after another (round 3's form) instead of side by   *
+                                 * side in shared launches (test hook / A-B)                                            */
+
 typedef struct la_ctx la_ctx;
 
 /* la_create / la_create_multi flags */
@@ -279,7 +282,9 @@ typedef struct la_device_batch {
      * library then looks at every topic's size on the host (a few ns per topic) and
      * sends it down the wave-tile path, the block path (one workgroup per topic, up to
      * 8192 partitions x 2048 consumers, all such topics side by side) or the large path
-     * (device-wide sort, one topic after another).  Also read when LA_FLAG_RAGGED is set.
+     * (device-wide radix sort + one greedy workgroup per topic, the batch's large topics side by side in
+     * shared launches; beyond 8192 consumers the bins live in HBM and every greedy round is a device
+     * sort: any consumer count, Main.java:240-263 has no bound).  Also read when LA_FLAG_RAGGED is set.
      * NULL otherwise -- or NULL anyway: the library then fetches the offsets itself, which
      * makes that call wait on `stream` (not asynchronous, not capturable).  Calls on one context are expected to be stream-ordered: the
      * per-call topic lists live in context-owned device memory. */

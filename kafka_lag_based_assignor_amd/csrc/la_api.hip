@@ -357,15 +357,29 @@ int launch_block_topics(la_ctx* ctx, Lane& ln, const la_device_batch* b, const B
 }
 
 int launch_large_topics(la_ctx* ctx, Lane& ln, const la_device_batch* b, const BatchPlan& plan, bool argmin, hipStream_t stream) {
+    // The per-topic loop of assign(Map,Map) (Main.java:177-184) is independent across topics: all large topics of the batch
+    // run SIDE BY SIDE (la::large_topics_launch: every phase one launch over all of them, one greedy workgroup per topic),
+    // in groups bounded by scratch memory.  Topics with more consumers than the one-workgroup greedy holds take the
+    // bins-in-HBM form, one after another; the literal-argmin test hook stays serial.
+    std::vector<la::LargeArgs> group;
+    int64_t group_n = 0;
+    auto flush = [&]() -> int {
+        if (group.empty()) return LA_OK;
+        const hipError_t e = la::large_topics_launch(ln.large, group.data(), (int)group.size(), stream);
+        group.clear();
+        group_n = 0;
+        if (e != hipSuccess)
+            return fail(ctx, e == hipErrorOutOfMemory ? LA_ENOMEM : LA_EHIP, "large topics: %s", hipGetErrorString(e));
+        return LA_OK;
+    };
+    constexpr int64_t kGroupPartitions = (int64_t)1 << 30;          // ~26 GB of sort buffers
+    constexpr size_t kGroupTopics = 8192;
     for (int64_t t = 0; t < b->n_topics; ++t) {
         if (plan.code[t] != kLargeCode) continue;
         const int64_t p = b->h_part_off[t + 1] - b->h_part_off[t], c = b->h_cons_off[t + 1] - b->h_cons_off[t];
-        if (c > la::kLargeMaxConsumers)
-            return fail(ctx, LA_ESHAPE, "topic %lld has %lld consumers; at most %lld are supported", (long long)t,
-                        (long long)c, (long long)la::kLargeMaxConsumers);
-        if (p > 0x7FFFFFFF)
-            return fail(ctx, LA_ESHAPE, "topic %lld has %lld partitions; at most 2^31-1 are supported", (long long)t,
-                        (long long)p);
+        if (p > 0x7FFFFFFF || c > 0x7FFFFFFF)
+            return fail(ctx, LA_ESHAPE, "topic %lld has %lld partitions and %lld consumers; at most 2^31-1 of each are supported",
+                        (long long)t, (long long)p, (long long)c);
         la::LargeArgs g{};
         g.p0 = b->h_part_off[t];
         g.n_part = p;
@@ -385,12 +399,27 @@ int launch_large_topics(la_ctx* ctx, Lane& ln, const la_device_batch* b, const B
         g.sort_multi_kernel = (b->flags & LA_FLAG_SORT_MULTIKERNEL) ? 1 : 0;
         g.no_run_merge = (b->flags & LA_FLAG_NO_RUN_MERGE) ? 1 : 0;
         g.status = ln.status();
-        hipError_t e = la::large_topic_launch(ln.large, g, argmin, stream);
+        hipError_t e = hipSuccess;
+        if (c > la::kLargeMaxConsumers) {
+            if (int rc = flush()) return rc;
+            if (argmin)
+                return fail(ctx, LA_ESHAPE, "topic %lld has %lld consumers; LA_ALGO_ARGMIN (a test hook) holds at most %lld",
+                            (long long)t, (long long)c, (long long)la::kLargeMaxConsumers);
+            e = la::huge_topic_launch(ln.large, g, stream);
+        } else if (argmin || p == 0 || (b->flags & LA_FLAG_SERIAL_LARGE)) {
+            if (int rc = flush()) return rc;
+            e = la::large_topic_launch(ln.large, g, argmin, stream);
+        } else {
+            if (group.size() >= kGroupTopics || (group_n > 0 && group_n + p > kGroupPartitions))
+                if (int rc = flush()) return rc;
+            group.push_back(g);
+            group_n += p;
+        }
         if (e != hipSuccess)
             return fail(ctx, e == hipErrorOutOfMemory ? LA_ENOMEM : LA_EHIP, "large topic %lld: %s", (long long)t,
                         hipGetErrorString(e));
     }
-    return LA_OK;
+    return flush();
 }
 
 // The dispatcher shared by the host and device entry points.

@@ -147,6 +147,16 @@ struct LargeScratch {
     void* buf = nullptr;
     size_t cap = 0;
     LargeProfile prof;
+    // several large topics side by side (large_topics_launch): their argument blocks are built in a pinned slot (two, used in
+    // turn: a slot is rewritten only after the copy that read it has completed) and copied to d_items on the call's stream
+    struct Stage {
+        void* h = nullptr;
+        size_t cap = 0;
+        hipEvent_t done = nullptr;
+    } stage[2];
+    unsigned stage_next = 0;
+    void* d_items = nullptr;
+    size_t d_items_cap = 0;
 };
 
 struct LargeArgs {
@@ -173,6 +183,15 @@ struct LargeArgs {
 hipError_t large_init_device();
 int large_atomic_rank_supported();      // of the current device: 1 = ranks come from returning LDS atomics, 0 = match form
 hipError_t large_topic_launch(LargeScratch& scratch, const LargeArgs& a, bool argmin, hipStream_t stream);
+// `count` large topics (each with n_part > 0 and at most kLargeMaxConsumers consumers) SIDE BY SIDE: the per-topic loop of
+// assign(Map,Map) (Main.java:177-184) is independent across topics, so every phase is one launch over all of them -- keys,
+// plan, each radix pass (grid.y = topic), ids, one greedy workgroup per topic, ranks -- instead of ~15 launches and a
+// one-CU chain per topic, one topic after another.  Falls back to that serial form for a single topic and for the
+// four-kernel-pass test hook.
+hipError_t large_topics_launch(LargeScratch& scratch, const LargeArgs* args, int count, hipStream_t stream);
+// A topic with more than kLargeMaxConsumers consumers: bins in HBM, every round one stable device sort of the bins + one
+// pass that hands the round's partitions out (ceil(P / C) rounds of ~11 launches).  Any C up to 2^31 - 1.
+hipError_t huge_topic_launch(LargeScratch& scratch, const LargeArgs& a, hipStream_t stream);
 void large_scratch_release(LargeScratch& scratch);
 // Waits for the profiled topic's events; ms[3] = keys + plan, sort passes, ids + greedy; passes[2] = active id / key passes.
 hipError_t large_profile_read(LargeScratch& scratch, float* ms, int* passes, int64_t* n);

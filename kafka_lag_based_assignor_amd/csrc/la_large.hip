@@ -26,7 +26,9 @@
 #include "la_device.h"
 #include "la_sort64.h"
 
+#include <algorithm>
 #include <type_traits>
+#include <vector>
 
 namespace la {
 
@@ -65,6 +67,47 @@ struct SortBufs {
     int sweep_threads;                 // workgroup size of the single-kernel passes: 512 (tiles of 8 192) or 256 (4 096)
 };
 
+// One large topic of a batched launch (large_topics_launch): kernels launched over SEVERAL topics at once read where their
+// topic's partitions / consumers are and where its sort lives from a device array -- blockIdx.y (or an order list) picks the
+// item -- instead of from the kernel arguments.  `items == nullptr` is the single-topic form: the arguments are the kernel's own.
+// An item holds NO pointers: the per-partition arrays are the batch's (the kernel's own LargeArgs, shared by every item) and
+// the sort's buffers are byte offsets into the scratch block, whose base is a kernel argument.  A pointer LOADED from memory
+// is a generic pointer to the compiler -- every access through it a flat_* instruction (tests/test_isa_hazards.py) -- while
+// one derived from a kernel argument is known to be global.
+struct LargeItem {
+    int64_t p0, n_part, c0, n_cons;
+    int64_t n;
+    int32_t n_tiles, n_groups;
+    uint64_t o_ctl, o_hist, o_ticket, o_state, o_gbase, o_k0, o_k1, o_v0, o_v1;
+};
+
+// b.key[x] / b.val[x] with a run-time x, as a select: indexing the pointer pair of a LOCAL SortBufs dynamically would put the
+// struct in scratch memory and bring the pointers back generic (flat_* accesses)
+__device__ __forceinline__ uint64_t* key_buf(const SortBufs& b, uint32_t x) { return x ? b.key[1] : b.key[0]; }
+__device__ __forceinline__ uint32_t* val_buf(const SortBufs& b, uint32_t x) { return x ? b.val[1] : b.val[0]; }
+
+__device__ __forceinline__ void bind_item(LargeArgs& a, SortBufs& b, const LargeItem& it, char* scratch) {
+    a.p0 = it.p0; a.n_part = it.n_part; a.c0 = it.c0; a.n_cons = it.n_cons;
+    b.ctl = (SortCtl*)(scratch + it.o_ctl);
+    b.hist = (uint32_t*)(scratch + it.o_hist);
+    b.ticket = (uint32_t*)(scratch + it.o_ticket);
+    b.tile_state = (unsigned long long*)(scratch + it.o_state);
+    b.gbase = (uint32_t*)(scratch + it.o_gbase);
+    b.key[0] = (uint64_t*)(scratch + it.o_k0);
+    b.key[1] = (uint64_t*)(scratch + it.o_k1);
+    b.val[0] = (uint32_t*)(scratch + it.o_v0);
+    b.val[1] = (uint32_t*)(scratch + it.o_v1);
+    b.n = it.n;
+    b.n_tiles = it.n_tiles;
+    b.n_groups = it.n_groups;
+}
+
+// (a0 / b0 of a batched launch: the batch's arrays and flags; atomic_rank / sweep_threads of the launch's tile class)
+#define LA_PICK_ITEM(a, b, a0, b0, items, scratch, which)  \
+    LargeArgs a = a0;                                       \
+    SortBufs b = b0;                                        \
+    if (items) bind_item(a, b, (items)[which], scratch);
+
 // bijection [0, n) -> [0, n): workgroups with equal (w % 8) get consecutive results
 __device__ __forceinline__ int xcd_contiguous(int w, int n) {
     const int per = n / 8, rem = n % 8;                  // XCD x owns per (+1 if x < rem) values
@@ -77,7 +120,9 @@ __device__ __forceinline__ uint32_t digit_of(int pass, uint64_t key, uint32_t va
 }
 
 // ---- kernel 1: keys + all digit histograms ---------------------------------------------------
-__global__ __launch_bounds__(256) void build_keys_kernel(LargeArgs a, SortBufs b) {
+__global__ __launch_bounds__(256) void build_keys_kernel(LargeArgs a0, SortBufs b0, const LargeItem* items, char* scratch) {
+    LA_PICK_ITEM(a, b, a0, b0, items, scratch, blockIdx.y)
+    if ((int64_t)blockIdx.x * blockDim.x >= b.n) return;              // (a grid sized for the largest topic of the launch)
     __shared__ uint32_t h[kDigits * kRadix];
     for (int i = threadIdx.x; i < kDigits * kRadix; i += blockDim.x) h[i] = 0;
     __syncthreads();
@@ -121,7 +166,10 @@ __global__ __launch_bounds__(256) void build_keys_kernel(LargeArgs a, SortBufs b
 }
 
 // ---- plan: which passes are no-ops, where the data lives before each pass --------------------
-__global__ __launch_bounds__(kRadix) void plan_kernel(SortBufs b) {
+__global__ __launch_bounds__(kRadix) void plan_kernel(SortBufs b0, const LargeItem* items, char* scratch) {
+    LargeArgs unused{};
+    SortBufs b = b0;
+    if (items) bind_item(unused, b, items[blockIdx.y], scratch);
     // block p: global first position of every digit of pass p (exclusive scan of its histogram): the single-kernel passes
     // add a tile's look-back result to it
     __shared__ uint32_t wsum[kRadix / kWave];
@@ -535,7 +583,14 @@ constexpr int kLookWindow = LA_LOOK_WINDOW;           // predecessors a walk pol
 constexpr uint32_t kLookbackSpinLimit = 1u << 22;     // polls of one granule (~1 us each with the sleep) before giving up
 
 template <bool ATOMIC_RANK, int THREADS>
-__global__ __launch_bounds__(THREADS, 4) void onesweep_pass_kernel(SortBufs b, int pass, uint32_t* status) {
+__global__ __launch_bounds__(THREADS, 4) void onesweep_pass_kernel(SortBufs b0, int pass, uint32_t* status, const LargeItem* items,
+                                                                   char* scratch) {
+    LargeArgs unused{};
+    SortBufs b = b0;
+    if (items) bind_item(unused, b, items[blockIdx.y], scratch);
+    // several topics per launch: the grid is as wide as the launch's largest topic, and only workgroups that have a tile to
+    // sort may draw a ticket (tiles are taken by arrival, so exactly n_tiles workgroups of a topic must arrive)
+    if ((int)blockIdx.x >= b.n_tiles) return;
     if (b.ctl->skip[pass]) return;
     static_assert(THREADS >= kRadix && THREADS % kWave == 0, "one thread per digit in the look-back");
     constexpr int WAVES = THREADS / kWave, TILE = THREADS * kItems;
@@ -552,10 +607,10 @@ __global__ __launch_bounds__(THREADS, 4) void onesweep_pass_kernel(SortBufs b, i
     for (int i = threadIdx.x; i < WAVES * kRadix; i += THREADS) (&cnt[0][0])[i] = 0;
     __syncthreads();
     const uint32_t cur = b.ctl->cur[pass];
-    const uint64_t* kin = b.key[cur];
-    const uint32_t* vin = b.val[cur];
-    uint64_t* kout = b.key[cur ^ 1];
-    uint32_t* vout = b.val[cur ^ 1];
+    const uint64_t* kin = key_buf(b, cur);
+    const uint32_t* vin = val_buf(b, cur);
+    uint64_t* kout = key_buf(b, cur ^ 1u);
+    uint32_t* vout = val_buf(b, cur ^ 1u);
     const int tile = (int)s_ticket;
     const int64_t t0 = (int64_t)tile * TILE;
     const int64_t w0 = t0 + (int64_t)wave * kItems * kWave;
@@ -739,10 +794,13 @@ __global__ __launch_bounds__(THREADS, 4) void onesweep_pass_kernel(SortBufs b, i
 // (one returning LDS atomic per element) is stable only because colliding lanes are served in lane order -- a property of
 // the hardware checked once at la_create on an idle device, not a promise of the ISA.  A violation under load would scramble
 // the order silently; here it raises kStatusOrder (LA_EHIP at the next sync) for 8 B more read per element.
-__global__ __launch_bounds__(256) void emit_ids_kernel(LargeArgs a, SortBufs b, int fill_rank_minus1) {
+__global__ __launch_bounds__(256) void emit_ids_kernel(LargeArgs a0, SortBufs b0, const LargeItem* items, char* scratch) {
+    LA_PICK_ITEM(a, b, a0, b0, items, scratch, blockIdx.y)
+    if ((int64_t)blockIdx.x * blockDim.x >= b.n) return;
+    const bool fill_rank_minus1 = a.n_cons == 0;                       // nobody to assign to: Main.java:211-214
     const uint32_t fin = b.ctl->cur[kDigits];
-    const uint32_t* val = b.val[fin];
-    const uint64_t* key = b.key[fin];
+    const uint32_t* val = val_buf(b, fin);
+    const uint64_t* key = key_buf(b, fin);
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     bool bad = false;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < b.n; i += stride) {
@@ -1292,14 +1350,16 @@ __device__ void greedy_rounds_packed(const LargeArgs& a, const uint64_t* key, in
 // ---- kernel 3: round-structured greedy, one workgroup -----------------------------------------------
 // n = EC * blockDim.x consumer slots (power of two >= C); slot i = tid*EC + r.
 template <int EC>
-__global__ __launch_bounds__(1024) void greedy_rounds_kernel(LargeArgs a, SortBufs b) {
+__global__ __launch_bounds__(1024) void greedy_rounds_kernel(LargeArgs a0, SortBufs b0, const LargeItem* items, char* scratch,
+                                                            const int32_t* order) {
+    LA_PICK_ITEM(a, b, a0, b0, items, scratch, order[blockIdx.x])               // one workgroup per topic of this (EC, threads) class
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     const int tid = threadIdx.x;
     const int n = EC * blockDim.x;
     uint32_t* s_hi = smem;
     uint32_t* s_lo = smem + n;
     uint32_t* s_tb = smem + 2 * n;
-    const uint64_t* key = b.key[b.ctl->cur[kDigits]];
+    const uint64_t* key = key_buf(b, b.ctl->cur[kDigits]);
     const int64_t P = a.n_part;
     const int C = (int)a.n_cons;
 
@@ -1443,14 +1503,20 @@ __global__ __launch_bounds__(1024) void greedy_argmin_kernel(LargeArgs a, SortBu
 // The rounds kernels store the chosen consumer's INDEX (position in the topic's rank-sorted list): looking the rank up
 // there would put a dependent global load into every round of the one-workgroup chain (~6 us of 27 per round at
 // 8 192 consumers).  This pass, over all CUs, turns the indices into member ranks.
-__global__ __launch_bounds__(256) void map_ranks_kernel(LargeArgs a) {
+__global__ __launch_bounds__(256) void map_ranks_kernel(LargeArgs a0, const LargeItem* items) {
+    LargeArgs a = a0;
+    if (items) { const LargeItem& it = items[blockIdx.y]; a.p0 = it.p0; a.n_part = it.n_part; a.c0 = it.c0; a.n_cons = it.n_cons; }
+    if (a.n_cons == 0) return;                                         // emit_ids_kernel wrote -1: no index to map
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.n_part; i += stride)
         a.out_rank[a.p0 + i] = a.cons_rank[a.c0 + a.out_rank[a.p0 + i]];
 }
 
+// `items` null: ONE topic (a, b).  Otherwise `count` topics of this (EC, threads) class, one workgroup each, side by side:
+// the chain of rounds is serial inside a topic and independent across topics (Main.java:177-184).
 template <int EC>
-hipError_t launch_rounds(const LargeArgs& a, const SortBufs& b, int threads, hipStream_t stream) {
+hipError_t launch_rounds(const LargeArgs& a, const SortBufs& b, int threads, hipStream_t stream, const LargeItem* items = nullptr,
+                         char* scratch = nullptr, const int32_t* order = nullptr, int count = 1) {
     // packed bins: two exchange buffers of 8 B per bin; 96-bit bins: 12 B per bin; sample sort (EC >= 2): its own layout
     size_t lds = (size_t)4 * EC * threads * sizeof(uint32_t);
     if (EC >= 2 && sample_lds_bytes(EC) > lds) lds = sample_lds_bytes(EC);
@@ -1460,10 +1526,31 @@ hipError_t launch_rounds(const LargeArgs& a, const SortBufs& b, int threads, hip
                                    160 * 1024);
     });
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((greedy_rounds_kernel<EC>), dim3(1), dim3(threads), lds, stream, a, b);
-    int grid = (int)((a.n_part + 255) / 256);
-    hipLaunchKernelGGL(map_ranks_kernel, dim3(grid > 2048 ? 2048 : grid), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL((greedy_rounds_kernel<EC>), dim3(count), dim3(threads), lds, stream, a, b, items, scratch, order);
+    if (!items) {
+        int grid = (int)((a.n_part + 255) / 256);
+        hipLaunchKernelGGL(map_ranks_kernel, dim3(grid > 2048 ? 2048 : grid), dim3(256), 0, stream, a, (const LargeItem*)nullptr);
+    }
     return hipGetLastError();
+}
+
+// (EC, threads) of the rounds kernel for a topic with n_cons consumers (1 <= n_cons <= kLargeMaxConsumers)
+inline void rounds_class(int64_t n_cons, int* ec, int* threads) {
+    int cp2 = 64;
+    while (cp2 < n_cons) cp2 <<= 1;
+    if (cp2 <= 1024) { *ec = 1; *threads = cp2; }
+    else { *ec = cp2 / 1024 >= 8 ? 8 : cp2 / 1024; *threads = 1024; }
+}
+
+inline hipError_t launch_rounds_class(int ec, int threads, const LargeArgs& a, const SortBufs& b, hipStream_t stream,
+                                      const LargeItem* items = nullptr, char* scratch = nullptr, const int32_t* order = nullptr,
+                                      int count = 1) {
+    switch (ec) {
+        case 1: return launch_rounds<1>(a, b, threads, stream, items, scratch, order, count);
+        case 2: return launch_rounds<2>(a, b, threads, stream, items, scratch, order, count);
+        case 4: return launch_rounds<4>(a, b, threads, stream, items, scratch, order, count);
+        default: return launch_rounds<8>(a, b, threads, stream, items, scratch, order, count);
+    }
 }
 
 
@@ -1566,66 +1653,96 @@ int large_atomic_rank_supported() {
     return g_atomic_rank_ok[dev].load(std::memory_order_acquire) == 2 ? 1 : 0;
 }
 
-// Carves the sort's working set for n elements out of the grow-only scratch and zeroes what a sort expects zeroed:
-// ctl, hist and -- single-kernel passes -- the arrival tickets and the look-back granules.
+// The sort's working set for n elements, in two parts: what a sort expects zeroed (ctl, hist and -- single-kernel passes --
+// the arrival tickets and the look-back granules) and the rest.  Several topics sorted side by side put all their zero parts
+// first, so that ONE memset clears them.
 // `multi_kernel`: the four-kernel passes (count, scans, scatter) instead of the single-kernel ones; also taken when a
 // digit count would not fit a granule's 32-bit count with room for the tag arithmetic (n >= 2^30).
-static hipError_t sort_prepare(LargeScratch& scratch, int64_t n, hipStream_t stream, SortBufs* out, bool multi_kernel = false) {
+struct SortLayout {
+    int64_t n = 0;
+    bool multi_kernel = false;
+    int sweep_threads = 256, n_tiles = 0, n_groups = 0;
+    size_t o_ctl = 0, o_hist = 0, o_ticket = 0, o_state = 0, zero_bytes = 0;                        // offsets into the zero part
+    size_t o_gbase = 0, o_k0 = 0, o_k1 = 0, o_v0 = 0, o_v1 = 0, o_to = 0, o_gs = 0, data_bytes = 0;   // ... into the data part
+};
+
+static SortLayout sort_layout(int64_t n, bool multi_kernel) {
+    SortLayout L;
+    L.n = n;
     if (n >= ((int64_t)1 << 30)) multi_kernel = true;
     if (const char* env = getenv("LA_SORT_MULTIKERNEL")) multi_kernel = multi_kernel || atoi(env) != 0;
+    L.multi_kernel = multi_kernel;
     // Tiles of 16 elements per thread: the larger the workgroup, the fewer tiles publish and walk (the look-back costs a
     // tile ~10 us whatever its size) and the longer the runs a tile writes per digit -- 33.5 M partitions: 2.25 / 2.02 / 1.93 ms
     // with 256 / 512 / 1 024 threads on the same box, four-kernel passes 2.56; but a 1 M-partition topic (cfg5) has only 64
     // tiles of 16 384: 0.136 / 0.125 / 0.144 ms (profiles/r03_sort_tile_sizes.txt)
     int sweep_threads = n >= (3 << 20) ? 1024 : (n >= (1 << 17) ? 512 : 256);
     if (const char* env = getenv("LA_SWEEP_THREADS")) { const int w = atoi(env); sweep_threads = w == 256 || w == 1024 ? w : 512; }
+    L.sweep_threads = sweep_threads;
     const int64_t tile = multi_kernel ? kTile : (int64_t)sweep_threads * kItems;
-    const int n_tiles = (int)((n + tile - 1) / tile);
+    L.n_tiles = (int)((n + tile - 1) / tile);
+    L.n_groups = (L.n_tiles + kScanRows - 1) / kScanRows;
     size_t off = 0;
     auto carve = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
-    const size_t o_ctl = carve(sizeof(SortCtl));
-    const size_t o_hist = carve(sizeof(uint32_t) * kDigits * kRadix);
-    const size_t o_ticket = carve(sizeof(uint32_t) * kDigits);
-    const size_t o_state = carve(multi_kernel ? 0 : sizeof(unsigned long long) * kRadix * (size_t)n_tiles);
-    const size_t zero_bytes = off;                                  // everything up to here is zeroed per sort
-    const size_t o_gbase = carve(sizeof(uint32_t) * kDigits * kRadix);
-    const size_t o_k0 = carve(sizeof(uint64_t) * n), o_k1 = carve(sizeof(uint64_t) * n);
-    const size_t o_v0 = carve(sizeof(uint32_t) * n), o_v1 = carve(sizeof(uint32_t) * n);
-    const int n_groups = (n_tiles + kScanRows - 1) / kScanRows;
-    const size_t o_to = carve(multi_kernel ? sizeof(uint32_t) * kRadix * (size_t)n_tiles : 0);
-    const size_t o_gs = carve(multi_kernel ? sizeof(uint32_t) * kRadix * (size_t)n_groups : 0);
-    hipError_t e;
-    if (off > scratch.cap) {
-        if (scratch.buf) {
-            if ((e = hipStreamSynchronize(stream)) != hipSuccess) return e;   // earlier work may still use it
-            if ((e = hipFree(scratch.buf)) != hipSuccess) return e;
-            scratch.buf = nullptr;
-            scratch.cap = 0;
-        }
-        const size_t want = off + off / 4;
-        if ((e = hipMalloc(&scratch.buf, want)) != hipSuccess) return e;
-        scratch.cap = want;
-    }
-    char* base = (char*)scratch.buf;
+    L.o_ctl = carve(sizeof(SortCtl));
+    L.o_hist = carve(sizeof(uint32_t) * kDigits * kRadix);
+    L.o_ticket = carve(sizeof(uint32_t) * kDigits);
+    L.o_state = carve(multi_kernel ? 0 : sizeof(unsigned long long) * kRadix * (size_t)L.n_tiles);
+    L.zero_bytes = off;
+    off = 0;
+    L.o_gbase = carve(sizeof(uint32_t) * kDigits * kRadix);
+    L.o_k0 = carve(sizeof(uint64_t) * n); L.o_k1 = carve(sizeof(uint64_t) * n);
+    L.o_v0 = carve(sizeof(uint32_t) * n); L.o_v1 = carve(sizeof(uint32_t) * n);
+    L.o_to = carve(multi_kernel ? sizeof(uint32_t) * kRadix * (size_t)L.n_tiles : 0);
+    L.o_gs = carve(multi_kernel ? sizeof(uint32_t) * kRadix * (size_t)L.n_groups : 0);
+    L.data_bytes = off;
+    return L;
+}
+
+static SortBufs sort_bind(const SortLayout& L, char* zero, char* data) {
     SortBufs b{};
-    b.ctl = (SortCtl*)(base + o_ctl);
-    b.hist = (uint32_t*)(base + o_hist);
-    b.ticket = (uint32_t*)(base + o_ticket);
-    b.tile_state = multi_kernel ? nullptr : (unsigned long long*)(base + o_state);
-    b.gbase = (uint32_t*)(base + o_gbase);
-    b.key[0] = (uint64_t*)(base + o_k0);
-    b.key[1] = (uint64_t*)(base + o_k1);
-    b.val[0] = (uint32_t*)(base + o_v0);
-    b.val[1] = (uint32_t*)(base + o_v1);
-    b.tile_off = (uint32_t*)(base + o_to);
-    b.group_sum = (uint32_t*)(base + o_gs);
-    b.n = n;
-    b.n_tiles = n_tiles;
-    b.n_groups = n_groups;
+    b.ctl = (SortCtl*)(zero + L.o_ctl);
+    b.hist = (uint32_t*)(zero + L.o_hist);
+    b.ticket = (uint32_t*)(zero + L.o_ticket);
+    b.tile_state = L.multi_kernel ? nullptr : (unsigned long long*)(zero + L.o_state);
+    b.gbase = (uint32_t*)(data + L.o_gbase);
+    b.key[0] = (uint64_t*)(data + L.o_k0);
+    b.key[1] = (uint64_t*)(data + L.o_k1);
+    b.val[0] = (uint32_t*)(data + L.o_v0);
+    b.val[1] = (uint32_t*)(data + L.o_v1);
+    b.tile_off = (uint32_t*)(data + L.o_to);
+    b.group_sum = (uint32_t*)(data + L.o_gs);
+    b.n = L.n;
+    b.n_tiles = L.n_tiles;
+    b.n_groups = L.n_groups;
     b.atomic_rank = large_atomic_rank_supported();
-    b.sweep_threads = sweep_threads;
-    *out = b;
-    return hipMemsetAsync(base, 0, zero_bytes, stream);
+    b.sweep_threads = L.sweep_threads;
+    return b;
+}
+
+// grow-only; earlier work on `stream` may still use the old block
+static hipError_t scratch_reserve(LargeScratch& scratch, size_t bytes, hipStream_t stream) {
+    if (bytes <= scratch.cap) return hipSuccess;
+    hipError_t e;
+    if (scratch.buf) {
+        if ((e = hipStreamSynchronize(stream)) != hipSuccess) return e;
+        if ((e = hipFree(scratch.buf)) != hipSuccess) return e;
+        scratch.buf = nullptr;
+        scratch.cap = 0;
+    }
+    const size_t want = bytes + bytes / 4;
+    if ((e = hipMalloc(&scratch.buf, want)) != hipSuccess) return e;
+    scratch.cap = want;
+    return hipSuccess;
+}
+
+static hipError_t sort_prepare(LargeScratch& scratch, int64_t n, hipStream_t stream, SortBufs* out, bool multi_kernel = false) {
+    const SortLayout L = sort_layout(n, multi_kernel);
+    hipError_t e;
+    if ((e = scratch_reserve(scratch, L.zero_bytes + L.data_bytes, stream)) != hipSuccess) return e;
+    char* base = (char*)scratch.buf;
+    *out = sort_bind(L, base, base + L.zero_bytes);
+    return hipMemsetAsync(base, 0, L.zero_bytes, stream);
 }
 
 // plan + the 12 (mostly skipped) passes; keys/vals/hist/unsorted flag must already be in buffer 0
@@ -1635,22 +1752,25 @@ static hipError_t sort_prepare(LargeScratch& scratch, int64_t n, hipStream_t str
 // constant (key bits that cannot be set) or the ids ascending.
 // A pass is ONE launch (onesweep_pass_kernel) -- or four, when the sort was prepared for the multi-kernel form.
 static void sort_run_passes(const SortBufs& b, hipStream_t stream, uint32_t* status, hipEvent_t planned = nullptr,
-                            uint32_t pass_mask = (1u << kDigits) - 1) {
-    hipLaunchKernelGGL(plan_kernel, dim3(kDigits), dim3(kRadix), 0, stream, b);
+                            uint32_t pass_mask = (1u << kDigits) - 1, const LargeItem* items = nullptr, int count = 1,
+                            int max_tiles = 0, char* scratch = nullptr) {
+    // `items`: `count` topics of ONE tile class (b.sweep_threads), sorted side by side -- grid.y picks the topic, grid.x is as
+    // wide as the class's largest topic (max_tiles); the plan of all of them is the caller's (one launch over every class)
+    if (!items) hipLaunchKernelGGL(plan_kernel, dim3(kDigits), dim3(kRadix), 0, stream, b, (const LargeItem*)nullptr, (char*)nullptr);
     if (planned) (void)hipEventRecord(planned, stream);
     for (int p = 0; p < kDigits; ++p) {
         if (!((pass_mask >> p) & 1u)) continue;
         if (b.tile_state) {
-            const dim3 grid(b.n_tiles);
+            const dim3 grid(items ? max_tiles : b.n_tiles, items ? count : 1);
             if (b.sweep_threads == 1024) {
-                if (b.atomic_rank) hipLaunchKernelGGL((onesweep_pass_kernel<true, 1024>), grid, dim3(1024), 0, stream, b, p, status);
-                else hipLaunchKernelGGL((onesweep_pass_kernel<false, 1024>), grid, dim3(1024), 0, stream, b, p, status);
+                if (b.atomic_rank) hipLaunchKernelGGL((onesweep_pass_kernel<true, 1024>), grid, dim3(1024), 0, stream, b, p, status, items, scratch);
+                else hipLaunchKernelGGL((onesweep_pass_kernel<false, 1024>), grid, dim3(1024), 0, stream, b, p, status, items, scratch);
             } else if (b.sweep_threads == 512) {
-                if (b.atomic_rank) hipLaunchKernelGGL((onesweep_pass_kernel<true, 512>), grid, dim3(512), 0, stream, b, p, status);
-                else hipLaunchKernelGGL((onesweep_pass_kernel<false, 512>), grid, dim3(512), 0, stream, b, p, status);
+                if (b.atomic_rank) hipLaunchKernelGGL((onesweep_pass_kernel<true, 512>), grid, dim3(512), 0, stream, b, p, status, items, scratch);
+                else hipLaunchKernelGGL((onesweep_pass_kernel<false, 512>), grid, dim3(512), 0, stream, b, p, status, items, scratch);
             } else {
-                if (b.atomic_rank) hipLaunchKernelGGL((onesweep_pass_kernel<true, 256>), grid, dim3(256), 0, stream, b, p, status);
-                else hipLaunchKernelGGL((onesweep_pass_kernel<false, 256>), grid, dim3(256), 0, stream, b, p, status);
+                if (b.atomic_rank) hipLaunchKernelGGL((onesweep_pass_kernel<true, 256>), grid, dim3(256), 0, stream, b, p, status, items, scratch);
+                else hipLaunchKernelGGL((onesweep_pass_kernel<false, 256>), grid, dim3(256), 0, stream, b, p, status, items, scratch);
             }
             continue;
         }
@@ -1689,10 +1809,10 @@ hipError_t large_topic_launch(LargeScratch& scratch, const LargeArgs& a, bool ar
         LargeProfile& pf; bool on; hipStream_t st;
         ~Done() { if (on) (void)hipEventRecord(pf.ev[3], st); }
     } done{pf, profile, stream};
-    hipLaunchKernelGGL(build_keys_kernel, dim3(grid), dim3(256), 0, stream, a, b);
+    hipLaunchKernelGGL(build_keys_kernel, dim3(grid), dim3(256), 0, stream, a, b, (const LargeItem*)nullptr, (char*)nullptr);
     sort_run_passes(b, stream, a.status, profile ? pf.ev[1] : nullptr);
     if (profile) (void)hipEventRecord(pf.ev[2], stream);
-    hipLaunchKernelGGL(emit_ids_kernel, dim3(grid), dim3(256), 0, stream, a, b, a.n_cons == 0 ? 1 : 0);
+    hipLaunchKernelGGL(emit_ids_kernel, dim3(grid), dim3(256), 0, stream, a, b, (const LargeItem*)nullptr, (char*)nullptr);
     if ((e = hipGetLastError()) != hipSuccess) return e;
     if (a.n_cons == 0) return hipSuccess;
 
@@ -1710,14 +1830,213 @@ hipError_t large_topic_launch(LargeScratch& scratch, const LargeArgs& a, bool ar
         hipLaunchKernelGGL(greedy_argmin_kernel, dim3(1), dim3(threads), lds, stream, a, b);
         return hipGetLastError();
     }
-    int cp2 = 64;
-    while (cp2 < a.n_cons) cp2 <<= 1;
-    if (cp2 <= 1024) return launch_rounds<1>(a, b, cp2, stream);
-    switch (cp2 / 1024) {
-        case 2: return launch_rounds<2>(a, b, 1024, stream);
-        case 4: return launch_rounds<4>(a, b, 1024, stream);
-        default: return launch_rounds<8>(a, b, 1024, stream);
+    int ec = 1, threads = 64;
+    rounds_class(a.n_cons, &ec, &threads);
+    return launch_rounds_class(ec, threads, a, b, stream);
+}
+
+hipError_t large_topics_launch(LargeScratch& scratch, const LargeArgs* args, int count, hipStream_t stream) {
+    if (count <= 0) return hipSuccess;
+    hipError_t e;
+    std::vector<SortLayout> lay((size_t)count);
+    bool serial = count == 1;
+    for (int i = 0; i < count; ++i) {
+        if (args[i].n_part <= 0 || args[i].n_part > 0x7FFFFFFF || args[i].n_cons > kLargeMaxConsumers) return hipErrorInvalidValue;
+        lay[(size_t)i] = sort_layout(args[i].n_part, args[i].sort_multi_kernel != 0);
+        serial = serial || lay[(size_t)i].multi_kernel;
     }
+    if (serial) {
+        for (int i = 0; i < count; ++i)
+            if ((e = large_topic_launch(scratch, args[i], false, stream)) != hipSuccess) return e;
+        return hipSuccess;
+    }
+    // items in tile-class order (every class a contiguous range for the pass launches; stable: the call's first large topic
+    // of the first class sits at offset 0, where large_profile_read looks for a control block)
+    std::vector<int> idx((size_t)count);
+    for (int i = 0; i < count; ++i) idx[(size_t)i] = i;
+    std::stable_sort(idx.begin(), idx.end(), [&](int x, int y) { return lay[(size_t)x].sweep_threads < lay[(size_t)y].sweep_threads; });
+    size_t zero = 0, data = 0;
+    std::vector<size_t> zoff((size_t)count), doff((size_t)count);
+    for (int j = 0; j < count; ++j) {
+        const SortLayout& L = lay[(size_t)idx[(size_t)j]];
+        zoff[(size_t)j] = zero; zero += L.zero_bytes;
+        doff[(size_t)j] = data; data += L.data_bytes;
+    }
+    if ((e = scratch_reserve(scratch, zero + data, stream)) != hipSuccess) return e;
+    char* base = (char*)scratch.buf;
+
+    // the argument blocks + the greedy's order list (topics grouped by the (EC, threads) class of their rounds kernel)
+    const size_t items_bytes = align_up(sizeof(LargeItem) * (size_t)count, 256), bytes = items_bytes + sizeof(int32_t) * (size_t)count;
+    LargeScratch::Stage& sg = scratch.stage[scratch.stage_next++ & 1u];
+    if (sg.done) { if ((e = hipEventSynchronize(sg.done)) != hipSuccess) return e; }
+    else if ((e = hipEventCreateWithFlags(&sg.done, hipEventDisableTiming)) != hipSuccess) return e;
+    if (sg.cap < bytes) {
+        if (sg.h) { (void)hipHostFree(sg.h); sg.h = nullptr; sg.cap = 0; }
+        if ((e = hipHostMalloc(&sg.h, bytes + bytes / 2, hipHostMallocDefault)) != hipSuccess) return e;
+        sg.cap = bytes + bytes / 2;
+    }
+    if (scratch.d_items_cap < bytes) {
+        if (scratch.d_items) {
+            if ((e = hipStreamSynchronize(stream)) != hipSuccess) return e;
+            (void)hipFree(scratch.d_items);
+            scratch.d_items = nullptr; scratch.d_items_cap = 0;
+        }
+        if ((e = hipMalloc(&scratch.d_items, bytes + bytes / 2)) != hipSuccess) return e;
+        scratch.d_items_cap = bytes + bytes / 2;
+    }
+    LargeItem* h_items = (LargeItem*)sg.h;
+    int32_t* h_order = (int32_t*)((char*)sg.h + items_bytes);
+    int64_t max_n = 0;
+    for (int j = 0; j < count; ++j) {
+        const int i = idx[(size_t)j];
+        const SortLayout& L = lay[(size_t)i];
+        LargeItem& it = h_items[j];
+        it.p0 = args[i].p0; it.n_part = args[i].n_part; it.c0 = args[i].c0; it.n_cons = args[i].n_cons;
+        it.n = L.n; it.n_tiles = L.n_tiles; it.n_groups = L.n_groups;
+        const uint64_t z = zoff[(size_t)j], d = zero + doff[(size_t)j];
+        it.o_ctl = z + L.o_ctl; it.o_hist = z + L.o_hist; it.o_ticket = z + L.o_ticket; it.o_state = z + L.o_state;
+        it.o_gbase = d + L.o_gbase; it.o_k0 = d + L.o_k0; it.o_k1 = d + L.o_k1; it.o_v0 = d + L.o_v0; it.o_v1 = d + L.o_v1;
+        if (args[i].n_part > max_n) max_n = args[i].n_part;
+    }
+    struct Cls { int ec, threads, first, n; };
+    std::vector<Cls> cls;
+    {
+        std::vector<int> with;                                     // items that have consumers, by (EC, threads)
+        for (int j = 0; j < count; ++j) if (h_items[j].n_cons > 0) with.push_back(j);
+        auto key = [&](int j) { int ec, th; rounds_class(h_items[j].n_cons, &ec, &th); return ec * 2048 + th; };
+        std::stable_sort(with.begin(), with.end(), [&](int x, int y) { return key(x) < key(y); });
+        for (size_t k = 0; k < with.size(); ++k) {
+            h_order[k] = with[k];
+            int ec, th;
+            rounds_class(h_items[with[k]].n_cons, &ec, &th);
+            if (cls.empty() || cls.back().ec != ec || cls.back().threads != th) cls.push_back({ec, th, (int)k, 0});
+            ++cls.back().n;
+        }
+    }
+    if ((e = hipMemcpyAsync(scratch.d_items, sg.h, bytes, hipMemcpyHostToDevice, stream)) != hipSuccess) return e;
+    (void)hipEventRecord(sg.done, stream);
+    const LargeItem* d_items = (const LargeItem*)scratch.d_items;
+    const int32_t* d_order = (const int32_t*)((const char*)scratch.d_items + items_bytes);
+    if ((e = hipMemsetAsync(base, 0, zero, stream)) != hipSuccess) return e;
+
+    LargeProfile& pf = scratch.prof;
+    const bool profile = pf.armed && !pf.recorded;
+    if (profile) {
+        for (hipEvent_t& ev : pf.ev)
+            if (!ev && (e = hipEventCreate(&ev)) != hipSuccess) return e;
+        pf.n = h_items[0].n_part;
+        pf.recorded = true;
+        (void)hipEventRecord(pf.ev[0], stream);
+    }
+    int gx = (int)((max_n + 255) / 256);
+    if (gx > 2048) gx = 2048;
+    // a0: the batch's arrays and flags, shared by every item (an item overrides the four segment fields); b0: what is common
+    // to a launch's items besides their buffers
+    LargeArgs a0 = args[0];
+    SortBufs b0{};
+    b0.atomic_rank = large_atomic_rank_supported();
+    uint32_t* status = args[0].status;
+    hipLaunchKernelGGL(build_keys_kernel, dim3(gx, count), dim3(256), 0, stream, a0, b0, d_items, base);
+    hipLaunchKernelGGL(plan_kernel, dim3(kDigits, count), dim3(kRadix), 0, stream, b0, d_items, base);
+    if (profile) (void)hipEventRecord(pf.ev[1], stream);
+    for (int first = 0; first < count;) {                          // one set of pass launches per tile class
+        const int sweep = lay[(size_t)idx[(size_t)first]].sweep_threads;
+        int n = 0, max_tiles = 0;
+        while (first + n < count && lay[(size_t)idx[(size_t)(first + n)]].sweep_threads == sweep) {
+            if (h_items[first + n].n_tiles > max_tiles) max_tiles = h_items[first + n].n_tiles;
+            ++n;
+        }
+        SortBufs bc = b0;
+        bc.sweep_threads = sweep;
+        bc.tile_state = (unsigned long long*)base;                 // (non-null: the single-kernel passes; items carry the real one)
+        sort_run_passes(bc, stream, status, nullptr, (1u << kDigits) - 1, d_items + first, n, max_tiles, base);
+        first += n;
+    }
+    if (profile) (void)hipEventRecord(pf.ev[2], stream);
+    hipLaunchKernelGGL(emit_ids_kernel, dim3(gx, count), dim3(256), 0, stream, a0, b0, d_items, base);
+    for (const Cls& c : cls)
+        if ((e = launch_rounds_class(c.ec, c.threads, a0, b0, stream, d_items, base, d_order + c.first, c.n)) != hipSuccess) return e;
+    if (!cls.empty()) hipLaunchKernelGGL(map_ranks_kernel, dim3(gx, count), dim3(256), 0, stream, a0, d_items);
+    if (profile) (void)hipEventRecord(pf.ev[3], stream);
+    return hipGetLastError();
+}
+
+// ---- more consumers than one workgroup's registers hold (> kLargeMaxConsumers): bins in HBM -------------------------------
+// Collections.min over the bins takes any C (Main.java:240-263).  The round structure still holds: in round r the k-th
+// sorted partition of the round goes to the k-th bin in (total, member) order as of the round start -- so a round is ONE
+// stable device sort of the C bins by total (payload = consumer index, ascending on input: ties keep member order) with the
+// radix passes above, and one pass that hands the round's lags out in that order.  ceil(P / C) rounds of ~11 launches:
+// slow next to the one-workgroup kernels (which stop at 8 192 bins), exact, and without a limit.
+//   huge_round_kernel   position k of the current order: total += lag of the round's k-th partition, member rank out; the
+//                       new total goes to slot `consumer index` of the next sort's input, with its digit histograms.
+__global__ __launch_bounds__(256) void huge_round_kernel(LargeArgs a, SortBufs parts, SortBufs cur, SortBufs next, int64_t round,
+                                                         int first, int last) {
+    __shared__ uint32_t h[8 * kRadix];
+    for (int i = threadIdx.x; i < 8 * kRadix; i += blockDim.x) h[i] = 0;
+    __syncthreads();
+    const int64_t C = a.n_cons, P = a.n_part;
+    const uint64_t* lagkey = parts.key[parts.ctl->cur[kDigits]];
+    const uint32_t fin = first ? 0u : cur.ctl->cur[kDigits];
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < C; k += stride) {
+        uint64_t total = kTotalBias;                                  // biased: unsigned order = Java's signed order
+        uint32_t idx = (uint32_t)k;
+        if (!first) { total = cur.key[fin][k]; idx = cur.val[fin][k]; }
+        const int64_t s = round * C + k;
+        if (s < P) {
+            total += lagkey[s] ^ kLagKeyFlip;                         // Main.java:265, wrapping like a long
+            a.out_rank[a.p0 + s] = a.cons_rank[a.c0 + idx];
+        }
+        if (last) {
+            if (a.out_total) a.out_total[a.c0 + idx] = (int64_t)(total ^ kTotalBias);
+        } else {
+            next.key[0][idx] = total;
+            next.val[0][idx] = idx;
+#pragma unroll
+            for (int d = 0; d < 8; ++d) atomicAdd(&h[d * kRadix + ((uint32_t)(total >> (8 * d)) & 0xFFu)], 1u);
+        }
+    }
+    if (last) return;
+    __syncthreads();
+    for (int i = threadIdx.x; i < 8 * kRadix; i += blockDim.x)
+        if (h[i]) atomicAdd(&next.hist[4 * kRadix + i], h[i]);
+    // the id digits: the payload is ascending (slot = consumer index), the plan skips their passes
+    if (blockIdx.x == 0 && threadIdx.x < 4) next.hist[threadIdx.x * kRadix] = (uint32_t)C;
+}
+
+hipError_t huge_topic_launch(LargeScratch& scratch, const LargeArgs& a, hipStream_t stream) {
+    const int64_t P = a.n_part, C = a.n_cons;
+    if (P <= 0) {
+        if (C > 0 && a.out_total) return hipMemsetAsync(a.out_total + a.c0, 0, (size_t)C * sizeof(int64_t), stream);
+        return hipSuccess;
+    }
+    if (P > 0x7FFFFFFF || C > 0x7FFFFFFF || C <= 0) return hipErrorInvalidValue;
+    const SortLayout lp = sort_layout(P, a.sort_multi_kernel != 0), lc = sort_layout(C, false);
+    hipError_t e;
+    const size_t zero = lp.zero_bytes + 2 * lc.zero_bytes, data = lp.data_bytes + 2 * lc.data_bytes;
+    if ((e = scratch_reserve(scratch, zero + data, stream)) != hipSuccess) return e;
+    char* base = (char*)scratch.buf;
+    const SortBufs bp = sort_bind(lp, base, base + zero);
+    SortBufs bins[2] = {sort_bind(lc, base + lp.zero_bytes, base + zero + lp.data_bytes),
+                        sort_bind(lc, base + lp.zero_bytes + lc.zero_bytes, base + zero + lp.data_bytes + lc.data_bytes)};
+    if ((e = hipMemsetAsync(base, 0, lp.zero_bytes, stream)) != hipSuccess) return e;
+    int grid = (int)((P + 255) / 256);
+    if (grid > 2048) grid = 2048;
+    hipLaunchKernelGGL(build_keys_kernel, dim3(grid), dim3(256), 0, stream, a, bp, (const LargeItem*)nullptr, (char*)nullptr);
+    sort_run_passes(bp, stream, a.status);
+    hipLaunchKernelGGL(emit_ids_kernel, dim3(grid), dim3(256), 0, stream, a, bp, (const LargeItem*)nullptr, (char*)nullptr);
+    int cgrid = (int)((C + 255) / 256);
+    if (cgrid > 1024) cgrid = 1024;
+    const int64_t rounds = (P + C - 1) / C;
+    for (int64_t r = 0; r < rounds; ++r) {
+        const SortBufs& cur = bins[r & 1];
+        const SortBufs& next = bins[(r + 1) & 1];
+        const int last = r + 1 == rounds;
+        if (!last && (e = hipMemsetAsync((char*)next.ctl, 0, lc.zero_bytes, stream)) != hipSuccess) return e;
+        hipLaunchKernelGGL(huge_round_kernel, dim3(cgrid), dim3(256), 0, stream, a, bp, cur, next, r, r == 0 ? 1 : 0, last);
+        if (!last) sort_run_passes(next, stream, a.status, nullptr, 0xFF0u);       // the 8 digits of the totals; ids stay in order
+    }
+    return hipGetLastError();
 }
 
 // ---- the same grouping for what a real rebalance is: a few hundred entries -------------------------------------------------
@@ -1853,6 +2172,15 @@ void large_scratch_release(LargeScratch& s) {
     if (s.buf) (void)hipFree(s.buf);
     s.buf = nullptr;
     s.cap = 0;
+    for (LargeScratch::Stage& sg : s.stage) {
+        if (sg.done) { (void)hipEventSynchronize(sg.done); (void)hipEventDestroy(sg.done); sg.done = nullptr; }
+        if (sg.h) (void)hipHostFree(sg.h);
+        sg.h = nullptr;
+        sg.cap = 0;
+    }
+    if (s.d_items) (void)hipFree(s.d_items);
+    s.d_items = nullptr;
+    s.d_items_cap = 0;
     for (hipEvent_t& ev : s.prof.ev) {
         if (ev) (void)hipEventDestroy(ev);
         ev = nullptr;

@@ -260,3 +260,119 @@ def test_calls_leave_the_current_device_alone(ctx, torch_dev):
     ctx.assign_batch(w.part_off, w.partition_id, w.begin, w.end, w.committed, N.LA_RESET_EARLIEST, w.cons_off, w.cons_rank)
     ctx.device_features(0)
     assert torch.cuda.current_device() == before
+
+
+# ---- large topics side by side and more than 8 192 consumers (#6) ------------------------------------------
+from oracle.round_form import round_form  # noqa: E402
+
+
+def _batch_of(shapes, seed, kinds=None, negative=False):
+    """A batch of topics with the given (partitions, consumers) shapes; lags per `kinds` (default: mixed)."""
+    rng = np.random.default_rng(seed)
+    ps = [s[0] for s in shapes]
+    cs = [s[1] for s in shapes]
+    part_off = np.concatenate([[0], np.cumsum(ps)]).astype(np.int64)
+    cons_off = np.concatenate([[0], np.cumsum(cs)]).astype(np.int64)
+    pid = np.concatenate([rng.permutation(p) if i % 3 else np.arange(p) for i, p in enumerate(ps)] + [np.empty(0, np.int64)]).astype(np.int32)
+    lags = []
+    for i, p in enumerate(ps):
+        kind = (kinds or ["u40", "ties", "pareto", "zero", "u20", "full"])[i % (len(kinds) if kinds else 6)]
+        if kind == "u40":
+            l = rng.integers(0, 1 << 40, p)
+        elif kind == "u20":
+            l = rng.integers(0, 1 << 20, p)
+        elif kind == "ties":
+            l = rng.integers(0, 7, p) * 1000
+        elif kind == "zero":
+            l = np.zeros(p, np.int64)
+        elif kind == "pareto":
+            l = np.floor(np.minimum(float(1 << 40), 1000.0 * (1.0 - rng.random(p)) ** (-1.0 / 1.5))).astype(np.int64)
+        else:
+            l = rng.integers(-(1 << 63), (1 << 63) - 1, p)
+            if not negative:
+                l = np.where(l < 0, ~l, l)
+        lags.append(np.asarray(l, np.int64))
+    lag = np.concatenate(lags + [np.empty(0, np.int64)])
+    ranks = np.concatenate([np.sort(rng.choice(3 * c + 5, c, replace=False)) for c in cs] + [np.empty(0, np.int64)]).astype(np.int32)
+    n = int(part_off[-1])
+    return synth.Workload("batch", len(shapes), part_off, pid, np.zeros(n, np.int64), lag.copy(), np.zeros(n, np.int64), lag,
+                          cons_off, ranks, max(ps) if ps else 0, max(cs) if cs else 0)
+
+
+def _device_call(ctx, w, flags=0, algo=N.LA_ALGO_AUTO, want_totals=True):
+    import ctypes
+    import torch
+    dev = torch.device("cuda", 0)
+    d = {k: torch.from_numpy(np.ascontiguousarray(getattr(w, k))).to(dev) for k in ("part_off", "partition_id", "lag", "cons_off", "cons_rank")}
+    out_pid = torch.full((max(w.n_partitions, 1),), -7, device=dev, dtype=torch.int32)
+    out_rank = torch.full((max(w.n_partitions, 1),), -7, device=dev, dtype=torch.int32)
+    out_total = torch.full((max(w.cons_rank.size, 1),), -7, device=dev, dtype=torch.int64)
+    b = N.DeviceBatch()
+    b.n_topics, b.reset_mode, b.algo, b.flags = w.n_topics, N.LA_RESET_LATEST, algo, flags
+    b.n_partitions, b.n_consumers = w.n_partitions, w.cons_rank.size
+    b.max_partitions_per_topic, b.max_consumers_per_topic = w.max_partitions, w.max_consumers
+    b.d_part_off, b.d_partition_id, b.d_lag = d["part_off"].data_ptr(), d["partition_id"].data_ptr(), d["lag"].data_ptr()
+    b.d_cons_off, b.d_cons_rank = d["cons_off"].data_ptr(), d["cons_rank"].data_ptr()
+    b.d_out_partition, b.d_out_member_rank = out_pid.data_ptr(), out_rank.data_ptr()
+    b.d_out_total_lag = out_total.data_ptr() if want_totals else None
+    po, co = np.ascontiguousarray(w.part_off, np.int64), np.ascontiguousarray(w.cons_off, np.int64)
+    b.h_part_off = po.ctypes.data_as(ctypes.POINTER(ctypes.c_int64))
+    b.h_cons_off = co.ctypes.data_as(ctypes.POINTER(ctypes.c_int64))
+    stream = torch.cuda.current_stream().cuda_stream
+    ctx.assign_batch_device(b, stream)
+    ctx.sync(stream)
+    return out_pid.cpu().numpy()[: w.n_partitions], out_rank.cpu().numpy()[: w.n_partitions], out_total.cpu().numpy()[: w.cons_rank.size]
+
+
+def _same3(got, exp, what=""):
+    for g, e, name in zip(got, exp, ("partition order", "member", "totals")):
+        np.testing.assert_array_equal(g, e, err_msg="%s %s" % (name, what))
+
+
+def test_large_topics_side_by_side_mixed_batch(ctx):
+    """Large topics of every tile class and rounds class, with and without consumers, between tile- and block-sized topics and
+    topics without partitions: the shared launches give what the serial form gives, which is what the oracle gives."""
+    shapes = [(100, 5), (20000, 50), (0, 3), (70000, 300), (3000, 200), (18000, 3000), (17000, 0), (150000, 8192),
+              (40000, 1), (0, 0), (16385, 64), (300000, 700), (20000, 2049), (64, 8), (3300000, 5)]
+    w = _batch_of(shapes, 11)
+    exp = round_form(w.part_off, w.partition_id, w.lag, w.cons_off, w.cons_rank)
+    got = _device_call(ctx, w)
+    _same3(got, exp, "side by side")
+    serial = _device_call(ctx, w, flags=N.LA_FLAG_SERIAL_LARGE)
+    _same3(serial, exp, "serial hook")
+    host = ctx.assign_batch_lags(w.part_off, w.partition_id, w.lag, w.cons_off, w.cons_rank)       # the host entry, chunks and all
+    _same3(host, exp, "host entry")
+    # and twice in a row on the same context (the staging slots alternate; scratch is reused)
+    _same3(_device_call(ctx, w), exp, "second call")
+    # test hooks of the sort / the greedy still apply to every topic of the launch
+    for fl in (N.LA_FLAG_NO_SAMPLE_SORT, N.LA_FLAG_SAMPLE_TIGHT, N.LA_FLAG_NO_RUN_MERGE, N.LA_FLAG_SORT_MULTIKERNEL):
+        _same3(_device_call(ctx, w, flags=fl), exp, "flag %d" % fl)
+
+
+def test_many_equal_large_topics_literal_oracle(ctx):
+    """24 topics x 20 000 partitions x 2 100 consumers with wide, negative and tied lags, against the LITERAL oracle."""
+    w = _batch_of([(20000, 2100)] * 24, 5, kinds=["full", "u40", "ties"], negative=True)
+    exp = oracle.assign_flat(w.part_off, w.partition_id, w.lag, w.cons_off, w.cons_rank)
+    _same3(_device_call(ctx, w), exp)
+
+
+@pytest.mark.parametrize("p,c,kind", [
+    (200000, 20000, "pareto"), (8193 * 3, 8193, "u40"), (5000, 9000, "u40"), (18000, 9000, "ties"), (30000, 10000, "zero"),
+    (27000, 9000, "full"), (100000, 70000, "u20")])
+def test_more_consumers_than_one_workgroup_holds(ctx, p, c, kind):
+    """> 8 192 consumers: bins in HBM, a device sort per round.  P < C (one partial round), P = k * C exactly,
+    ties, zero lags, negative lags with wrapping totals."""
+    w = _batch_of([(p, c)], p + c, kinds=[kind], negative=True)
+    exp = round_form(w.part_off, w.partition_id, w.lag, w.cons_off, w.cons_rank)
+    _same3(_device_call(ctx, w), exp, "%d x %d %s" % (p, c, kind))
+    if p * c <= 200_000_000:                                             # the literal per-step min where it is affordable
+        _same3(exp, oracle.assign_flat(w.part_off, w.partition_id, w.lag, w.cons_off, w.cons_rank), "round form vs literal")
+    got = _device_call(ctx, w, want_totals=False)
+    np.testing.assert_array_equal(got[1], exp[1])
+
+
+def test_huge_consumer_topic_inside_a_batch(ctx):
+    w = _batch_of([(256, 32), (30000, 8300), (20000, 100), (0, 9000), (60000, 20000), (5000, 300)], 21)
+    exp = round_form(w.part_off, w.partition_id, w.lag, w.cons_off, w.cons_rank)
+    _same3(_device_call(ctx, w), exp)
+    _same3(ctx.assign_batch_lags(w.part_off, w.partition_id, w.lag, w.cons_off, w.cons_rank), exp, "host entry")
