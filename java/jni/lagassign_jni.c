@@ -123,6 +123,30 @@ Java_com_github_grantneale_kafka_gpu_LagAssignNative_assignBatchGrouped(
 }
 
 JNIEXPORT jint JNICALL
+Java_com_github_grantneale_kafka_gpu_LagAssignNative_assignBatchGroupedSparse(
+    JNIEnv *env, jclass cls, jlong ctx, jint n_topics, jobject part_off, jobject partition_id, jobject end,
+    jobject committed, jint reset_mode, jlong n_none, jobject none_index, jobject none_begin, jobject cons_off,
+    jobject cons_rank, jint n_members, jobject member_off, jobject grouped_topic, jobject grouped_partition,
+    jobject out_total_lag) {
+    (void)cls;
+    return la_assign_batch_grouped_sparse(CTX(ctx), n_topics,
+                                          (const int64_t *)ADDR(env, part_off), (const int32_t *)ADDR(env, partition_id),
+                                          (const int64_t *)ADDR(env, end), (const int64_t *)ADDR(env, committed), reset_mode,
+                                          (int64_t)n_none, (const int64_t *)ADDR(env, none_index),
+                                          (const int64_t *)ADDR(env, none_begin),
+                                          (const int64_t *)ADDR(env, cons_off), (const int32_t *)ADDR(env, cons_rank),
+                                          n_members, (int64_t *)ADDR(env, member_off), (int32_t *)ADDR(env, grouped_topic),
+                                          (int32_t *)ADDR(env, grouped_partition), (int64_t *)ADDR(env, out_total_lag));
+}
+
+JNIEXPORT jint JNICALL
+Java_com_github_grantneale_kafka_gpu_LagAssignNative_version(JNIEnv *env, jclass cls) {
+    (void)env;
+    (void)cls;
+    return la_version();
+}
+
+JNIEXPORT jint JNICALL
 Java_com_github_grantneale_kafka_gpu_LagAssignNative_groupLastByMember(
     JNIEnv *env, jclass cls, jlong ctx, jint n_members, jobject member_off, jobject grouped_topic,
     jobject grouped_partition) {

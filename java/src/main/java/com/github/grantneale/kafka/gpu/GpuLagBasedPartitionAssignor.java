@@ -189,6 +189,11 @@ public class GpuLagBasedPartitionAssignor implements ConsumerPartitionAssignor, 
         final LongBuffer endOff = engine.end.longs;
         final LongBuffer committedOff = engine.committed.longs;
         final IntBuffer consRank = engine.consRank.ints;
+        // The beginning offset is read only where there is no committed offset (Main.java:384-396): those partitions are
+        // listed as (position, begin) pairs and the dense array stays on this side of PCIe (la_assign_batch_grouped_sparse).
+        final LongBuffer noneIndex = engine.noneIndex.longs;
+        final LongBuffer noneBegin = engine.noneBegin.longs;
+        long nNone = 0;
         int cursor = 0;
         int k = 0;
         for (int t = 0; t < nTopics; t++) {
@@ -197,10 +202,16 @@ public class GpuLagBasedPartitionAssignor implements ConsumerPartitionAssignor, 
             for (int i = 0; i < partCount[t]; i++, cursor++) {
                 final TopicPartition tp = all.get(cursor);
                 final OffsetAndMetadata md = committed.get(tp);
+                final long b = begin.getOrDefault(tp, 0L);
                 partitionId.put(cursor, tp.partition());
-                beginOff.put(cursor, begin.getOrDefault(tp, 0L));
+                beginOff.put(cursor, b);
                 endOff.put(cursor, end.getOrDefault(tp, 0L));
                 committedOff.put(cursor, md == null ? LagAssignNative.NO_COMMITTED : md.offset());
+                if (md == null) {
+                    noneIndex.put((int) nNone, cursor);
+                    noneBegin.put((int) nNone, b);
+                    nNone++;
+                }
             }
             final int[] ranks = plan.topicRanks.get(t);
             for (int r : ranks) {
@@ -223,13 +234,13 @@ public class GpuLagBasedPartitionAssignor implements ConsumerPartitionAssignor, 
             lists = engine.memberLists(plan, n);
         } else {
             // normally the ungrouped result never leaves the device, and assignment + every member's list are ONE native
-            // call: for a rebalance of ordinary size one upload, one download, one wait (la_assign_batch_grouped)
+            // call: for a rebalance of ordinary size one upload, one download, one wait (la_assign_batch_grouped_sparse)
             final int nMembers = plan.byRank.length;
             engine.memberOff.ensure(engine, 8L * (nMembers + 1));
-            engine.check(LagAssignNative.assignBatchGrouped(engine.ctx, nTopics, engine.partOff.bytes,
-                engine.partitionId.bytes, engine.begin.bytes, engine.end.bytes, engine.committed.bytes, reset,
-                engine.consOff.bytes, engine.consRank.bytes, nMembers, engine.memberOff.bytes,
-                engine.groupedTopic.bytes, engine.groupedPartition.bytes, engine.outTotal.bytes));
+            engine.check(LagAssignNative.assignBatchGroupedSparse(engine.ctx, nTopics, engine.partOff.bytes,
+                engine.partitionId.bytes, engine.end.bytes, engine.committed.bytes, reset, nNone,
+                engine.noneIndex.bytes, engine.noneBegin.bytes, engine.consOff.bytes, engine.consRank.bytes, nMembers,
+                engine.memberOff.bytes, engine.groupedTopic.bytes, engine.groupedPartition.bytes, engine.outTotal.bytes));
             lists = engine.wrapLists(plan);
         }
         if (trace) {
@@ -451,6 +462,8 @@ public class GpuLagBasedPartitionAssignor implements ConsumerPartitionAssignor, 
         final Buf consOff = new Buf();
         final Buf partitionId = new Buf();
         final Buf begin = new Buf();
+        final Buf noneIndex = new Buf();
+        final Buf noneBegin = new Buf();
         final Buf end = new Buf();
         final Buf committed = new Buf();
         final Buf lag = new Buf();
@@ -464,6 +477,11 @@ public class GpuLagBasedPartitionAssignor implements ConsumerPartitionAssignor, 
 
         void open() {
             if (ctx == 0) {
+                // the sparse-begin entry point exists since ABI 0.3.0 (include/lagassign.h: LA_VERSION)
+                final int version = LagAssignNative.version();
+                if (version < 300) {
+                    throw new NativeAssignException("liblagassign ABI " + version + " is older than the 300 this host binds");
+                }
                 try {
                     ctx = LagAssignNative.createMulti(devices);  // the shim throws IllegalStateException(la_last_error)
                 } catch (IllegalStateException e) {
@@ -479,6 +497,8 @@ public class GpuLagBasedPartitionAssignor implements ConsumerPartitionAssignor, 
             consOff.ensure(this, 8L * (nTopics + 1));
             partitionId.ensure(this, 4L * n);
             begin.ensure(this, 8L * n);
+            noneIndex.ensure(this, 8L * n);
+            noneBegin.ensure(this, 8L * n);
             end.ensure(this, 8L * n);
             committed.ensure(this, 8L * n);
             lag.ensure(this, 8L * n);
@@ -609,7 +629,7 @@ public class GpuLagBasedPartitionAssignor implements ConsumerPartitionAssignor, 
 
         void close() {
             if (ctx != 0) {
-                for (Buf b : new Buf[] {partOff, consOff, partitionId, begin, end, committed, lag, consRank,
+                for (Buf b : new Buf[] {partOff, consOff, partitionId, begin, noneIndex, noneBegin, end, committed, lag, consRank,
                                         outPartition, outMemberRank, outTotal, memberOff, groupedTopic,
                                         groupedPartition}) {
                     b.release(this);

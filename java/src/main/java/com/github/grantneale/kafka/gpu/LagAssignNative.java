@@ -73,6 +73,21 @@ final class LagAssignNative {
                                          ByteBuffer consOff, ByteBuffer consRank, int nMembers, ByteBuffer memberOff,
                                          ByteBuffer groupedTopic, ByteBuffer groupedPartition, ByteBuffer outTotalLag);
 
+    /**
+     * la_assign_batch_grouped_sparse: assignBatchGrouped with the beginning offsets handed over only where they are read --
+     * for the {@code nNone} partitions without a committed offset (LagBasedPartitionAssignor.java:384-396 of the reference):
+     * noneIndex int64[nNone] = their positions in the per-partition arrays, ascending; noneBegin int64[nNone] = their
+     * beginning offsets.  8 of the 28 input bytes per partition no longer cross PCIe.  Needs la_version() &gt;= 300.
+     */
+    static native int assignBatchGroupedSparse(long ctx, int nTopics, ByteBuffer partOff, ByteBuffer partitionId,
+                                               ByteBuffer end, ByteBuffer committed, int resetMode, long nNone,
+                                               ByteBuffer noneIndex, ByteBuffer noneBegin, ByteBuffer consOff,
+                                               ByteBuffer consRank, int nMembers, ByteBuffer memberOff,
+                                               ByteBuffer groupedTopic, ByteBuffer groupedPartition, ByteBuffer outTotalLag);
+
+    /** la_version of the loaded library: major * 10000 + minor * 100 + patch. */
+    static native int version();
+
     /** la_assign_batch_lags: the static assign(Map,Map) seam, on precomputed lags (any int64). */
     static native int assignBatchLags(long ctx, int nTopics, ByteBuffer partOff, ByteBuffer partitionId,
                                       ByteBuffer lag, ByteBuffer consOff, ByteBuffer consRank,

@@ -118,7 +118,10 @@ struct TopicData {
 struct Flat {
     std::vector<int64_t> part_off{0}, cons_off{0};
     std::vector<int32_t> pid, cons_rank;
-    std::vector<int64_t> lag, begin, end, committed;
+    std::vector<int64_t> lag, end, committed;
+    // the beginning offset is read only where a partition has no committed offset (Main.java:384-396): it crosses the
+    // boundary as (position, begin) pairs for those partitions alone (la_assign_batch_grouped_sparse)
+    std::vector<int64_t> none_index, none_begin;
 };
 
 Assignment run_native(const Plan& plan, const std::vector<const TopicData*>& data, bool offsets_mode,
@@ -130,7 +133,12 @@ Assignment run_native(const Plan& plan, const std::vector<const TopicData*>& dat
         if (d) {
             f.pid.insert(f.pid.end(), d->partition.begin(), d->partition.end());
             if (offsets_mode) {
-                f.begin.insert(f.begin.end(), d->begin.begin(), d->begin.end());
+                const int64_t base = (int64_t)f.end.size();
+                for (size_t i = 0; i < d->committed.size(); ++i)
+                    if (d->committed[i] < 0) {                        // partitionMetadata == null, Main.java:384
+                        f.none_index.push_back(base + (int64_t)i);
+                        f.none_begin.push_back(d->begin[i]);
+                    }
                 f.end.insert(f.end.end(), d->end.begin(), d->end.end());
                 f.committed.insert(f.committed.end(), d->committed.begin(), d->committed.end());
             } else {
@@ -154,11 +162,12 @@ Assignment run_native(const Plan& plan, const std::vector<const TopicData*>& dat
         la_ctx* ctx = shared_ctx_locked();
         if (offsets_mode) {
             // assign(Cluster, GroupSubscription): both steps in ONE native call -- for a rebalance of ordinary size one
-            // upload, one download, one wait (la_assign_batch_grouped)
-            check(ctx, la_assign_batch_grouped(ctx, (int32_t)plan.topics.size(), f.part_off.data(), f.pid.data(),
-                                               f.begin.data(), f.end.data(), f.committed.data(), reset_mode,
-                                               f.cons_off.data(), f.cons_rank.data(), n_members, member_off.data(),
-                                               grouped_topic.data(), grouped_pid.data(), out_total.data()));
+            // upload, one download, one wait (la_assign_batch_grouped_sparse: `begin` only where it is read)
+            check(ctx, la_assign_batch_grouped_sparse(ctx, (int32_t)plan.topics.size(), f.part_off.data(), f.pid.data(),
+                                                      f.end.data(), f.committed.data(), reset_mode,
+                                                      (int64_t)f.none_index.size(), f.none_index.data(), f.none_begin.data(),
+                                                      f.cons_off.data(), f.cons_rank.data(), n_members, member_off.data(),
+                                                      grouped_topic.data(), grouped_pid.data(), out_total.data()));
         } else {
             check(ctx, la_assign_batch_lags(ctx, (int32_t)plan.topics.size(), f.part_off.data(), f.pid.data(), f.lag.data(),
                                             f.cons_off.data(), f.cons_rank.data(), nullptr, nullptr, out_total.data()));
