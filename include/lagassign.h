@@ -173,6 +173,7 @@ int la_plan_shards(int32_t n_topics, const int64_t *part_off, int32_t n_shards, 
 int la_last_shard_bounds(const la_ctx *ctx, int32_t *bounds, int32_t capacity);
 
 /* How the last la_assign_batch / la_assign_batch_lags call moved its data (diagnostics, tests):
+ *   LA_PIPELINE_ZERO_COPY the call a real rebalance is: kernels read and write host memory in place, no copy, no stream wait
  *   LA_PIPELINE_ONE_COPY  a small batch: one H2D and one D2H of a staging buffer
  *   LA_PIPELINE_LANES     chunks over the shard's lanes, one short-lived host thread per lane (pageable caller arrays:
  *                         their copies block the issuing thread)
@@ -182,6 +183,10 @@ int la_last_shard_bounds(const la_ctx *ctx, int32_t *bounds, int32_t capacity);
 #define LA_PIPELINE_ONE_COPY 0
 #define LA_PIPELINE_LANES    1
 #define LA_PIPELINE_STREAMS  2
+#define LA_PIPELINE_ZERO_COPY 3   /* the smallest calls (staging layout up to 128 KB, ~2 500 partitions; environment
+                                   * LA_ZERO_COPY_BYTES overrides, 0 = never): no copy at all -- the kernels read the inputs in
+                                   * place from coherent, device-mapped host memory and write totals / results / member lists
+                                   * into it; the call's last launch stores the status where the calling thread is spinning */
 int la_last_pipeline(const la_ctx *ctx);
 
 /* Pinned host memory for the arrays handed to the host-buffer calls (a JNI shim wraps it in a direct ByteBuffer

@@ -101,6 +101,7 @@ struct Shard {
     // through these two staging buffers (device, pinned host) instead of eight copies of caller arrays
     DevBuf small_d, small_g;
     HostBuf small_h, small_gh;
+    HostBuf zc_h;                        // zero-copy small calls: coherent, device-mapped staging the kernels read and write in place
     // pinned caller arrays (la_host_alloc): one host thread, three streams -- every H2D of the call in order on copy_in,
     // the kernels on lane 0's stream, every D2H on copy_out, chained per chunk by events (run_shard_async)
     static constexpr int kCopyIn = 2;    // input streams, alternating per chunk: a copy costs ~20 us of engine latency before its
@@ -119,6 +120,7 @@ struct la_ctx {
     int last_pipeline = 0;               // how the last host-buffer call moved its data: 0 = one copy each way (small batch),
                                          // 1 = lanes (a host thread per stream; pageable arrays), 2 = three streams, no threads (pinned)
     std::vector<void*> comms;            // la_allgather_results: one ncclComm_t per shard, created on first use
+    size_t zero_copy_bytes = 0;          // calls whose staging layout is at most this large run zero-copy (assign_small_zc)
     int last_shards = 0;                 // shards the last call used
     int32_t last_bounds[65] = {};        // their topic ranges
 };
@@ -865,8 +867,16 @@ int run_shard_async(la_ctx* ctx, const HostCall& c, Shard& sh, ShardPlan& sp) {
     Lane& ln = sh.lanes[0];
     hipStream_t sk = ln.stream, so = sh.copy_out;
     // the consumer ranks of the whole shard go up once (4 B per entry: too small to be worth a copy per chunk)
-    if (sp.k) {
-        LA_HIP(ctx, hipMemcpyAsync(sh.cons_rank.p, c.cons_rank + sp.K0, (size_t)sp.k * 4, hipMemcpyHostToDevice, sh.copy_in[1]));
+    // ... and so does the shard's slice of a sparse begin list (16 B per listed partition: one copy pair, not one per chunk --
+    // every copy costs ~20 us of engine latency before its first byte moves)
+    const size_t m_all = c.sparse ? (size_t)(sp.none_at[(size_t)n_chunks] - sp.none_at[0]) : 0;
+    if (sp.k || m_all) {
+        if (sp.k)
+            LA_HIP(ctx, hipMemcpyAsync(sh.cons_rank.p, c.cons_rank + sp.K0, (size_t)sp.k * 4, hipMemcpyHostToDevice, sh.copy_in[1]));
+        if (m_all) {
+            LA_HIP(ctx, hipMemcpyAsync(sh.none_idx.p, c.none_index + sp.none_at[0], m_all * 8, hipMemcpyHostToDevice, sh.copy_in[1]));
+            LA_HIP(ctx, hipMemcpyAsync(sh.none_val.p, c.none_begin + sp.none_at[0], m_all * 8, hipMemcpyHostToDevice, sh.copy_in[1]));
+        }
         LA_HIP(ctx, hipEventRecord(sh.chunk_ev[(size_t)(2 * n_chunks)], sh.copy_in[1]));
         LA_HIP(ctx, hipStreamWaitEvent(sk, sh.chunk_ev[(size_t)(2 * n_chunks)], 0));
     }
@@ -887,17 +897,13 @@ int run_shard_async(la_ctx* ctx, const HostCall& c, Shard& sh, ShardPlan& sp) {
                 if (c.use_begin && !c.sparse)
                     LA_HIP(ctx, hipMemcpyAsync((int64_t*)sh.begin.p + p0, c.begin + gp, np * 8, hipMemcpyHostToDevice, si));
             }
-            if (c.sparse) {
-                // the list's slice rides the input stream with the chunk's other arrays; zero + scatter run on the kernel stream
-                if (int rc = sparse_begin_chunk(ctx, c, sh, sp, ci, ln, si, nullptr)) return rc;
-            }
             LA_HIP(ctx, hipEventRecord(ev_in, si));
             LA_HIP(ctx, hipStreamWaitEvent(sk, ev_in, 0));
             if (c.sparse)
                 if (int rc = sparse_begin_chunk(ctx, c, sh, sp, ci, ln, nullptr, sk)) return rc;
         }
         if (c.sparse && !np && sp.none_at[(size_t)ci + 1] > sp.none_at[(size_t)ci])      // entries where there are no partitions:
-            if (int rc = sparse_begin_chunk(ctx, c, sh, sp, ci, ln, sk, sk)) return rc;       // the kernel reports them
+            if (int rc = sparse_begin_chunk(ctx, c, sh, sp, ci, ln, nullptr, sk)) return rc;  // the kernel reports them
         if (nk)
             LA_HIP(ctx, la::check_consumers_launch(z - a, (const int64_t*)sh.cons_off.p + a, (const int32_t*)sh.cons_rank.p,
                                                    ln.d_status, sk));
@@ -1032,15 +1038,133 @@ SmallLayout small_layout(const HostCall& c) {
     return L;
 }
 
-int assign_small(la_ctx* ctx, const HostCall& c, Shard& sh, const SmallLayout& L) {
+// ---- the smallest calls: zero copies ----------------------------------------------------------------------------------
+// For a rebalance of a few dozen topics even the two DMA submissions of assign_small are most of the call (~8 us each of ~35).
+// Here the staging buffer is coherent host memory mapped into the device: the kernels READ the inputs in place over PCIe (all
+// loads of a tile go out back to back: a couple of ~1.5 us round trips), write what the caller wants back -- totals, results
+// or every member's list -- straight into it, and the call's last launch stores `done | status` where this thread is spinning.
+// The ungrouped result of a grouped call never leaves the device.  No hipMemcpy, no stream synchronize.
+constexpr size_t kZeroCopyBytes = 128u << 10;  // staging layouts up to this size (~2 500 partitions): beyond, PCIe reads at
+                                               // kernel rate lose to one DMA copy
+
+int reserve_host_coherent(la_ctx* ctx, HostBuf& b, size_t bytes) {
+    if (bytes <= b.cap) return LA_OK;
+    if (b.p) { LA_HIP(ctx, hipHostFree(b.p)); b.p = nullptr; b.cap = 0; }
+    const size_t want = bytes + bytes / 4 + 256;
+    LA_HIP(ctx, hipHostMalloc(&b.p, want, hipHostMallocPortable | hipHostMallocMapped | hipHostMallocCoherent));
+    b.cap = want;
+    return LA_OK;
+}
+
+int small_fill_inputs(la_ctx* ctx, const HostCall& c, const SmallLayout& L, char* h);
+
+int assign_small_zc(la_ctx* ctx, const HostCall& c, Shard& sh, const SmallLayout& L) {
     LA_HIP(ctx, hipSetDevice(sh.device));
     Lane& ln = sh.lanes[0];
     hipStream_t st = ln.stream;
-    const size_t T = (size_t)c.T, n = (size_t)c.shape.n, k = (size_t)c.shape.k;
-    if (int rc = reserve(ctx, sh.small_d, L.total)) return rc;
-    if (int rc = reserve_host(ctx, sh.small_h, L.total)) return rc;
-    char* h = (char*)sh.small_h.p;
+    const size_t n = (size_t)c.shape.n, k = (size_t)c.shape.k;
+    if (int rc = reserve_host_coherent(ctx, sh.zc_h, L.total)) return rc;
+    if (int rc = reserve(ctx, sh.small_d, L.total)) return rc;           // the ungrouped result (same layout, device side)
+    char* h = (char*)sh.zc_h.p;
     char* d = (char*)sh.small_d.p;
+    void* hd = nullptr;                                                  // the device's view of the staging buffer
+    LA_HIP(ctx, hipHostGetDevicePointer(&hd, h, 0));
+    char* m = (char*)hd;
+    if (int rc = small_fill_inputs(ctx, c, L, h)) return rc;
+    volatile uint32_t* flag = (volatile uint32_t*)(h + L.status);
+    *flag = 0;
+    std::atomic_thread_fence(std::memory_order_seq_cst);
+    if (k > kSmallHostCheck)
+        LA_HIP(ctx, la::check_consumers_launch(c.T, (const int64_t*)(m + L.co), (const int32_t*)(m + L.cr), ln.d_status, st));
+    const bool grouped = c.g_members >= 0;
+    la_device_batch b{};
+    b.n_topics = c.T;
+    b.reset_mode = c.reset_mode == LA_RESET_LATEST ? LA_RESET_LATEST : LA_RESET_EARLIEST;
+    b.algo = LA_ALGO_AUTO;
+    b.flags = LA_FLAG_RAGGED;
+    b.n_partitions = c.shape.n;
+    b.n_consumers = c.shape.k;
+    b.max_partitions_per_topic = c.shape.max_p;
+    b.max_consumers_per_topic = c.shape.max_c;
+    b.d_part_off = (const int64_t*)(m + L.po);
+    b.d_partition_id = (const int32_t*)(m + L.pid);
+    b.d_begin_off = c.use_begin ? (const int64_t*)(m + L.beg) : nullptr;
+    b.d_end_off = (const int64_t*)(m + L.end);
+    b.d_committed_off = (const int64_t*)(m + L.com);
+    b.d_lag = c.lag ? (const int64_t*)(m + L.end) : nullptr;
+    b.d_cons_off = (const int64_t*)(m + L.co);
+    b.d_cons_rank = (const int32_t*)(m + L.cr);
+    // results the caller reads go to the host's memory; those only the grouping reads stay on the device
+    char* res = (c.out_pid && !grouped) ? m : d;
+    b.d_out_partition = (int32_t*)(res + L.op);
+    b.d_out_member_rank = (int32_t*)(res + L.orank);
+    b.d_out_total_lag = c.out_total ? (int64_t*)(m + L.ot) : nullptr;
+    b.h_part_off = c.part_off;
+    b.h_cons_off = c.cons_off;
+    int rc = enqueue_batch(ctx, ln, &b, st);
+    if (rc == LA_OK && grouped) {
+        const hipError_t e = la::group_by_member_launch(ln.large, c.shape.n, c.g_members, c.T, (const int64_t*)(m + L.po),
+                                                        (const int32_t*)(d + L.op), (const int32_t*)(d + L.orank),
+                                                        (int64_t*)(m + L.goff), c.g_topic ? (int32_t*)(m + L.gt) : nullptr,
+                                                        (int32_t*)(m + L.gp), nullptr, ln.d_status, st);
+        if (e != hipSuccess) rc = fail(ctx, e == hipErrorOutOfMemory ? LA_ENOMEM : LA_EHIP, "group_by_member: %s", hipGetErrorString(e));
+    }
+    if (rc == LA_OK) {
+        const hipError_t e = la::finish_status_launch(ln.d_status, (uint32_t*)(m + L.status), st);
+        if (e != hipSuccess) rc = fail(ctx, LA_EHIP, "finish launch: %s", hipGetErrorString(e));
+    }
+    if (rc != LA_OK) {
+        (void)hipStreamSynchronize(st);
+        return rc;
+    }
+    // the wait: a spin on the flag word; should the flag never come (a fault on the stream), the runtime will say why
+    uint32_t f = 0;
+    for (uint64_t spins = 0;; ++spins) {
+        f = *flag;
+        if (f & 0x80000000u) break;
+        if ((spins & 0xFFFu) == 0xFFFu) {
+            const hipError_t q = hipStreamQuery(st);
+            if (q == hipSuccess) { f = *flag; if (f & 0x80000000u) break; LA_HIP(ctx, hipStreamSynchronize(st)); f = *flag | 0x80000000u; break; }
+            if (q != hipErrorNotReady) return fail(ctx, LA_EHIP, "zero-copy call: %s", hipGetErrorString(q));
+        }
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    const uint32_t status = f & 0x7FFFFFFFu;
+    if (status) {
+        LA_HIP(ctx, hipMemsetAsync(ln.d_status, 0, sizeof(uint32_t), st));
+        LA_HIP(ctx, hipStreamSynchronize(st));
+        return status_error(ctx, status);
+    }
+    if (c.out_total && k) memcpy(c.out_total, h + L.ot, k * 8);
+    if (c.out_pid && n) {
+        if (grouped) {
+            // (no caller asks for both forms today: the ungrouped arrays would need their own trip)
+            LA_HIP(ctx, hipMemcpyAsync(c.out_pid, d + L.op, n * 4, hipMemcpyDeviceToHost, st));
+            LA_HIP(ctx, hipMemcpyAsync(c.out_rank, d + L.orank, n * 4, hipMemcpyDeviceToHost, st));
+            LA_HIP(ctx, hipStreamSynchronize(st));
+        } else {
+            memcpy(c.out_pid, h + L.op, n * 4);
+            memcpy(c.out_rank, h + L.orank, n * 4);
+        }
+    }
+    if (grouped) {
+        memcpy(c.g_off, h + L.goff, ((size_t)c.g_members + 1) * 8);
+        if (n) {
+            memcpy(c.g_part, h + L.gp, n * 4);
+            if (c.g_topic) memcpy(c.g_topic, h + L.gt, n * 4);
+        }
+        if (c.grouped_done) *c.grouped_done = true;
+    }
+    // what la_group_last_by_member would read: valid only where the results stayed on the device
+    sh.last_part_off = (const int64_t*)(m + L.po);
+    sh.last_out_pid = (const int32_t*)(res + L.op);
+    sh.last_out_rank = (const int32_t*)(res + L.orank);
+    return LA_OK;
+}
+
+// The inputs of a small call, packed into its staging buffer (and validated where that is cheaper here than on the device).
+int small_fill_inputs(la_ctx* ctx, const HostCall& c, const SmallLayout& L, char* h) {
+    const size_t T = (size_t)c.T, n = (size_t)c.shape.n, k = (size_t)c.shape.k;
     memcpy(h + L.po, c.part_off, (T + 1) * 8);
     memcpy(h + L.co, c.cons_off, (T + 1) * 8);
     if (n) {
@@ -1072,6 +1196,19 @@ int assign_small(la_ctx* ctx, const HostCall& c, Shard& sh, const SmallLayout& L
                 if (c.cons_rank[j - 1] >= c.cons_rank[j])
                     return fail(ctx, LA_EINVAL, "a topic's cons_rank segment is not strictly ascending");
     }
+    return LA_OK;
+}
+
+int assign_small(la_ctx* ctx, const HostCall& c, Shard& sh, const SmallLayout& L) {
+    LA_HIP(ctx, hipSetDevice(sh.device));
+    Lane& ln = sh.lanes[0];
+    hipStream_t st = ln.stream;
+    const size_t n = (size_t)c.shape.n, k = (size_t)c.shape.k;
+    if (int rc = reserve(ctx, sh.small_d, L.total)) return rc;
+    if (int rc = reserve_host(ctx, sh.small_h, L.total)) return rc;
+    char* h = (char*)sh.small_h.p;
+    char* d = (char*)sh.small_d.p;
+    if (int rc = small_fill_inputs(ctx, c, L, h)) return rc;
     memset(h + L.status, 0, 256);
     LA_HIP(ctx, hipMemcpyAsync(d, h, L.status + 256, hipMemcpyHostToDevice, st));
     ln.status_word = (uint32_t*)(d + L.status);
@@ -1195,8 +1332,9 @@ int assign_host(la_ctx* ctx, int32_t T, const int64_t* part_off, const int32_t* 
         if (L.total <= kSmallBytes) {
             Shard& sh = ctx->shards[0];
             sh.last_t0 = 0; sh.last_topics = T; sh.last_p0 = 0; sh.last_n = s.n;
-            ctx->last_pipeline = 0;
-            if (int rc = assign_small(ctx, c, sh, L)) return rc;
+            const bool zc = L.total <= ctx->zero_copy_bytes;
+            ctx->last_pipeline = zc ? LA_PIPELINE_ZERO_COPY : LA_PIPELINE_ONE_COPY;
+            if (int rc = zc ? assign_small_zc(ctx, c, sh, L) : assign_small(ctx, c, sh, L)) return rc;
             ctx->last_valid = true;
             return LA_OK;
         }
@@ -1405,6 +1543,8 @@ LA_API int la_create_multi(la_ctx** out, int n_devices, const int* device_ids, u
         if (!ctx) return fail(nullptr, LA_ENOMEM, "out of host memory");
         ctx->split_always = (flags & LA_CREATE_SPLIT_ALWAYS) != 0;
         if (const char* env = getenv("LA_CHUNK_PARTITIONS")) ctx->chunk_partitions = atoll(env);
+        ctx->zero_copy_bytes = kZeroCopyBytes;
+        if (const char* env = getenv("LA_ZERO_COPY_BYTES")) ctx->zero_copy_bytes = (size_t)atoll(env);
         ctx->shards.resize(ids.size());
         for (size_t i = 0; i < ids.size(); ++i) {
             Shard& sh = ctx->shards[i];
@@ -1451,7 +1591,7 @@ LA_API void la_destroy(la_ctx* ctx) {
         for (DevBuf* b : {&sh.part_off, &sh.pid, &sh.begin, &sh.end, &sh.committed, &sh.cons_off, &sh.cons_rank,
                           &sh.out_pid, &sh.out_rank, &sh.out_total, &sh.small_d, &sh.small_g, &sh.none_idx, &sh.none_val})
             release(*b);
-        for (HostBuf* h : {&sh.g_off, &sh.g_topic, &sh.g_part, &sh.small_h, &sh.small_gh})
+        for (HostBuf* h : {&sh.g_off, &sh.g_topic, &sh.g_part, &sh.small_h, &sh.small_gh, &sh.zc_h})
             if (h->p) (void)hipHostFree(h->p);
         if (sh.ready) (void)hipEventDestroy(sh.ready);
         for (hipEvent_t e : sh.chunk_ev) (void)hipEventDestroy(e);

@@ -90,6 +90,22 @@ hipError_t check_consumers_launch(int64_t n_topics, const int64_t* cons_off, con
     return hipGetLastError();
 }
 
+// ---- zero-copy small calls: the last launch of the call hands the device status word to the host --------------------------
+// Kernels before it on the stream have completed (their stores to the host-mapped result area included); one plain store of
+// `done bit | status` into coherent host memory is what the calling thread spins on instead of a stream synchronize.
+__global__ void finish_status_kernel(const uint32_t* d_status, uint32_t* h_flag) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        const uint32_t st = *d_status;
+        __threadfence_system();
+        __hip_atomic_store(h_flag, 0x80000000u | st, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+hipError_t finish_status_launch(const uint32_t* d_status, uint32_t* h_flag, hipStream_t stream) {
+    hipLaunchKernelGGL(finish_status_kernel, dim3(1), dim3(64), 0, stream, d_status, h_flag);
+    return hipGetLastError();
+}
+
 // ---- sparse begin offsets (la_assign_batch_sparse) ---------------------------------------------------------
 // The earliest-offset fallback reads `begin` only where a partition has no committed offset (Main.java:384-396) -- ~1 % of
 // a batch -- so the boundary can hand over (position, begin) pairs for just those instead of a dense 8 B/partition array.

@@ -2039,36 +2039,46 @@ hipError_t huge_topic_launch(LargeScratch& scratch, const LargeArgs& a, hipStrea
     return hipGetLastError();
 }
 
-// ---- the same grouping for what a real rebalance is: a few hundred entries -------------------------------------------------
-// member_keys + plan + one or two radix passes + emit are five dependent launches (~25 us) for a job one workgroup does in a
-// few microseconds: count the entries of every group (group = member rank + 1; 0 = topics without consumers), scan, and place
-// entry i behind the entries of its group that come before it -- a stable counting sort, the order of member_emit_kernel.
-constexpr int kSmallGroupN = 1024;       // entries: one per thread; the placement walks the entries before its own (n^2 / 2 compares in all)
-constexpr int kSmallGroupM = 4096;       // groups (members + 1)
+// ---- the same grouping for what a real rebalance is: up to a few ten thousand entries, ONE workgroup ------------------------
+// member_keys + plan + one or two radix passes + emit are five dependent launches (~25 us, 84 us for 2 000 entries) for a job one
+// workgroup does in a few microseconds: a stable counting sort in LDS, LINEAR in n (round 3's form placed an entry by walking
+// all entries before it: n^2 / 2 compares, hence its 1 024-entry limit).
+//   1. count the entries of every group (group = member rank + 1; 0 = topics without consumers), exclusive scan -> cursors;
+//   2. chunks of 64 consecutive entries, chunk c to wavefront c % 16: inside a chunk every lane finds its peers (the lanes with
+//      the same group: one ballot per group-id bit) -- its rank among them and, for the first of them, their number;
+//   3. the chunks take their places IN ORDER: wavefront-ordered hand-over -- a chunk waits until `turn` says its predecessor
+//      has advanced the cursors, its group leaders advance them by their peers' count (one LDS atomic), it passes the turn on.
+//      Chunk c - 1 belongs to another wavefront of the same workgroup that waits for nothing later: no deadlock; the ordered
+//      section is one atomic instruction per chunk.
+// Stable by construction (chunk order, then lane order), no reliance on how colliding lanes of an atomic are served.
+constexpr int kSmallGroupN = 16384;      // entries (256 chunks: the ordered hand-over is a chain of ~0.1 us per chunk)
+constexpr int kSmallGroupM = 8192;       // groups (members + 2)
+constexpr int kSmallGroupBits = 13;      // bits of a group id
 
 __global__ __launch_bounds__(1024) void group_small_kernel(int n, int32_t n_members, int64_t n_topics, const int64_t* part_off,
                                                            const int32_t* out_partition, const int32_t* member_rank,
                                                            int64_t* member_off, int32_t* grouped_topic,
                                                            int32_t* grouped_partition, int32_t* grouped_entry) {
-    __shared__ __attribute__((aligned(16))) uint32_t g[kSmallGroupN];
-    __shared__ uint32_t start[kSmallGroupM];          // counts, then exclusive starts
+    __shared__ uint32_t start[kSmallGroupM];          // counts, then the groups' cursors
     __shared__ uint32_t wsum[1024 / kWave];
+    __shared__ uint32_t turn;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int G = n_members + 1;
-    for (int k = tid; k < kSmallGroupM; k += 1024) start[k] = 0;
+    const uint32_t G = (uint32_t)n_members + 1;                      // a rank >= n_members (out of contract) sorts behind every
+                                                                       // member, as in member_emit_kernel: member_off[n_members]
+    for (int k = tid; k < kSmallGroupM; k += 1024) start[k] = 0;      // is then where such entries start
+    if (tid == 0) turn = 0;
     __syncthreads();
     for (int i = tid; i < n; i += 1024) {
         uint32_t gi = (uint32_t)(member_rank[i] + 1);
-        gi = gi < (uint32_t)G ? gi : (uint32_t)G;                     // a rank >= n_members (out of contract) sorts behind every member, as in
-                                                                       // member_emit_kernel: member_off[n_members] is then where such entries start
-        g[i] = gi;
+        gi = gi < G ? gi : G;
         atomicAdd(&start[gi], 1u);
     }
     __syncthreads();
-    // exclusive scan over the kSmallGroupM counts: four per thread, a wavefront scan, the wavefronts' sums
-    uint32_t c[4], run = 0;
+    // exclusive scan over the kSmallGroupM counts: eight per thread, a wavefront scan, the wavefronts' sums
+    constexpr int PER = kSmallGroupM / 1024;
+    uint32_t c[PER], run = 0;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) { c[r] = start[4 * tid + r]; run += c[r]; }
+    for (int r = 0; r < PER; ++r) { c[r] = start[PER * tid + r]; run += c[r]; }
     uint32_t incl = run;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
@@ -2080,29 +2090,53 @@ __global__ __launch_bounds__(1024) void group_small_kernel(int n, int32_t n_memb
     uint32_t base = incl - run;
     for (int w = 0; w < wave; ++w) base += wsum[w];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) { start[4 * tid + r] = base; base += c[r]; }
+    for (int r = 0; r < PER; ++r) { start[PER * tid + r] = base; base += c[r]; }
     __syncthreads();
     // member r's list starts where the groups 0 .. r end; positions before member_off[0] belong to topics without consumers
     for (int k = tid; k <= n_members; k += 1024) member_off[k] = (int64_t)start[k + 1];
-    for (int i = tid; i < n; i += 1024) {
-        const uint32_t gi = g[i];
-        uint32_t before = 0;
-        int j = 0;                                                     // (all lanes of a wavefront read the same words: broadcasts)
-        for (; j + 4 <= i; j += 4) {
-            const uint4 q = *reinterpret_cast<const uint4*>(&g[j]);
-            before += (q.x == gi ? 1u : 0u) + (q.y == gi ? 1u : 0u) + (q.z == gi ? 1u : 0u) + (q.w == gi ? 1u : 0u);
+    __syncthreads();                                                    // (the cursors move from here on)
+    const uint64_t below = ((uint64_t)1 << lane) - 1;
+    const int n_chunks = (n + kWave - 1) / kWave;
+    for (int chunk = wave; chunk < n_chunks; chunk += 1024 / kWave) {
+        const int i = chunk * kWave + lane;
+        const bool valid = i < n;
+        uint32_t gi = 0;
+        int32_t part = 0;
+        if (valid) {
+            gi = (uint32_t)(member_rank[i] + 1);
+            gi = gi < G ? gi : G;
+            part = out_partition ? out_partition[i] : 0;
         }
-        for (; j < i; ++j) before += g[j] == gi ? 1u : 0u;
-        const uint32_t pos = start[gi] + before;
-        if (grouped_entry) grouped_entry[pos] = i;
-        if (grouped_partition) grouped_partition[pos] = out_partition[i];
-        if (grouped_topic) {
+        uint64_t peers = __ballot(valid);
+#pragma unroll
+        for (int bit = 0; bit < kSmallGroupBits + 1; ++bit) {           // (G itself may need one bit more than G - 1)
+            const bool one = (gi >> bit) & 1u;
+            const uint64_t bal = __ballot(one);
+            peers &= one ? bal : ~bal;
+        }
+        const uint32_t rank = (uint32_t)__popcll(peers & below);
+        const int leader = __ffsll((unsigned long long)peers) - 1;
+        int64_t topic = 0;
+        if (valid && grouped_topic) {
             int64_t lo = 0, hi = n_topics;                             // largest t with part_off[t] <= i
             while (hi - lo > 1) {
                 const int64_t mid = (lo + hi) >> 1;
                 if (part_off[mid] <= (int64_t)i) lo = mid; else hi = mid;
             }
-            grouped_topic[pos] = (int32_t)lo;
+            topic = lo;
+        }
+        // the ordered section: wait for the chunk before this one, advance the cursors, pass the turn on
+        while (__hip_atomic_load(&turn, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != (uint32_t)chunk) __builtin_amdgcn_s_sleep(1);
+        uint32_t first = 0;
+        if (valid && lane == leader) first = atomicAdd(&start[gi], (uint32_t)__popcll(peers));
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (lane == 0) __hip_atomic_store(&turn, (uint32_t)chunk + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        first = (uint32_t)__shfl((int)first, leader < 0 ? 0 : leader);
+        if (valid) {
+            const uint32_t pos = first + rank;
+            if (grouped_entry) grouped_entry[pos] = i;
+            if (grouped_partition) grouped_partition[pos] = part;
+            if (grouped_topic) grouped_topic[pos] = (int32_t)topic;
         }
     }
 }
@@ -2114,7 +2148,8 @@ hipError_t group_by_member_launch(LargeScratch& scratch, int64_t n, int32_t n_me
     if (n < 0 || n > 0x7FFFFFFF || n_members < 0) return hipErrorInvalidValue;
     hipError_t e;
     if (n == 0) return hipMemsetAsync(member_off, 0, sizeof(int64_t) * ((size_t)n_members + 1), stream);
-    if (n <= kSmallGroupN && (int64_t)n_members + 2 <= kSmallGroupM && !getenv("LA_NO_SMALL_GROUP")) {
+    if (n <= kSmallGroupN && (int64_t)n_members + 2 <= kSmallGroupM && ((int64_t)n_members + 1) < ((int64_t)1 << (kSmallGroupBits + 1)) &&
+        !getenv("LA_NO_SMALL_GROUP")) {
         hipLaunchKernelGGL(group_small_kernel, dim3(1), dim3(1024), 0, stream, (int)n, n_members, n_topics, part_off, out_partition,
                            member_rank, member_off, grouped_topic, grouped_partition, grouped_entry);
         return hipGetLastError();

@@ -376,3 +376,52 @@ def test_huge_consumer_topic_inside_a_batch(ctx):
     exp = round_form(w.part_off, w.partition_id, w.lag, w.cons_off, w.cons_rank)
     _same3(_device_call(ctx, w), exp)
     _same3(ctx.assign_batch_lags(w.part_off, w.partition_id, w.lag, w.cons_off, w.cons_rank), exp, "host entry")
+
+
+# ---- zero-copy small calls ------------------------------------------------------------------------------------
+def test_smallest_calls_run_zero_copy_and_agree_with_the_copying_forms():
+    """Staging layouts up to 128 KB: the kernels read the inputs from coherent host memory in place and write results / totals /
+    lists into it; no hipMemcpy, no stream wait.  Same results as the one-copy form (LA_ZERO_COPY_BYTES=0) on every entry
+    point, across the threshold, alternating on one context; errors surface and leave the context usable."""
+    os.environ["LA_ZERO_COPY_BYTES"] = "0"
+    try:
+        ref_ctx = N.Context(0)
+    finally:
+        os.environ.pop("LA_ZERO_COPY_BYTES", None)
+    with N.Context(0) as c, ref_ctx:
+        seen = set()
+        for seed, (t, p, cc) in enumerate([(1, 3, 2), (10, 10, 3), (40, 50, 5), (3, 700, 90), (1, 2500, 3), (1, 1800, 300),
+                                           (60, 64, 8), (300, 100, 7), (1, 20, 0), (5, 0, 3)]):
+            w = synth.ragged(100 + seed, t, p, cc)
+            n_members = int(w.cons_rank.max()) + 1 if w.cons_rank.size else 0
+            for mode in (N.LA_RESET_EARLIEST, N.LA_RESET_LATEST):
+                a = (w.part_off, w.partition_id, None if mode == N.LA_RESET_LATEST else w.begin, w.end, w.committed, mode,
+                     w.cons_off, w.cons_rank)
+                exp = _expected(w, mode == N.LA_RESET_LATEST)
+                got = c.assign_batch(*a)
+                seen.add(c.last_pipeline())
+                _same3(got, exp, "zero copy? %d" % c.last_pipeline())
+                _same3(ref_ctx.assign_batch(*a), exp, "one copy")
+                assert ref_ctx.last_pipeline() != N.LA_PIPELINE_ZERO_COPY
+                g = c.assign_batch_grouped(*a, n_members)
+                g_ref = ref_ctx.assign_batch_grouped(*a, n_members)
+                for x, y in zip(g, g_ref):
+                    np.testing.assert_array_equal(x, y)
+                # results kept on the device, grouped by a second call
+                c.assign_batch(*a, keep_on_device=True)
+                g2 = c.group_last_by_member(w.n_partitions, n_members)
+                for x, y in zip(g2, (g[0], g[1], g[2])):
+                    np.testing.assert_array_equal(x, y)
+            idx, val = N.sparse_begin(w.begin, w.committed)
+            got = c.assign_batch_sparse(w.part_off, w.partition_id, w.end, w.committed, N.LA_RESET_EARLIEST, idx, val, w.cons_off, w.cons_rank)
+            _same3(got, _expected(w, False), "sparse")
+            _same3(c.assign_batch_lags(w.part_off, w.partition_id, w.lag, w.cons_off, w.cons_rank),
+                   oracle.assign_flat(w.part_off, w.partition_id, w.lag, w.cons_off, w.cons_rank), "lags")
+        assert N.LA_PIPELINE_ZERO_COPY in seen and N.LA_PIPELINE_ONE_COPY in seen
+        # errors: unsorted ranks (validated on the host for a small call), then the context still works
+        with pytest.raises(N.LagAssignError) as e:
+            c.assign_batch_lags([0, 2], [0, 1], [5, 6], [0, 2], [3, 1])
+        assert e.value.code == N.LA_EINVAL
+        p, m, t = c.assign_batch_lags([0, 3], [0, 1, 2], [100000, 50000, 60000], [0, 2], [0, 1])      # README.md:42-57
+        assert c.last_pipeline() == N.LA_PIPELINE_ZERO_COPY
+        assert p.tolist() == [0, 2, 1] and m.tolist() == [0, 1, 1] and t.tolist() == [100000, 110000]
