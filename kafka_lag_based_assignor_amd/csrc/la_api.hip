@@ -680,7 +680,11 @@ int prepare_shard(la_ctx* ctx, const HostCall& c, Shard& sh, ShardPlan& sp) {
         if (ctx->chunk_partitions <= 0 && target < kMinChunkPartitions) target = kMinChunkPartitions;
         // three-stream form: chunks of ~1 M partitions (28 MB of input) measured best on the 25.6 M-partition batch -- 13.6 ms
         // against 18-20 ms at 512 K, 14.4 at 2 M, 14.5 with few chunks that are small at both ends (profiles/r03_host_probe.txt)
-        if (ctx->chunk_partitions <= 0 && ctx->last_pipeline == 2) target = 1 << 20;
+        // (by bytes: 1 M partitions of the dense offsets form = 28 MB of input; the sparse-begin and the lags forms move fewer
+        //  bytes per partition and take proportionally more partitions per chunk -- a chunk's copies cost ~20 us each before their
+        //  first byte moves, whatever they carry)
+        if (ctx->chunk_partitions <= 0 && ctx->last_pipeline == 2)
+            target = ((int64_t)28 << 20) / (c.lag ? 12 : (c.use_begin && !c.sparse ? 28 : 20));
         const int64_t want = (sp.n + target - 1) / target;
         n_chunks = (int)(want < 1 ? 1 : (want > kMaxChunks ? kMaxChunks : want));
         if (n_chunks > Ts) n_chunks = Ts > 0 ? Ts : 1;
@@ -1102,14 +1106,16 @@ int assign_small_zc(la_ctx* ctx, const HostCall& c, Shard& sh, const SmallLayout
     b.h_part_off = c.part_off;
     b.h_cons_off = c.cons_off;
     int rc = enqueue_batch(ctx, ln, &b, st);
+    bool finished = false;                                               // (the one-workgroup grouping also finishes the call)
     if (rc == LA_OK && grouped) {
         const hipError_t e = la::group_by_member_launch(ln.large, c.shape.n, c.g_members, c.T, (const int64_t*)(m + L.po),
                                                         (const int32_t*)(d + L.op), (const int32_t*)(d + L.orank),
                                                         (int64_t*)(m + L.goff), c.g_topic ? (int32_t*)(m + L.gt) : nullptr,
-                                                        (int32_t*)(m + L.gp), nullptr, ln.d_status, st);
+                                                        (int32_t*)(m + L.gp), nullptr, ln.d_status, st,
+                                                        (uint32_t*)(m + L.status), &finished);
         if (e != hipSuccess) rc = fail(ctx, e == hipErrorOutOfMemory ? LA_ENOMEM : LA_EHIP, "group_by_member: %s", hipGetErrorString(e));
     }
-    if (rc == LA_OK) {
+    if (rc == LA_OK && !finished) {
         const hipError_t e = la::finish_status_launch(ln.d_status, (uint32_t*)(m + L.status), st);
         if (e != hipSuccess) rc = fail(ctx, LA_EHIP, "finish launch: %s", hipGetErrorString(e));
     }

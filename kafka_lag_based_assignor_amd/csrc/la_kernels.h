@@ -203,7 +203,10 @@ hipError_t large_profile_read(LargeScratch& scratch, float* ms, int* passes, int
 hipError_t group_by_member_launch(LargeScratch& scratch, int64_t n, int32_t n_members, int64_t n_topics,
                                   const int64_t* part_off, const int32_t* out_partition, const int32_t* member_rank,
                                   int64_t* member_off, int32_t* grouped_topic, int32_t* grouped_partition,
-                                  int32_t* grouped_entry, uint32_t* status, hipStream_t stream);
+                                  int32_t* grouped_entry, uint32_t* status, hipStream_t stream, uint32_t* fin_flag = nullptr,
+                                  bool* fin_done = nullptr);
+// (fin_flag: a zero-copy call's completion word in host memory; when the one-workgroup form runs it also finishes the call --
+//  *fin_done says whether it did, otherwise the caller launches finish_status_launch)
 
 // ---- narrow wire format of the all-gather (la_wire.hip) -----------------------------------------------------------
 void wire_format_for(int64_t max_partition_id, int64_t n_members, int* elem_bytes, int* id_bits);     // pure host code

@@ -2058,7 +2058,8 @@ constexpr int kSmallGroupBits = 13;      // bits of a group id
 __global__ __launch_bounds__(1024) void group_small_kernel(int n, int32_t n_members, int64_t n_topics, const int64_t* part_off,
                                                            const int32_t* out_partition, const int32_t* member_rank,
                                                            int64_t* member_off, int32_t* grouped_topic,
-                                                           int32_t* grouped_partition, int32_t* grouped_entry) {
+                                                           int32_t* grouped_partition, int32_t* grouped_entry,
+                                                           const uint32_t* fin_status, uint32_t* fin_flag) {
     __shared__ uint32_t start[kSmallGroupM];          // counts, then the groups' cursors
     __shared__ uint32_t wsum[1024 / kWave];
     __shared__ uint32_t turn;
@@ -2139,19 +2140,29 @@ __global__ __launch_bounds__(1024) void group_small_kernel(int n, int32_t n_memb
             if (grouped_topic) grouped_topic[pos] = (int32_t)topic;
         }
     }
+    if (fin_flag) {
+        // the last launch of a zero-copy call (la_api.hip, assign_small_zc): this ONE workgroup's stores into the host's memory
+        // are out, then `done | status` goes where the calling thread is spinning -- no separate finishing launch
+        __threadfence_system();
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(fin_flag, 0x80000000u | *fin_status, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 
 hipError_t group_by_member_launch(LargeScratch& scratch, int64_t n, int32_t n_members, int64_t n_topics,
                                   const int64_t* part_off, const int32_t* out_partition, const int32_t* member_rank,
                                   int64_t* member_off, int32_t* grouped_topic, int32_t* grouped_partition,
-                                  int32_t* grouped_entry, uint32_t* status, hipStream_t stream) {
+                                  int32_t* grouped_entry, uint32_t* status, hipStream_t stream, uint32_t* fin_flag, bool* fin_done) {
+    if (fin_done) *fin_done = false;
     if (n < 0 || n > 0x7FFFFFFF || n_members < 0) return hipErrorInvalidValue;
     hipError_t e;
     if (n == 0) return hipMemsetAsync(member_off, 0, sizeof(int64_t) * ((size_t)n_members + 1), stream);
     if (n <= kSmallGroupN && (int64_t)n_members + 2 <= kSmallGroupM && ((int64_t)n_members + 1) < ((int64_t)1 << (kSmallGroupBits + 1)) &&
         !getenv("LA_NO_SMALL_GROUP")) {
         hipLaunchKernelGGL(group_small_kernel, dim3(1), dim3(1024), 0, stream, (int)n, n_members, n_topics, part_off, out_partition,
-                           member_rank, member_off, grouped_topic, grouped_partition, grouped_entry);
+                           member_rank, member_off, grouped_topic, grouped_partition, grouped_entry, (const uint32_t*)status,
+                           fin_flag);
+        if (fin_done) *fin_done = fin_flag != nullptr;
         return hipGetLastError();
     }
     SortBufs b{};
