@@ -303,12 +303,16 @@ def live_sort_traffic(n, form):
         os.environ.pop("LA_SORT_MULTIKERNEL", None)
     if not d:
         return None
-    names = ("onesweep_pass_kernel",) if form == "single" else ("tile_count_kernel", "scan_group_sums_kernel", "scan_offsets_kernel", "tile_scatter_kernel")
+    # launches of a sort per kernel: 12 pass slots + 12 redo slots (no-ops unless a keys-first sort has to be redone) and the
+    # tie repair in the single-kernel form; 12 of each in the four-kernel form
+    names = ({"onesweep_pass_kernel": 24, "tie_repair_kernel": 1} if form == "single" else
+             {"tile_count_kernel": 12, "scan_group_sums_kernel": 12, "scan_offsets_kernel": 12, "tile_scatter_kernel": 12})
     rd = wr = 0.0
     for k, e in d["kernels"].items():
-        if any(x in k for x in names):
-            rd += 12 * e.get("fetch_bytes_calibrated", 0.0)
-            wr += 12 * e.get("write_bytes_calibrated", 0.0)
+        for x, launches in names.items():
+            if x in k:
+                rd += launches * e.get("fetch_bytes_calibrated", 0.0)
+                wr += launches * e.get("write_bytes_calibrated", 0.0)
     if rd <= 0 or wr <= 0:
         return None
     return {"hbm_bytes_per_launch": round(rd + wr), "read_bytes": round(rd), "written_bytes": round(wr), "source": d["how"]}
@@ -464,7 +468,9 @@ def run_sort_phase(torch, N, ctx, dev, n, reps, stream, form="single", live=Fals
     call_ms = (time.perf_counter() - t0) / reps * 1e3
     ms = float(np.mean(sort_ms))
     bytes_id, bytes_key = SORT_BYTES[form]
-    algo_bytes = n * (t.id_passes * bytes_id + t.key_passes * bytes_key)
+    keys_first = bool(getattr(t, "keys_first", 0))
+    # a keys-first sort (no id passes) reads every key once more to find and repair the runs of equal lags
+    algo_bytes = n * (t.id_passes * bytes_id + t.key_passes * bytes_key + (8 if keys_first else 0))
     achieved = algo_bytes / (ms * 1e-3) / 1e9
     # sortedness of what came out: ids in (lag desc, id asc) order
     pid = sh.out_pid[:n].to(torch.int64)
@@ -484,6 +490,9 @@ def run_sort_phase(torch, N, ctx, dev, n, reps, stream, form="single", live=Fals
             "form": form, "rank": "ds_add_rtn" if ctx.device_features(0) & N.LA_FEATURE_ATOMIC_RANK else "wave match",
             "kernel_ms": round(ms, 4), "partitions": n, "id_passes": int(t.id_passes), "key_passes": int(t.key_passes),
             "ids": ids or os.environ.get("LA_SORT_IDS") or "random", "bytes_per_partition": round(algo_bytes / n, 1),
+            "keys_first": keys_first, "redone": bool(getattr(t, "redone", 0)),
+            "order_of_passes": ("key digits only, then tie_repair_kernel puts runs of equal lags in id order (the sample of the "
+                                "lags showed no frequent one)" if keys_first else "id digits, then key digits (LSD)"),
             "traffic_bytes_per_partition": round(tr["hbm_bytes_per_launch"] / n, 1) if tr else None,
             "frac_moved": round(tr["hbm_bytes_per_launch"] / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if tr else None,
             "algorithmic_bytes_per_launch": int(algo_bytes),
@@ -959,7 +968,8 @@ def main():
             torch.cuda.empty_cache()
             sp = run_sort_phase(torch, N, ctx, dev, SORT_PHASE_PARTITIONS, 5, stream, args.sort_form,
                                 live=world == 1 and not args.no_live_traffic and not args.no_cpu_baseline)
-            sort_phase = {k: sp[k] for k in ("frac", "frac_moved", "achieved", "unit", "kernel", "form", "rank", "kernel_ms", "partitions",
+            sort_phase = {k: sp[k] for k in ("frac", "frac_moved", "achieved", "unit", "kernel", "form", "rank", "kernel_ms", "partitions", "keys_first",
+                                             "redone", "order_of_passes",
                                              "id_passes", "ids", "algorithmic_bytes", "bytes_per_partition", "traffic_bytes_per_partition",
                                              "key_passes", "algorithmic_bytes_per_launch", "traffic", "traffic_source", "sorted_ok", "source")}
             # the round-1/2 workload beside it: ids as the affine permutation i -> (a*i + c) mod 2^k, whose id
@@ -967,7 +977,14 @@ def main():
             if world == 1 and not args.no_cpu_baseline:
                 torch.cuda.empty_cache()
                 sa = run_sort_phase(torch, N, ctx, dev, SORT_PHASE_PARTITIONS, 3, stream, args.sort_form, live=False, ids="affine")
-                sort_phase["affine_ids"] = {k: sa[k] for k in ("kernel_ms", "frac", "id_passes", "key_passes", "sorted_ok")}
+                sort_phase["affine_ids"] = {k: sa[k] for k in ("kernel_ms", "frac", "id_passes", "key_passes", "keys_first", "sorted_ok")}
+                # ... and the round-3 order of passes (ids first) on the headline workload, same box, same process
+                os.environ["LA_SORT_KEYS_FIRST"] = "0"
+                try:
+                    s0 = run_sort_phase(torch, N, ctx, dev, SORT_PHASE_PARTITIONS, 3, stream, args.sort_form, live=False)
+                    sort_phase["ids_first"] = {k: s0[k] for k in ("kernel_ms", "frac", "id_passes", "key_passes", "keys_first", "bytes_per_partition", "sorted_ok")}
+                finally:
+                    os.environ.pop("LA_SORT_KEYS_FIRST", None)
         except Exception as exc:  # noqa: BLE001 -- a reported extra
             sort_phase = {"error": str(exc)}
 

@@ -327,8 +327,11 @@ typedef struct la_phase_times {
     int32_t id_passes;     /* active 8-bit passes over the partition-id digits (0 when ids arrive ascending)  */
     int32_t key_passes;    /* active passes over the lag-key digits; constant digits are skipped on the device */
     float keys_ms;         /* lag + keys + the 12 digit histograms, pass plan                                  */
-    float sort_ms;         /* tile counts + scans + stable scatter of every active pass                        */
+    float sort_ms;         /* every active radix pass (+ the tie repair of a keys-first sort): until the order is final */
     float greedy_ms;       /* ids in assignment order + the greedy rounds                                      */
+    int32_t keys_first;    /* 1: the sort skipped the id passes and put runs of equal lags in id order afterwards
+                            * (large topics with shuffled ids and no frequent lag; since ABI 0.3.0)             */
+    int32_t redone;        /* 1: a run of equal lags did not fit the repair and the sort was redone in full     */
 } la_phase_times;
 int la_last_phase_times(la_ctx *ctx, la_phase_times *out);
 

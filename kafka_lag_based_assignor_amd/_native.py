@@ -78,7 +78,8 @@ class WireFormat(ctypes.Structure):
 class PhaseTimes(ctypes.Structure):
     """struct la_phase_times"""
     _fields_ = [("n_partitions", ctypes.c_int64), ("id_passes", ctypes.c_int32), ("key_passes", ctypes.c_int32),
-                ("keys_ms", ctypes.c_float), ("sort_ms", ctypes.c_float), ("greedy_ms", ctypes.c_float)]
+                ("keys_ms", ctypes.c_float), ("sort_ms", ctypes.c_float), ("greedy_ms", ctypes.c_float),
+                ("keys_first", ctypes.c_int32), ("redone", ctypes.c_int32)]
 
 
 _lib: Optional[ctypes.CDLL] = None

@@ -2203,7 +2203,7 @@ LA_API int la_last_phase_times(la_ctx* ctx, la_phase_times* out) {
         Shard& sh = ctx->shards[0];
         LA_HIP(ctx, hipSetDevice(sh.device));
         float ms[3] = {};
-        int passes[2] = {};
+        int passes[4] = {};
         int64_t n = 0;
         const hipError_t e = la::large_profile_read(sh.lanes[0].large, ms, passes, &n);
         if (e == hipErrorNotReady)
@@ -2215,6 +2215,8 @@ LA_API int la_last_phase_times(la_ctx* ctx, la_phase_times* out) {
         out->keys_ms = ms[0];
         out->sort_ms = ms[1];
         out->greedy_ms = ms[2];
+        out->keys_first = passes[2];
+        out->redone = passes[3];
         return LA_OK;
     } catch (...) {
         return fail(ctx, LA_ENOMEM, "exception in la_last_phase_times");

@@ -196,7 +196,8 @@ hipError_t large_topics_launch(LargeScratch& scratch, const LargeArgs* args, int
 // pass that hands the round's partitions out (ceil(P / C) rounds of ~11 launches).  Any C up to 2^31 - 1.
 hipError_t huge_topic_launch(LargeScratch& scratch, const LargeArgs& a, hipStream_t stream);
 void large_scratch_release(LargeScratch& scratch);
-// Waits for the profiled topic's events; ms[3] = keys + plan, sort passes, ids + greedy; passes[2] = active id / key passes.
+// Waits for the profiled topic's events; ms[3] = keys + plan, sort passes (+ tie repair), ids + greedy; passes[4] = active id
+// passes, active key passes, 1 if the sort went keys first, 1 if it had to be redone in full.
 hipError_t large_profile_read(LargeScratch& scratch, float* ms, int* passes, int64_t* n);
 
 // Stable grouping of the n assignment entries by member rank (see la_group_by_member in lagassign.h).

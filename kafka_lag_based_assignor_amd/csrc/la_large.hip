@@ -41,12 +41,21 @@ constexpr int kSortWaves = kSortThreads / kWave;
 constexpr int kItems = 16;
 constexpr int kTile = kSortThreads * kItems;     // 4096 elements per workgroup
 constexpr int kScanRows = 32;                    // tiles per workgroup of the offset scan
+constexpr uint32_t kSampleHeavy = 8;             // 1 in 256 keys is sampled: a counter at 8 ~ a lag shared by ~2 000 partitions
+
+// Pass slots: 0 .. kDigits-1 are the sort's passes (digit = slot); kDigits .. 2*kDigits-1 are the same digits again, for the one
+// case in which a keys-first sort has to be redone in full (see tie_repair_kernel); they are no-ops otherwise.
+constexpr int kSlots = 2 * kDigits;
+constexpr int kFinal = kSlots;         // ctl->cur[kFinal]: the buffer that holds the sorted data
 
 struct SortCtl {
-    uint32_t skip[kDigits];
-    uint32_t cur[kDigits + 1];         // which buffer (0/1) holds the data before pass d
+    uint32_t skip[kSlots];
+    uint32_t cur[kSlots + 1];          // which buffer (0/1) holds the data before pass slot s; [kFinal]: after the last
     uint32_t unsorted_ids;             // != 0: input ids are not ascending
-    uint32_t pad[6];
+    uint32_t tie_heavy;                // build_keys: a key came up often in the sample (or filled a whole wavefront): many equal lags
+    uint32_t keys_first;               // plan: the id passes are skipped, ties are put in id order by tie_repair_kernel
+    uint32_t redo;                     // tie_repair: a run of equal keys did not fit its workgroup -> the redo slots sort in full
+    uint32_t pad[11];
 };
 
 struct SortBufs {
@@ -57,7 +66,7 @@ struct SortBufs {
     uint32_t* tile_off;                // [n_tiles][256] (a tile's 256 digit counts / offsets are one 1 KB row)
     uint32_t* group_sum;               // [n_groups][256] digit counts of kScanRows consecutive tiles
     // single-kernel passes (decoupled look-back): zeroed per sort together with ctl and hist
-    uint32_t* ticket;                  // [kDigits] arrival counter of every pass
+    uint32_t* ticket;                  // [kSlots] arrival counter of every pass slot
     uint32_t* gbase;                   // [kDigits][256] exclusive scan of hist: global first position of every digit
     unsigned long long* tile_state;    // [n_tiles][256] granules {tag = (pass + 1) << 2 | status, count}; null: multi-kernel passes
     int64_t n;
@@ -65,6 +74,11 @@ struct SortBufs {
     int n_groups;
     int atomic_rank;                   // ranks from returning LDS atomics (the device passed lds_atomic_order_test_kernel)
     int sweep_threads;                 // workgroup size of the single-kernel passes: 512 (tiles of 8 192) or 256 (4 096)
+    // keys-first sorts (large n, shuffled ids): a hash table of SAMPLED keys (zeroed with ctl) tells whether some lag is so
+    // frequent that its run could not be repaired in one workgroup; null: this sort never goes keys first
+    uint32_t* samp;
+    uint32_t samp_bits;                // table of 2^samp_bits counters
+    int keys_first_force;              // test hook: keys first whatever the sample says (long runs then take the redo slots)
 };
 
 // One large topic of a batched launch (large_topics_launch): kernels launched over SEVERAL topics at once read where their
@@ -79,6 +93,8 @@ struct LargeItem {
     int64_t n;
     int32_t n_tiles, n_groups;
     uint64_t o_ctl, o_hist, o_ticket, o_state, o_gbase, o_k0, o_k1, o_v0, o_v1;
+    uint64_t o_samp;                   // 0: no sample table (this topic never sorts keys first)
+    uint32_t samp_bits, pad;
 };
 
 // b.key[x] / b.val[x] with a run-time x, as a select: indexing the pointer pair of a LOCAL SortBufs dynamically would put the
@@ -97,6 +113,8 @@ __device__ __forceinline__ void bind_item(LargeArgs& a, SortBufs& b, const Large
     b.key[1] = (uint64_t*)(scratch + it.o_k1);
     b.val[0] = (uint32_t*)(scratch + it.o_v0);
     b.val[1] = (uint32_t*)(scratch + it.o_v1);
+    b.samp = it.o_samp ? (uint32_t*)(scratch + it.o_samp) : nullptr;
+    b.samp_bits = it.samp_bits;
     b.n = it.n;
     b.n_tiles = it.n_tiles;
     b.n_groups = it.n_groups;
@@ -146,6 +164,21 @@ __global__ __launch_bounds__(256) void build_keys_kernel(LargeArgs a0, SortBufs 
             if (i + 1 < b.n && a.pid[g + 1] < id) b.ctl->unsorted_ids = 1;
         }
         const uint64_t vmask = __ballot(valid);
+        if (b.samp) {
+            // How frequent is the most frequent lag?  (keys-first sorts repair runs of equal keys inside one workgroup: a run
+            // must fit.)  64 equal neighbours say "very"; otherwise every fourth wavefront counts its first key in a hash
+            // table of n / 32 counters (n / 256 samples): a counter that reaches kSampleHeavy belongs to a lag that some
+            // thousand partitions share.  Sampling stops once the answer is yes: a hot counter would serialize the atomics.
+            const uint64_t k0 = ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(key >> 32)) << 32) |
+                                __builtin_amdgcn_readfirstlane((uint32_t)key);
+            if (vmask == ~0ull && __ballot(key == k0) == ~0ull) {
+                if (__lane_id() == 0) b.ctl->tie_heavy = 1;
+            } else if (((base + (threadIdx.x & ~63)) >> 6) % 4 == 0 && (vmask & 1ull) && __lane_id() == 0 &&
+                       __hip_atomic_load(&b.ctl->tie_heavy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+                const uint32_t h = (uint32_t)((k0 * 0x9E3779B97F4A7C15ull) >> (64 - b.samp_bits));
+                if (atomicAdd(&b.samp[h], 1u) + 1u >= kSampleHeavy) b.ctl->tie_heavy = 1;
+            }
+        }
 #pragma unroll
         for (int p = 0; p < kDigits; ++p) {
             const uint32_t d = digit_of(p, key, val);
@@ -197,16 +230,48 @@ __global__ __launch_bounds__(kRadix) void plan_kernel(SortBufs b0, const LargeIt
         if (b.hist[p * kRadix + threadIdx.x] == (uint32_t)b.n) skip[p] = 1;   // one bin holds everything
     __syncthreads();
     if (threadIdx.x == 0) {
+        // Keys first: the id passes only order partitions with EQUAL lags.  When the ids arrive shuffled and no lag is
+        // frequent, sort by the key digits alone (stable: equal keys stay in input order) and let tie_repair_kernel put every
+        // run of equal keys in id order afterwards -- for lags without long runs that is 5 scatter passes + one read where
+        // the full LSD sort takes 9.  Frequent lags (the sample) keep the full order of passes: nothing changes for them.
+        bool key_digits = false;
+        for (int p = 4; p < kDigits; ++p) key_digits |= skip[p] == 0;
+        const bool keys_first = b.samp != nullptr && b.ctl->unsorted_ids != 0 && key_digits &&
+                                (b.keys_first_force || b.ctl->tie_heavy == 0);
+        b.ctl->keys_first = keys_first ? 1u : 0u;
         uint32_t cur = 0;
         for (int p = 0; p < kDigits; ++p) {
             uint32_t s = skip[p];
-            if (p < 4 && b.ctl->unsorted_ids == 0) s = 1;     // stable passes keep the input's id order
+            if (p < 4 && (b.ctl->unsorted_ids == 0 || keys_first)) s = 1;     // stable passes keep the input's id order
             b.ctl->skip[p] = s;
             b.ctl->cur[p] = cur;
             cur ^= (s ? 0u : 1u);
         }
-        b.ctl->cur[kDigits] = cur;
+        for (int p = kDigits; p < kSlots; ++p) {              // the redo slots: idle unless replan_kernel arms them
+            b.ctl->skip[p] = 1;
+            b.ctl->cur[p] = cur;
+        }
+        b.ctl->cur[kFinal] = cur;
     }
+}
+
+// After tie_repair_kernel: a run of equal keys that did not fit its workgroup (ctl->redo) sends the sort through the redo
+// slots -- the full order of passes, ids first, from wherever the data stands; any permutation is a valid LSD input.
+__global__ void replan_kernel(SortBufs b0, const LargeItem* items, char* scratch) {
+    LargeArgs unused{};
+    SortBufs b = b0;
+    if (items) bind_item(unused, b, items[blockIdx.x], scratch);
+    if (threadIdx.x != 0 || !b.ctl->keys_first || !b.ctl->redo) return;
+    uint32_t cur = b.ctl->cur[kDigits];
+    for (int p = 0; p < kDigits; ++p) {
+        bool constant = false;
+        for (int d = 0; d < kRadix; ++d) constant |= b.hist[p * kRadix + d] == (uint32_t)b.n;
+        const uint32_t s = constant ? 1u : 0u;                 // (the ids are not ascending: keys first was chosen)
+        b.ctl->skip[kDigits + p] = s;
+        b.ctl->cur[kDigits + p] = cur;
+        cur ^= (s ? 0u : 1u);
+    }
+    b.ctl->cur[kFinal] = cur;
 }
 
 // ---- per pass: tile digit counts ------------------------------------------------------------------
@@ -591,7 +656,9 @@ __global__ __launch_bounds__(THREADS, 4) void onesweep_pass_kernel(SortBufs b0, 
     // several topics per launch: the grid is as wide as the launch's largest topic, and only workgroups that have a tile to
     // sort may draw a ticket (tiles are taken by arrival, so exactly n_tiles workgroups of a topic must arrive)
     if ((int)blockIdx.x >= b.n_tiles) return;
-    if (b.ctl->skip[pass]) return;
+    const int slot = pass;                            // control-block slot (skip / cur / ticket / tag of the granules) ...
+    if (b.ctl->skip[slot]) return;
+    pass = slot >= kDigits ? slot - kDigits : slot;   // ... and the digit it sorts by (the redo slots repeat the digits)
     static_assert(THREADS >= kRadix && THREADS % kWave == 0, "one thread per digit in the look-back");
     constexpr int WAVES = THREADS / kWave, TILE = THREADS * kItems;
     __shared__ uint32_t cnt[WAVES][kRadix];
@@ -603,10 +670,10 @@ __global__ __launch_bounds__(THREADS, 4) void onesweep_pass_kernel(SortBufs b0, 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const bool digit_thread = threadIdx.x < kRadix;   // (whole wavefronts: 0 .. 3)
     LA_SCLK_START;
-    if (threadIdx.x == 0) s_ticket = atomicAdd(&b.ticket[pass], 1u);
+    if (threadIdx.x == 0) s_ticket = atomicAdd(&b.ticket[slot], 1u);
     for (int i = threadIdx.x; i < WAVES * kRadix; i += THREADS) (&cnt[0][0])[i] = 0;
     __syncthreads();
-    const uint32_t cur = b.ctl->cur[pass];
+    const uint32_t cur = b.ctl->cur[slot];
     const uint64_t* kin = key_buf(b, cur);
     const uint32_t* vin = val_buf(b, cur);
     uint64_t* kout = key_buf(b, cur ^ 1u);
@@ -615,7 +682,7 @@ __global__ __launch_bounds__(THREADS, 4) void onesweep_pass_kernel(SortBufs b0, 
     const int64_t t0 = (int64_t)tile * TILE;
     const int64_t w0 = t0 + (int64_t)wave * kItems * kWave;
     const int n_here = (int)((b.n - t0) < TILE ? (b.n - t0) : TILE);
-    const uint32_t epoch = (uint32_t)(pass + 1) << 2;
+    const uint32_t epoch = (uint32_t)(slot + 1) << 2;
     unsigned long long* my_state = b.tile_state + (int64_t)tile * kRadix + (threadIdx.x & (kRadix - 1));
 
     uint64_t key[kItems];
@@ -798,7 +865,7 @@ __global__ __launch_bounds__(256) void emit_ids_kernel(LargeArgs a0, SortBufs b0
     LA_PICK_ITEM(a, b, a0, b0, items, scratch, blockIdx.y)
     if ((int64_t)blockIdx.x * blockDim.x >= b.n) return;
     const bool fill_rank_minus1 = a.n_cons == 0;                       // nobody to assign to: Main.java:211-214
-    const uint32_t fin = b.ctl->cur[kDigits];
+    const uint32_t fin = b.ctl->cur[kFinal];
     const uint32_t* val = val_buf(b, fin);
     const uint64_t* key = key_buf(b, fin);
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -1359,7 +1426,7 @@ __global__ __launch_bounds__(1024) void greedy_rounds_kernel(LargeArgs a0, SortB
     uint32_t* s_hi = smem;
     uint32_t* s_lo = smem + n;
     uint32_t* s_tb = smem + 2 * n;
-    const uint64_t* key = key_buf(b, b.ctl->cur[kDigits]);
+    const uint64_t* key = key_buf(b, b.ctl->cur[kFinal]);
     const int64_t P = a.n_part;
     const int C = (int)a.n_cons;
 
@@ -1448,6 +1515,118 @@ __global__ __launch_bounds__(1024) void greedy_rounds_kernel(LargeArgs a0, SortB
     }
 }
 
+// ---- keys-first sorts: every run of equal keys into id order ------------------------------------------------------------------
+// After the key passes of a keys-first sort the partitions are in (lag desc) order and partitions with EQUAL lags stand in
+// input order; the comparator wants them in id order (Main.java:228-235).  Windows of kRepairWindow positions, one workgroup
+// per window (grid-stride): a window without two equal neighbours -- nearly all of them when lags are wide -- costs its 8 B
+// per partition of reading.  Otherwise the workgroup takes the runs that START in its window, whole, up to kRepairCap
+// positions: (index of the run) << 32 | id into registers, the block-wide bitonic network of the greedy's bins (la_sort64.h
+// inside a wavefront, LDS exchanges across), ids back in place.  A window writes only the runs that start in it and reads no
+// ids but theirs, so windows do not interfere.  A run that reaches beyond the capacity is left alone and raises ctl->redo:
+// the sample said there was no such run (or the test hook forced keys first), and the redo slots then sort in full.
+constexpr int kRepairThreads = 1024, kRepairEC = 8;
+constexpr int kRepairCap = kRepairThreads * kRepairEC;     // 8 192 positions a workgroup sorts at once
+constexpr int kRepairWindow = kRepairCap / 2;              // so a run of up to 4 096 starting anywhere in a window fits
+
+__global__ __launch_bounds__(kRepairThreads) void tie_repair_kernel(SortBufs b0, const LargeItem* items, char* scratch) {
+    extern __shared__ __attribute__((aligned(16))) uint64_t s_x[];        // two exchange buffers of kRepairCap words
+    __shared__ int s_first, s_last, s_end;
+    __shared__ uint32_t s_wsum[kRepairThreads / kWave];
+    LargeArgs unused{};
+    SortBufs b = b0;
+    if (items) bind_item(unused, b, items[blockIdx.y], scratch);
+    if (!b.ctl->keys_first) return;
+    constexpr int EC = kRepairEC, NT = kRepairThreads, W = kRepairWindow, CAP = kRepairCap;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t fin = b.ctl->cur[kDigits];                               // (the data after the sort's own slots)
+    const uint64_t* key = key_buf(b, fin);
+    uint32_t* val = val_buf(b, fin);
+    const int64_t n = b.n;
+    for (int64_t w0 = (int64_t)blockIdx.x * W; w0 < n; w0 += (int64_t)gridDim.x * W) {
+        const int64_t w1 = w0 + W < n ? w0 + W : n;
+        bool tie = false;
+        for (int64_t p = w0 + tid; p < w1; p += NT) tie |= p + 1 < n && key[p] == key[p + 1];
+        if (!__syncthreads_or(tie)) continue;
+        // the first and the last run start inside the window; where the last run ends (searched up to the capacity)
+        if (tid == 0) { s_first = 0x7FFFFFFF; s_last = -1; s_end = 0x7FFFFFFF; }
+        __syncthreads();
+        {
+            int lo = 0x7FFFFFFF, hi = -1;
+            for (int64_t p = w0 + tid; p < w1; p += NT)
+                if (p == 0 || key[p] != key[p - 1]) { const int o = (int)(p - w0); lo = o < lo ? o : lo; hi = o > hi ? o : hi; }
+            if (lo != 0x7FFFFFFF) { atomicMin(&s_first, lo); atomicMax(&s_last, hi); }
+        }
+        __syncthreads();
+        if (s_last < 0) continue;                                           // the whole window lies inside an earlier run (uniform)
+        const int64_t first = w0 + s_first;
+        {
+            int e = 0x7FFFFFFF;
+            for (int64_t p = w1 + tid; p <= first + CAP && p <= n; p += NT)
+                if (p == n || key[p] != key[p - 1]) { const int o = (int)(p - first); e = o < e ? o : e; }
+            if (e != 0x7FFFFFFF) atomicMin(&s_end, e);
+        }
+        __syncthreads();
+        int len;
+        if (s_end != 0x7FFFFFFF) {
+            len = s_end;                                                    // every run that starts in the window, whole
+        } else {
+            len = (int)(w0 + s_last - first);                               // the last run does not fit: without it,
+            if (tid == 0) b.ctl->redo = 1;                                  // and the sort is redone in full
+        }
+        __syncthreads();                                                    // (s_* are rewritten by the next window)
+        if (len <= 1) continue;
+        // composites: (index of the run in the region) << 32 | biased id; slots beyond the region sort last
+        P64 rec[EC];
+        uint32_t flags = 0, own = 0;
+        uint64_t prev = first + (int64_t)tid * EC > 0 && tid * EC < len ? key[first + (int64_t)tid * EC - 1] : 0;
+        uint32_t v[EC];
+#pragma unroll
+        for (int r = 0; r < EC; ++r) {
+            const int i = tid * EC + r;
+            const bool valid = i < len;
+            const uint64_t k = valid ? key[first + i] : 0;
+            v[r] = valid ? val[first + i] : 0;
+            const bool start = valid && (i == 0 || k != prev);
+            flags |= start ? 1u << r : 0u;
+            own += start ? 1u : 0u;
+            prev = k;
+        }
+        uint32_t incl = own;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t y = __shfl_up(incl, o);
+            if (lane >= o) incl += y;
+        }
+        if (lane == 63) s_wsum[wave] = incl;
+        __syncthreads();
+        uint32_t run = incl - own;                                          // runs that start before this thread's positions
+        for (int x = 0; x < wave; ++x) run += s_wsum[x];
+#pragma unroll
+        for (int r = 0; r < EC; ++r) {
+            run += (flags >> r) & 1u;
+            rec[r] = p64_from(tid * EC + r < len ? ((uint64_t)run << 32) | v[r] : ~0ull);
+        }
+        // the network of greedy_rounds_packed's bins: inside every wavefront, then merges across wavefronts
+        constexpr int kSpan = 64 * EC;
+        dpp_fence<EC>(rec);
+        bitonic_sort_tile_p64<64, EC>(rec);
+        ExchangeBufs xb{s_x, CAP};
+        for (int K = 2 * kSpan; K <= CAP; K <<= 1) {
+            cross_wave_step<EC>(rec, xb, tid, K - 1, K >> 1);
+            for (int j = K >> 2; j >= kSpan; j >>= 1) cross_wave_step<EC>(rec, xb, tid, j, j);
+            dpp_fence<EC>(rec);
+            clean_p64<64, EC, kSpan / 2, false>(rec);
+        }
+        lds_barrier();
+#pragma unroll
+        for (int r = 0; r < EC; ++r) {
+            const int i = tid * EC + r;
+            if (i < len) val[first + i] = (uint32_t)p64_value(rec[r]);
+        }
+        __syncthreads();
+    }
+}
+
 // ---- kernel 3, literal form: bins in LDS, wavefront argmin per partition ------------------------------
 __global__ __launch_bounds__(1024) void greedy_argmin_kernel(LargeArgs a, SortBufs b) {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
@@ -1456,7 +1635,7 @@ __global__ __launch_bounds__(1024) void greedy_argmin_kernel(LargeArgs a, SortBu
     uint32_t* s_hi = smem + C;              // biased assigned lag, high / low dword
     uint32_t* s_lo = smem + 2 * C;
     uint32_t* w_best = smem + 3 * C;        // [16 waves][4]
-    const uint64_t* key = b.key[b.ctl->cur[kDigits]];
+    const uint64_t* key = b.key[b.ctl->cur[kFinal]];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
     for (int i = tid; i < C; i += blockDim.x) { s_cnt[i] = 0; s_hi[i] = (uint32_t)(kTotalBias >> 32); s_lo[i] = 0; }
     __syncthreads();
@@ -1587,7 +1766,7 @@ __global__ __launch_bounds__(256) void member_emit_kernel(SortBufs b, int32_t n_
                                                           const int64_t* part_off, const int32_t* out_partition,
                                                           int64_t* member_off, int32_t* grouped_topic,
                                                           int32_t* grouped_partition, int32_t* grouped_entry, uint32_t* status) {
-    const uint32_t fin = b.ctl->cur[kDigits];
+    const uint32_t fin = b.ctl->cur[kFinal];
     const uint64_t* key = b.key[fin];
     const uint32_t* val = b.val[fin];
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -1662,11 +1841,23 @@ struct SortLayout {
     int64_t n = 0;
     bool multi_kernel = false;
     int sweep_threads = 256, n_tiles = 0, n_groups = 0;
-    size_t o_ctl = 0, o_hist = 0, o_ticket = 0, o_state = 0, zero_bytes = 0;                        // offsets into the zero part
+    size_t o_ctl = 0, o_hist = 0, o_ticket = 0, o_state = 0, o_samp = 0, zero_bytes = 0;            // offsets into the zero part
+    int keys_first = 0;                                                                             // 0 never, 1 by the sample, 2 forced
+    uint32_t samp_bits = 0;
     size_t o_gbase = 0, o_k0 = 0, o_k1 = 0, o_v0 = 0, o_v1 = 0, o_to = 0, o_gs = 0, data_bytes = 0;   // ... into the data part
 };
 
-static SortLayout sort_layout(int64_t n, bool multi_kernel) {
+// Keys-first sorts (plan_kernel): worth their extra launches from a few million partitions on; LA_SORT_KEYS_FIRST=0 never,
+// =2 always and whatever the sample says (test hook: small topics, long runs through the redo slots).
+static int keys_first_mode(int64_t n, bool multi_kernel) {
+    int mode = 1;
+    if (const char* env = getenv("LA_SORT_KEYS_FIRST")) mode = atoi(env);
+    if (multi_kernel || mode <= 0) return 0;
+    if (mode >= 2) return 2;
+    return n >= ((int64_t)1 << 22) ? 1 : 0;
+}
+
+static SortLayout sort_layout(int64_t n, bool multi_kernel, bool may_sort_keys_first = false) {
     SortLayout L;
     L.n = n;
     if (n >= ((int64_t)1 << 30)) multi_kernel = true;
@@ -1686,8 +1877,14 @@ static SortLayout sort_layout(int64_t n, bool multi_kernel) {
     auto carve = [&](size_t bytes) { size_t o = off; off = align_up(off + bytes, 256); return o; };
     L.o_ctl = carve(sizeof(SortCtl));
     L.o_hist = carve(sizeof(uint32_t) * kDigits * kRadix);
-    L.o_ticket = carve(sizeof(uint32_t) * kDigits);
+    L.o_ticket = carve(sizeof(uint32_t) * kSlots);
     L.o_state = carve(multi_kernel ? 0 : sizeof(unsigned long long) * kRadix * (size_t)L.n_tiles);
+    L.keys_first = may_sort_keys_first ? keys_first_mode(n, multi_kernel) : 0;
+    if (L.keys_first) {
+        L.samp_bits = 10;                                           // n / 32 counters for n / 256 samples (at least 1 024)
+        while (((int64_t)1 << L.samp_bits) < n / 32 && L.samp_bits < 28) ++L.samp_bits;
+        L.o_samp = carve(sizeof(uint32_t) << L.samp_bits);
+    }
     L.zero_bytes = off;
     off = 0;
     L.o_gbase = carve(sizeof(uint32_t) * kDigits * kRadix);
@@ -1717,6 +1914,9 @@ static SortBufs sort_bind(const SortLayout& L, char* zero, char* data) {
     b.n_groups = L.n_groups;
     b.atomic_rank = large_atomic_rank_supported();
     b.sweep_threads = L.sweep_threads;
+    b.samp = L.keys_first ? (uint32_t*)(zero + L.o_samp) : nullptr;
+    b.samp_bits = L.samp_bits;
+    b.keys_first_force = L.keys_first == 2 ? 1 : 0;
     return b;
 }
 
@@ -1736,8 +1936,9 @@ static hipError_t scratch_reserve(LargeScratch& scratch, size_t bytes, hipStream
     return hipSuccess;
 }
 
-static hipError_t sort_prepare(LargeScratch& scratch, int64_t n, hipStream_t stream, SortBufs* out, bool multi_kernel = false) {
-    const SortLayout L = sort_layout(n, multi_kernel);
+static hipError_t sort_prepare(LargeScratch& scratch, int64_t n, hipStream_t stream, SortBufs* out, bool multi_kernel = false,
+                               bool may_sort_keys_first = false) {
+    const SortLayout L = sort_layout(n, multi_kernel, may_sort_keys_first);
     hipError_t e;
     if ((e = scratch_reserve(scratch, L.zero_bytes + L.data_bytes, stream)) != hipSuccess) return e;
     char* base = (char*)scratch.buf;
@@ -1753,13 +1954,16 @@ static hipError_t sort_prepare(LargeScratch& scratch, int64_t n, hipStream_t str
 // A pass is ONE launch (onesweep_pass_kernel) -- or four, when the sort was prepared for the multi-kernel form.
 static void sort_run_passes(const SortBufs& b, hipStream_t stream, uint32_t* status, hipEvent_t planned = nullptr,
                             uint32_t pass_mask = (1u << kDigits) - 1, const LargeItem* items = nullptr, int count = 1,
-                            int max_tiles = 0, char* scratch = nullptr) {
+                            int max_tiles = 0, char* scratch = nullptr, int slot0 = 0) {
     // `items`: `count` topics of ONE tile class (b.sweep_threads), sorted side by side -- grid.y picks the topic, grid.x is as
-    // wide as the class's largest topic (max_tiles); the plan of all of them is the caller's (one launch over every class)
-    if (!items) hipLaunchKernelGGL(plan_kernel, dim3(kDigits), dim3(kRadix), 0, stream, b, (const LargeItem*)nullptr, (char*)nullptr);
+    // wide as the class's largest topic (max_tiles); the plan of all of them is the caller's (one launch over every class).
+    // slot0 = kDigits: the redo slots of a keys-first sort (same digits, see tie_repair_kernel).
+    if (!items && slot0 == 0)
+        hipLaunchKernelGGL(plan_kernel, dim3(kDigits), dim3(kRadix), 0, stream, b, (const LargeItem*)nullptr, (char*)nullptr);
     if (planned) (void)hipEventRecord(planned, stream);
-    for (int p = 0; p < kDigits; ++p) {
-        if (!((pass_mask >> p) & 1u)) continue;
+    for (int d = 0; d < kDigits; ++d) {
+        if (!((pass_mask >> d) & 1u)) continue;
+        const int p = slot0 + d;
         if (b.tile_state) {
             const dim3 grid(items ? max_tiles : b.n_tiles, items ? count : 1);
             if (b.sweep_threads == 1024) {
@@ -1782,6 +1986,23 @@ static void sort_run_passes(const SortBufs& b, hipStream_t stream, uint32_t* sta
     }
 }
 
+// The tail of sorts that may have gone keys first (b.samp of the single form; any item of a batched launch): ties into id
+// order, then -- no-ops unless a run did not fit -- the redo slots.  `max_n`: partitions of the largest topic.
+static hipError_t sort_repair_launch(const SortBufs& b, hipStream_t stream, const LargeItem* items, int count, char* scratch,
+                                     int64_t max_n) {
+    static PerDeviceOnce lds_opt_in;
+    const hipError_t e = lds_opt_in.run([] {
+        return hipFuncSetAttribute((const void*)tie_repair_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    });
+    if (e != hipSuccess) return e;
+    int64_t gx = (max_n + kRepairWindow - 1) / kRepairWindow;
+    if (gx > 4096) gx = 4096;
+    hipLaunchKernelGGL(tie_repair_kernel, dim3((unsigned)gx, items ? count : 1), dim3(kRepairThreads),
+                       (size_t)2 * kRepairCap * sizeof(uint64_t), stream, b, items, scratch);
+    hipLaunchKernelGGL(replan_kernel, dim3(items ? count : 1), dim3(64), 0, stream, b, items, scratch);
+    return hipGetLastError();
+}
+
 hipError_t large_topic_launch(LargeScratch& scratch, const LargeArgs& a, bool argmin, hipStream_t stream) {
     const int64_t n = a.n_part;
     if (n <= 0) {
@@ -1793,7 +2014,7 @@ hipError_t large_topic_launch(LargeScratch& scratch, const LargeArgs& a, bool ar
     if (n > 0x7FFFFFFF || a.n_cons > kLargeMaxConsumers) return hipErrorInvalidValue;
     SortBufs b{};
     hipError_t e;
-    if ((e = sort_prepare(scratch, n, stream, &b, a.sort_multi_kernel != 0)) != hipSuccess) return e;
+    if ((e = sort_prepare(scratch, n, stream, &b, a.sort_multi_kernel != 0, true)) != hipSuccess) return e;
     int grid = (int)((n + 255) / 256);
     if (grid > 2048) grid = 2048;
     LargeProfile& pf = scratch.prof;
@@ -1811,6 +2032,10 @@ hipError_t large_topic_launch(LargeScratch& scratch, const LargeArgs& a, bool ar
     } done{pf, profile, stream};
     hipLaunchKernelGGL(build_keys_kernel, dim3(grid), dim3(256), 0, stream, a, b, (const LargeItem*)nullptr, (char*)nullptr);
     sort_run_passes(b, stream, a.status, profile ? pf.ev[1] : nullptr);
+    if (b.samp) {
+        if ((e = sort_repair_launch(b, stream, nullptr, 1, nullptr, n)) != hipSuccess) return e;
+        sort_run_passes(b, stream, a.status, nullptr, (1u << kDigits) - 1, nullptr, 1, 0, nullptr, kDigits);
+    }
     if (profile) (void)hipEventRecord(pf.ev[2], stream);
     hipLaunchKernelGGL(emit_ids_kernel, dim3(grid), dim3(256), 0, stream, a, b, (const LargeItem*)nullptr, (char*)nullptr);
     if ((e = hipGetLastError()) != hipSuccess) return e;
@@ -1842,7 +2067,7 @@ hipError_t large_topics_launch(LargeScratch& scratch, const LargeArgs* args, int
     bool serial = count == 1;
     for (int i = 0; i < count; ++i) {
         if (args[i].n_part <= 0 || args[i].n_part > 0x7FFFFFFF || args[i].n_cons > kLargeMaxConsumers) return hipErrorInvalidValue;
-        lay[(size_t)i] = sort_layout(args[i].n_part, args[i].sort_multi_kernel != 0);
+        lay[(size_t)i] = sort_layout(args[i].n_part, args[i].sort_multi_kernel != 0, true);
         serial = serial || lay[(size_t)i].multi_kernel;
     }
     if (serial) {
@@ -1887,6 +2112,7 @@ hipError_t large_topics_launch(LargeScratch& scratch, const LargeArgs* args, int
     LargeItem* h_items = (LargeItem*)sg.h;
     int32_t* h_order = (int32_t*)((char*)sg.h + items_bytes);
     int64_t max_n = 0;
+    bool any_keys_first = false, force_keys_first = false;
     for (int j = 0; j < count; ++j) {
         const int i = idx[(size_t)j];
         const SortLayout& L = lay[(size_t)i];
@@ -1896,6 +2122,10 @@ hipError_t large_topics_launch(LargeScratch& scratch, const LargeArgs* args, int
         const uint64_t z = zoff[(size_t)j], d = zero + doff[(size_t)j];
         it.o_ctl = z + L.o_ctl; it.o_hist = z + L.o_hist; it.o_ticket = z + L.o_ticket; it.o_state = z + L.o_state;
         it.o_gbase = d + L.o_gbase; it.o_k0 = d + L.o_k0; it.o_k1 = d + L.o_k1; it.o_v0 = d + L.o_v0; it.o_v1 = d + L.o_v1;
+        it.o_samp = L.keys_first ? z + L.o_samp : 0;               // (z + o_samp > 0: the control block comes first)
+        it.samp_bits = L.samp_bits; it.pad = 0;
+        any_keys_first = any_keys_first || L.keys_first != 0;
+        force_keys_first = force_keys_first || L.keys_first == 2;
         if (args[i].n_part > max_n) max_n = args[i].n_part;
     }
     struct Cls { int ec, threads, first, n; };
@@ -1935,6 +2165,7 @@ hipError_t large_topics_launch(LargeScratch& scratch, const LargeArgs* args, int
     LargeArgs a0 = args[0];
     SortBufs b0{};
     b0.atomic_rank = large_atomic_rank_supported();
+    b0.keys_first_force = force_keys_first ? 1 : 0;
     uint32_t* status = args[0].status;
     hipLaunchKernelGGL(build_keys_kernel, dim3(gx, count), dim3(256), 0, stream, a0, b0, d_items, base);
     hipLaunchKernelGGL(plan_kernel, dim3(kDigits, count), dim3(kRadix), 0, stream, b0, d_items, base);
@@ -1951,6 +2182,22 @@ hipError_t large_topics_launch(LargeScratch& scratch, const LargeArgs* args, int
         bc.tile_state = (unsigned long long*)base;                 // (non-null: the single-kernel passes; items carry the real one)
         sort_run_passes(bc, stream, status, nullptr, (1u << kDigits) - 1, d_items + first, n, max_tiles, base);
         first += n;
+    }
+    if (any_keys_first) {
+        if ((e = sort_repair_launch(b0, stream, d_items, count, base, max_n)) != hipSuccess) return e;
+        for (int first = 0; first < count;) {                      // the redo slots (no-ops unless a run did not fit), per class
+            const int sweep = lay[(size_t)idx[(size_t)first]].sweep_threads;
+            int n = 0, max_tiles = 0;
+            while (first + n < count && lay[(size_t)idx[(size_t)(first + n)]].sweep_threads == sweep) {
+                if (h_items[first + n].n_tiles > max_tiles) max_tiles = h_items[first + n].n_tiles;
+                ++n;
+            }
+            SortBufs bc = b0;
+            bc.sweep_threads = sweep;
+            bc.tile_state = (unsigned long long*)base;
+            sort_run_passes(bc, stream, status, nullptr, (1u << kDigits) - 1, d_items + first, n, max_tiles, base, kDigits);
+            first += n;
+        }
     }
     if (profile) (void)hipEventRecord(pf.ev[2], stream);
     hipLaunchKernelGGL(emit_ids_kernel, dim3(gx, count), dim3(256), 0, stream, a0, b0, d_items, base);
@@ -1975,8 +2222,8 @@ __global__ __launch_bounds__(256) void huge_round_kernel(LargeArgs a, SortBufs p
     for (int i = threadIdx.x; i < 8 * kRadix; i += blockDim.x) h[i] = 0;
     __syncthreads();
     const int64_t C = a.n_cons, P = a.n_part;
-    const uint64_t* lagkey = parts.key[parts.ctl->cur[kDigits]];
-    const uint32_t fin = first ? 0u : cur.ctl->cur[kDigits];
+    const uint64_t* lagkey = parts.key[parts.ctl->cur[kFinal]];
+    const uint32_t fin = first ? 0u : cur.ctl->cur[kFinal];
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < C; k += stride) {
         uint64_t total = kTotalBias;                                  // biased: unsigned order = Java's signed order
@@ -2011,7 +2258,7 @@ hipError_t huge_topic_launch(LargeScratch& scratch, const LargeArgs& a, hipStrea
         return hipSuccess;
     }
     if (P > 0x7FFFFFFF || C > 0x7FFFFFFF || C <= 0) return hipErrorInvalidValue;
-    const SortLayout lp = sort_layout(P, a.sort_multi_kernel != 0), lc = sort_layout(C, false);
+    const SortLayout lp = sort_layout(P, a.sort_multi_kernel != 0, true), lc = sort_layout(C, false);
     hipError_t e;
     const size_t zero = lp.zero_bytes + 2 * lc.zero_bytes, data = lp.data_bytes + 2 * lc.data_bytes;
     if ((e = scratch_reserve(scratch, zero + data, stream)) != hipSuccess) return e;
@@ -2024,6 +2271,10 @@ hipError_t huge_topic_launch(LargeScratch& scratch, const LargeArgs& a, hipStrea
     if (grid > 2048) grid = 2048;
     hipLaunchKernelGGL(build_keys_kernel, dim3(grid), dim3(256), 0, stream, a, bp, (const LargeItem*)nullptr, (char*)nullptr);
     sort_run_passes(bp, stream, a.status);
+    if (bp.samp) {
+        if ((e = sort_repair_launch(bp, stream, nullptr, 1, nullptr, P)) != hipSuccess) return e;
+        sort_run_passes(bp, stream, a.status, nullptr, (1u << kDigits) - 1, nullptr, 1, 0, nullptr, kDigits);
+    }
     hipLaunchKernelGGL(emit_ids_kernel, dim3(grid), dim3(256), 0, stream, a, bp, (const LargeItem*)nullptr, (char*)nullptr);
     int cgrid = (int)((C + 255) / 256);
     if (cgrid > 1024) cgrid = 1024;
@@ -2242,8 +2493,10 @@ hipError_t large_profile_read(LargeScratch& s, float* ms, int* passes, int64_t* 
     SortCtl ctl;                                    // the control block sits at the start of the scratch
     if ((e = hipMemcpy(&ctl, s.buf, sizeof ctl, hipMemcpyDeviceToHost)) != hipSuccess) return e;
     passes[0] = passes[1] = 0;
-    for (int p = 0; p < kDigits; ++p)
-        if (!ctl.skip[p]) ++passes[p < 4 ? 0 : 1];
+    for (int p = 0; p < kSlots; ++p)
+        if (!ctl.skip[p]) ++passes[p % kDigits < 4 ? 0 : 1];
+    passes[2] = (int)ctl.keys_first;
+    passes[3] = (int)ctl.redo;
     *n = s.prof.n;
     return hipSuccess;
 }

@@ -425,3 +425,84 @@ def test_smallest_calls_run_zero_copy_and_agree_with_the_copying_forms():
         p, m, t = c.assign_batch_lags([0, 3], [0, 1, 2], [100000, 50000, 60000], [0, 2], [0, 1])      # README.md:42-57
         assert c.last_pipeline() == N.LA_PIPELINE_ZERO_COPY
         assert p.tolist() == [0, 2, 1] and m.tolist() == [0, 1, 1] and t.tolist() == [100000, 110000]
+
+
+# ---- keys-first sorts with tie repair ----------------------------------------------------------------------
+def _sort_topic(n, kind, seed, shuffled=True, dup_ids=False):
+    rng = np.random.default_rng(seed)
+    if kind == "wide":
+        lag = rng.integers(0, 1 << 40, n)
+    elif kind == "runs":                                    # thousands of short runs
+        lag = rng.integers(0, max(2, n // 300), n)
+    elif kind == "run4096":                                 # one run of exactly 4 096 (fits anywhere), the rest distinct
+        lag = rng.permutation(n).astype(np.int64) + 10
+        lag[rng.choice(n, 4096, replace=False)] = 5
+    elif kind == "run9000":                                 # one run too long for a workgroup: the redo slots
+        lag = rng.permutation(n).astype(np.int64) + 10
+        lag[rng.choice(n, 9000, replace=False)] = 7
+    elif kind == "run20000_top":                            # ... at the top of the order, next to short runs
+        lag = rng.integers(0, n // 50, n)
+        lag[rng.choice(n, 20000, replace=False)] = 1 << 41
+    elif kind == "equal":
+        lag = np.full(n, 12345)
+    elif kind == "full":
+        lag = rng.integers(-(1 << 63), (1 << 63) - 1, n)
+        lag[rng.choice(n, n // 10, replace=False)] = -3      # ties among negative lags
+    else:
+        raise ValueError(kind)
+    pid = rng.permutation(n) if shuffled else np.arange(n)
+    if dup_ids:
+        pid = pid // 3
+    lag = np.asarray(lag, np.int64)
+    pid = pid.astype(np.int32)
+    return synth.Workload("sort", 1, np.array([0, n], np.int64), pid, np.zeros(n, np.int64), lag.copy(), np.zeros(n, np.int64), lag,
+                          np.array([0, 0], np.int64), np.zeros(0, np.int32), n, 0)
+
+
+@pytest.mark.parametrize("n,kind,shuffled,dup,expect_first,expect_redo", [
+    (70000, "wide", True, False, 1, 0), (200000, "runs", True, False, 1, 0), (150000, "run4096", True, False, 1, 0),
+    (150000, "run9000", True, False, 1, 1), (300000, "run20000_top", True, False, 1, 1), (50000, "equal", True, False, 0, 0),
+    (90000, "full", True, False, 1, 0), (120000, "runs", True, True, 1, 0), (80000, "runs", False, False, 0, 0),
+    (20000, "runs", True, False, 1, 0), (4097, "wide", True, False, 1, 0)])
+def test_keys_first_sort_forced_on_small_topics(n, kind, shuffled, dup, expect_first, expect_redo):
+    """LA_SORT_KEYS_FIRST=2 (test hook): every large-path sort with shuffled ids skips its id passes and repairs the runs of
+    equal lags afterwards, whatever the sample says.  Same order as the comparator's (lag desc, id asc): no ties, thousands of
+    short runs, a run that just fits a workgroup, runs that do not (the redo slots), negative lags, duplicate ids; ids already
+    ascending and all-equal lags never go keys first."""
+    os.environ["LA_SORT_KEYS_FIRST"] = "2"
+    try:
+        with N.Context(0) as c:
+            w = _sort_topic(n, kind, n + len(kind), shuffled, dup)
+            got = _device_call(c, w, flags=N.LA_FLAG_PROFILE)
+            t = c.last_phase_times()
+            assert (t.keys_first, t.redone) == (expect_first, expect_redo), (t.keys_first, t.redone)
+            order = np.lexsort((w.partition_id, ~w.lag))
+            np.testing.assert_array_equal(got[0], w.partition_id[order])
+            assert (got[1] == -1).all()
+            # with consumers: the greedy reads the repaired order
+            w2 = _batch_of([(n, 37)], n, kinds=["ties"])
+            _same3(_device_call(c, w2), round_form(w2.part_off, w2.partition_id, w2.lag, w2.cons_off, w2.cons_rank), "with consumers")
+            # several topics side by side, each with its own decision
+            w3 = _batch_of([(30000, 5), (50000, 0), (20000, 100), (65536, 3)], n + 1, kinds=["ties", "u40", "zero", "pareto"])
+            _same3(_device_call(c, w3), round_form(w3.part_off, w3.partition_id, w3.lag, w3.cons_off, w3.cons_rank), "side by side")
+    finally:
+        os.environ.pop("LA_SORT_KEYS_FIRST", None)
+
+
+@pytest.mark.parametrize("kind,expect_first", [("wide", 1), ("runs", 0), ("run20000_top", 0), ("equal", 0)])
+def test_keys_first_sort_by_the_sample_at_five_million(ctx, kind, expect_first):
+    """The default rule: from 4 M partitions on, with shuffled ids, keys first unless the sample of the lags shows a frequent one."""
+    n = 5_000_000
+    w = _sort_topic(n, kind, 77)
+    got = _device_call(ctx, w, flags=N.LA_FLAG_PROFILE)
+    t = ctx.last_phase_times()
+    assert t.keys_first == expect_first and t.redone == 0, (t.keys_first, t.redone, t.id_passes, t.key_passes)
+    order = np.lexsort((w.partition_id, ~w.lag))
+    np.testing.assert_array_equal(got[0], w.partition_id[order])
+    os.environ["LA_SORT_KEYS_FIRST"] = "0"                  # never: the round-3 order of passes, same answer
+    try:
+        got0 = _device_call(ctx, w, flags=N.LA_FLAG_PROFILE)
+        assert ctx.last_phase_times().keys_first == 0
+        np.testing.assert_array_equal(got0[0], got[0])
+    finally:
+        os.environ.pop("LA_SORT_KEYS_FIRST", None)
