@@ -1992,7 +1992,9 @@ static hipError_t sort_repair_launch(const SortBufs& b, hipStream_t stream, cons
                                      int64_t max_n) {
     static PerDeviceOnce lds_opt_in;
     const hipError_t e = lds_opt_in.run([] {
-        return hipFuncSetAttribute((const void*)tie_repair_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        // (exactly what the launch asks for: the kernel also has static LDS, and dynamic + static must fit the CU's 160 KB)
+        return hipFuncSetAttribute((const void*)tie_repair_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)(2 * kRepairCap * sizeof(uint64_t)));
     });
     if (e != hipSuccess) return e;
     int64_t gx = (max_n + kRepairWindow - 1) / kRepairWindow;
