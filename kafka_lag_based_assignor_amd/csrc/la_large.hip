@@ -42,6 +42,9 @@ constexpr int kItems = 16;
 constexpr int kTile = kSortThreads * kItems;     // 4096 elements per workgroup
 constexpr int kScanRows = 32;                    // tiles per workgroup of the offset scan
 constexpr uint32_t kSampleHeavy = 8;             // 1 in 256 keys is sampled: a counter at 8 ~ a lag shared by ~2 000 partitions
+constexpr int kRepairThreads = 1024, kRepairEC = 8;        // tie_repair_kernel
+constexpr int kRepairCap = kRepairThreads * kRepairEC;     // 8 192 positions a workgroup sorts at once
+constexpr int kRepairWindow = kRepairCap / 2;              // so a run of up to 4 096 starting anywhere in a window fits
 
 // Pass slots: 0 .. kDigits-1 are the sort's passes (digit = slot); kDigits .. 2*kDigits-1 are the same digits again, for the one
 // case in which a keys-first sort has to be redone in full (see tie_repair_kernel); they are no-ops otherwise.
@@ -78,6 +81,7 @@ struct SortBufs {
     // frequent that its run could not be repaired in one workgroup; null: this sort never goes keys first
     uint32_t* samp;
     uint32_t samp_bits;                // table of 2^samp_bits counters
+    uint32_t* tie_flag;                // [ceil(n / kRepairWindow)] != 0: the window holds two equal neighbours (tie_scan_kernel)
     int keys_first_force;              // test hook: keys first whatever the sample says (long runs then take the redo slots)
 };
 
@@ -94,6 +98,7 @@ struct LargeItem {
     int32_t n_tiles, n_groups;
     uint64_t o_ctl, o_hist, o_ticket, o_state, o_gbase, o_k0, o_k1, o_v0, o_v1;
     uint64_t o_samp;                   // 0: no sample table (this topic never sorts keys first)
+    uint64_t o_flag;
     uint32_t samp_bits, pad;
 };
 
@@ -114,6 +119,7 @@ __device__ __forceinline__ void bind_item(LargeArgs& a, SortBufs& b, const Large
     b.val[0] = (uint32_t*)(scratch + it.o_v0);
     b.val[1] = (uint32_t*)(scratch + it.o_v1);
     b.samp = it.o_samp ? (uint32_t*)(scratch + it.o_samp) : nullptr;
+    b.tie_flag = (uint32_t*)(scratch + it.o_flag);
     b.samp_bits = it.samp_bits;
     b.n = it.n;
     b.n_tiles = it.n_tiles;
@@ -1518,15 +1524,35 @@ __global__ __launch_bounds__(1024) void greedy_rounds_kernel(LargeArgs a0, SortB
 // ---- keys-first sorts: every run of equal keys into id order ------------------------------------------------------------------
 // After the key passes of a keys-first sort the partitions are in (lag desc) order and partitions with EQUAL lags stand in
 // input order; the comparator wants them in id order (Main.java:228-235).  Windows of kRepairWindow positions, one workgroup
-// per window (grid-stride): a window without two equal neighbours -- nearly all of them when lags are wide -- costs its 8 B
-// per partition of reading.  Otherwise the workgroup takes the runs that START in its window, whole, up to kRepairCap
+// per window (grid-stride): a window without two equal neighbours -- nearly all of them when lags are wide -- cost its 8 B
+// per partition of reading in tie_scan_kernel and is skipped here.  Otherwise the workgroup takes the runs that START in its window, whole, up to kRepairCap
 // positions: (index of the run) << 32 | id into registers, the block-wide bitonic network of the greedy's bins (la_sort64.h
 // inside a wavefront, LDS exchanges across), ids back in place.  A window writes only the runs that start in it and reads no
 // ids but theirs, so windows do not interfere.  A run that reaches beyond the capacity is left alone and raises ctl->redo:
 // the sample said there was no such run (or the test hook forced keys first), and the redo slots then sort in full.
-constexpr int kRepairThreads = 1024, kRepairEC = 8;
-constexpr int kRepairCap = kRepairThreads * kRepairEC;     // 8 192 positions a workgroup sorts at once
-constexpr int kRepairWindow = kRepairCap / 2;              // so a run of up to 4 096 starting anywhere in a window fits
+
+// Which windows hold ties at all: a plain streaming read of the sorted keys at full occupancy (the repair kernel below keeps
+// 128 KB of LDS per workgroup -- one workgroup per CU -- and would read them at a sixth of the bandwidth).
+__global__ __launch_bounds__(256) void tie_scan_kernel(SortBufs b0, const LargeItem* items, char* scratch) {
+    LargeArgs unused{};
+    SortBufs b = b0;
+    if (items) bind_item(unused, b, items[blockIdx.y], scratch);
+    if (!b.ctl->keys_first) return;
+    const uint64_t* key = key_buf(b, b.ctl->cur[kDigits]);
+    const int64_t n = b.n, pairs = (n + 1) / 2;
+    struct __attribute__((aligned(16))) U64x2 { uint64_t x, y; };
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < pairs; j += stride) {
+        const int64_t i = 2 * j;                                            // positions i, i + 1 (16-byte load), neighbour i + 2
+        uint64_t k0, k1 = 0, k2 = 0;
+        if (i + 1 < n) { const U64x2 v = *reinterpret_cast<const U64x2*>(key + i); k0 = v.x; k1 = v.y; }
+        else k0 = key[i];
+        const bool has2 = i + 2 < n;
+        if (has2) k2 = key[i + 2];
+        if (i + 1 < n && k0 == k1) b.tie_flag[i / kRepairWindow] = 1;
+        if (has2 && k1 == k2) b.tie_flag[(i + 1) / kRepairWindow] = 1;
+    }
+}
 
 __global__ __launch_bounds__(kRepairThreads) void tie_repair_kernel(SortBufs b0, const LargeItem* items, char* scratch) {
     extern __shared__ __attribute__((aligned(16))) uint64_t s_x[];        // two exchange buffers of kRepairCap words
@@ -1544,10 +1570,9 @@ __global__ __launch_bounds__(kRepairThreads) void tie_repair_kernel(SortBufs b0,
     const int64_t n = b.n;
     for (int64_t w0 = (int64_t)blockIdx.x * W; w0 < n; w0 += (int64_t)gridDim.x * W) {
         const int64_t w1 = w0 + W < n ? w0 + W : n;
-        bool tie = false;
-        for (int64_t p = w0 + tid; p < w1; p += NT) tie |= p + 1 < n && key[p] == key[p + 1];
-        if (!__syncthreads_or(tie)) continue;
+        if (b.tie_flag[w0 / W] == 0) continue;                              // (uniform) no two equal neighbours: nothing to repair
         // the first and the last run start inside the window; where the last run ends (searched up to the capacity)
+        __syncthreads();                                                    // (the window before this one is done with s_*)
         if (tid == 0) { s_first = 0x7FFFFFFF; s_last = -1; s_end = 0x7FFFFFFF; }
         __syncthreads();
         {
@@ -1841,7 +1866,7 @@ struct SortLayout {
     int64_t n = 0;
     bool multi_kernel = false;
     int sweep_threads = 256, n_tiles = 0, n_groups = 0;
-    size_t o_ctl = 0, o_hist = 0, o_ticket = 0, o_state = 0, o_samp = 0, zero_bytes = 0;            // offsets into the zero part
+    size_t o_ctl = 0, o_hist = 0, o_ticket = 0, o_state = 0, o_samp = 0, o_flag = 0, zero_bytes = 0;  // offsets into the zero part
     int keys_first = 0;                                                                             // 0 never, 1 by the sample, 2 forced
     uint32_t samp_bits = 0;
     size_t o_gbase = 0, o_k0 = 0, o_k1 = 0, o_v0 = 0, o_v1 = 0, o_to = 0, o_gs = 0, data_bytes = 0;   // ... into the data part
@@ -1884,6 +1909,7 @@ static SortLayout sort_layout(int64_t n, bool multi_kernel, bool may_sort_keys_f
         L.samp_bits = 10;                                           // n / 32 counters for n / 256 samples (at least 1 024)
         while (((int64_t)1 << L.samp_bits) < n / 32 && L.samp_bits < 28) ++L.samp_bits;
         L.o_samp = carve(sizeof(uint32_t) << L.samp_bits);
+        L.o_flag = carve(sizeof(uint32_t) * (size_t)((n + kRepairWindow - 1) / kRepairWindow));
     }
     L.zero_bytes = off;
     off = 0;
@@ -1915,6 +1941,7 @@ static SortBufs sort_bind(const SortLayout& L, char* zero, char* data) {
     b.atomic_rank = large_atomic_rank_supported();
     b.sweep_threads = L.sweep_threads;
     b.samp = L.keys_first ? (uint32_t*)(zero + L.o_samp) : nullptr;
+    b.tie_flag = (uint32_t*)(zero + L.o_flag);
     b.samp_bits = L.samp_bits;
     b.keys_first_force = L.keys_first == 2 ? 1 : 0;
     return b;
@@ -1997,6 +2024,9 @@ static hipError_t sort_repair_launch(const SortBufs& b, hipStream_t stream, cons
                                    (int)(2 * kRepairCap * sizeof(uint64_t)));
     });
     if (e != hipSuccess) return e;
+    int64_t gs = (max_n / 2 + 255) / 256;
+    if (gs > 4096) gs = 4096;
+    hipLaunchKernelGGL(tie_scan_kernel, dim3((unsigned)(gs < 1 ? 1 : gs), items ? count : 1), dim3(256), 0, stream, b, items, scratch);
     int64_t gx = (max_n + kRepairWindow - 1) / kRepairWindow;
     if (gx > 4096) gx = 4096;
     hipLaunchKernelGGL(tie_repair_kernel, dim3((unsigned)gx, items ? count : 1), dim3(kRepairThreads),
@@ -2125,6 +2155,7 @@ hipError_t large_topics_launch(LargeScratch& scratch, const LargeArgs* args, int
         it.o_ctl = z + L.o_ctl; it.o_hist = z + L.o_hist; it.o_ticket = z + L.o_ticket; it.o_state = z + L.o_state;
         it.o_gbase = d + L.o_gbase; it.o_k0 = d + L.o_k0; it.o_k1 = d + L.o_k1; it.o_v0 = d + L.o_v0; it.o_v1 = d + L.o_v1;
         it.o_samp = L.keys_first ? z + L.o_samp : 0;               // (z + o_samp > 0: the control block comes first)
+        it.o_flag = z + L.o_flag;
         it.samp_bits = L.samp_bits; it.pad = 0;
         any_keys_first = any_keys_first || L.keys_first != 0;
         force_keys_first = force_keys_first || L.keys_first == 2;

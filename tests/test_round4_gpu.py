@@ -462,7 +462,7 @@ def _sort_topic(n, kind, seed, shuffled=True, dup_ids=False):
 @pytest.mark.parametrize("n,kind,shuffled,dup,expect_first,expect_redo", [
     (70000, "wide", True, False, 1, 0), (200000, "runs", True, False, 1, 0), (150000, "run4096", True, False, 1, 0),
     (150000, "run9000", True, False, 1, 1), (300000, "run20000_top", True, False, 1, 1), (50000, "equal", True, False, 0, 0),
-    (90000, "full", True, False, 1, 0), (120000, "runs", True, True, 1, 0), (80000, "runs", False, False, 0, 0),
+    (90000, "full", True, False, 1, 1), (120000, "runs", True, True, 1, 0), (80000, "runs", False, False, 0, 0),
     (20000, "runs", True, False, 1, 0), (4097, "wide", True, False, 1, 0)])
 def test_keys_first_sort_forced_on_small_topics(n, kind, shuffled, dup, expect_first, expect_redo):
     """LA_SORT_KEYS_FIRST=2 (test hook): every large-path sort with shuffled ids skips its id passes and repairs the runs of
