@@ -81,7 +81,7 @@ struct SortBufs {
     // frequent that its run could not be repaired in one workgroup; null: this sort never goes keys first
     uint32_t* samp;
     uint32_t samp_bits;                // table of 2^samp_bits counters
-    uint32_t* tie_flag;                // [ceil(n / kRepairWindow)] != 0: the window holds two equal neighbours (tie_scan_kernel)
+    uint32_t* tie_flag;                // [ceil(n / kRepairWindow)] != 0: a run of more than four equal keys starts in the window
     int keys_first_force;              // test hook: keys first whatever the sample says (long runs then take the redo slots)
 };
 
@@ -1531,26 +1531,43 @@ __global__ __launch_bounds__(1024) void greedy_rounds_kernel(LargeArgs a0, SortB
 // ids but theirs, so windows do not interfere.  A run that reaches beyond the capacity is left alone and raises ctl->redo:
 // the sample said there was no such run (or the test hook forced keys first), and the redo slots then sort in full.
 
-// Which windows hold ties at all: a plain streaming read of the sorted keys at full occupancy (the repair kernel below keeps
-// 128 KB of LDS per workgroup -- one workgroup per CU -- and would read them at a sixth of the bandwidth).
+// First a plain streaming read of the sorted keys at full occupancy (the repair kernel below keeps 128 KB of LDS per workgroup
+// -- one workgroup per CU -- and would read them at a sixth of the bandwidth).  The thread that meets the START of a run of
+// equal keys settles it on the spot when the run has at most four members -- with wide lags nearly every tie is a pair: four
+// ids into registers, a five-step network, back -- and otherwise marks the window the run starts in for tie_repair_kernel.
+__device__ __forceinline__ void tie_run_start(const uint64_t* key, uint32_t* val, int64_t p, int64_t n, uint32_t* tie_flag) {
+    const uint64_t k = key[p];
+    int len = 2;                                                            // (key[p + 1] == k is why we are here)
+    while (len < 5 && p + len < n && key[p + len] == k) ++len;
+    if (len > 4) { tie_flag[p / kRepairWindow] = 1; return; }
+    uint32_t v0 = val[p], v1 = val[p + 1], v2 = len > 2 ? val[p + 2] : 0xFFFFFFFFu, v3 = len > 3 ? val[p + 3] : 0xFFFFFFFFu;
+    auto cx = [](uint32_t& a, uint32_t& b) { const uint32_t lo = a < b ? a : b, hi = a < b ? b : a; a = lo; b = hi; };
+    cx(v0, v1); cx(v2, v3); cx(v0, v2); cx(v1, v3); cx(v1, v2);             // (pads are the largest value: they stay behind)
+    val[p] = v0; val[p + 1] = v1;
+    if (len > 2) val[p + 2] = v2;
+    if (len > 3) val[p + 3] = v3;
+}
+
 __global__ __launch_bounds__(256) void tie_scan_kernel(SortBufs b0, const LargeItem* items, char* scratch) {
     LargeArgs unused{};
     SortBufs b = b0;
     if (items) bind_item(unused, b, items[blockIdx.y], scratch);
     if (!b.ctl->keys_first) return;
-    const uint64_t* key = key_buf(b, b.ctl->cur[kDigits]);
+    const uint32_t fin = b.ctl->cur[kDigits];
+    const uint64_t* key = key_buf(b, fin);
+    uint32_t* val = val_buf(b, fin);
     const int64_t n = b.n, pairs = (n + 1) / 2;
     struct __attribute__((aligned(16))) U64x2 { uint64_t x, y; };
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < pairs; j += stride) {
-        const int64_t i = 2 * j;                                            // positions i, i + 1 (16-byte load), neighbour i + 2
-        uint64_t k0, k1 = 0, k2 = 0;
+        const int64_t i = 2 * j;                                            // positions i, i + 1 (one 16-byte load) and their neighbours
+        uint64_t km = 0, k0, k1 = 0, k2 = 0;
         if (i + 1 < n) { const U64x2 v = *reinterpret_cast<const U64x2*>(key + i); k0 = v.x; k1 = v.y; }
         else k0 = key[i];
-        const bool has2 = i + 2 < n;
-        if (has2) k2 = key[i + 2];
-        if (i + 1 < n && k0 == k1) b.tie_flag[i / kRepairWindow] = 1;
-        if (has2 && k1 == k2) b.tie_flag[(i + 1) / kRepairWindow] = 1;
+        if (i > 0) km = key[i - 1];
+        if (i + 2 < n) k2 = key[i + 2];
+        if (i + 1 < n && k0 == k1 && (i == 0 || km != k0)) tie_run_start(key, val, i, n, b.tie_flag);
+        if (i + 2 < n && k1 == k2 && k0 != k1) tie_run_start(key, val, i + 1, n, b.tie_flag);
     }
 }
 
@@ -1570,7 +1587,7 @@ __global__ __launch_bounds__(kRepairThreads) void tie_repair_kernel(SortBufs b0,
     const int64_t n = b.n;
     for (int64_t w0 = (int64_t)blockIdx.x * W; w0 < n; w0 += (int64_t)gridDim.x * W) {
         const int64_t w1 = w0 + W < n ? w0 + W : n;
-        if (b.tie_flag[w0 / W] == 0) continue;                              // (uniform) no two equal neighbours: nothing to repair
+        if (b.tie_flag[w0 / W] == 0) continue;                              // (uniform) no run of more than four starts here
         // the first and the last run start inside the window; where the last run ends (searched up to the capacity)
         __syncthreads();                                                    // (the window before this one is done with s_*)
         if (tid == 0) { s_first = 0x7FFFFFFF; s_last = -1; s_end = 0x7FFFFFFF; }
@@ -2028,7 +2045,7 @@ static hipError_t sort_repair_launch(const SortBufs& b, hipStream_t stream, cons
     if (gs > 4096) gs = 4096;
     hipLaunchKernelGGL(tie_scan_kernel, dim3((unsigned)(gs < 1 ? 1 : gs), items ? count : 1), dim3(256), 0, stream, b, items, scratch);
     int64_t gx = (max_n + kRepairWindow - 1) / kRepairWindow;
-    if (gx > 4096) gx = 4096;
+    if (gx > 1024) gx = 1024;                                   // (128 KB of LDS each: one per CU at a time; windows grid-stride)
     hipLaunchKernelGGL(tie_repair_kernel, dim3((unsigned)gx, items ? count : 1), dim3(kRepairThreads),
                        (size_t)2 * kRepairCap * sizeof(uint64_t), stream, b, items, scratch);
     hipLaunchKernelGGL(replan_kernel, dim3(items ? count : 1), dim3(64), 0, stream, b, items, scratch);

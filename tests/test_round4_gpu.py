@@ -443,6 +443,8 @@ def _sort_topic(n, kind, seed, shuffled=True, dup_ids=False):
     elif kind == "run20000_top":                            # ... at the top of the order, next to short runs
         lag = rng.integers(0, n // 50, n)
         lag[rng.choice(n, 20000, replace=False)] = 1 << 41
+    elif kind == "pairs":                                   # runs of two, three and four (settled by the scan itself) and of five
+        lag = rng.permutation(np.repeat(rng.permutation(n), rng.integers(1, 6, n))[:n] + 3)
     elif kind == "equal":
         lag = np.full(n, 12345)
     elif kind == "full":
@@ -463,7 +465,7 @@ def _sort_topic(n, kind, seed, shuffled=True, dup_ids=False):
     (70000, "wide", True, False, 1, 0), (200000, "runs", True, False, 1, 0), (150000, "run4096", True, False, 1, 0),
     (150000, "run9000", True, False, 1, 1), (300000, "run20000_top", True, False, 1, 1), (50000, "equal", True, False, 0, 0),
     (90000, "full", True, False, 1, 1), (120000, "runs", True, True, 1, 0), (80000, "runs", False, False, 0, 0),
-    (20000, "runs", True, False, 1, 0), (4097, "wide", True, False, 1, 0)])
+    (20000, "runs", True, False, 1, 0), (16385, "wide", True, False, 1, 0), (40000, "pairs", True, False, 1, 0)])
 def test_keys_first_sort_forced_on_small_topics(n, kind, shuffled, dup, expect_first, expect_redo):
     """LA_SORT_KEYS_FIRST=2 (test hook): every large-path sort with shuffled ids skips its id passes and repairs the runs of
     equal lags afterwards, whatever the sample says.  Same order as the comparator's (lag desc, id asc): no ties, thousands of
