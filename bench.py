@@ -879,8 +879,20 @@ def main():
                     pp, pm, pt = ctx.assign_batch(*pa, out=pout)
                     ptimes.append(time.perf_counter() - c0)
                 pdt = min(ptimes[1:])
+                pinned_pipe = ctx.last_pipeline()
                 pinned_ok = bool(np.array_equal(pp, ref_p) and np.array_equal(pm, ref_m)) and \
-                    ctx.last_pipeline() == N.LA_PIPELINE_STREAMS
+                    pinned_pipe in (N.LA_PIPELINE_STREAMS, N.LA_PIPELINE_MAPPED)
+                # ... and the round-3 form on the same arrays: three copy streams (LA_NO_MAPPED_PIPELINE)
+                os.environ["LA_NO_MAPPED_PIPELINE"] = "1"
+                try:
+                    s3 = []
+                    for _ in range(3):
+                        c0 = time.perf_counter()
+                        ctx.assign_batch(*pa, out=pout)
+                        s3.append(time.perf_counter() - c0)
+                    streams_ms = min(s3[1:]) * 1e3 if ctx.last_pipeline() == N.LA_PIPELINE_STREAMS else None
+                finally:
+                    os.environ.pop("LA_NO_MAPPED_PIPELINE", None)
                 # the same call with `begin` handed over only where there is no committed offset (la_assign_batch_sparse): 20 B
                 # instead of 28 B per partition cross the link
                 sparse_ms = sparse_ok = None
@@ -896,7 +908,7 @@ def main():
                         stimes.append(time.perf_counter() - c0)
                     sparse_ms = min(stimes[1:])
                     sparse_ok = bool(np.array_equal(sp_, ref_p) and np.array_equal(sm_, ref_m)) and \
-                        ctx.last_pipeline() == N.LA_PIPELINE_STREAMS
+                        ctx.last_pipeline() in (N.LA_PIPELINE_STREAMS, N.LA_PIPELINE_MAPPED)
                 # what the Java host really does with a batch: the ungrouped result stays on the device, every member's
                 # list comes back grouped (la_group_last_by_member: a stable device sort by member rank, then the D2H)
                 n_members = int(w.cons_rank.max()) + 1 if w.cons_rank.size else 0
@@ -919,6 +931,8 @@ def main():
                 host_leg = {"ms": round(dt * 1e3, 2), "value": round(w.n_partitions / dt, 1), "unit": "partition-assignments/sec",
                             "pinned_ms": round(pdt * 1e3, 2), "pinned_value": round(w.n_partitions / pdt, 1),
                             "pinned_ms_all": [round(x * 1e3, 2) for x in ptimes], "pinned_bit_exact_and_three_streams": pinned_ok,
+                            "pinned_pipeline": {2: "three copy streams", 4: "mapped: the kernels read / write the pinned arrays in place, no copies"}.get(pinned_pipe, pinned_pipe),
+                            "pinned_three_streams_ms": round(streams_ms, 2) if streams_ms else None,
                             "sparse_begin_ms": round(sparse_ms * 1e3, 2) if sparse_ms else None,
                             "sparse_begin_value": round(w.n_partitions / sparse_ms, 1) if sparse_ms else None,
                             "sparse_begin_bit_exact_and_three_streams": sparse_ok,

@@ -177,12 +177,16 @@ int la_last_shard_bounds(const la_ctx *ctx, int32_t *bounds, int32_t capacity);
  *   LA_PIPELINE_ONE_COPY  a small batch: one H2D and one D2H of a staging buffer
  *   LA_PIPELINE_LANES     chunks over the shard's lanes, one short-lived host thread per lane (pageable caller arrays:
  *                         their copies block the issuing thread)
- *   LA_PIPELINE_STREAMS   every array of the call is pinned (la_host_alloc): no threads; all H2D copies in order on one
- *                         stream, kernels on a second, D2H copies on a third, chained per chunk by events -- the input
- *                         link stays busy from the first byte to the last */
+ *   LA_PIPELINE_STREAMS   every array of the call is pinned but not device-mapped (hipHostRegister without the mapped flag;
+ *                         LA_NO_MAPPED_PIPELINE=1): no threads; all H2D copies in order on one stream, kernels on a second, D2H
+ *                         copies on a third, chained per chunk by events -- the input link stays busy from the first byte to the last
+ *   LA_PIPELINE_MAPPED    every array is pinned and mapped (la_host_alloc): the kernels work on the caller's arrays in place */
 #define LA_PIPELINE_ONE_COPY 0
 #define LA_PIPELINE_LANES    1
 #define LA_PIPELINE_STREAMS  2
+#define LA_PIPELINE_MAPPED    4   /* every array of the call is pinned AND device-mapped (la_host_alloc): no copies and no chunks --
+                                   * the kernels read the caller's arrays in place over PCIe (each input byte is touched once,
+                                   * `begin` only where there is no committed offset) and write the results straight into them */
 #define LA_PIPELINE_ZERO_COPY 3   /* the smallest calls (staging layout up to 128 KB, ~2 500 partitions; environment
                                    * LA_ZERO_COPY_BYTES overrides, 0 = never): no copy at all -- the kernels read the inputs in
                                    * place from coherent, device-mapped host memory and write totals / results / member lists
@@ -358,7 +362,9 @@ int la_group_by_member(la_ctx *ctx, int32_t n_topics, const int64_t *part_off,
  * on the device: nothing is uploaded again.  A caller that only wants the grouped form gives that call
  * out_partition = out_member_rank = NULL (both), which also skips their download: the assignment then crosses
  * PCIe once, as member_off + grouped_topic + grouped_partition.  LA_EINVAL when there is no such result (no
- * assign call yet, or another host-buffer call on this context since).  grouped_topic may be NULL. */
+ * assign call yet, or another host-buffer call on this context since).  grouped_topic may be NULL.
+ * (After a call on pinned, device-mapped arrays -- LA_PIPELINE_MAPPED -- that DID take the ungrouped results, "on the device"
+ * means the caller's own result arrays, which the kernels wrote in place: leave them as they are until this call.) */
 int la_group_last_by_member(la_ctx *ctx, int32_t n_members,
                             int64_t *member_off, int32_t *grouped_topic, int32_t *grouped_partition);
 

@@ -24,7 +24,7 @@ LA_FLAG_SORT_MULTIKERNEL = 128
 LA_FLAG_NO_RUN_MERGE = 256
 LA_FLAG_SERIAL_LARGE = 512
 LA_FEATURE_ATOMIC_RANK = 1
-LA_PIPELINE_ONE_COPY, LA_PIPELINE_LANES, LA_PIPELINE_STREAMS, LA_PIPELINE_ZERO_COPY = 0, 1, 2, 3
+LA_PIPELINE_ONE_COPY, LA_PIPELINE_LANES, LA_PIPELINE_STREAMS, LA_PIPELINE_ZERO_COPY, LA_PIPELINE_MAPPED = 0, 1, 2, 3, 4
 LA_CREATE_LANES_MASK, LA_CREATE_SPLIT_ALWAYS = 0xF, 0x10
 
 EXPORTED_SYMBOLS = (

@@ -616,6 +616,7 @@ struct HostCall {
     bool use_begin = false;
     // la_assign_batch_sparse: `begin` arrives as (position, value) pairs for the partitions without a committed offset; the
     // dense array the kernels read is rebuilt on the device (zero + scatter), chunk by chunk
+    bool mapped = false;                 // every array of the call is pinned AND device-mapped: the kernels read / write it in place
     bool sparse = false;
     int64_t n_none = 0;
     const int64_t *none_index = nullptr, *none_begin = nullptr;
@@ -657,13 +658,21 @@ int prepare_shard(la_ctx* ctx, const HostCall& c, Shard& sh, ShardPlan& sp) {
     const size_t nb8 = (size_t)sp.n * 8, nb4 = (size_t)sp.n * 4, kb8 = (size_t)sp.k * 8, kb4 = (size_t)sp.k * 4;
     const size_t tb = (size_t)(Ts + 1) * 8;
     int rc;
-    if ((rc = reserve(ctx, sh.part_off, tb)) || (rc = reserve(ctx, sh.cons_off, tb)) ||
-        (rc = reserve(ctx, sh.pid, nb4 + 16)) || (rc = reserve(ctx, sh.end, nb8 + 16)) ||
-        (rc = reserve(ctx, sh.committed, c.lag ? 16 : nb8 + 16)) ||
-        (rc = reserve(ctx, sh.begin, c.use_begin ? nb8 + 16 : 16)) ||
-        (rc = reserve(ctx, sh.cons_rank, kb4 + 16)) || (rc = reserve(ctx, sh.out_pid, nb4 + 16)) ||
-        (rc = reserve(ctx, sh.out_rank, nb4 + 16)) || (rc = reserve(ctx, sh.out_total, kb8 + 16)))
+    if ((rc = reserve(ctx, sh.part_off, tb)) || (rc = reserve(ctx, sh.cons_off, tb))) return rc;
+    if (c.mapped) {
+        // the kernels work on the caller's arrays in place: only what is NOT the caller's lives here -- the results of a call
+        // that keeps them on the device, and the dense `begin` rebuilt from a sparse list (indexed by the caller's positions,
+        // begin[0] included: the tile kernels park idle lanes there)
+        if (!c.out_pid && ((rc = reserve(ctx, sh.out_pid, nb4 + 16)) || (rc = reserve(ctx, sh.out_rank, nb4 + 16)))) return rc;
+        if (!c.out_total && (rc = reserve(ctx, sh.out_total, kb8 + 16))) return rc;
+        if (c.sparse && (rc = reserve(ctx, sh.begin, (size_t)c.shape.n * 8 + 16))) return rc;
+    } else if ((rc = reserve(ctx, sh.pid, nb4 + 16)) || (rc = reserve(ctx, sh.end, nb8 + 16)) ||
+               (rc = reserve(ctx, sh.committed, c.lag ? 16 : nb8 + 16)) ||
+               (rc = reserve(ctx, sh.begin, c.use_begin ? nb8 + 16 : 16)) ||
+               (rc = reserve(ctx, sh.cons_rank, kb4 + 16)) || (rc = reserve(ctx, sh.out_pid, nb4 + 16)) ||
+               (rc = reserve(ctx, sh.out_rank, nb4 + 16)) || (rc = reserve(ctx, sh.out_total, kb8 + 16))) {
         return rc;
+    }
     hipStream_t st = sh.lanes[0].stream;
     LA_HIP(ctx, hipMemcpyAsync(sh.part_off.p, sp.lpo, tb, hipMemcpyHostToDevice, st));
     LA_HIP(ctx, hipMemcpyAsync(sh.cons_off.p, sp.lco, tb, hipMemcpyHostToDevice, st));
@@ -671,7 +680,9 @@ int prepare_shard(la_ctx* ctx, const HostCall& c, Shard& sh, ShardPlan& sp) {
 
     // chunks: enough of them that the copies of one overlap the kernels and the opposite copies of another
     int n_chunks = 1;
-    if (ctx->split_always) {
+    if (c.mapped) {
+        n_chunks = 1;                                    // the kernels pull the shard's bytes themselves: nothing to overlap
+    } else if (ctx->split_always) {
         n_chunks = Ts < 3 ? (Ts > 0 ? Ts : 1) : 3;
     } else if ((int)sh.lanes.size() > 1 || ctx->last_pipeline == 2) {
         // (pinned arrays, one enqueueing thread: finer chunks -- the call ends one chunk's kernels + result copy after
@@ -949,6 +960,79 @@ int run_shard_async(la_ctx* ctx, const HostCall& c, Shard& sh, ShardPlan& sp) {
             LA_HIP(ctx, hipMemcpyAsync(c.out_total + gk, (const int64_t*)sh.out_total.p + k0, nk * 8, hipMemcpyDeviceToHost, so));
     }
     return LA_OK;
+}
+
+// ---- pinned AND mapped caller arrays: no copies at all ------------------------------------------------------------------
+// la_host_alloc memory (hipHostMalloc: portable, mapped) has a device address.  The tile kernels issue all the loads of a tile
+// back to back and touch every input byte exactly once, so letting THEM pull the batch across PCIe needs no staging, no
+// chunks and no copy engine: measured on the 25.6 M-partition target, 10.1 ms per call against 13.6 ms for the three-stream
+// copy pipeline (tools/mapped_probe.py: 52-55 GB/s of kernel loads over the link, whose one-copy floor is 57 GB/s) -- and
+// `begin` crosses the link only where a partition has no committed offset, because that is all the kernels read of it.
+// Results are written straight into the caller's arrays.  Every shard works on the SAME arrays (positions are the caller's:
+// part_off stays absolute), on its own range of topics.
+template <typename T>
+T* mapped_ptr(T* host) {
+    if (!host) return nullptr;
+    void* d = nullptr;
+    if (hipHostGetDevicePointer(&d, (void*)host, 0) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    return (T*)d;
+}
+
+bool call_is_mapped(const HostCall& c) {
+    auto ok = [](const void* p) { return p == nullptr || mapped_ptr((const char*)p) != nullptr; };
+    return ok(c.part_off) && ok(c.cons_off) && ok(c.pid) && ok(c.end) && ok(c.committed) && ok(c.lag) && ok(c.begin) &&
+           ok(c.none_index) && ok(c.none_begin) && ok(c.cons_rank) && ok(c.out_pid) && ok(c.out_rank) && ok(c.out_total);
+}
+
+int run_shard_mapped(la_ctx* ctx, const HostCall& c, Shard& sh, ShardPlan& sp) {
+    LA_HIP(ctx, hipSetDevice(sh.device));
+    Lane& ln = sh.lanes[0];
+    hipStream_t st = ln.stream;
+    const int32_t Ts = sp.t1 - sp.t0;
+    const int64_t* m_part_off = mapped_ptr(c.part_off);
+    const int64_t* m_cons_off = mapped_ptr(c.cons_off);
+    const int32_t* m_cons_rank = mapped_ptr(c.cons_rank);
+    if (sp.k)
+        LA_HIP(ctx, la::check_consumers_launch(Ts, m_cons_off + sp.t0, m_cons_rank, ln.d_status, st));
+    const int64_t* d_begin = c.use_begin ? mapped_ptr(c.begin) : nullptr;
+    if (c.sparse) {
+        int64_t* db = (int64_t*)sh.begin.p;
+        const int64_t j0 = sp.none_at.front(), j1 = sp.none_at.back();
+        LA_HIP(ctx, hipMemsetAsync(db, 0, 8, st));                               // begin[0]: where idle lanes park
+        if (sp.n) LA_HIP(ctx, hipMemsetAsync(db + sp.P0, 0, (size_t)sp.n * 8, st));
+        LA_HIP(ctx, la::sparse_begin_launch(j1 - j0, mapped_ptr(c.none_index) + j0, mapped_ptr(c.none_begin) + j0, 0, sp.P0,
+                                            sp.P0 + sp.n, db, ln.d_status, st));
+        d_begin = db;
+    }
+    la_device_batch b{};
+    b.n_topics = Ts;
+    b.reset_mode = c.reset_mode == LA_RESET_LATEST ? LA_RESET_LATEST : LA_RESET_EARLIEST;
+    b.algo = LA_ALGO_AUTO;
+    b.n_partitions = c.shape.n;                                                  // (positions are the caller's: the bound is too)
+    b.n_consumers = c.shape.k;
+    b.max_partitions_per_topic = c.shape.max_p;
+    b.max_consumers_per_topic = c.shape.max_c;
+    b.d_part_off = m_part_off + sp.t0;
+    b.d_partition_id = mapped_ptr(c.pid);
+    b.d_begin_off = d_begin;
+    b.d_end_off = mapped_ptr(c.lag ? c.lag : c.end);
+    b.d_committed_off = mapped_ptr(c.committed);
+    b.d_lag = c.lag ? mapped_ptr(c.lag) : nullptr;
+    b.d_cons_off = m_cons_off + sp.t0;
+    b.d_cons_rank = m_cons_rank;
+    // results the caller asked for land in its arrays; those it leaves on the device go to the shard's own buffers, addressed
+    // by the caller's positions (only positions of this shard's topics are ever stored)
+    b.d_out_partition = c.out_pid ? mapped_ptr(c.out_pid) : (int32_t*)sh.out_pid.p - sp.P0;
+    b.d_out_member_rank = c.out_pid ? mapped_ptr(c.out_rank) : (int32_t*)sh.out_rank.p - sp.P0;
+    b.d_out_total_lag = c.out_total ? mapped_ptr(c.out_total) : nullptr;
+    b.h_part_off = c.part_off + sp.t0;
+    b.h_cons_off = c.cons_off + sp.t0;
+    b.flags = LA_FLAG_RAGGED;
+    if (sp.n == 0) {
+        if (c.out_total && sp.k) LA_HIP(ctx, hipMemsetAsync(mapped_ptr(c.out_total) + sp.K0, 0, (size_t)sp.k * 8, st));
+        return LA_OK;
+    }
+    return enqueue_batch(ctx, ln, &b, st);
 }
 
 // Waits for everything run_shard_async enqueued on this shard (also after an error elsewhere: nothing stays in flight).
@@ -1349,7 +1433,8 @@ int assign_host(la_ctx* ctx, int32_t T, const int64_t* part_off, const int32_t* 
     struct Work { int shard, lane; };
     std::vector<Work> work;
     const bool pinned = call_is_pinned(c) && !getenv("LA_NO_ASYNC_PIPELINE");
-    ctx->last_pipeline = pinned ? 2 : 1;
+    c.mapped = pinned && !getenv("LA_NO_MAPPED_PIPELINE") && call_is_mapped(c);
+    ctx->last_pipeline = c.mapped ? LA_PIPELINE_MAPPED : (pinned ? 2 : 1);
     for (int i = 0; i < S; ++i) {
         ShardPlan& sp = plans[(size_t)i];
         Shard& sh = ctx->shards[(size_t)i];
@@ -1369,6 +1454,12 @@ int assign_host(la_ctx* ctx, int32_t T, const int64_t* part_off, const int32_t* 
                     (void)hipStreamSynchronize(ctx->shards[(size_t)j].lanes[0].stream);
             return rc;
         }
+        if (c.mapped && c.out_pid) {
+            // the kernels wrote the ungrouped results into the caller's own (mapped) arrays: that is where a following
+            // la_group_last_by_member reads them, in place
+            sh.last_out_pid = mapped_ptr(c.out_pid) + sp.P0;
+            sh.last_out_rank = mapped_ptr(c.out_rank) + sp.P0;
+        }
         const int n_chunks = (int)sp.chunk.size() - 1;
         const int lanes = n_chunks < (int)sh.lanes.size() ? n_chunks : (int)sh.lanes.size();
         if (!pinned)
@@ -1379,7 +1470,8 @@ int assign_host(la_ctx* ctx, int32_t T, const int64_t* part_off, const int32_t* 
         int rc = LA_OK;
         for (int i = 0; i < S && rc == LA_OK; ++i)
             if (plans[(size_t)i].t1 > plans[(size_t)i].t0)
-                rc = run_shard_async(ctx, c, ctx->shards[(size_t)i], plans[(size_t)i]);
+                rc = c.mapped ? run_shard_mapped(ctx, c, ctx->shards[(size_t)i], plans[(size_t)i])
+                              : run_shard_async(ctx, c, ctx->shards[(size_t)i], plans[(size_t)i]);
         for (int i = 0; i < S; ++i) {
             if (plans[(size_t)i].t1 == plans[(size_t)i].t0) continue;
             const int rf = finish_shard_async(ctx, ctx->shards[(size_t)i]);

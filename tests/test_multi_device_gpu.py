@@ -356,7 +356,18 @@ def test_default_context_pipelines_a_large_batch(ctx1):
     assert ctx1.last_shard_bounds().tolist() == [0, w.n_topics]
 
 
-def test_pinned_host_arrays(ctx1):
+@pytest.fixture(params=["mapped", "streams"])
+def pinned_pipeline(request):
+    """Pinned caller arrays take one of two forms: `mapped` (the default since round 4: the kernels read and write the arrays
+    in place over PCIe, no copies) or `streams` (LA_NO_MAPPED_PIPELINE=1: the three-stream copy pipeline of round 3)."""
+    import os
+    if request.param == "streams":
+        os.environ["LA_NO_MAPPED_PIPELINE"] = "1"
+    yield N.LA_PIPELINE_MAPPED if request.param == "mapped" else N.LA_PIPELINE_STREAMS
+    os.environ.pop("LA_NO_MAPPED_PIPELINE", None)
+
+
+def test_pinned_host_arrays(ctx1, pinned_pipeline):
     w = synth.config("cfg3", 2.0)
     pin = {k: ctx1.host_alloc(getattr(w, k).shape, getattr(w, k).dtype) for k in
            ("part_off", "partition_id", "begin", "end", "committed", "cons_off", "cons_rank")}
@@ -369,7 +380,7 @@ def test_pinned_host_arrays(ctx1):
     got = ctx1.assign_batch(pin["part_off"], pin["partition_id"], pin["begin"], pin["end"], pin["committed"],
                             N.LA_RESET_EARLIEST, pin["cons_off"], pin["cons_rank"], out=out)
     _same(got, exp, "pinned")
-    assert ctx1.last_pipeline() == N.LA_PIPELINE_STREAMS        # every array pinned: three streams, no worker threads
+    assert ctx1.last_pipeline() == pinned_pipeline              # every array pinned: no worker threads
     got = ctx1.assign_batch(w.part_off, w.partition_id, w.begin, w.end, w.committed, N.LA_RESET_EARLIEST, w.cons_off, w.cons_rank)
     _same(got, exp, "pageable")
     assert ctx1.last_pipeline() == N.LA_PIPELINE_LANES
@@ -387,8 +398,8 @@ def _pin(ctx, a):
 
 
 @pytest.mark.parametrize("which", ["4 shards", "1 shard, 3 chunks", "default context"])
-def test_stream_pipeline_on_pinned_arrays(ctx4, ctx1_chunked, ctx1, which):
-    """The three-stream form (pinned caller arrays) over shards x chunks: a mixed batch through tile, block and large
+def test_stream_pipeline_on_pinned_arrays(ctx4, ctx1_chunked, ctx1, which, pinned_pipeline):
+    """The two forms for pinned caller arrays (in place / three streams) over shards x chunks: a mixed batch through tile, block and large
     paths, the target shape, results left on the device + grouped lists, LATEST mode without begin, and an unsorted
     cons_rank segment in a late chunk -- same results and errors as the lanes form."""
     c = {"4 shards": ctx4, "1 shard, 3 chunks": ctx1_chunked, "default context": ctx1}[which]
@@ -398,7 +409,7 @@ def test_stream_pipeline_on_pinned_arrays(ctx4, ctx1_chunked, ctx1, which):
     out = (c.host_alloc((pid.size,), np.int32), c.host_alloc((pid.size,), np.int32), c.host_alloc((ranks.size,), np.int64))
     _same(c.assign_batch_lags(*P, out=out), exp, "mixed batch, pinned, " + which)
     if which != "default context":                              # (the default context sends a batch this small in one copy)
-        assert c.last_pipeline() == N.LA_PIPELINE_STREAMS
+        assert c.last_pipeline() == pinned_pipeline
     w = synth.config("target", 0.03 if which == "default context" else 0.01)
     names = ("part_off", "partition_id", "begin", "end", "committed", "cons_off", "cons_rank")
     pw = {k: _pin(c, getattr(w, k)) for k in names}
@@ -411,7 +422,7 @@ def test_stream_pipeline_on_pinned_arrays(ctx4, ctx1_chunked, ctx1, which):
         got = c.assign_batch(pw["part_off"], pw["partition_id"], None if latest else pw["begin"], pw["end"], pw["committed"],
                              mode, pw["cons_off"], pw["cons_rank"], out=o)
         _same(got, e, "target, pinned, latest=%s, %s" % (latest, which))
-        assert c.last_pipeline() == N.LA_PIPELINE_STREAMS
+        assert c.last_pipeline() == pinned_pipeline
     # results stay on the device, only the grouped lists come back
     c.assign_batch(pw["part_off"], pw["partition_id"], pw["begin"], pw["end"], pw["committed"], N.LA_RESET_EARLIEST,
                    pw["cons_off"], pw["cons_rank"], want_totals=False, keep_on_device=True)
@@ -428,7 +439,7 @@ def test_stream_pipeline_on_pinned_arrays(ctx4, ctx1_chunked, ctx1, which):
     with pytest.raises(N.LagAssignError) as ei:
         c.assign_batch(pw["part_off"], pw["partition_id"], pw["begin"], pw["end"], pw["committed"], N.LA_RESET_EARLIEST,
                        pw["cons_off"], badp, out=o)
-    assert ei.value.code == N.LA_EINVAL and c.last_pipeline() == N.LA_PIPELINE_STREAMS
+    assert ei.value.code == N.LA_EINVAL and c.last_pipeline() == pinned_pipeline
     got = c.assign_batch(pw["part_off"], pw["partition_id"], pw["begin"], pw["end"], pw["committed"], N.LA_RESET_EARLIEST,
                          pw["cons_off"], pw["cons_rank"], out=o)
     np.testing.assert_array_equal(got[0], e_p)

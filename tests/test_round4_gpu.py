@@ -132,29 +132,42 @@ def _workload(seed, frac_none, topics=300, big=False):
 
 
 @pytest.mark.parametrize("frac_none", [0.0, 0.01, 0.3, 1.0])
-@pytest.mark.parametrize("kind", ["one_copy", "lanes", "streams", "shards"])
+@pytest.mark.parametrize("kind", ["one_copy", "lanes", "streams", "mapped", "shards", "mapped_shards"])
 def test_sparse_begin_equals_the_dense_call(frac_none, kind):
     big = kind != "one_copy"
     w = _workload(int(frac_none * 100) + len(kind), frac_none, topics=400 if big else 60, big=big)
     idx, val = N.sparse_begin(w.begin, w.committed)
     assert idx.size == int((w.committed < 0).sum())
-    flags = {"one_copy": 0, "lanes": N.LA_CREATE_SPLIT_ALWAYS | 3, "streams": 0, "shards": N.LA_CREATE_SPLIT_ALWAYS}[kind]
-    dev = [0, 0, 0] if kind == "shards" else 0
+    flags = {"one_copy": 0, "lanes": N.LA_CREATE_SPLIT_ALWAYS | 3, "streams": 0, "mapped": 0, "shards": N.LA_CREATE_SPLIT_ALWAYS,
+             "mapped_shards": N.LA_CREATE_SPLIT_ALWAYS}[kind]
+    dev = [0, 0, 0] if kind in ("shards", "mapped_shards") else 0
     with N.Context(dev, flags=flags) as c:
         if kind == "streams":
             os.environ["LA_CHUNK_PARTITIONS"] = "20000"
+            os.environ["LA_NO_MAPPED_PIPELINE"] = "1"
         try:
             exp = _expected(w, False)
             args = (w.part_off, w.partition_id, w.end, w.committed, N.LA_RESET_EARLIEST)
-            if kind == "streams":
-                # every array pinned: the thread-less three-stream pipeline
-                with N.Context(0) as cp:                                          # (a context created under the chunk override)
+            if kind in ("streams", "mapped", "mapped_shards"):
+                # every array pinned: the thread-less three-stream pipeline, or -- the default -- the kernels on the arrays in place
+                with N.Context(dev, flags=flags) as cp:                           # (a context created under the chunk override)
                     pin = lambda a: _pinned(cp, a)                                # noqa: E731
                     out = (cp.host_alloc((w.n_partitions,), np.int32), cp.host_alloc((w.n_partitions,), np.int32),
                            cp.host_alloc((w.cons_rank.size,), np.int64))
                     got = cp.assign_batch_sparse(pin(w.part_off), pin(w.partition_id), pin(w.end), pin(w.committed),
                                                  N.LA_RESET_EARLIEST, pin(idx), pin(val), pin(w.cons_off), pin(w.cons_rank), out=out)
-                    assert cp.last_pipeline() == N.LA_PIPELINE_STREAMS
+                    assert cp.last_pipeline() == (N.LA_PIPELINE_STREAMS if kind == "streams" else N.LA_PIPELINE_MAPPED)
+                    # the dense call on the same pinned arrays, and the results left on the device + grouped
+                    dense = cp.assign_batch(pin(w.part_off), pin(w.partition_id), pin(w.begin), pin(w.end), pin(w.committed),
+                                            N.LA_RESET_EARLIEST, pin(w.cons_off), pin(w.cons_rank), out=out)
+                    for g, e in zip(dense, exp):
+                        np.testing.assert_array_equal(g, e)
+                    n_members = int(w.cons_rank.max()) + 1 if w.cons_rank.size else 0
+                    cp.assign_batch_sparse(pin(w.part_off), pin(w.partition_id), pin(w.end), pin(w.committed), N.LA_RESET_EARLIEST,
+                                           pin(idx), pin(val), pin(w.cons_off), pin(w.cons_rank), keep_on_device=True)
+                    g_off, g_t, g_p = cp.group_last_by_member(w.n_partitions, n_members)
+                    order = np.argsort(exp[1], kind="stable")
+                    np.testing.assert_array_equal(g_p, exp[0][order])
             else:
                 got = c.assign_batch_sparse(*args, idx, val, w.cons_off, w.cons_rank)
                 assert c.last_pipeline() == (N.LA_PIPELINE_ONE_COPY if kind == "one_copy" else N.LA_PIPELINE_LANES)
@@ -166,6 +179,7 @@ def test_sparse_begin_equals_the_dense_call(frac_none, kind):
                 np.testing.assert_array_equal(g, e)
         finally:
             os.environ.pop("LA_CHUNK_PARTITIONS", None)
+            os.environ.pop("LA_NO_MAPPED_PIPELINE", None)
 
 
 def _pinned(c, a):

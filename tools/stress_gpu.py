@@ -102,7 +102,7 @@ def main():
                       c.host_alloc((w.cons_rank.size,), np.int64))
                 got = c.assign_batch_lags(*pw, out=po)
                 assert all(np.array_equal(g, e) for g, e in zip(got, exp)), "assignment, pinned arrays"
-                assert w.n_partitions == 0 or c.last_pipeline() == N.LA_PIPELINE_STREAMS, "pipeline %d" % c.last_pipeline()
+                assert w.n_partitions == 0 or c.last_pipeline() in (N.LA_PIPELINE_STREAMS, N.LA_PIPELINE_MAPPED), "pipeline %d" % c.last_pipeline()
             except (AssertionError, N.LagAssignError) as e:
                 bad += 1; print("MULTI seed", seed, "shards", c.shard_count, "FAILED:", str(e)[:200])
     for c in multi:
