@@ -946,6 +946,11 @@ def main():
                                             "(la_assign_batch + la_group_last_by_member): the Java host's flow; best of the last 2 of 3",
                             "grouped_lists_equal_stable_sort_by_member": grouped_ok,
                             "h2d_floor_ms": round(w.n_partitions * (bpp - 8) / 57.2e9 * 1e3, 2),
+                            "mapped_floor_ms": round((w.n_partitions * 20 + int((w.committed < 0).sum()) * (0 if latest else 8) +
+                                                      w.cons_rank.size * 4) / 57.2e9 * 1e3, 2),
+                            "mapped_floor": "what the kernels of the mapped form read over the link (end, committed, id; `begin` only where "
+                                            "there is no committed offset; the consumer ranks) at the same 57.2 GB/s",
+
                             "h2d_floor": "the input bytes of the call at the 57.2 GB/s one pinned hipMemcpy sustains on this "
                                          "link (tools/pcie_probe.py, profiles/r03_pcie_probe.txt): no host-buffer call can be faster",
                             "what": "one la_assign_batch call on pageable host buffers (results into reused, already touched "
