@@ -211,6 +211,30 @@ def test_native_rccl_allgather_of_the_results(ctx4):
             rank = np.concatenate([g[r, 1, :counts[r]] for r in range(S)])
             np.testing.assert_array_equal(pid, exp[0], err_msg="gathered partition order on device %d" % i)
             np.testing.assert_array_equal(rank, exp[1], err_msg="gathered member ranks on device %d" % i)
+        # the same reassembly through the narrow wire format (round 4): pack on every shard, ONE all-gather of 2-byte elements per
+        # shard in a group, unpack on every device -- the whole native N > 1 step of a process that drives all GPUs itself
+        fmt = N.wire_format_for(int(w.partition_id.max()), int(w.cons_rank.max()) + 1)
+        assert fmt.elem_bytes == 2
+        capw = (cap + 7) // 8 * 8
+        wire_s, wire_r, outs = [], [], []
+        for i in range(S):
+            dev = torch.device("cuda", c.shard_device(i))
+            wire_s.append(torch.zeros(capw * 2, device=dev, dtype=torch.uint8))
+            wire_r.append(torch.full((S * capw * 2,), 0xEE, device=dev, dtype=torch.uint8))
+            outs.append(torch.full((2 * S * capw,), -9, device=dev, dtype=torch.int32))
+        for i in range(S):
+            c.assign_batch_device(shards[i]["b"], c.shard_stream(i), shard=i)
+            c.pack_results(counts[i], packed[i].data_ptr(), packed[i].data_ptr() + 4 * cap, fmt, wire_s[i].data_ptr(),
+                           c.shard_stream(i), shard=i)
+        c.allgather_packed(capw, fmt.elem_bytes, [x.data_ptr() for x in wire_s], [x.data_ptr() for x in wire_r])
+        for i in range(S):
+            c.unpack_results(S * capw, wire_r[i].data_ptr(), fmt, outs[i].data_ptr(), outs[i].data_ptr() + 4 * S * capw,
+                             c.shard_stream(i), shard=i)
+            c.sync(c.shard_stream(i), shard=i)
+        for i in range(S):
+            g = outs[i].cpu().numpy().reshape(2, S, capw)
+            np.testing.assert_array_equal(np.concatenate([g[0, r, :counts[r]] for r in range(S)]), exp[0])
+            np.testing.assert_array_equal(np.concatenate([g[1, r, :counts[r]] for r in range(S)]), exp[1])
     finally:
         c.close()
     # several shards on ONE device: refused
@@ -218,6 +242,11 @@ def test_native_rccl_allgather_of_the_results(ctx4):
     with pytest.raises(N.LagAssignError) as ei:
         ctx4.allgather_results(2, [d.data_ptr()] * 4, [d.data_ptr()] * 4)
     assert ei.value.code == N.LA_EINVAL and "distinct device" in str(ei.value)
+    with pytest.raises(N.LagAssignError) as ei:
+        ctx4.allgather_packed(2, 2, [d.data_ptr()] * 4, [d.data_ptr()] * 4)
+    assert ei.value.code == N.LA_EINVAL and "distinct device" in str(ei.value)
+    with pytest.raises(N.LagAssignError):
+        ctx4.allgather_packed(2, 3, [d.data_ptr()] * 4, [d.data_ptr()] * 4)          # an element is 2, 4 or 8 bytes
     # argument errors of the per-shard entry points: codes, not crashes
     import ctypes
     lib = ctx4._lib
