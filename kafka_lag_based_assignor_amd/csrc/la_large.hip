@@ -152,6 +152,8 @@ __global__ __launch_bounds__(256) void build_keys_kernel(LargeArgs a0, SortBufs 
     __syncthreads();
     const bool latest = a.reset_latest != 0;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    uint64_t last_sample = 0;                                          // (lane 0 of a sampling wavefront)
+    bool have_sample = false;
     for (int64_t base = (int64_t)blockIdx.x * blockDim.x; base < b.n; base += stride) {
         const int64_t i = base + threadIdx.x;
         const bool valid = i < b.n;
@@ -173,16 +175,24 @@ __global__ __launch_bounds__(256) void build_keys_kernel(LargeArgs a0, SortBufs 
         if (b.samp) {
             // How frequent is the most frequent lag?  (keys-first sorts repair runs of equal keys inside one workgroup: a run
             // must fit.)  64 equal neighbours say "very"; otherwise every fourth wavefront counts its first key in a hash
-            // table of n / 32 counters (n / 256 samples): a counter that reaches kSampleHeavy belongs to a lag that some
-            // thousand partitions share.  Sampling stops once the answer is yes: a hot counter would serialize the atomics.
+            // table of n / 32 counters (n / 256 samples) with a FIRE-AND-FORGET atomic -- waiting for the counter's old value
+            // put a ~2 us round trip into every fourth iteration, 70 us of a 300 us kernel -- and sample_scan_kernel looks for a
+            // counter at kSampleHeavy afterwards (~ a lag that some thousand partitions share).  A wavefront that draws the same
+            // key twice in a row says "frequent" at once, and nobody samples after that: a hot counter would serialize the atomics.
             const uint64_t k0 = ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(key >> 32)) << 32) |
                                 __builtin_amdgcn_readfirstlane((uint32_t)key);
             if (vmask == ~0ull && __ballot(key == k0) == ~0ull) {
                 if (__lane_id() == 0) b.ctl->tie_heavy = 1;
             } else if (((base + (threadIdx.x & ~63)) >> 6) % 4 == 0 && (vmask & 1ull) && __lane_id() == 0 &&
                        __hip_atomic_load(&b.ctl->tie_heavy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
-                const uint32_t h = (uint32_t)((k0 * 0x9E3779B97F4A7C15ull) >> (64 - b.samp_bits));
-                if (atomicAdd(&b.samp[h], 1u) + 1u >= kSampleHeavy) b.ctl->tie_heavy = 1;
+                if (have_sample && k0 == last_sample) {
+                    b.ctl->tie_heavy = 1;
+                } else {
+                    const uint32_t h = (uint32_t)((k0 * 0x9E3779B97F4A7C15ull) >> (64 - b.samp_bits));
+                    (void)__hip_atomic_fetch_add(&b.samp[h], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                last_sample = k0;
+                have_sample = true;
             }
         }
 #pragma unroll
@@ -202,6 +212,22 @@ __global__ __launch_bounds__(256) void build_keys_kernel(LargeArgs a0, SortBufs 
     __syncthreads();
     for (int i = threadIdx.x; i < kDigits * kRadix; i += blockDim.x)
         if (h[i]) atomicAdd(&b.hist[i], h[i]);
+}
+
+// ---- the sample of the lags: did any counter reach kSampleHeavy? ----------------------------------------------------------
+__global__ __launch_bounds__(256) void sample_scan_kernel(SortBufs b0, const LargeItem* items, char* scratch) {
+    LargeArgs unused{};
+    SortBufs b = b0;
+    if (items) bind_item(unused, b, items[blockIdx.y], scratch);
+    if (!b.samp) return;
+    const uint4* t = reinterpret_cast<const uint4*>(b.samp);
+    const int64_t words = ((int64_t)1 << b.samp_bits) / 4, stride = (int64_t)gridDim.x * blockDim.x;
+    bool heavy = false;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < words; i += stride) {
+        const uint4 v = t[i];
+        heavy |= v.x >= kSampleHeavy || v.y >= kSampleHeavy || v.z >= kSampleHeavy || v.w >= kSampleHeavy;
+    }
+    if (__any(heavy) && (threadIdx.x & (kWave - 1)) == 0) b.ctl->tie_heavy = 1;
 }
 
 // ---- plan: which passes are no-ops, where the data lives before each pass --------------------
@@ -2080,6 +2106,7 @@ hipError_t large_topic_launch(LargeScratch& scratch, const LargeArgs& a, bool ar
         ~Done() { if (on) (void)hipEventRecord(pf.ev[3], st); }
     } done{pf, profile, stream};
     hipLaunchKernelGGL(build_keys_kernel, dim3(grid), dim3(256), 0, stream, a, b, (const LargeItem*)nullptr, (char*)nullptr);
+    if (b.samp) hipLaunchKernelGGL(sample_scan_kernel, dim3(256), dim3(256), 0, stream, b, (const LargeItem*)nullptr, (char*)nullptr);
     sort_run_passes(b, stream, a.status, profile ? pf.ev[1] : nullptr);
     if (b.samp) {
         if ((e = sort_repair_launch(b, stream, nullptr, 1, nullptr, n)) != hipSuccess) return e;
@@ -2218,6 +2245,7 @@ hipError_t large_topics_launch(LargeScratch& scratch, const LargeArgs* args, int
     b0.keys_first_force = force_keys_first ? 1 : 0;
     uint32_t* status = args[0].status;
     hipLaunchKernelGGL(build_keys_kernel, dim3(gx, count), dim3(256), 0, stream, a0, b0, d_items, base);
+    if (any_keys_first) hipLaunchKernelGGL(sample_scan_kernel, dim3(64, count), dim3(256), 0, stream, b0, d_items, base);
     hipLaunchKernelGGL(plan_kernel, dim3(kDigits, count), dim3(kRadix), 0, stream, b0, d_items, base);
     if (profile) (void)hipEventRecord(pf.ev[1], stream);
     for (int first = 0; first < count;) {                          // one set of pass launches per tile class
@@ -2320,6 +2348,7 @@ hipError_t huge_topic_launch(LargeScratch& scratch, const LargeArgs& a, hipStrea
     int grid = (int)((P + 255) / 256);
     if (grid > 2048) grid = 2048;
     hipLaunchKernelGGL(build_keys_kernel, dim3(grid), dim3(256), 0, stream, a, bp, (const LargeItem*)nullptr, (char*)nullptr);
+    if (bp.samp) hipLaunchKernelGGL(sample_scan_kernel, dim3(256), dim3(256), 0, stream, bp, (const LargeItem*)nullptr, (char*)nullptr);
     sort_run_passes(bp, stream, a.status);
     if (bp.samp) {
         if ((e = sort_repair_launch(bp, stream, nullptr, 1, nullptr, P)) != hipSuccess) return e;
@@ -2347,10 +2376,10 @@ hipError_t huge_topic_launch(LargeScratch& scratch, const LargeArgs& a, hipStrea
 //   1. count the entries of every group (group = member rank + 1; 0 = topics without consumers), exclusive scan -> cursors;
 //   2. chunks of 64 consecutive entries, chunk c to wavefront c % 16: inside a chunk every lane finds its peers (the lanes with
 //      the same group: one ballot per group-id bit) -- its rank among them and, for the first of them, their number;
-//   3. the chunks take their places IN ORDER: wavefront-ordered hand-over -- a chunk waits until `turn` says its predecessor
-//      has advanced the cursors, its group leaders advance them by their peers' count (one LDS atomic), it passes the turn on.
-//      Chunk c - 1 belongs to another wavefront of the same workgroup that waits for nothing later: no deadlock; the ordered
-//      section is one atomic instruction per chunk.
+//   3. the chunks take their places IN ORDER: wavefront-ordered hand-over -- a wavefront's turn (four consecutive chunks) waits
+//      until `turn` says its predecessor has advanced the cursors, its group leaders advance them by their peers' counts (one
+//      LDS atomic per chunk, back to back), it passes the turn on.  Turn t - 1 belongs to another wavefront of the same
+//      workgroup that waits for nothing later: no deadlock; the ordered section is four atomic instructions per 256 entries.
 // Stable by construction (chunk order, then lane order), no reliance on how colliding lanes of an atomic are served.
 constexpr int kSmallGroupN = 16384;      // entries (256 chunks: the ordered hand-over is a chain of ~0.1 us per chunk)
 constexpr int kSmallGroupM = 8192;       // groups (members + 2)
@@ -2398,47 +2427,70 @@ __global__ __launch_bounds__(1024) void group_small_kernel(int n, int32_t n_memb
     for (int k = tid; k <= n_members; k += 1024) member_off[k] = (int64_t)start[k + 1];
     __syncthreads();                                                    // (the cursors move from here on)
     const uint64_t below = ((uint64_t)1 << lane) - 1;
-    const int n_chunks = (n + kWave - 1) / kWave;
-    for (int chunk = wave; chunk < n_chunks; chunk += 1024 / kWave) {
-        const int i = chunk * kWave + lane;
-        const bool valid = i < n;
-        uint32_t gi = 0;
-        int32_t part = 0;
-        if (valid) {
-            gi = (uint32_t)(member_rank[i] + 1);
-            gi = gi < G ? gi : G;
-            part = out_partition ? out_partition[i] : 0;
-        }
-        uint64_t peers = __ballot(valid);
+    // a TURN is kSub consecutive chunks of one wavefront: their ranks are found first, side by side; inside the turn the
+    // wavefront's cursor atomics go out back to back (LDS executes one wavefront's operations in order), so the ordered
+    // hand-over -- ~0.4 us per turn -- is paid once per 256 entries
+    constexpr int kSub = 4;
+    const int n_turns = (n + kSub * kWave - 1) / (kSub * kWave);
+    for (int turn_i = wave; turn_i < n_turns; turn_i += 1024 / kWave) {
+        uint32_t gi[kSub], rank[kSub], cnt[kSub], first[kSub];
+        int leader[kSub];
+        int32_t part[kSub], topic[kSub];
+        bool valid[kSub];
 #pragma unroll
-        for (int bit = 0; bit < kSmallGroupBits + 1; ++bit) {           // (G itself may need one bit more than G - 1)
-            const bool one = (gi >> bit) & 1u;
-            const uint64_t bal = __ballot(one);
-            peers &= one ? bal : ~bal;
-        }
-        const uint32_t rank = (uint32_t)__popcll(peers & below);
-        const int leader = __ffsll((unsigned long long)peers) - 1;
-        int64_t topic = 0;
-        if (valid && grouped_topic) {
-            int64_t lo = 0, hi = n_topics;                             // largest t with part_off[t] <= i
-            while (hi - lo > 1) {
-                const int64_t mid = (lo + hi) >> 1;
-                if (part_off[mid] <= (int64_t)i) lo = mid; else hi = mid;
+        for (int u = 0; u < kSub; ++u) {
+            const int i = (turn_i * kSub + u) * kWave + lane;
+            valid[u] = i < n;
+            gi[u] = 0;
+            part[u] = 0;
+            if (valid[u]) {
+                gi[u] = (uint32_t)(member_rank[i] + 1);
+                gi[u] = gi[u] < G ? gi[u] : G;
+                part[u] = out_partition ? out_partition[i] : 0;
             }
-            topic = lo;
         }
-        // the ordered section: wait for the chunk before this one, advance the cursors, pass the turn on
-        while (__hip_atomic_load(&turn, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != (uint32_t)chunk) __builtin_amdgcn_s_sleep(1);
-        uint32_t first = 0;
-        if (valid && lane == leader) first = atomicAdd(&start[gi], (uint32_t)__popcll(peers));
+#pragma unroll
+        for (int u = 0; u < kSub; ++u) {
+            uint64_t peers = __ballot(valid[u]);
+#pragma unroll
+            for (int bit = 0; bit < kSmallGroupBits + 1; ++bit) {       // (G itself may need one bit more than G - 1)
+                const bool one = (gi[u] >> bit) & 1u;
+                const uint64_t bal = __ballot(one);
+                peers &= one ? bal : ~bal;
+            }
+            rank[u] = (uint32_t)__popcll(peers & below);
+            cnt[u] = (uint32_t)__popcll(peers);
+            leader[u] = __ffsll((unsigned long long)peers) - 1;
+            topic[u] = 0;
+            if (valid[u] && grouped_topic) {
+                const int64_t i = (int64_t)(turn_i * kSub + u) * kWave + lane;
+                int64_t lo = 0, hi = n_topics;                         // largest t with part_off[t] <= i
+                while (hi - lo > 1) {
+                    const int64_t mid = (lo + hi) >> 1;
+                    if (part_off[mid] <= i) lo = mid; else hi = mid;
+                }
+                topic[u] = (int32_t)lo;
+            }
+        }
+        // the ordered section: wait for the turn before this one, advance the cursors, pass the turn on
+        while (__hip_atomic_load(&turn, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != (uint32_t)turn_i) __builtin_amdgcn_s_sleep(1);
+#pragma unroll
+        for (int u = 0; u < kSub; ++u) {
+            first[u] = 0;
+            if (valid[u] && lane == leader[u]) first[u] = atomicAdd(&start[gi[u]], cnt[u]);
+        }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        if (lane == 0) __hip_atomic_store(&turn, (uint32_t)chunk + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-        first = (uint32_t)__shfl((int)first, leader < 0 ? 0 : leader);
-        if (valid) {
-            const uint32_t pos = first + rank;
-            if (grouped_entry) grouped_entry[pos] = i;
-            if (grouped_partition) grouped_partition[pos] = part;
-            if (grouped_topic) grouped_topic[pos] = (int32_t)topic;
+        if (lane == 0) __hip_atomic_store(&turn, (uint32_t)turn_i + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+#pragma unroll
+        for (int u = 0; u < kSub; ++u) {
+            const uint32_t f = (uint32_t)__shfl((int)first[u], leader[u] < 0 ? 0 : leader[u]);
+            if (valid[u]) {
+                const int i = (turn_i * kSub + u) * kWave + lane;
+                const uint32_t pos = f + rank[u];
+                if (grouped_entry) grouped_entry[pos] = i;
+                if (grouped_partition) grouped_partition[pos] = part[u];
+                if (grouped_topic) grouped_topic[pos] = topic[u];
+            }
         }
     }
     if (fin_flag) {
