@@ -153,7 +153,7 @@ __global__ __launch_bounds__(256) void build_keys_kernel(LargeArgs a0, SortBufs 
     const bool latest = a.reset_latest != 0;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     uint64_t last_sample = 0;                                          // (lane 0 of a sampling wavefront)
-    bool have_sample = false;
+    bool have_sample = false, sampling = true;
     for (int64_t base = (int64_t)blockIdx.x * blockDim.x; base < b.n; base += stride) {
         const int64_t i = base + threadIdx.x;
         const bool valid = i < b.n;
@@ -178,15 +178,16 @@ __global__ __launch_bounds__(256) void build_keys_kernel(LargeArgs a0, SortBufs 
             // table of n / 32 counters (n / 256 samples) with a FIRE-AND-FORGET atomic -- waiting for the counter's old value
             // put a ~2 us round trip into every fourth iteration, 70 us of a 300 us kernel -- and sample_scan_kernel looks for a
             // counter at kSampleHeavy afterwards (~ a lag that some thousand partitions share).  A wavefront that draws the same
-            // key twice in a row says "frequent" at once, and nobody samples after that: a hot counter would serialize the atomics.
+            // key twice in a row says "frequent" at once and stops sampling: a hot counter sees a few atomics per wavefront, not
+            // one per sample (reading the shared flag instead cost an L2 round trip per sample: 60 us of this kernel).
             const uint64_t k0 = ((uint64_t)__builtin_amdgcn_readfirstlane((uint32_t)(key >> 32)) << 32) |
                                 __builtin_amdgcn_readfirstlane((uint32_t)key);
             if (vmask == ~0ull && __ballot(key == k0) == ~0ull) {
                 if (__lane_id() == 0) b.ctl->tie_heavy = 1;
-            } else if (((base + (threadIdx.x & ~63)) >> 6) % 4 == 0 && (vmask & 1ull) && __lane_id() == 0 &&
-                       __hip_atomic_load(&b.ctl->tie_heavy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+            } else if (((base + (threadIdx.x & ~63)) >> 6) % 4 == 0 && (vmask & 1ull) && __lane_id() == 0 && sampling) {
                 if (have_sample && k0 == last_sample) {
                     b.ctl->tie_heavy = 1;
+                    sampling = false;                                  // (this wavefront has said what it had to say)
                 } else {
                     const uint32_t h = (uint32_t)((k0 * 0x9E3779B97F4A7C15ull) >> (64 - b.samp_bits));
                     (void)__hip_atomic_fetch_add(&b.samp[h], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -2385,52 +2386,15 @@ constexpr int kSmallGroupN = 16384;      // entries (256 chunks: the ordered han
 constexpr int kSmallGroupM = 8192;       // groups (members + 2)
 constexpr int kSmallGroupBits = 13;      // bits of a group id
 
-__global__ __launch_bounds__(1024) void group_small_kernel(int n, int32_t n_members, int64_t n_topics, const int64_t* part_off,
-                                                           const int32_t* out_partition, const int32_t* member_rank,
-                                                           int64_t* member_off, int32_t* grouped_topic,
-                                                           int32_t* grouped_partition, int32_t* grouped_entry,
-                                                           const uint32_t* fin_status, uint32_t* fin_flag) {
-    __shared__ uint32_t start[kSmallGroupM];          // counts, then the groups' cursors
-    __shared__ uint32_t wsum[1024 / kWave];
-    __shared__ uint32_t turn;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const uint32_t G = (uint32_t)n_members + 1;                      // a rank >= n_members (out of contract) sorts behind every
-                                                                       // member, as in member_emit_kernel: member_off[n_members]
-    for (int k = tid; k < kSmallGroupM; k += 1024) start[k] = 0;      // is then where such entries start
-    if (tid == 0) turn = 0;
-    __syncthreads();
-    for (int i = tid; i < n; i += 1024) {
-        uint32_t gi = (uint32_t)(member_rank[i] + 1);
-        gi = gi < G ? gi : G;
-        atomicAdd(&start[gi], 1u);
-    }
-    __syncthreads();
-    // exclusive scan over the kSmallGroupM counts: eight per thread, a wavefront scan, the wavefronts' sums
-    constexpr int PER = kSmallGroupM / 1024;
-    uint32_t c[PER], run = 0;
-#pragma unroll
-    for (int r = 0; r < PER; ++r) { c[r] = start[PER * tid + r]; run += c[r]; }
-    uint32_t incl = run;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const uint32_t y = __shfl_up(incl, o);
-        if (lane >= o) incl += y;
-    }
-    if (lane == 63) wsum[wave] = incl;
-    __syncthreads();
-    uint32_t base = incl - run;
-    for (int w = 0; w < wave; ++w) base += wsum[w];
-#pragma unroll
-    for (int r = 0; r < PER; ++r) { start[PER * tid + r] = base; base += c[r]; }
-    __syncthreads();
-    // member r's list starts where the groups 0 .. r end; positions before member_off[0] belong to topics without consumers
-    for (int k = tid; k <= n_members; k += 1024) member_off[k] = (int64_t)start[k + 1];
-    __syncthreads();                                                    // (the cursors move from here on)
+// A TURN is kSub consecutive chunks of one wavefront: their ranks are found first, side by side; inside the turn the wavefront's
+// cursor atomics go out back to back (LDS executes one wavefront's operations in order), so the ordered hand-over -- ~0.4 us per
+// turn -- is paid once per kSub * 64 entries.  kSub = 1 for small inputs (every wavefront gets work), 4 beyond 4 096 entries.
+template <int kSub>
+__device__ __forceinline__ void group_small_place(int n, uint32_t G, int64_t n_topics, const int64_t* part_off, const int32_t* out_partition,
+                                                  const int32_t* member_rank, int32_t* grouped_topic, int32_t* grouped_partition,
+                                                  int32_t* grouped_entry, uint32_t* start, uint32_t* turn_p, int lane, int wave) {
+    uint32_t& turn = *turn_p;
     const uint64_t below = ((uint64_t)1 << lane) - 1;
-    // a TURN is kSub consecutive chunks of one wavefront: their ranks are found first, side by side; inside the turn the
-    // wavefront's cursor atomics go out back to back (LDS executes one wavefront's operations in order), so the ordered
-    // hand-over -- ~0.4 us per turn -- is paid once per 256 entries
-    constexpr int kSub = 4;
     const int n_turns = (n + kSub * kWave - 1) / (kSub * kWave);
     for (int turn_i = wave; turn_i < n_turns; turn_i += 1024 / kWave) {
         uint32_t gi[kSub], rank[kSub], cnt[kSub], first[kSub];
@@ -2493,6 +2457,53 @@ __global__ __launch_bounds__(1024) void group_small_kernel(int n, int32_t n_memb
             }
         }
     }
+}
+
+__global__ __launch_bounds__(1024) void group_small_kernel(int n, int32_t n_members, int64_t n_topics, const int64_t* part_off,
+                                                           const int32_t* out_partition, const int32_t* member_rank,
+                                                           int64_t* member_off, int32_t* grouped_topic,
+                                                           int32_t* grouped_partition, int32_t* grouped_entry,
+                                                           const uint32_t* fin_status, uint32_t* fin_flag) {
+    __shared__ uint32_t start[kSmallGroupM];          // counts, then the groups' cursors
+    __shared__ uint32_t wsum[1024 / kWave];
+    __shared__ uint32_t turn;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t G = (uint32_t)n_members + 1;                      // a rank >= n_members (out of contract) sorts behind every
+                                                                       // member, as in member_emit_kernel: member_off[n_members]
+    for (int k = tid; k < kSmallGroupM; k += 1024) start[k] = 0;      // is then where such entries start
+    if (tid == 0) turn = 0;
+    __syncthreads();
+    for (int i = tid; i < n; i += 1024) {
+        uint32_t gi = (uint32_t)(member_rank[i] + 1);
+        gi = gi < G ? gi : G;
+        atomicAdd(&start[gi], 1u);
+    }
+    __syncthreads();
+    // exclusive scan over the kSmallGroupM counts: eight per thread, a wavefront scan, the wavefronts' sums
+    constexpr int PER = kSmallGroupM / 1024;
+    uint32_t c[PER], run = 0;
+#pragma unroll
+    for (int r = 0; r < PER; ++r) { c[r] = start[PER * tid + r]; run += c[r]; }
+    uint32_t incl = run;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t y = __shfl_up(incl, o);
+        if (lane >= o) incl += y;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    uint32_t base = incl - run;
+    for (int w = 0; w < wave; ++w) base += wsum[w];
+#pragma unroll
+    for (int r = 0; r < PER; ++r) { start[PER * tid + r] = base; base += c[r]; }
+    __syncthreads();
+    // member r's list starts where the groups 0 .. r end; positions before member_off[0] belong to topics without consumers
+    for (int k = tid; k <= n_members; k += 1024) member_off[k] = (int64_t)start[k + 1];
+    __syncthreads();                                                    // (the cursors move from here on)
+    if (n > 4096)
+        group_small_place<4>(n, G, n_topics, part_off, out_partition, member_rank, grouped_topic, grouped_partition, grouped_entry, start, &turn, lane, wave);
+    else
+        group_small_place<1>(n, G, n_topics, part_off, out_partition, member_rank, grouped_topic, grouped_partition, grouped_entry, start, &turn, lane, wave);
     if (fin_flag) {
         // the last launch of a zero-copy call (la_api.hip, assign_small_zc): this ONE workgroup's stores into the host's memory
         // are out, then `done | status` goes where the calling thread is spinning -- no separate finishing launch
