@@ -2370,7 +2370,7 @@ hipError_t huge_topic_launch(LargeScratch& scratch, const LargeArgs& a, hipStrea
     return hipGetLastError();
 }
 
-// ---- the same grouping for what a real rebalance is: up to a few ten thousand entries, ONE workgroup ------------------------
+// ---- the same grouping for what a real rebalance is: up to a few thousand entries, ONE workgroup ---------------------------
 // member_keys + plan + one or two radix passes + emit are five dependent launches (~25 us, 84 us for 2 000 entries) for a job one
 // workgroup does in a few microseconds: a stable counting sort in LDS, LINEAR in n (round 3's form placed an entry by walking
 // all entries before it: n^2 / 2 compares, hence its 1 024-entry limit).
@@ -2382,13 +2382,18 @@ hipError_t huge_topic_launch(LargeScratch& scratch, const LargeArgs& a, hipStrea
 //      LDS atomic per chunk, back to back), it passes the turn on.  Turn t - 1 belongs to another wavefront of the same
 //      workgroup that waits for nothing later: no deadlock; the ordered section is four atomic instructions per 256 entries.
 // Stable by construction (chunk order, then lane order), no reliance on how colliding lanes of an atomic are served.
-constexpr int kSmallGroupN = 16384;      // entries (256 chunks: the ordered hand-over is a chain of ~0.1 us per chunk)
+constexpr int kSmallGroupN = 2560;       // entries.  Measured on one box, device-resident, back to back (tools/group_probe.py,
+                                         // profiles/r04_group_probe.txt): this kernel 4.0 us at 100 entries, 9 at 1 000, 14.8 at 2 000, 26 at
+                                         // 4 096 (its chunks' global loads and topic searches are dependent round trips, 16 chunks deep per
+                                         // wavefront at 16 384: 90-100 us), the radix form 17-23 us whatever the size: beyond ~2 500 entries
+                                         // the five launches win
 constexpr int kSmallGroupM = 8192;       // groups (members + 2)
 constexpr int kSmallGroupBits = 13;      // bits of a group id
 
 // A TURN is kSub consecutive chunks of one wavefront: their ranks are found first, side by side; inside the turn the wavefront's
 // cursor atomics go out back to back (LDS executes one wavefront's operations in order), so the ordered hand-over -- ~0.4 us per
-// turn -- is paid once per kSub * 64 entries.  kSub = 1 for small inputs (every wavefront gets work), 4 beyond 4 096 entries.
+// turn -- is paid once per kSub * 64 entries.  kSub = 1 is what runs (every wavefront gets work); 4 was measured 2-3 us slower at
+// every size the kernel is used for (lab builds with -DLA_GROUP_SUB=4).
 template <int kSub>
 __device__ __forceinline__ void group_small_place(int n, uint32_t G, int64_t n_topics, const int64_t* part_off, const int32_t* out_partition,
                                                   const int32_t* member_rank, int32_t* grouped_topic, int32_t* grouped_partition,
@@ -2501,13 +2506,10 @@ __global__ __launch_bounds__(1024) void group_small_kernel(int n, int32_t n_memb
     for (int k = tid; k <= n_members; k += 1024) member_off[k] = (int64_t)start[k + 1];
     __syncthreads();                                                    // (the cursors move from here on)
 #ifdef LA_GROUP_SUB                                   // (lab builds: tools/group_probe.py compares the forms on one box)
-    const bool four = LA_GROUP_SUB == 4;
-#else
-    const bool four = n > 4096;
-#endif
-    if (four)
+    if (LA_GROUP_SUB == 4)
         group_small_place<4>(n, G, n_topics, part_off, out_partition, member_rank, grouped_topic, grouped_partition, grouped_entry, start, &turn, lane, wave);
     else
+#endif
         group_small_place<1>(n, G, n_topics, part_off, out_partition, member_rank, grouped_topic, grouped_partition, grouped_entry, start, &turn, lane, wave);
     if (fin_flag) {
         // the last launch of a zero-copy call (la_api.hip, assign_small_zc): this ONE workgroup's stores into the host's memory
