@@ -107,7 +107,77 @@ def main():
                 bad += 1; print("MULTI seed", seed, "shards", c.shard_count, "FAILED:", str(e)[:200])
     for c in multi:
         c.close()
-    print("stress done: %d tile + %d large + %d block + %d sample-sort + %d multi-shard seeds, %d failures" % (nt, nl, nb, ns, nm, bad))
+    # round 4: random tie structures through the keys-first sort (forced on small topics: LA_SORT_KEYS_FIRST=2) -- runs of every
+    # length around the scan's four, the repair's window (4 096) and capacity (8 192), at every offset; several large topics side
+    # by side; topics beyond 8 192 consumers; the sparse-begin entry, dense and sparse, pageable and pinned (in place / three streams)
+    n4 = int(sys.argv[6]) if len(sys.argv) > 6 else 40
+    from oracle.round_form import round_form
+    spec4 = importlib.util.spec_from_file_location("tr4", os.path.join(ROOT, "tests", "test_round4_gpu.py"))
+    tr4 = importlib.util.module_from_spec(spec4); spec4.loader.exec_module(tr4)
+    os.environ["LA_SORT_KEYS_FIRST"] = "2"
+    try:
+        for seed in range(100, 100 + n4):
+            rng = np.random.default_rng(seed)
+            n = int(rng.integers(17000, 90000))
+            lens = []
+            while sum(lens) < n:
+                kind = rng.integers(0, 6)
+                lens.append(int({0: 1, 1: rng.integers(2, 6), 2: rng.integers(5, 70), 3: rng.integers(3000, 4200),
+                                 4: rng.integers(8000, 8400), 5: rng.integers(1, 3)}[int(kind)]) if rng.random() < 0.9 else int(rng.integers(1, 12000)))
+            lag = np.repeat(rng.permutation(len(lens)).astype(np.int64) * 3 + int(rng.integers(0, 1 << 30)), lens)[:n]
+            lag = lag[rng.permutation(n)] if rng.random() < 0.7 else lag
+            pid = rng.permutation(n).astype(np.int32)
+            c_ = int(rng.choice([0, 3, 100]))
+            w = synth.Workload("ties", 1, np.array([0, n], np.int64), pid, np.zeros(n, np.int64), lag.copy(), np.zeros(n, np.int64), lag,
+                               np.array([0, c_], np.int64), np.arange(c_, dtype=np.int32), n, c_)
+            try:
+                got = tr4._device_call(ctx, w)
+                exp = round_form(w.part_off, w.partition_id, w.lag, w.cons_off, w.cons_rank)
+                assert all(np.array_equal(g, e) for g, e in zip(got, exp)), "keys-first order"
+            except (AssertionError, N.LagAssignError) as e:
+                bad += 1; print("TIES seed", seed, "n", n, "FAILED:", str(e)[:200])
+    finally:
+        os.environ.pop("LA_SORT_KEYS_FIRST", None)
+    for seed in range(100, 100 + n4 // 2):
+        rng = np.random.default_rng(seed)
+        shapes = [(int(rng.integers(16385, 120000)), int(rng.choice([0, 1, 50, 1500, 5000, 8192]))) for _ in range(int(rng.integers(2, 7)))]
+        shapes += [(int(rng.integers(1, 3000)), int(rng.integers(0, 200))) for _ in range(int(rng.integers(0, 5)))]
+        if seed % 4 == 0:
+            shapes.append((int(rng.integers(9000, 40000)), int(rng.integers(8193, 12000))))
+        order = rng.permutation(len(shapes))
+        w = tr4._batch_of([shapes[i] for i in order], seed, negative=bool(rng.integers(0, 2)))
+        try:
+            exp = round_form(w.part_off, w.partition_id, w.lag, w.cons_off, w.cons_rank)
+            got = tr4._device_call(ctx, w)
+            assert all(np.array_equal(g, e) for g, e in zip(got, exp)), "side by side"
+            got = ctx.assign_batch_lags(w.part_off, w.partition_id, w.lag, w.cons_off, w.cons_rank)
+            assert all(np.array_equal(g, e) for g, e in zip(got, exp)), "host entry"
+        except (AssertionError, N.LagAssignError) as e:
+            bad += 1; print("MANY seed", seed, shapes, "FAILED:", str(e)[:200])
+    for seed in range(100, 100 + n4):
+        rng = np.random.default_rng(seed)
+        w = tr4._workload(seed, float(rng.choice([0.0, 0.01, 0.5, 1.0])), topics=int(rng.integers(1, 500)), big=bool(rng.integers(0, 2)))
+        idx, val = N.sparse_begin(w.begin, w.committed)
+        exp = tr4._expected(w, False)
+        try:
+            got = ctx.assign_batch_sparse(w.part_off, w.partition_id, w.end, w.committed, N.LA_RESET_EARLIEST, idx, val, w.cons_off, w.cons_rank)
+            assert all(np.array_equal(g, e) for g, e in zip(got, exp)), "sparse, pageable (pipeline %d)" % ctx.last_pipeline()
+            pin = lambda a: tr4._pinned(ctx, a)
+            out = (ctx.host_alloc((w.n_partitions,), np.int32), ctx.host_alloc((w.n_partitions,), np.int32), ctx.host_alloc((w.cons_rank.size,), np.int64))
+            for env in (None, "1"):
+                if env: os.environ["LA_NO_MAPPED_PIPELINE"] = env
+                try:
+                    got = ctx.assign_batch_sparse(pin(w.part_off), pin(w.partition_id), pin(w.end), pin(w.committed), N.LA_RESET_EARLIEST,
+                                                  pin(idx), pin(val), pin(w.cons_off), pin(w.cons_rank), out=out)
+                    assert all(np.array_equal(g, e) for g, e in zip(got, exp)), "sparse, pinned (pipeline %d)" % ctx.last_pipeline()
+                    got = ctx.assign_batch(pin(w.part_off), pin(w.partition_id), pin(w.begin), pin(w.end), pin(w.committed), N.LA_RESET_EARLIEST,
+                                           pin(w.cons_off), pin(w.cons_rank), out=out)
+                    assert all(np.array_equal(g, e) for g, e in zip(got, exp)), "dense, pinned (pipeline %d)" % ctx.last_pipeline()
+                finally:
+                    os.environ.pop("LA_NO_MAPPED_PIPELINE", None)
+        except (AssertionError, N.LagAssignError) as e:
+            bad += 1; print("SPARSE seed", seed, "FAILED:", str(e)[:200])
+    print("stress done: %d tile + %d large + %d block + %d sample-sort + %d multi-shard + %d round-4 seeds, %d failures" % (nt, nl, nb, ns, nm, n4, bad))
     ctx.close()
 
 if __name__ == "__main__":
