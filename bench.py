@@ -305,7 +305,8 @@ def live_sort_traffic(n, form):
         return None
     # launches of a sort per kernel: 12 pass slots + 12 redo slots (no-ops unless a keys-first sort has to be redone) and the
     # tie repair in the single-kernel form; 12 of each in the four-kernel form
-    names = ({"onesweep_pass_kernel": 24, "tie_repair_kernel": 1} if form == "single" else
+    capable = n >= (1 << 22) and os.environ.get("LA_SORT_KEYS_FIRST") != "0"      # (la_large.hip, keys_first_mode)
+    names = ({"onesweep_pass_kernel": 24 if capable else 12, "tie_scan_kernel": 1, "tie_repair_kernel": 1} if form == "single" else
              {"tile_count_kernel": 12, "scan_group_sums_kernel": 12, "scan_offsets_kernel": 12, "tile_scatter_kernel": 12})
     rd = wr = 0.0
     for k, e in d["kernels"].items():
