@@ -53,6 +53,26 @@ int main(void) {
     ok &= member_off[0] == 0 && member_off[1] == 1 && member_off[2] == 3;
     ok &= grouped_partition[0] == 0 && grouped_partition[1] == 2 && grouped_partition[2] == 1;
     ok &= total[0] == 100000 && total[1] == 110000;
+
+    /* The same rebalance in ONE call, with the beginning offsets handed over only where they are read (ABI 0.3.0): partition 1
+     * has no committed offset (-1), so under auto.offset.reset=earliest its lag is end - begin = 50 000 - 0 (Main.java:384-396). */
+    if (la_version() >= 300) {
+        const int64_t committed_sparse[3] = {0, LA_NO_COMMITTED, 0};
+        const int64_t none_index[1] = {1}, none_begin[1] = {0};
+        int64_t off2[3], total2[2];
+        int32_t topic2[3], part2[3];
+        rc = la_assign_batch_grouped_sparse(ctx, 1, part_off, partition_id, end_off, committed_sparse, LA_RESET_EARLIEST, 1,
+                                            none_index, none_begin, cons_off, cons_rank, 2, off2, topic2, part2, total2);
+        if (rc != LA_OK) {
+            fprintf(stderr, "la_assign_batch_grouped_sparse: %d %s\n", rc, la_last_error(ctx));
+            return 1;
+        }
+        ok &= off2[0] == 0 && off2[1] == 1 && off2[2] == 3 && part2[0] == 0 && part2[1] == 2 && part2[2] == 1;
+        ok &= total2[0] == 100000 && total2[1] == 110000;
+        /* what one assigned partition costs on the wire of the multi-GPU all-gather: ids < 3, 2 members -> 2 bytes */
+        la_wire_format fmt;
+        ok &= la_wire_format_for(2, 2, &fmt) == LA_OK && fmt.elem_bytes == 2 && fmt.id_bits == 2;
+    }
     la_destroy(ctx);
     printf(ok ? "matches the reference's README example\n" : "MISMATCH\n");
     return ok ? 0 : 2;
