@@ -178,6 +178,10 @@ class DeviceShard:
         self.out_pid = self.out2[:cap]
         self.out_rank = self.out2[cap:]
         self.out_total = torch.zeros(max(self.k, 1), device=dev, dtype=torch.int64)
+        # (max end offset, max partition id) of the shard, or None when an offset or an id is negative
+        e, p_ = w.end[ps], w.partition_id[ps]
+        self.bounds = ((int(e.max()), int(p_.max())) if e.size and int(e.min()) >= 0 and int(w.begin[ps].min()) >= 0 and
+                       int(p_.min()) >= 0 else None)
         self.max_p = int(np.diff(po).max()) if po.size > 1 else 0
         self.max_c = int(np.diff(co).max()) if co.size > 1 else 0
         self._N = N
@@ -209,6 +213,11 @@ class DeviceShard:
         if b.max_partitions_per_topic > 1024 or b.max_consumers_per_topic > 64:
             b.h_part_off = self.h_part_off.ctypes.data_as(ctypes.POINTER(ctypes.c_int64))
             b.h_cons_off = self.h_cons_off.ctypes.data_as(ctypes.POINTER(ctypes.c_int64))
+        if self.bounds is not None and not os.environ.get("LA_BENCH_NO_BOUNDS"):
+            # what a marshaller knows without looking at a lag: the largest end offset (no lag exceeds it) and the largest
+            # partition id.  When they prove that every tile packs, the tile path is ONE launch (LA_FLAG_BOUNDS)
+            b.flags |= N.LA_FLAG_BOUNDS
+            b.max_lag_hint, b.max_partition_id_hint = self.bounds
         return b
 
 
@@ -1042,6 +1051,11 @@ def main():
                              "pack_ms": round(pack_ms_max, 4), "gather_ms": round(gather_ms_max, 4), "unpack_ms": round(unpack_ms_max, 4),
                              "kernels_ms": round(kern_ms_max, 4)} if do_gather else None),
                    "backend": ("rccl" if backend == "nccl" else "gloo, ranks sharing devices (test hook: not a performance number)") if use_dist else None,
+                   "bounds_hint": ({"max_end_offset": sh.bounds[0], "max_partition_id": sh.bounds[1],
+                                    "what": "LA_FLAG_BOUNDS: the caller's bounds on lags (the largest end offset) and ids prove that every tile "
+                                            "packs into 64-bit records, so the tile path is ONE launch per step (no empty wide-record launch "
+                                            "behind it); a violated bound is LA_EINVAL, never a different result"}
+                                   if (sh.bounds is not None and not os.environ.get("LA_BENCH_NO_BOUNDS")) else None),
                    "settle_ms": args.settle_ms, "settle_steps": settle_steps},
         "roofline": roofline,
         "cold_call_ms": cold["ms"],

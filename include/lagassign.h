@@ -118,6 +118,12 @@ extern "C" {
 #define LA_FLAG_NO_RUN_MERGE 256 /* large path: greedy rounds whose bins form a few ascending runs sort them like any other   *
                                  * round instead of merging the runs (test hook / A-B)                                  */
 
+#define LA_FLAG_BOUNDS      1024 /* max_lag_hint and max_partition_id_hint below are valid: the caller guarantees 0 <= lag <=          *
+                                 * max_lag_hint for every lag the batch produces (the largest end offset will do: a lag never exceeds    *
+                                 * it) and 0 <= partition id <= max_partition_id_hint.  When the bounds PROVE that every tile's records  *
+                                 * pack into 64 bits, the tile path drops its second launch (the wide-record kernel over the list of     *
+                                 * deferred tiles, empty in that case): one launch per batch instead of two.  A partition that violates  *
+                                 * the bounds is reported by la_sync as LA_EINVAL -- never a silently different result.                  */
 #define LA_FLAG_SERIAL_LARGE 512 /* large path: the batch's large topics one after another (round 3's form) instead of side by   *
                                  * side in shared launches (test hook / A-B)                                            */
 
@@ -299,6 +305,9 @@ typedef struct la_device_batch {
      * per-call topic lists live in context-owned device memory. */
     const int64_t *h_part_off;
     const int64_t *h_cons_off;
+    /* with LA_FLAG_BOUNDS (since ABI 0.3.0; ignored without the flag) */
+    int64_t max_lag_hint;            /* upper bound of every lag of the batch, >= 0                */
+    int64_t max_partition_id_hint;   /* upper bound of every partition id, >= 0                    */
 } la_device_batch;
 
 /* Enqueues the whole batch on `stream` and returns without waiting.  `stream` is a

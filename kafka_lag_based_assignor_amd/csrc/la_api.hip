@@ -471,8 +471,19 @@ int enqueue_batch(la_ctx* ctx, Lane& ln, const la_device_batch* b, hipStream_t s
     hipStreamCaptureStatus capture = hipStreamCaptureStatusNone;
     if (tile_mode == 0) LA_HIP(ctx, hipStreamIsCapturing(stream, &capture));
     hipError_t counter_err = hipSuccess;
+    // LA_FLAG_BOUNDS: when the caller's bounds prove that every tile of a launch packs, that launch defers nothing, needs no
+    // wide kernel behind it and leaves the counter pair alone (it neither counts nor has a wide kernel to zero the idle one)
+    const bool bounded = tile_mode == 0 && (b->flags & LA_FLAG_BOUNDS) && b->max_lag_hint >= 0 && b->max_partition_id_hint >= 0;
+    auto proven = [&](int64_t mp, int64_t mc) {
+        return bounded && la::wave_tile_always_packs(mp, mc, b->max_lag_hint, b->max_partition_id_hint);
+    };
     auto next_counters = [&](la::TileArgs& t) {
         int32_t* pair = (int32_t*)(ln.d_status + 16);
+        if (t.flags & la::kTileNoDefer) {
+            t.defer_count = pair + (ln.launches & 1u);
+            t.defer_count_next = pair + ((ln.launches + 1u) & 1u);
+            return;
+        }
         if (capture != hipStreamCaptureStatusNone) {
             t.defer_count = pair + 2;
             t.defer_count_next = pair + 3;
@@ -496,6 +507,7 @@ int enqueue_batch(la_ctx* ctx, Lane& ln, const la_device_batch* b, hipStream_t s
     const bool fits_hint = la::wave_tile_fits(b->max_partitions_per_topic, b->max_consumers_per_topic);
     if (fits_hint && !(have_host && (b->flags & LA_FLAG_RAGGED) && tile_mode == 0)) {
         // the plain case: every topic fits a wave tile, one shape for all, nothing read on the host
+        if (proven(b->max_partitions_per_topic, b->max_consumers_per_topic)) a.flags |= la::kTileNoDefer;
         next_counters(a);
         LA_HIP(ctx, counter_err);
         LA_HIP(ctx, la::wave_tile_launch(a, b->max_partitions_per_topic, b->max_consumers_per_topic, tile_mode, stream));
@@ -533,6 +545,7 @@ int enqueue_batch(la_ctx* ctx, Lane& ln, const la_device_batch* b, hipStream_t s
             la::TileArgs run = a;
             run.n_topics = plan.tile[k].n;
             run.topic_list = d_lists + plan.tile_at[k];
+            if (proven(plan.tile[k].mp, plan.tile[k].mc)) run.flags |= la::kTileNoDefer;
             next_counters(run);
             LA_HIP(ctx, counter_err);
             LA_HIP(ctx, la::wave_tile_launch(run, plan.tile[k].mp, plan.tile[k].mc, tile_mode, stream));
@@ -540,6 +553,7 @@ int enqueue_batch(la_ctx* ctx, Lane& ln, const la_device_batch* b, hipStream_t s
     } else if (plan.n_tile > 0) {
         la::TileArgs run = a;
         run.flags |= la::kTileSkipOversize;
+        if (proven(plan.tile_mp, plan.tile_mc)) run.flags |= la::kTileNoDefer;
         next_counters(run);
         LA_HIP(ctx, counter_err);
         LA_HIP(ctx, la::wave_tile_launch(run, plan.tile_mp, plan.tile_mc, tile_mode, stream));
@@ -559,6 +573,8 @@ int status_error(la_ctx* ctx, uint32_t st) {
         return fail(ctx, LA_EHIP, "internal error: a device radix sort left its result out of order");
     if (st & la::kStatusUnsorted)
         return fail(ctx, LA_EINVAL, "a topic's cons_rank segment is not strictly ascending");
+    if (st & la::kStatusBounds)
+        return fail(ctx, LA_EINVAL, "a lag or a partition id lies outside the bounds given with LA_FLAG_BOUNDS");
     if (st & la::kStatusSparse)
         return fail(ctx, LA_EINVAL, "none_index must hold ascending positions inside the batch");
     if (st & la::kStatusWire)

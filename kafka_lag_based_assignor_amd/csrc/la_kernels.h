@@ -39,6 +39,10 @@ constexpr uint32_t kStatusWire = 16u;      // la_pack_results_on: a partition id
 
 constexpr uint32_t kStatusSparse = 32u;    // la_assign_batch_sparse: none_index is not ascending, or points outside the batch
 
+constexpr uint32_t kStatusBounds = 64u;    // LA_FLAG_BOUNDS: a lag or a partition id lies outside the bounds the caller guaranteed
+
+constexpr int32_t kTileNoDefer = 8;       // TileArgs::flags: the bounds prove that every tile packs -- no deferred list, no wide
+                                          // launch; a tile that does not pack after all raises kStatusBounds
 constexpr int32_t kTileSkipOversize = 4;  // TileArgs::flags: topics beyond the tile belong to another path, no error
 
 constexpr int64_t kTileMaxPartitions = 1024;   // 64 lanes x 16 records
@@ -80,6 +84,8 @@ inline bool wave_tile_fits(int64_t max_p, int64_t max_c) {
     return max_p <= kTileMaxPartitions && max_c <= kTileMaxConsumers;
 }
 void wave_tile_pick(int64_t max_p, int64_t max_c, int* L, int* E);
+// true when ids in [0, max_id] and lags in [0, max_lag] pack into 64-bit records in every tile of the shape the launch would pick
+bool wave_tile_always_packs(int64_t max_p, int64_t max_c, int64_t max_lag, int64_t max_id);
 // mode: 0 = rounds, record format picked per wavefront; 1 = rounds, wide records forced; 2 = literal argmin
 hipError_t wave_tile_launch(TileArgs a, int64_t max_p, int64_t max_c, int mode, hipStream_t stream);
 

@@ -28,6 +28,22 @@ void wave_tile_pick(int64_t max_p, int64_t max_c, int* L, int* E) {
     *E = e;
 }
 
+// The packed format's condition (la_wave_tile_impl.h, packed_tile): sh = bits of the ids' OR (at least 1), lbw = bits of the
+// largest lag; a wavefront packs when sh < 32 and lbw <= min(63 - sh, 57 - log2(lanes x records)).  Bounds on ids and lags
+// bound sh and lbw from above for every wavefront.
+bool wave_tile_always_packs(int64_t max_p, int64_t max_c, int64_t max_lag, int64_t max_id) {
+    if (max_lag < 0 || max_id < 0 || max_id > 0x7FFFFFFFll) return false;
+    int L, E;
+    wave_tile_pick(max_p, max_c, &L, &E);
+    auto bits = [](uint64_t v) { int b = 0; while (v) { ++b; v >>= 1; } return b; };
+    int log2cap = 0;
+    while ((1 << log2cap) < L * E) ++log2cap;
+    const int sh = bits((uint64_t)max_id | 1u), lbw = bits((uint64_t)max_lag);
+    int lim = 63 - sh;
+    if (lim > 57 - log2cap) lim = 57 - log2cap;
+    return sh < 32 && lbw <= lim;
+}
+
 hipError_t wave_tile_launch(TileArgs a, int64_t max_p, int64_t max_c, int mode, hipStream_t stream) {
     int L, E;
     if (a.n_total <= 0) return hipSuccess;

@@ -638,7 +638,8 @@ __device__ __forceinline__ void packed_tile(const TileArgs& a, const TopicDescT<
     } else if constexpr (INLINE_WIDE) {
         assign_wide<L, E, false>(a, slice, (int64_t)cur.p0, (int64_t)cur.c0, cur.P, cur.C, gl, lag, pid);
     } else if (lane == 0) {
-        a.defer_list[atomicAdd(a.defer_count, 1)] = (int32_t)tile;
+        if (a.flags & kTileNoDefer) atomicOr(a.status, kStatusBounds);      // the caller's bounds said this could not happen
+        else a.defer_list[atomicAdd(a.defer_count, 1)] = (int32_t)tile;
     }
 }
 
@@ -785,6 +786,7 @@ static hipError_t launch_one(const TileArgs& a, int mode, hipStream_t stream) {
             hipLaunchKernelGGL((wave_tile_packed_kernel<L, E, uint32_t, false>), dim3((unsigned)blocks), b, 0, stream, a);
         else
             hipLaunchKernelGGL((wave_tile_packed_kernel<L, E, int64_t, false>), dim3((unsigned)blocks), b, 0, stream, a);
+        if (a.flags & kTileNoDefer) return hipGetLastError();      // proven: nothing can be deferred, no second launch
         // usually nothing was deferred: every wavefront reads the count and leaves
 #ifdef LA_LAB
         if (getenv("LA_NO_WIDE")) return hipGetLastError();

@@ -31,8 +31,8 @@ def test_library_exports_every_declared_symbol():
 
 
 def test_device_batch_struct_matches_header_layout():
-    # 4 x int32 + 4 x int64 + 13 pointers
-    assert ctypes.sizeof(_native.DeviceBatch) == 16 + 32 + 13 * 8
+    # 4 x int32 + 4 x int64 + 13 pointers + 2 x int64 (the LA_FLAG_BOUNDS hints)
+    assert ctypes.sizeof(_native.DeviceBatch) == 16 + 32 + 13 * 8 + 16
 
 
 def test_binding_constants_match_the_header():

@@ -522,3 +522,52 @@ def test_keys_first_sort_by_the_sample_at_five_million(ctx, kind, expect_first):
         np.testing.assert_array_equal(got0[0], got[0])
     finally:
         os.environ.pop("LA_SORT_KEYS_FIRST", None)
+
+
+# ---- LA_FLAG_BOUNDS: one launch when the caller's bounds prove that every tile packs ---------------------------------------------
+def test_bounds_hint_single_launch_and_violations(ctx):
+    """With bounds on lags and ids that prove the packed format for every tile the tile path skips its second launch; results are
+    the same; a tile that does not pack after all (the bounds were wrong) is LA_EINVAL, not a different result; launches with
+    and without the hint, deferring and not, alternate on one context without disturbing the deferred-tile counters."""
+    import ctypes
+    import torch
+    dev = torch.device("cuda", 0)
+
+    def run(w, bounds=None, flags=0):
+        d = {k: torch.from_numpy(np.ascontiguousarray(getattr(w, k))).to(dev) for k in ("part_off", "partition_id", "lag", "cons_off", "cons_rank")}
+        out_p = torch.full((w.n_partitions,), -7, device=dev, dtype=torch.int32)
+        out_m = torch.full((w.n_partitions,), -7, device=dev, dtype=torch.int32)
+        out_t = torch.full((max(w.cons_rank.size, 1),), -7, device=dev, dtype=torch.int64)
+        b = N.DeviceBatch()
+        b.n_topics, b.reset_mode, b.algo, b.flags = w.n_topics, N.LA_RESET_LATEST, N.LA_ALGO_AUTO, flags
+        b.n_partitions, b.n_consumers = w.n_partitions, w.cons_rank.size
+        b.max_partitions_per_topic, b.max_consumers_per_topic = w.max_partitions, w.max_consumers
+        b.d_part_off, b.d_partition_id, b.d_lag = d["part_off"].data_ptr(), d["partition_id"].data_ptr(), d["lag"].data_ptr()
+        b.d_cons_off, b.d_cons_rank = d["cons_off"].data_ptr(), d["cons_rank"].data_ptr()
+        b.d_out_partition, b.d_out_member_rank, b.d_out_total_lag = out_p.data_ptr(), out_m.data_ptr(), out_t.data_ptr()
+        if bounds is not None:
+            b.flags |= N.LA_FLAG_BOUNDS
+            b.max_lag_hint, b.max_partition_id_hint = bounds
+        stream = torch.cuda.current_stream().cuda_stream
+        ctx.assign_batch_device(b, stream)
+        ctx.sync(stream)
+        return out_p.cpu().numpy(), out_m.cpu().numpy(), out_t.cpu().numpy()[: w.cons_rank.size]
+
+    small = synth.make_uniform("b", 41, 3000, 256, 32, "zipf", offsets=False)          # lags <= 1e9, ids < 256: packs
+    wide = synth.make_uniform("b", 42, 3000, 64, 8, "uniform63", offsets=False)        # 63-bit lags: every tile defers
+    e_small = oracle.assign_flat(small.part_off, small.partition_id, small.lag, small.cons_off, small.cons_rank)
+    e_wide = oracle.assign_flat(wide.part_off, wide.partition_id, wide.lag, wide.cons_off, wide.cons_rank)
+    tight = (int(small.lag.max()), int(small.partition_id.max()))
+    for step in range(3):
+        _same3(run(wide, flags=N.LA_FLAG_DEFER_WIDE), e_wide, "deferring launch %d" % step)
+        _same3(run(small, tight, flags=N.LA_FLAG_DEFER_WIDE), e_small, "bounded launch %d" % step)
+        _same3(run(small, flags=N.LA_FLAG_DEFER_WIDE), e_small, "unbounded launch %d" % step)
+        _same3(run(small, tight), e_small, "bounded, single-launch form")
+    # bounds that prove nothing (too wide) are simply not used
+    _same3(run(wide, ((1 << 62), 63), flags=N.LA_FLAG_DEFER_WIDE), e_wide, "bounds too wide to prove anything")
+    # bounds that are wrong: a tile that cannot pack after all is an error
+    with pytest.raises(N.LagAssignError) as e:
+        run(wide, (1000, 63), flags=N.LA_FLAG_DEFER_WIDE)
+    assert e.value.code == N.LA_EINVAL and "LA_FLAG_BOUNDS" in str(e.value)
+    _same3(run(wide, flags=N.LA_FLAG_DEFER_WIDE), e_wide, "after the error")
+    _same3(run(small, tight, flags=N.LA_FLAG_DEFER_WIDE), e_small, "bounded, after the error")
