@@ -1038,8 +1038,11 @@ int run_shard_mapped(la_ctx* ctx, const HostCall& c, Shard& sh, ShardPlan& sp) {
     b.d_cons_rank = m_cons_rank;
     // results the caller asked for land in its arrays; those it leaves on the device go to the shard's own buffers, addressed
     // by the caller's positions (only positions of this shard's topics are ever stored)
-    b.d_out_partition = c.out_pid ? mapped_ptr(c.out_pid) : (int32_t*)sh.out_pid.p - sp.P0;
-    b.d_out_member_rank = c.out_pid ? mapped_ptr(c.out_rank) : (int32_t*)sh.out_rank.p - sp.P0;
+    // (the shard's own buffers hold positions [P0, P0 + n) only; their "position 0" is an address computed in integers, never
+    //  dereferenced below P0)
+    auto rebased = [&](void* base) { return (int32_t*)((uintptr_t)base - (uintptr_t)sp.P0 * sizeof(int32_t)); };
+    b.d_out_partition = c.out_pid ? mapped_ptr(c.out_pid) : rebased(sh.out_pid.p);
+    b.d_out_member_rank = c.out_pid ? mapped_ptr(c.out_rank) : rebased(sh.out_rank.p);
     b.d_out_total_lag = c.out_total ? mapped_ptr(c.out_total) : nullptr;
     b.h_part_off = c.part_off + sp.t0;
     b.h_cons_off = c.cons_off + sp.t0;
