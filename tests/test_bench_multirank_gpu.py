@@ -46,9 +46,11 @@ def test_default_at_two_ranks_is_the_north_star_workload():
     assert d["parity"]["bit_exact"] is True and d["parity"]["checked_topics"] > 0
     assert len(d["roofline"]["per_rank_kernel_ms"]) == 2 and min(d["roofline"]["per_rank_kernel_ms"]) > 0
     assert d["cold_call_ms"] > 0                                 # rank 0's extras survive at N > 1
-    # the default wire format: 2 bytes per assigned partition (ids < 256, 32 members), expanded again on every rank
+    # the default wire format: 2 bytes per assigned partition (ids < 256, 32 members); the map stays packed on every rank and the
+    # expansion is timed beside the step
     wire = d["config"]["wire"]
-    assert wire["format"] == "packed" and wire["elem_bytes"] == 2 and wire["id_bits"] == 8 and wire["unpacked_in_step"] is True
+    assert wire["format"] == "packed" and wire["elem_bytes"] == 2 and wire["id_bits"] == 8 and wire["unpacked_in_step"] is False
+    assert wire["unpack_ms"] > 0 and 0 < wire["value_if_unpacked_in_step"] < d["value"]
     assert wire["gather_bytes_per_rank"] == 2 * 12800000
 
 
@@ -72,12 +74,12 @@ def test_strong_scaling_four_ranks_cfg4():
 
 @pytest.mark.timeout(1200)
 def test_strong_scaling_three_ranks_other_wire_forms():
-    """The round-3 form ([2, cap] int32) and the packed form left packed: same global arrays (checked by rank 0's oracle)."""
+    """The round-3 form ([2, cap] int32) and the packed form expanded inside the step: same global arrays (rank 0's oracle)."""
     d = _run(3, ["--workload", "cfg4", "--wire", "int32"], GLOO)
     assert d["config"]["wire"]["format"] == "int32" and d["config"]["wire"]["elem_bytes"] == 8
     assert d["parity"]["bit_exact"] is True and d["parity"]["checked_topics"] == 100000 and d["config"]["collectives_per_step"] == 1
-    d = _run(3, ["--workload", "cfg4", "--no-unpack"], GLOO)
-    assert d["config"]["wire"]["unpacked_in_step"] is False and d["config"]["wire"]["elem_bytes"] == 2
+    d = _run(3, ["--workload", "cfg4", "--unpack"], GLOO)
+    assert d["config"]["wire"]["unpacked_in_step"] is True and d["config"]["wire"]["elem_bytes"] == 2
     assert d["parity"]["bit_exact"] is True and d["parity"]["checked_topics"] == 100000
 
 
