@@ -400,6 +400,7 @@ int launch_large_topics(la_ctx* ctx, Lane& ln, const la_device_batch* b, const B
         g.no_sample_sort = (b->flags & LA_FLAG_NO_SAMPLE_SORT) ? 1 : ((b->flags & LA_FLAG_SAMPLE_TIGHT) ? 2 : 0);
         g.sort_multi_kernel = (b->flags & LA_FLAG_SORT_MULTIKERNEL) ? 1 : 0;
         g.no_run_merge = (b->flags & LA_FLAG_NO_RUN_MERGE) ? 1 : 0;
+        g.no_moved_sort = (b->flags & LA_FLAG_NO_MOVED_SORT) ? 1 : 0;
         g.status = ln.status();
         hipError_t e = hipSuccess;
         if (c > la::kLargeMaxConsumers) {

@@ -186,6 +186,7 @@ struct LargeArgs {
                                 // 2 = LA_FLAG_SAMPLE_TIGHT: bucket limit 6, so sample-sorted and fallback rounds interleave
     int32_t no_run_merge;       // LA_FLAG_NO_RUN_MERGE: greedy rounds never merge ascending runs (they sort as if there were none)
     int32_t sort_multi_kernel;  // LA_FLAG_SORT_MULTIKERNEL: four kernels per radix pass (count, scans, scatter) instead of one
+    int32_t no_moved_sort;      // LA_FLAG_NO_MOVED_SORT: greedy rounds never sort only the bins that move
 };
 
 // Once per device at context creation (synchronous): checks the hardware property the radix sort's atomic ranking relies on.

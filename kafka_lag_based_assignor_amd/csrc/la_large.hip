@@ -994,10 +994,13 @@ struct SampleLds {
                           //      by slower threads when the fastest start the next round)
     uint32_t* cnt;        // [NS + 1] bucket counts, then (first position | size << 16)
     uint32_t* misc;       // [32] per-wavefront sums and maxima; [32 .. 32 + 66) second-level bucket counts, flag
+    uint32_t* moved;      // [kMovedWords] the moved-bins sort's own words (moved_sort_bins): nothing else touches them
 };
+constexpr int kMovedWords = 160;
 
 __host__ __device__ constexpr size_t sample_lds_bytes(int ec) {
-    return ((size_t)ec * kSampleThreads + kWalkPad) * 16 + (size_t)kSamplesPerThread * kSampleThreads * (16 + 4) + 64 + (32 + 128) * 4;
+    return ((size_t)ec * kSampleThreads + kWalkPad) * 16 + (size_t)kSamplesPerThread * kSampleThreads * (16 + 4) + 64 + (32 + 128) * 4 +
+           (size_t)kMovedWords * 4;
 }
 
 __device__ __forceinline__ SampleLds sample_lds_carve(void* smem, int n) {
@@ -1006,6 +1009,7 @@ __device__ __forceinline__ SampleLds sample_lds_carve(void* smem, int n) {
     L.spl = reinterpret_cast<uint64_t*>(L.stage + n + kWalkPad);   // stage[n ..): sentinels, larger than any bin
     L.cnt = reinterpret_cast<uint32_t*>(L.spl + 2 * kSamplesPerThread * kSampleThreads);
     L.misc = L.cnt + kSamplesPerThread * kSampleThreads + 16;
+    L.moved = L.misc + 32 + 128;
     return L;
 }
 
@@ -1326,6 +1330,231 @@ __device__ __forceinline__ bool merge_runs_bins(P64 (&rec)[EC], const SampleLds&
     return true;
 }
 
+// ---- a round that moves few bins: only those are sorted ------------------------------------------------------------------
+// Out of a round the bins are (ascending totals) + (descending lags).  On a power-law topic most of the consumers stand far
+// apart after the first round -- the few that took the huge lags, a long thin tail -- and a round's lags differ by less than
+// their distances: they keep their places.  Only the dense bulk moves: cfg5 (8 192 consumers) moves 3 168 bins in round 1,
+// 1 263 in round 2, 850 - 1 060 in rounds 3 - 75 and ~500 after that, while the round's bins are up to 600 ascending runs
+// (`profiles/r04_cfg5_rounds.txt`).  A bin STAYS where it is when it is larger than every bin before it and smaller than
+// every bin behind it (a prefix maximum and a suffix minimum); such a bin separates what comes before it from what comes
+// behind it, so the bins that do not stay are sorted among themselves and go back, in order, to the places they came from.
+//   1. per thread (EC consecutive bins): ascending inside, above the maximum of everything before, below the minimum of
+//      everything behind?  A wavefront whose 64 * EC bins ascend needs no scan for that (its maximum is its last bin); the
+//      others scan their lanes (DPP).  Across wavefronts: 16 maxima / minima through LDS.  A thread with one bin that moves
+//      hands in all EC (more bins than necessary is harmless: a bin that stays, stays).
+//   2. the threads that hand in bins write them side by side (m = EC * threads, at most kMovedPerThread * 1 024); a sort of m
+//      bins with one or two per thread, the scheme of the sample sort one level down: 64 of them sorted by one wavefront
+//      (DPP), every bin finds its bucket among those (7 LDS reads), takes a slot, is staged by bucket and ranked by the walk
+//      over its bucket (~m / 64 bins).
+//   3. the sorted bins go back to the threads they came from.
+// Eight barriers and ~60 LDS operations in the threads that take part; the wavefronts whose bins all stay (13 of 16 on cfg5)
+// spend ~100 VALU instructions on the round's sort.  Returns false -- rec untouched -- when more bins move than fit (or a
+// bucket is larger than `bucket_limit`): the caller sorts the round as before.  *moved_out = the number of bins handed in.
+constexpr int kMovedPad = 164;                               // sentinels behind the staged bins (the walk reads four at a time)
+constexpr uint32_t kMovedBucket = 160;
+
+// inclusive prefix maximum over the lanes of the wavefront (row shifts, then the row broadcasts; a lane without a source
+// reads zero, the identity)
+__device__ __forceinline__ uint64_t wave_incl_max_u64(uint64_t v) {
+#define LA_MAX_STEP(CTRL, ROWS)                                                                                          \
+    {                                                                                                                    \
+        const uint32_t lo_ = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)v, CTRL, ROWS, 0xF, false);         \
+        const uint32_t hi_ = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(v >> 32), CTRL, ROWS, 0xF, false); \
+        const uint64_t o_ = ((uint64_t)hi_ << 32) | lo_;                                                                 \
+        v = o_ > v ? o_ : v;                                                                                             \
+    }
+    LA_MAX_STEP(0x111, 0xF)        // row_shr:1
+    LA_MAX_STEP(0x112, 0xF)        // row_shr:2
+    LA_MAX_STEP(0x114, 0xF)        // row_shr:4
+    LA_MAX_STEP(0x118, 0xF)        // row_shr:8
+    LA_MAX_STEP(0x142, 0xA)        // row_bcast:15 -> rows 1, 3
+    LA_MAX_STEP(0x143, 0xC)        // row_bcast:31 -> rows 2, 3
+#undef LA_MAX_STEP
+    return v;
+}
+
+__device__ __forceinline__ uint64_t wave_shr1_u64(uint64_t v) {            // lane - 1's value; lane 0 reads zero
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)v, 0x138, 0xF, 0xF, false);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(v >> 32), 0x138, 0xF, 0xF, false);
+    return ((uint64_t)hi << 32) | lo;
+}
+
+__device__ __forceinline__ uint64_t wave_mirror_u64(uint64_t v) {          // lane 63 - lane's value
+    return ((uint64_t)shfl_mirror<64>((uint32_t)(v >> 32)) << 32) | shfl_mirror<64>((uint32_t)v);
+}
+
+template <int J>
+__device__ __forceinline__ uint64_t shfl_xor_u64(uint64_t v) {
+    return ((uint64_t)shfl_xor<J>((uint32_t)(v >> 32)) << 32) | shfl_xor<J>((uint32_t)v);
+}
+
+__device__ __forceinline__ uint64_t readlane_u64(uint64_t v, int lane) {
+    return ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), lane) << 32) |
+           (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, lane);
+}
+
+template <int EC>
+__device__ __forceinline__ bool moved_sort_bins(P64 (&rec)[EC], const SampleLds& L, int tid, uint32_t bucket_limit, int* moved_out) {
+    constexpr int NT = kSampleThreads;
+    constexpr int CPT = EC >= 8 ? 2 : 1;                         // bins of the small sort per thread
+    constexpr int kCap = 256 * EC;                               // its capacity (a quarter of the round's bins)
+    static_assert(kCap <= CPT * NT && NT == 1024, "capacity");
+    const int lane = tid & 63, wave = tid >> 6;
+    uint64_t* wmax = reinterpret_cast<uint64_t*>(L.moved);       // [16] a wavefront's largest bin
+    uint64_t* wmin = wmax + 16;                                  // [16] its smallest
+    uint32_t* wcnt = L.moved + 64;                               // [16] its threads that hand in bins
+    uint32_t* cnt2 = L.moved + 80;                               // [64 + 1] bucket counts, then (first | size << 16); [65] largest
+    uint64_t* comp = reinterpret_cast<uint64_t*>(L.stage);       // [kCap] the bins handed in, register-major; then the sorted ones
+    ulonglong2* stage2 = reinterpret_cast<ulonglong2*>(comp + kCap);     // [kCap + kMovedPad] staged by bucket
+    uint64_t* sup = reinterpret_cast<uint64_t*>(stage2 + kCap + kMovedPad);   // [64] the sorted samples
+    // 1. who stays
+    uint64_t v[EC];
+#pragma unroll
+    for (int r = 0; r < EC; ++r) v[r] = p64_value(rec[r]);
+    bool asc = true;
+#pragma unroll
+    for (int r = 1; r < EC; ++r) asc &= v[r - 1] < v[r];
+    const uint64_t prev_last = wave_shr1_u64(v[EC - 1]);         // (every lane executes the shift: la_sort64.h on masked sources)
+    const bool asc_w = asc & ((lane == 0) | (prev_last < v[0]));
+    const bool wave_asc = __builtin_amdgcn_ballot_w64(!asc_w) == 0;              // wavefront-uniform
+    uint64_t pm_in = 0, sm_in = ~0ull;                           // over the earlier / later lanes of this wavefront
+    uint64_t w_hi, w_lo;
+    if (wave_asc) {
+        w_hi = readlane_u64(v[EC - 1], 63);
+        w_lo = readlane_u64(v[0], 0);
+    } else {
+        uint64_t tmax = v[0], tmin = v[0];
+#pragma unroll
+        for (int r = 1; r < EC; ++r) { tmax = v[r] > tmax ? v[r] : tmax; tmin = v[r] < tmin ? v[r] : tmin; }
+        const uint64_t incl = wave_incl_max_u64(tmax);
+        pm_in = wave_shr1_u64(incl);
+        w_hi = readlane_u64(incl, 63);
+        // the suffix minimum is the prefix maximum of the complements, lanes mirrored
+        const uint64_t incl_m = wave_incl_max_u64(wave_mirror_u64(~tmin));
+        sm_in = ~wave_mirror_u64(wave_shr1_u64(incl_m));
+        w_lo = ~readlane_u64(incl_m, 63);
+    }
+    if (lane == 0) { wmax[wave] = w_hi; wmin[wave] = w_lo; }
+    if (tid < 66) cnt2[tid] = 0;
+    lds_barrier();                                               // (1)
+    uint64_t pm_w, sm_w;                                         // over the earlier / later wavefronts
+    {
+        uint64_t a = lane < wave ? wmax[lane & 15] : 0;
+        uint64_t b = (lane > wave && lane < NT / 64) ? wmin[lane & 15] : ~0ull;
+#define LA_RED_STEP(J)                                                        \
+        {                                                                     \
+            const uint64_t oa_ = shfl_xor_u64<J>(a), ob_ = shfl_xor_u64<J>(b); \
+            a = oa_ > a ? oa_ : a;                                            \
+            b = ob_ < b ? ob_ : b;                                            \
+        }
+        LA_RED_STEP(1) LA_RED_STEP(2) LA_RED_STEP(4) LA_RED_STEP(8)
+#undef LA_RED_STEP
+        pm_w = readlane_u64(a, 0);
+        sm_w = readlane_u64(b, 0);
+    }
+    const uint64_t before = pm_in > pm_w ? pm_in : pm_w, behind = sm_in < sm_w ? sm_in : sm_w;
+    const bool moves = !(asc & (before < v[0]) & (v[EC - 1] < behind));
+    const uint64_t bal = __builtin_amdgcn_ballot_w64(moves);
+    if (lane == 0) wcnt[wave] = (uint32_t)__builtin_popcountll(bal);
+    lds_barrier();                                               // (2)
+    uint32_t off = (uint32_t)__builtin_popcountll(bal & ((1ull << lane) - 1ull)), D = 0;
+    {
+        const uint4* cv = reinterpret_cast<const uint4*>(wcnt);
+#pragma unroll
+        for (int q4 = 0; q4 < 4; ++q4) {
+            const uint4 c = cv[q4];
+            off += (4 * q4 + 0 < wave ? c.x : 0u) + (4 * q4 + 1 < wave ? c.y : 0u) + (4 * q4 + 2 < wave ? c.z : 0u) +
+                   (4 * q4 + 3 < wave ? c.w : 0u);
+            D += c.x + c.y + c.z + c.w;
+        }
+    }
+    const int m = (int)D * EC;
+    *moved_out = m;
+    if (m == 0) return true;                                     // in order already
+    if (m > kCap) return false;                                  // (workgroup-uniform)
+    // 2. the bins that move, side by side (bin r of the k-th thread at r * D + k); sentinels behind the staged ones
+    if (moves) {
+#pragma unroll
+        for (int r = 0; r < EC; ++r) comp[r * D + off] = v[r];
+    }
+    if (tid < kMovedPad) stage2[m + tid] = make_ulonglong2(~0ull, 0);
+    lds_barrier();                                               // (3)
+    if (wave == 0) {
+        // 64 samples: bin (lane % EC) of 64 evenly spaced threads (of fewer threads several bins each)
+        P64 s = p64_from(comp[(uint32_t)(lane % EC) * D + ((uint32_t)lane * D) / 64u]);
+        asm volatile("s_nop 1" : "+v"(s.lo), "+v"(s.hi));
+        bitonic_sort_lanes_p64<64>(s);
+        sup[lane] = p64_value(s);
+    }
+    lds_barrier();                                               // (4)
+    uint64_t x[CPT];
+    uint32_t b2[CPT], slot[CPT];
+#pragma unroll
+    for (int u = 0; u < CPT; ++u) {
+        const int c = tid + u * NT;
+        x[u] = ~0ull; b2[u] = 0; slot[u] = 0;
+        if (u * NT < m) {                                        // (uniform)
+            const bool valid = c < m;
+            x[u] = comp[valid ? c : 0];
+            uint32_t b = 0;
+#pragma unroll
+            for (int step = 32; step >= 1; step >>= 1) b += (sup[b + step - 1] < x[u]) ? (uint32_t)step : 0u;
+            b += (sup[63] < x[u]) ? 1u : 0u;
+            b2[u] = b;
+            if (valid) slot[u] = atomicAdd(&cnt2[b], 1u);
+        }
+    }
+    lds_barrier();                                               // (5)
+    if (wave == 0) {                                             // first positions of the 65 buckets; the largest one
+        const uint32_t c = cnt2[lane];
+        const uint32_t incl = wave_incl_scan_u32(c);
+        const uint32_t last = cnt2[64];
+        const uint32_t mx = wave_max_u32(max(c, last));
+        __builtin_amdgcn_wave_barrier();
+        cnt2[lane] = (incl - c) | (c << 16);
+        if (lane == 63) { cnt2[64] = incl | (last << 16); cnt2[65] = mx; }
+    }
+    lds_barrier();                                               // (6)
+    if (cnt2[65] > bucket_limit) return false;                   // (workgroup-uniform)
+#pragma unroll
+    for (int u = 0; u < CPT; ++u) {
+        const int c = tid + u * NT;
+        if (c < m) {
+            const uint32_t sc = cnt2[b2[u]];
+            stage2[(sc & 0xFFFFu) + slot[u]] = make_ulonglong2(x[u], (uint64_t)((sc & 0xFFFF0000u) | slot[u]));
+        }
+    }
+    lds_barrier();                                               // (7)
+    const uint64_t* keys = reinterpret_cast<const uint64_t*>(stage2);
+#pragma unroll
+    for (int u = 0; u < CPT; ++u) {
+        const int c = tid + u * NT;
+        if (u * NT < m) {                                        // (uniform: the walk's bound is a wavefront maximum)
+            const bool valid = c < m;
+            const ulonglong2 e = valid ? stage2[c] : make_ulonglong2(~0ull, 0);
+            const uint32_t inf = (uint32_t)e.y;
+            const uint32_t s0 = valid ? (uint32_t)c - (inf & 0xFFFFu) : 0u;
+            const uint32_t cmax = wave_max_u32(inf >> 16);
+            const uint64_t* bk = keys + 2 * s0;
+            uint32_t below = 0;
+#pragma unroll 2
+            for (uint32_t k = 0; k < cmax; k += 4) {
+                const uint64_t o0 = bk[2 * k], o1 = bk[2 * k + 2], o2 = bk[2 * k + 4], o3 = bk[2 * k + 6];
+                below += (o0 < e.x ? 1u : 0u) + (o1 < e.x ? 1u : 0u) + (o2 < e.x ? 1u : 0u) + (o3 < e.x ? 1u : 0u);
+            }
+            // 3. position j of the sorted bins is bin j % EC of the (j / EC)-th thread that handed bins in
+            const uint32_t j = s0 + below;
+            if (valid) comp[(j % EC) * D + j / EC] = e.x;        // (comp was last read before barrier 5)
+        }
+    }
+    lds_barrier();                                               // (8)
+    if (moves) {
+#pragma unroll
+        for (int r = 0; r < EC; ++r) rec[r] = p64_from(comp[r * D + off]);
+    }
+    return true;
+}
+
 template <int EC>
 __device__ void greedy_rounds_packed(const LargeArgs& a, const uint64_t* key, int64_t P, int C, int64_t rounds,
                                      int idx_bits, void* smem) {
@@ -1351,14 +1580,26 @@ __device__ void greedy_rounds_packed(const LargeArgs& a, const uint64_t* key, in
         lag[r] = key[i < P ? i : P - 1];
     }
     [[maybe_unused]] int64_t next_look = 1;              // the next round that looks whether its bins are a few ascending runs
+    [[maybe_unused]] int64_t next_moved = 1;             // the next round that looks whether few of its bins move
+    [[maybe_unused]] int moved_wait = 0;
     for (int64_t q = 0; q < rounds; ++q) {
         if (q > 0) {
             bool sorted = false;
             if constexpr (EC >= 2) {
+                // few bins move?  A topic that has the property has it round after round (the bulk of a power-law topic);
+                // one that does not (lags spread like the totals) has every bin move in every round: after a look that
+                // found more than twice what fits, the next one waits 1, 2, 4 .. 32 rounds.
+                if (use_sample && a.no_moved_sort == 0 && q >= next_moved) {
+                    int moved = 0;
+                    sorted = moved_sort_bins<EC>(rec, L, tid, a.no_sample_sort == 2 ? 20u : kMovedBucket, &moved);
+                    if (sorted || moved <= 512 * EC) moved_wait = 0;
+                    else moved_wait = moved_wait ? (moved_wait < 32 ? 2 * moved_wait : 32) : 1;
+                    next_moved = q + 1 + moved_wait;
+                }
                 // few ascending runs?  The number of runs falls from round to round on the topics that have the property
                 // and stays in the thousands on those that do not: look again after as many rounds as the last look
                 // missed by (a factor of two per round is about what cfg5 does), every round once it has held.
-                if (use_sample && a.no_run_merge == 0 && q >= next_look) {
+                if (!sorted && use_sample && a.no_run_merge == 0 && q >= next_look) {
                     int runs = 0;
                     sorted = merge_runs_bins<EC>(rec, L, tid, &runs);
                     int wait = 0;

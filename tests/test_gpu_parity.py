@@ -901,6 +901,46 @@ def test_large_rounds_merge_ascending_runs(ctx, p, c, kind):
             np.testing.assert_array_equal(g, e, err_msg="%s, %s" % (name, what))
 
 
+@pytest.mark.parametrize("p,c,kind", [
+    (400_000, 8192, "pareto"), (300_000, 4096, "pareto"), (120_000, 2048, "pareto"), (150_000, 5000, "pareto"),
+    (200_000, 8192, "bulk16"), (200_000, 8192, "bulk5"), (200_000, 8192, "bulk3"), (100_000, 4000, "bulk16"),
+    (60_000, 2048, "bulk5"), (160_000, 8192, "apart"), (90_000, 3000, "apart"), (200_000, 8192, "pairs"),
+])
+def test_large_rounds_sort_only_the_bins_that_move(ctx, p, c, kind):
+    """Greedy rounds in which few bins change places (moved_sort_bins, la_large.hip) sort only those: the same result as
+    with LA_FLAG_NO_MOVED_SORT, as with the run merge off too, as with tight bucket limits (rounds of every form mixed),
+    the oracle's.  bulkN: 1 - 1/N of the consumers stand 10^9 apart after the first round, the rest is a dense bulk that
+    reshuffles in every round (N = 3: more than fits, the rounds fall back and the look backs off); apart: nothing ever moves
+    after round 1; pairs: neighbours swap."""
+    rng = np.random.default_rng(7 * p + c)
+    if kind == "pareto":
+        w = _pareto_topic(p + c, p, c)
+    else:
+        first = np.empty(c, dtype=np.int64)
+        if kind.startswith("bulk"):
+            far = c - c // int(kind[4:])
+            first[:far] = 10**13 - np.arange(far, dtype=np.int64) * 10**9
+            first[far:] = 10**6 + rng.integers(0, 1000, c - far)
+            rest = rng.integers(0, 100_000, p - c)
+        elif kind == "apart":
+            first[:] = 10**13 - np.arange(c, dtype=np.int64) * 10**9
+            rest = rng.integers(0, 1_000_000, p - c)
+        else:
+            first[:] = 10**13 - np.arange(c, dtype=np.int64) * 10**9
+            rest = rng.integers(0, 3 * 10**9, p - c)                         # a bin passes its neighbour, sometimes two
+        lag = np.ascontiguousarray(rng.permutation(np.concatenate([first, rest])), dtype=np.int64)
+        w = synth.Workload(kind, 1, np.array([0, p], np.int64), rng.permutation(p).astype(np.int32), np.zeros(p, np.int64),
+                           lag.copy(), np.zeros(p, np.int64), lag, np.array([0, c], np.int64),
+                           np.sort(rng.choice(3 * c + 1, c, replace=False)).astype(np.int32), p, c)
+    exp = oracle.assign_flat(w.part_off, w.partition_id, w.lag, w.cons_off, w.cons_rank)
+    for flags, what in ((0, "default"), (N.LA_FLAG_NO_MOVED_SORT, "moved sort off"),
+                        (N.LA_FLAG_NO_MOVED_SORT | N.LA_FLAG_NO_RUN_MERGE, "sample sort only"),
+                        (N.LA_FLAG_SAMPLE_TIGHT, "tight limits"), (N.LA_FLAG_NO_RUN_MERGE, "moved sort, no run merge")):
+        got = _run_device(ctx, w, N.LA_ALGO_AUTO, use_lag=True, flags=flags)
+        for g, e, name in zip(got, exp, ("partition order", "member", "totals")):
+            np.testing.assert_array_equal(g, e, err_msg="%s, %s" % (name, what))
+
+
 def test_large_path_rank_forms_in_fresh_processes():
     """The radix sort ranks equal digits with returning LDS atomics when the device passes the lane-order self-test of
     la_create (LA_FEATURE_ATOMIC_RANK) and with wave-match ballots otherwise; LA_SORT_RANK=match forces the second form.

@@ -40,7 +40,8 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream
     lag = np.maximum(w.end - np.where(w.committed >= 0, w.committed, w.begin), 0)
     exp = round_form(w.part_off, w.partition_id, lag, w.cons_off, w.cons_rank)
-    for flags, what in ((0, "default"), (N.LA_FLAG_NO_RUN_MERGE, "sample sort"), (N.LA_FLAG_NO_SAMPLE_SORT, "full network"),
+    for flags, what in ((0, "default"), (N.LA_FLAG_NO_MOVED_SORT, "run merge"),
+                        (N.LA_FLAG_NO_MOVED_SORT | N.LA_FLAG_NO_RUN_MERGE, "sample sort"), (N.LA_FLAG_NO_SAMPLE_SORT, "full network"),
                         (N.LA_FLAG_SAMPLE_TIGHT | N.LA_FLAG_NO_RUN_MERGE, "tight")):
         b.flags = flags | N.LA_FLAG_PROFILE
         ctx.assign_batch_device(b, stream); ctx.sync(stream)
