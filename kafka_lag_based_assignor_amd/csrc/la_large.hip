@@ -1407,6 +1407,7 @@ __device__ __forceinline__ bool moved_sort_bins(P64 (&rec)[EC], const SampleLds&
     uint64_t* comp = reinterpret_cast<uint64_t*>(L.stage);       // [kCap] the bins handed in, register-major; then the sorted ones
     ulonglong2* stage2 = reinterpret_cast<ulonglong2*>(comp + kCap);     // [kCap + kMovedPad] staged by bucket
     uint64_t* sup = reinterpret_cast<uint64_t*>(stage2 + kCap + kMovedPad);   // [64] the sorted samples
+    LA_CLK_START;
     // 1. who stays
     uint64_t v[EC];
 #pragma unroll
@@ -1437,6 +1438,7 @@ __device__ __forceinline__ bool moved_sort_bins(P64 (&rec)[EC], const SampleLds&
     if (lane == 0) { wmax[wave] = w_hi; wmin[wave] = w_lo; }
     if (tid < 66) cnt2[tid] = 0;
     lds_barrier();                                               // (1)
+    LA_CLK(7);
     uint64_t pm_w, sm_w;                                         // over the earlier / later wavefronts
     {
         uint64_t a = lane < wave ? wmax[lane & 15] : 0;
@@ -1457,6 +1459,7 @@ __device__ __forceinline__ bool moved_sort_bins(P64 (&rec)[EC], const SampleLds&
     const uint64_t bal = __builtin_amdgcn_ballot_w64(moves);
     if (lane == 0) wcnt[wave] = (uint32_t)__builtin_popcountll(bal);
     lds_barrier();                                               // (2)
+    LA_CLK(8);
     uint32_t off = (uint32_t)__builtin_popcountll(bal & ((1ull << lane) - 1ull)), D = 0;
     {
         const uint4* cv = reinterpret_cast<const uint4*>(wcnt);
@@ -1479,6 +1482,7 @@ __device__ __forceinline__ bool moved_sort_bins(P64 (&rec)[EC], const SampleLds&
     }
     if (tid < kMovedPad) stage2[m + tid] = make_ulonglong2(~0ull, 0);
     lds_barrier();                                               // (3)
+    LA_CLK(9);
     if (wave == 0) {
         // 64 samples: bin (lane % EC) of 64 evenly spaced threads (of fewer threads several bins each)
         P64 s = p64_from(comp[(uint32_t)(lane % EC) * D + ((uint32_t)lane * D) / 64u]);
@@ -1487,6 +1491,7 @@ __device__ __forceinline__ bool moved_sort_bins(P64 (&rec)[EC], const SampleLds&
         sup[lane] = p64_value(s);
     }
     lds_barrier();                                               // (4)
+    LA_CLK(10);
     uint64_t x[CPT];
     uint32_t b2[CPT], slot[CPT];
 #pragma unroll
@@ -1505,6 +1510,7 @@ __device__ __forceinline__ bool moved_sort_bins(P64 (&rec)[EC], const SampleLds&
         }
     }
     lds_barrier();                                               // (5)
+    LA_CLK(11);
     if (wave == 0) {                                             // first positions of the 65 buckets; the largest one
         const uint32_t c = cnt2[lane];
         const uint32_t incl = wave_incl_scan_u32(c);
@@ -1515,6 +1521,7 @@ __device__ __forceinline__ bool moved_sort_bins(P64 (&rec)[EC], const SampleLds&
         if (lane == 63) { cnt2[64] = incl | (last << 16); cnt2[65] = mx; }
     }
     lds_barrier();                                               // (6)
+    LA_CLK(12);
     if (cnt2[65] > bucket_limit) return false;                   // (workgroup-uniform)
 #pragma unroll
     for (int u = 0; u < CPT; ++u) {
@@ -1525,6 +1532,7 @@ __device__ __forceinline__ bool moved_sort_bins(P64 (&rec)[EC], const SampleLds&
         }
     }
     lds_barrier();                                               // (7)
+    LA_CLK(13);
     const uint64_t* keys = reinterpret_cast<const uint64_t*>(stage2);
 #pragma unroll
     for (int u = 0; u < CPT; ++u) {
@@ -1548,10 +1556,12 @@ __device__ __forceinline__ bool moved_sort_bins(P64 (&rec)[EC], const SampleLds&
         }
     }
     lds_barrier();                                               // (8)
+    LA_CLK(14);
     if (moves) {
 #pragma unroll
         for (int r = 0; r < EC; ++r) rec[r] = p64_from(comp[r * D + off]);
     }
+    LA_CLK(15);
     return true;
 }
 
@@ -1582,7 +1592,13 @@ __device__ void greedy_rounds_packed(const LargeArgs& a, const uint64_t* key, in
     [[maybe_unused]] int64_t next_look = 1;              // the next round that looks whether its bins are a few ascending runs
     [[maybe_unused]] int64_t next_moved = 1;             // the next round that looks whether few of its bins move
     [[maybe_unused]] int moved_wait = 0;
+    const int tid_fixed = tid;
     for (int64_t q = 0; q < rounds; ++q) {
+        // The thread index, opaque once per round: everything a round derives from it (lane predicates, LDS addresses, masks)
+        // is then computed in the round -- a few VALU instructions -- instead of once before the loop, where hipcc parks the
+        // values in scratch memory (the kernel sits at its 128-register cap) and reloads them in the middle of the chain.
+        int tid = tid_fixed;
+        asm volatile("" : "+v"(tid));
         if (q > 0) {
             bool sorted = false;
             if constexpr (EC >= 2) {
@@ -1631,13 +1647,15 @@ __device__ void greedy_rounds_packed(const LargeArgs& a, const uint64_t* key, in
         uint64_t next_lag[EC];
         if constexpr (EC >= 2) {
             struct __attribute__((aligned(8))) U64x2 { uint64_t x, y; };
+            // No branch around the loads, not even a uniform one (round 3 had `if (P >= 2)` here and hipcc put an
+            // s_waitcnt vmcnt(0) between every two of them: four serialized round trips to L2 per round, ~2k cycles).  A
+            // one-partition topic reads key[0 .. 1]: inside the buffer, whose size is rounded up to 256 bytes (sort_layout).
+            const int64_t last_pair = P >= 2 ? P - 2 : 0;
 #pragma unroll
             for (int r = 0; r < EC; r += 2) {
                 const int64_t s = (q + 1) * C + tid * EC + r;
-                const int64_t base = P >= 2 ? (s < P - 2 ? s : P - 2) : 0;      // the pair stays inside the array
-                U64x2 v;
-                if (P >= 2) v = *reinterpret_cast<const U64x2*>(key + base);    // (uniform branch)
-                else v.x = v.y = key[0];
+                const int64_t base = s < last_pair ? s : last_pair;              // the pair stays inside the array
+                const U64x2 v = *reinterpret_cast<const U64x2*>(key + base);
                 next_lag[r] = base == s ? v.x : v.y;        // s == P - 1: its key is the pair's second word
                 next_lag[r + 1] = v.y;                      // (positions past P - 1 are never used)
             }

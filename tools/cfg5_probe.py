@@ -58,10 +58,13 @@ def main():
         if hasattr(ctx._lib, "la_debug_round_clocks"):      # development build (-DLA_ROUND_CLOCKS)
             clk = (ctypes.c_ulonglong * 16)()
             ctx._lib.la_debug_round_clocks(clk, 1)
-            names = ("sample sort", "bucket search", "slots+scan", "stage", "rank walk", "final order", "add+stores")
-            tot = float(sum(clk[:7])) or 1.0
+            names = ("sample sort", "bucket search", "slots+scan", "stage", "rank walk", "final order", "add+stores",
+                     "moved: who stays", "moved: across waves", "moved: hand in", "moved: samples", "moved: buckets",
+                     "moved: scan", "moved: stage", "moved: walk", "moved: back")
+            tot = float(sum(clk[:16])) or 1.0
             print("   cycles per phase (thread 0, %d calls): " % (args.reps + 1) +
-                  ", ".join("%s %.1f%%" % (n, 100.0 * clk[i] / tot) for i, n in enumerate(names)) + "; total %.3g" % tot)
+                  ", ".join("%s %.1f%%" % (n, 100.0 * clk[i] / tot) for i, n in enumerate(names) if clk[i]) +
+                  "; total %.3g = %.0f per round" % (tot, tot / (args.reps + 1) / 127.0))
         print("%-13s keys %.3f ms, sort %.3f ms (%d id + %d key passes), ids+greedy %.3f ms, call %.3f ms wall; bit-exact vs round form: %s"
               % (what, k, s, t.id_passes, t.key_passes, g, wall, ok))
     ctx.close()
