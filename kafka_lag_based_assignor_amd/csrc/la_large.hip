@@ -1340,16 +1340,18 @@ __device__ __forceinline__ bool merge_runs_bins(P64 (&rec)[EC], const SampleLds&
 // behind it, so the bins that do not stay are sorted among themselves and go back, in order, to the places they came from.
 //   1. per thread (EC consecutive bins): ascending inside, above the maximum of everything before, below the minimum of
 //      everything behind?  A wavefront whose 64 * EC bins ascend needs no scan for that (its maximum is its last bin); the
-//      others scan their lanes (DPP).  Across wavefronts: 16 maxima / minima through LDS.  A thread with one bin that moves
-//      hands in all EC (more bins than necessary is harmless: a bin that stays, stays).
-//   2. the threads that hand in bins write them side by side (m = EC * threads, at most kMovedPerThread * 1 024); a sort of m
-//      bins with one or two per thread, the scheme of the sample sort one level down: 64 of them sorted by one wavefront
-//      (DPP), every bin finds its bucket among those (7 LDS reads), takes a slot, is staged by bucket and ranked by the walk
-//      over its bucket (~m / 64 bins).
-//   3. the sorted bins go back to the threads they came from.
-// Eight barriers and ~60 LDS operations in the threads that take part; the wavefronts whose bins all stay (13 of 16 on cfg5)
-// spend ~100 VALU instructions on the round's sort.  Returns false -- rec untouched -- when more bins move than fit (or a
-// bucket is larger than `bucket_limit`): the caller sorts the round as before.  *moved_out = the number of bins handed in.
+//      others scan their lanes (DPP).  Across wavefronts: 16 maxima / minima through LDS.  Only the wavefronts that hold a
+//      thread with a bin that moves look at single bins and count them.
+//   2. the bins that move are written side by side, in the order of their places (m of them, at most a quarter of the
+//      round's bins) and sorted with one or two per thread by the scheme of the sample sort one level down: 64 of them, evenly
+//      spaced, are ranked against each other (four per wavefront: one compare + ballot each), every bin finds its bucket
+//      among those (7 LDS reads), takes a slot, is staged by bucket and ranked by the walk over its bucket (~m / 64 bins).
+//      m <= 64: one wavefront sorts them in registers.
+//   3. the sorted bins go back to the places the bins that move came from.
+// Six barriers and ~60 LDS operations in the threads that take part; the wavefronts whose bins all stay (13 of 16 on cfg5)
+// spend ~100 VALU instructions on finding that out -- on a CU with 16 wavefronts every instruction that all of them execute
+// costs 16 cycles, which is what a round is made of.  Returns false -- rec untouched -- when more bins move than fit (or a
+// bucket is larger than `bucket_limit`): the caller sorts the round as before.  *moved_out = the number of bins that move.
 constexpr int kMovedPad = 164;                               // sentinels behind the staged bins (the walk reads four at a time)
 constexpr uint32_t kMovedBucket = 160;
 
@@ -1388,7 +1390,7 @@ __device__ __forceinline__ uint64_t shfl_xor_u64(uint64_t v) {
     return ((uint64_t)shfl_xor<J>((uint32_t)(v >> 32)) << 32) | shfl_xor<J>((uint32_t)v);
 }
 
-__device__ __forceinline__ uint64_t readlane_u64(uint64_t v, int lane) {
+__device__ __forceinline__ uint64_t readlane_u64(uint64_t v, int lane) {   // (lane: wavefront-uniform)
     return ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(v >> 32), lane) << 32) |
            (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, lane);
 }
@@ -1399,14 +1401,17 @@ __device__ __forceinline__ bool moved_sort_bins(P64 (&rec)[EC], const SampleLds&
     constexpr int CPT = EC >= 8 ? 2 : 1;                         // bins of the small sort per thread
     constexpr int kCap = 256 * EC;                               // its capacity (a quarter of the round's bins)
     static_assert(kCap <= CPT * NT && NT == 1024, "capacity");
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     uint64_t* wmax = reinterpret_cast<uint64_t*>(L.moved);       // [16] a wavefront's largest bin
     uint64_t* wmin = wmax + 16;                                  // [16] its smallest
-    uint32_t* wcnt = L.moved + 64;                               // [16] its threads that hand in bins
-    uint32_t* cnt2 = L.moved + 80;                               // [64 + 1] bucket counts, then (first | size << 16); [65] largest
-    uint64_t* comp = reinterpret_cast<uint64_t*>(L.stage);       // [kCap] the bins handed in, register-major; then the sorted ones
+    uint32_t* wcnt = L.moved + 64;                               // [16] its bins that move
+    uint32_t* cnt2 = L.moved + 80;                               // [64 + 1] bucket counts
+    uint32_t* taken = L.moved + 146;                             // [1] places of the side-by-side array handed out so far
+    uint64_t* comp = reinterpret_cast<uint64_t*>(L.stage);       // [kCap] the bins that move, in the order of their places; then sorted
     ulonglong2* stage2 = reinterpret_cast<ulonglong2*>(comp + kCap);     // [kCap + kMovedPad] staged by bucket
-    uint64_t* sup = reinterpret_cast<uint64_t*>(stage2 + kCap + kMovedPad);   // [64] the sorted samples
+    uint64_t* sup = reinterpret_cast<uint64_t*>(stage2 + kCap + kMovedPad);   // [64] the samples in order
+    uint64_t* sup1 = sup + 64;                                   // [8] every eighth of them (sup[7], sup[15] ..)
     LA_CLK_START;
     // 1. who stays
     uint64_t v[EC];
@@ -1436,7 +1441,8 @@ __device__ __forceinline__ bool moved_sort_bins(P64 (&rec)[EC], const SampleLds&
         w_lo = ~readlane_u64(incl_m, 63);
     }
     if (lane == 0) { wmax[wave] = w_hi; wmin[wave] = w_lo; }
-    if (tid < 66) cnt2[tid] = 0;
+    if (tid < 65) cnt2[tid] = 0;
+    if (tid == 65) *taken = 0;
     lds_barrier();                                               // (1)
     LA_CLK(7);
     uint64_t pm_w, sm_w;                                         // over the earlier / later wavefronts
@@ -1456,110 +1462,163 @@ __device__ __forceinline__ bool moved_sort_bins(P64 (&rec)[EC], const SampleLds&
     }
     const uint64_t before = pm_in > pm_w ? pm_in : pm_w, behind = sm_in < sm_w ? sm_in : sm_w;
     const bool moves = !(asc & (before < v[0]) & (v[EC - 1] < behind));
-    const uint64_t bal = __builtin_amdgcn_ballot_w64(moves);
-    if (lane == 0) wcnt[wave] = (uint32_t)__builtin_popcountll(bal);
+    const bool wave_moves = __builtin_amdgcn_ballot_w64(moves) != 0;             // wavefront-uniform
+    uint32_t mask = 0, off = 0;                                  // my bins that move; how many move before them
+    if (wave_moves) {
+        // bin r stays when everything before it is smaller and everything behind it is larger
+        uint64_t sm[EC];
+        {
+            uint64_t x = behind;
+#pragma unroll
+            for (int r = EC - 1; r >= 0; --r) { sm[r] = x; x = v[r] < x ? v[r] : x; }
+        }
+        uint64_t run = before;
+#pragma unroll
+        for (int r = 0; r < EC; ++r) {
+            mask |= ((run < v[r]) & (v[r] < sm[r])) ? 0u : (1u << r);
+            run = v[r] > run ? v[r] : run;
+        }
+        const uint32_t mine = (uint32_t)__builtin_popcount(mask);
+        const uint32_t incl = wave_incl_scan_u32(mine);
+        off = incl - mine;
+        // 2. the bins that move, side by side: the wavefront takes as many places as it needs (in whatever order the
+        //    wavefronts come: the order of the PLACES is kept in `off`, for the way back) and fills them
+        const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        uint32_t k = 0;
+        if (lane == 0) { k = atomicAdd(taken, total); wcnt[wave] = total; }
+        k = (uint32_t)__builtin_amdgcn_readfirstlane((int)k) + off;
+#pragma unroll
+        for (int r = 0; r < EC; ++r)
+            if (mask & (1u << r)) {
+                if (k < (uint32_t)kCap) comp[k] = v[r];
+                ++k;
+            }
+    } else if (lane == 0) {
+        wcnt[wave] = 0;
+    }
     lds_barrier();                                               // (2)
     LA_CLK(8);
-    uint32_t off = (uint32_t)__builtin_popcountll(bal & ((1ull << lane) - 1ull)), D = 0;
+    int m = 0;
     {
         const uint4* cv = reinterpret_cast<const uint4*>(wcnt);
+        uint32_t base = 0;
 #pragma unroll
         for (int q4 = 0; q4 < 4; ++q4) {
             const uint4 c = cv[q4];
-            off += (4 * q4 + 0 < wave ? c.x : 0u) + (4 * q4 + 1 < wave ? c.y : 0u) + (4 * q4 + 2 < wave ? c.z : 0u) +
-                   (4 * q4 + 3 < wave ? c.w : 0u);
-            D += c.x + c.y + c.z + c.w;
+            const uint32_t c0 = __builtin_amdgcn_readfirstlane(c.x), c1 = __builtin_amdgcn_readfirstlane(c.y),
+                           c2 = __builtin_amdgcn_readfirstlane(c.z), c3 = __builtin_amdgcn_readfirstlane(c.w);
+            base += (4 * q4 + 0 < wave ? c0 : 0u) + (4 * q4 + 1 < wave ? c1 : 0u) + (4 * q4 + 2 < wave ? c2 : 0u) +
+                    (4 * q4 + 3 < wave ? c3 : 0u);
+            m += (int)(c0 + c1 + c2 + c3);
         }
+        off += base;
     }
-    const int m = (int)D * EC;
     *moved_out = m;
     if (m == 0) return true;                                     // in order already
     if (m > kCap) return false;                                  // (workgroup-uniform)
-    // 2. the bins that move, side by side (bin r of the k-th thread at r * D + k); sentinels behind the staged ones
-    if (moves) {
-#pragma unroll
-        for (int r = 0; r < EC; ++r) comp[r * D + off] = v[r];
-    }
-    if (tid < kMovedPad) stage2[m + tid] = make_ulonglong2(~0ull, 0);
-    lds_barrier();                                               // (3)
-    LA_CLK(9);
-    if (wave == 0) {
-        // 64 samples: bin (lane % EC) of 64 evenly spaced threads (of fewer threads several bins each)
-        P64 s = p64_from(comp[(uint32_t)(lane % EC) * D + ((uint32_t)lane * D) / 64u]);
-        asm volatile("s_nop 1" : "+v"(s.lo), "+v"(s.hi));
-        bitonic_sort_lanes_p64<64>(s);
-        sup[lane] = p64_value(s);
-    }
-    lds_barrier();                                               // (4)
-    LA_CLK(10);
-    uint64_t x[CPT];
-    uint32_t b2[CPT], slot[CPT];
-#pragma unroll
-    for (int u = 0; u < CPT; ++u) {
-        const int c = tid + u * NT;
-        x[u] = ~0ull; b2[u] = 0; slot[u] = 0;
-        if (u * NT < m) {                                        // (uniform)
-            const bool valid = c < m;
-            x[u] = comp[valid ? c : 0];
-            uint32_t b = 0;
-#pragma unroll
-            for (int step = 32; step >= 1; step >>= 1) b += (sup[b + step - 1] < x[u]) ? (uint32_t)step : 0u;
-            b += (sup[63] < x[u]) ? 1u : 0u;
-            b2[u] = b;
-            if (valid) slot[u] = atomicAdd(&cnt2[b], 1u);
+    if (m <= 64) {
+        if (wave == 0) {                                         // one wavefront sorts them
+            P64 s = p64_from(lane < m ? comp[lane] : ~0ull);
+            asm volatile("s_nop 1" : "+v"(s.lo), "+v"(s.hi));
+            bitonic_sort_lanes_p64<64>(s);
+            if (lane < m) comp[lane] = p64_value(s);
         }
-    }
-    lds_barrier();                                               // (5)
-    LA_CLK(11);
-    if (wave == 0) {                                             // first positions of the 65 buckets; the largest one
-        const uint32_t c = cnt2[lane];
-        const uint32_t incl = wave_incl_scan_u32(c);
-        const uint32_t last = cnt2[64];
-        const uint32_t mx = wave_max_u32(max(c, last));
-        __builtin_amdgcn_wave_barrier();
-        cnt2[lane] = (incl - c) | (c << 16);
-        if (lane == 63) { cnt2[64] = incl | (last << 16); cnt2[65] = mx; }
-    }
-    lds_barrier();                                               // (6)
-    LA_CLK(12);
-    if (cnt2[65] > bucket_limit) return false;                   // (workgroup-uniform)
+        lds_barrier();
+    } else {
+        {
+            // 64 evenly spaced samples (distinct places: m > 64), every wavefront ranks four of them: the number of samples
+            // below one is its place among them
+            const uint64_t smp = comp[((uint32_t)lane * (uint32_t)m + (uint32_t)m / 2u) >> 6];
 #pragma unroll
-    for (int u = 0; u < CPT; ++u) {
-        const int c = tid + u * NT;
-        if (c < m) {
-            const uint32_t sc = cnt2[b2[u]];
-            stage2[(sc & 0xFFFFu) + slot[u]] = make_ulonglong2(x[u], (uint64_t)((sc & 0xFFFF0000u) | slot[u]));
-        }
-    }
-    lds_barrier();                                               // (7)
-    LA_CLK(13);
-    const uint64_t* keys = reinterpret_cast<const uint64_t*>(stage2);
-#pragma unroll
-    for (int u = 0; u < CPT; ++u) {
-        const int c = tid + u * NT;
-        if (u * NT < m) {                                        // (uniform: the walk's bound is a wavefront maximum)
-            const bool valid = c < m;
-            const ulonglong2 e = valid ? stage2[c] : make_ulonglong2(~0ull, 0);
-            const uint32_t inf = (uint32_t)e.y;
-            const uint32_t s0 = valid ? (uint32_t)c - (inf & 0xFFFFu) : 0u;
-            const uint32_t cmax = wave_max_u32(inf >> 16);
-            const uint64_t* bk = keys + 2 * s0;
-            uint32_t below = 0;
-#pragma unroll 2
-            for (uint32_t k = 0; k < cmax; k += 4) {
-                const uint64_t o0 = bk[2 * k], o1 = bk[2 * k + 2], o2 = bk[2 * k + 4], o3 = bk[2 * k + 6];
-                below += (o0 < e.x ? 1u : 0u) + (o1 < e.x ? 1u : 0u) + (o2 < e.x ? 1u : 0u) + (o3 < e.x ? 1u : 0u);
+            for (int k = 0; k < 64 / (NT / 64); ++k) {
+                const uint64_t s = readlane_u64(smp, wave * (64 / (NT / 64)) + k);
+                const int rank = __builtin_popcountll(__builtin_amdgcn_ballot_w64(smp < s));
+                if (lane == 0) {
+                    sup[rank] = s;
+                    if ((rank & 7) == 7) sup1[rank >> 3] = s;
+                }
             }
-            // 3. position j of the sorted bins is bin j % EC of the (j / EC)-th thread that handed bins in
-            const uint32_t j = s0 + below;
-            if (valid) comp[(j % EC) * D + j / EC] = e.x;        // (comp was last read before barrier 5)
+            if (tid < kMovedPad) stage2[m + tid] = make_ulonglong2(~0ull, 0);     // sentinels behind the staged bins
         }
-    }
-    lds_barrier();                                               // (8)
-    LA_CLK(14);
-    if (moves) {
+        lds_barrier();                                           // (3)
+        LA_CLK(10);
+        uint64_t x[CPT];
+        uint32_t b2[CPT], slot[CPT];
 #pragma unroll
-        for (int r = 0; r < EC; ++r) rec[r] = p64_from(comp[r * D + off]);
+        for (int u = 0; u < CPT; ++u) {
+            const int c = tid + u * NT;
+            x[u] = ~0ull; b2[u] = 0; slot[u] = 0;
+            if (u * NT < m) {                                    // (uniform)
+                const bool valid = c < m;
+                x[u] = comp[valid ? c : 0];
+                // bucket = the number of samples below the bin, in two steps of eight reads each (two dependent trips to
+                // LDS where a binary search makes seven): which eighth of the samples, then where inside it
+                uint32_t c1 = 0, c2 = 0;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) c1 += (sup1[i] < x[u]) ? 1u : 0u;
+                const uint64_t* row = sup + 8u * (c1 < 7u ? c1 : 7u);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) c2 += (row[i] < x[u]) ? 1u : 0u;       // (c1 < 8: row[7] is not below)
+                const uint32_t b = 8u * (c1 < 7u ? c1 : 7u) + c2;
+                b2[u] = b;
+                if (valid) slot[u] = atomicAdd(&cnt2[b], 1u);
+            }
+        }
+        lds_barrier();                                           // (4)
+        LA_CLK(11);
+        // first places of the 65 buckets, the largest bucket: every wavefront for itself (a scan over its lanes), no barrier
+        uint32_t first[CPT], size[CPT];
+        {
+            const uint32_t c = cnt2[lane];
+            const uint32_t incl = wave_incl_scan_u32(c);
+            const uint32_t last = cnt2[64];
+            if (wave_max_u32(max(c, last)) > bucket_limit) return false;         // (workgroup-uniform: same counts everywhere)
+            const uint32_t all = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+#pragma unroll
+            for (int u = 0; u < CPT; ++u) {
+                const uint32_t bl = b2[u] & 63u;
+                const uint32_t f = (uint32_t)__shfl((int)(incl - c), (int)bl), z = (uint32_t)__shfl((int)c, (int)bl);
+                first[u] = b2[u] < 64u ? f : all;
+                size[u] = b2[u] < 64u ? z : last;
+            }
+        }
+        LA_CLK(12);
+#pragma unroll
+        for (int u = 0; u < CPT; ++u) {
+            const int c = tid + u * NT;
+            if (c < m) stage2[first[u] + slot[u]] = make_ulonglong2(x[u], (uint64_t)((size[u] << 16) | slot[u]));
+        }
+        lds_barrier();                                           // (5)
+        LA_CLK(13);
+        const uint64_t* keys = reinterpret_cast<const uint64_t*>(stage2);
+#pragma unroll
+        for (int u = 0; u < CPT; ++u) {
+            const int c = tid + u * NT;
+            if (u * NT < m) {                                    // (uniform: the walk's bound is a wavefront maximum)
+                const bool valid = c < m;
+                const ulonglong2 e = valid ? stage2[c] : make_ulonglong2(~0ull, 0);
+                const uint32_t inf = (uint32_t)e.y;
+                const uint32_t s0 = valid ? (uint32_t)c - (inf & 0xFFFFu) : 0u;
+                const uint32_t cmax = wave_max_u32(inf >> 16);
+                const uint64_t* bk = keys + 2 * s0;
+                uint32_t below = 0;
+#pragma unroll 2
+                for (uint32_t k = 0; k < cmax; k += 4) {
+                    const uint64_t o0 = bk[2 * k], o1 = bk[2 * k + 2], o2 = bk[2 * k + 4], o3 = bk[2 * k + 6];
+                    below += (o0 < e.x ? 1u : 0u) + (o1 < e.x ? 1u : 0u) + (o2 < e.x ? 1u : 0u) + (o3 < e.x ? 1u : 0u);
+                }
+                if (valid) comp[s0 + below] = e.x;               // (comp was last read before barrier 4)
+            }
+        }
+        lds_barrier();                                           // (6)
+        LA_CLK(14);
+    }
+    // 3. back to the places the bins that move came from
+    if (wave_moves) {
+        uint32_t k = off;
+#pragma unroll
+        for (int r = 0; r < EC; ++r)
+            if (mask & (1u << r)) rec[r] = p64_from(comp[k++]);
     }
     LA_CLK(15);
     return true;
@@ -1665,6 +1724,28 @@ __device__ void greedy_rounds_packed(const LargeArgs& a, const uint64_t* key, in
         }
         int32_t who[EC];
         bool live[EC];
+        if (EC >= 4 && C == n && (q + 1) * C <= P) {
+            // a full round of a topic whose consumers fill every slot (cfg5: 127 of 128 rounds): every bin takes a partition
+            // -- no predicates, no 64-bit position arithmetic, two 16-byte stores
+#pragma unroll
+            for (int r = 0; r < EC; ++r) {
+                const uint64_t nb = p64_value(rec[r]) + ((lag[r] ^ kLagKeyFlip) << idx_bits);       // Main.java:265
+                rec[r] = p64_from(nb);
+                who[r] = (int32_t)((uint32_t)nb & idx_mask);
+                lag[r] = next_lag[r];
+            }
+            if constexpr (EC >= 4) {
+                typedef int I32x4 __attribute__((ext_vector_type(4), aligned(4)));
+                int32_t* dst = a.out_rank + a.p0 + q * C + tid * EC;
+#pragma unroll
+                for (int r = 0; r < EC; r += 4) {
+                    const I32x4 v4 = {who[r], who[r + 1], who[r + 2], who[r + 3]};
+                    *reinterpret_cast<I32x4*>(dst + r) = v4;
+                }
+            }
+            LA_CLK(6);
+            continue;
+        }
 #pragma unroll
         for (int r = 0; r < EC; ++r) {
             const int i = tid * EC + r;
