@@ -1548,7 +1548,7 @@ __device__ __forceinline__ bool moved_sort_bins(P64 (&rec)[EC], const SampleLds&
         for (int u = 0; u < CPT; ++u) {
             const int c = tid + u * NT;
             x[u] = ~0ull; b2[u] = 0; slot[u] = 0;
-            if (u * NT < m) {                                    // (uniform)
+            if (u * NT + wave * 64 < m) {                        // (wavefront-uniform: a wavefront without a bin skips the phase)
                 const bool valid = c < m;
                 x[u] = comp[valid ? c : 0];
                 // bucket = the number of samples below the bin, in two steps of eight reads each (two dependent trips to
@@ -1594,7 +1594,7 @@ __device__ __forceinline__ bool moved_sort_bins(P64 (&rec)[EC], const SampleLds&
 #pragma unroll
         for (int u = 0; u < CPT; ++u) {
             const int c = tid + u * NT;
-            if (u * NT < m) {                                    // (uniform: the walk's bound is a wavefront maximum)
+            if (u * NT + wave * 64 < m) {                        // (wavefront-uniform: the walk's bound is a wavefront maximum)
                 const bool valid = c < m;
                 const ulonglong2 e = valid ? stage2[c] : make_ulonglong2(~0ull, 0);
                 const uint32_t inf = (uint32_t)e.y;

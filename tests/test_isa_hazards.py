@@ -112,3 +112,15 @@ def test_lds_exchanges_stay_lds_instructions(isa):
         # SGPR offset is a private ARRAY in memory, which is what the bug looked like
         dyn = re.findall(r"^\s*scratch_(?:load|store)\w*\s+[^;\n]*\bs\d+\b[^;\n]*$", text, re.M)
         assert not dyn, "%s: dynamically addressed scratch: %s" % (os.path.basename(path), dyn[0].strip())
+
+
+def test_the_greedy_chain_keeps_nothing_in_scratch(isa):
+    """Round 4 regression: the one-workgroup greedy (1 024 threads: a 128-VGPR cap) had hipcc hoist what a round derives from
+    the thread index out of the loop of rounds and park it in scratch memory -- reloads in the middle of a dependent chain.
+    The thread index is opaque once per round now (greedy_rounds_packed): no kernel of the chain may need scratch at all."""
+    text = open([p for p in isa if os.path.basename(p) == "la_large.s"][0]).read()
+    found = 0
+    for m in re.finditer(r"^(_ZN[^\n:]*greedy_rounds_kernel[^\n:]*):\s*;.*?^; ScratchSize: (\d+)", text, re.M | re.S):
+        found += 1
+        assert int(m.group(2)) == 0, "%s keeps %s bytes per lane in scratch" % (m.group(1), m.group(2))
+    assert found >= 4, "greedy_rounds_kernel<1 / 2 / 4 / 8> not found in the ISA (%d)" % found
