@@ -1663,13 +1663,11 @@ __device__ void greedy_rounds_packed(const LargeArgs& a, const uint64_t* key, in
             if constexpr (EC >= 2) {
                 // few bins move?  A topic that has the property has it round after round (the bulk of a power-law topic);
                 // one that does not (lags spread like the totals) has every bin move in every round: after a look that
-                // found more than twice what fits, the next one waits 1, 2, 4 .. 32 rounds (8, 16, 32 when three quarters of
-                // the bins moved).
+                // found more than twice what fits, the next one waits 1, 2, 4 .. 32 rounds.
                 if (use_sample && a.no_moved_sort == 0 && q >= next_moved) {
                     int moved = 0;
                     sorted = moved_sort_bins<EC>(rec, L, tid, a.no_sample_sort == 2 ? 20u : kMovedBucket, &moved);
                     if (sorted || moved <= 512 * EC) moved_wait = 0;
-                    else if (moved > 768 * EC && moved_wait < 8) moved_wait = 8;     // (nearly) every bin moves: not this kind of topic
                     else moved_wait = moved_wait ? (moved_wait < 32 ? 2 * moved_wait : 32) : 1;
                     next_moved = q + 1 + moved_wait;
                 }
