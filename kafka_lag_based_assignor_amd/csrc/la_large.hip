@@ -1649,7 +1649,8 @@ __device__ void greedy_rounds_packed(const LargeArgs& a, const uint64_t* key, in
         lag[r] = key[i < P ? i : P - 1];
     }
     [[maybe_unused]] int64_t next_look = 1;              // the next round that looks whether its bins are a few ascending runs
-    [[maybe_unused]] int64_t next_moved = 1;             // the next round that looks whether few of its bins move
+    [[maybe_unused]] int64_t next_moved = 2;             // the next round that looks whether few of its bins move (round 1 sorts
+                                                         // what round 0 made of equal bins: every bin moves)
     [[maybe_unused]] int moved_wait = 0;
     const int tid_fixed = tid;
     for (int64_t q = 0; q < rounds; ++q) {

@@ -23,7 +23,7 @@ def main():
     tot = np.zeros(C, dtype=np.int64)
     idx = np.arange(C)
     print("# %s: %d partitions, %d consumers, lags %d .. %d" % (args.config, P, C, sl[-1], sl[0]))
-    print("# round: runs, distinct lags, bins that move (first .. last position), largest distance, first descents")
+    print("# row q = the bins AFTER round q's add, i.e. what round q + 1 has to sort\n# round: runs, distinct lags, bins handed to the small sort (not a prefix maximum and suffix minimum), bins that change places\n#        (first .. last position), largest distance, first descents")
     for q in range((P + C - 1) // C):
         L = sl[q * C:(q + 1) * C]
         o = np.lexsort((idx, tot))
@@ -32,9 +32,13 @@ def main():
         key = tot * C + idx
         fin = np.argsort(key, kind="stable")
         moved = np.nonzero(fin != np.arange(C))[0]
+        # what moved_sort_bins hands in: every bin that is not above all bins before it and below all bins behind it
+        pm = np.maximum.accumulate(np.concatenate(([-1], key[:-1])))
+        sm = np.minimum.accumulate(np.concatenate((key[1:], [np.iinfo(np.int64).max]))[::-1])[::-1]
+        handed = int(((key < pm) | (key > sm)).sum())
         d = np.nonzero(key[1:] < key[:-1])[0]
-        print("%3d: %4d runs, %4d distinct lags, %4d move (%s), distance <= %d, descents at %s" %
-              (q, d.size + 1, np.unique(L).size, moved.size,
+        print("%3d: %4d runs, %4d distinct lags, %4d handed in, %4d move (%s), distance <= %d, descents at %s" %
+              (q, d.size + 1, np.unique(L).size, handed, moved.size,
                "%d .. %d" % (moved.min(), moved.max()) if moved.size else "-",
                int(np.abs(fin - np.arange(C)).max()), d[:8].tolist()))
 
