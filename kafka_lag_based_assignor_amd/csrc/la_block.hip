@@ -164,15 +164,20 @@ __device__ __forceinline__ void block_sort_regs(Rec (&rec)[E], int n_eff, int ti
 // ~14.  Direction-free form (every block comes out ascending), so stopping at n_eff slots works here too.  The
 // workgroup decides per topic whether its records fit (no negative lag or id, lag bits + id bits <= 63).
 template <int E>
-__device__ __forceinline__ void block_sort_packed(P64 (&rec)[E], int n_eff, int tid, int nt, uint64_t* x_key) {
+__device__ __forceinline__ void block_sort_packed(P64 (&rec)[E], int n_eff, int live, int tid, int nt, uint64_t* x_key) {
+    // `live`: slots at or beyond it hold sentinels (all equal, larger than any record), and keep holding them: a block of
+    // slots that starts there is in order whatever is done to it, and a merge whose upper half starts there changes nothing.
     constexpr int kSpanSlots = kWave * E;                                // slots of one wavefront
-    const bool active = (tid & ~(kWave - 1)) * E < n_eff;                // wavefront-uniform
+    const int w0 = (tid & ~(kWave - 1)) * E;                             // my wavefront's first slot
+    const bool in_range = w0 < n_eff;                                    // wavefront-uniform
+    bool active = in_range && w0 < live;
     if (active) {
 #pragma unroll
         for (int r = 0; r < E; ++r) asm volatile("s_nop 1" : "+v"(rec[r].lo), "+v"(rec[r].hi));
         bitonic_sort_tile_p64<kWave, E>(rec);
     }
     for (int K = 2 * kSpanSlots; K <= n_eff; K <<= 1) {
+        active = in_range && (w0 & ~(K - 1)) + (K >> 1) < live;          // (all wavefronts of a block of K slots agree)
         for (int j = K >> 1; j >= kSpanSlots; j >>= 1) {
             // first step of a merge: i <-> i ^ (K-1) (mirror); the rest: i <-> i ^ j; the lower slot keeps the min
             const int mask = (j == (K >> 1)) ? (K - 1) : j;
@@ -508,6 +513,10 @@ __global__ __launch_bounds__(1024) void block_topic_kernel(BlockArgs a) {
     // starts), lag fused in --------------------------------------------------------------------------------
     const int n_eff = pow2ceil_dev(P);
     const int nt_eff = n_eff > E ? n_eff / E : 1;                       // threads holding slots < n_eff
+    // The records go to as FEW wavefronts as hold them (record r * nt_ld + tid in register r of thread tid < nt_ld): a topic of
+    // 10 000 partitions in the 16 384 class fills 10 wavefronts and leaves 6 with sentinels only, and the packed sort skips
+    // every merge whose upper half is all sentinels -- those 6 idle through 91 of the 105 steps and the 10 share the SIMDs.
+    const int nt_ld = min(nt_eff, ((P + E - 1) / E + kWave - 1) & ~(kWave - 1));
     int64_t lag[E];
     int32_t pid[E];
     uint64_t lag_or = 0;
@@ -525,8 +534,8 @@ __global__ __launch_bounds__(1024) void block_topic_kernel(BlockArgs a) {
         bool valid[E];
 #pragma unroll
         for (int r = 0; r < E; ++r) {
-            const int src = r * nt_eff + tid;
-            valid[r] = tid < nt_eff && src < P;
+            const int src = r * nt_ld + tid;
+            valid[r] = tid < nt_ld && src < P;
             g[r] = p0 + (valid[r] ? src : 0);
         }
         int32_t idv[E];
@@ -595,10 +604,10 @@ __global__ __launch_bounds__(1024) void block_topic_kernel(BlockArgs a) {
         P64 rec[E];
 #pragma unroll
         for (int r = 0; r < E; ++r) {
-            const bool valid = tid < nt_eff && r * nt_eff + tid < P;
+            const bool valid = tid < nt_ld && r * nt_ld + tid < P;
             rec[r] = p64_from(valid ? (((lag_max - (uint64_t)lag[r]) << sh) | (uint32_t)pid[r]) : ~0ull);
         }
-        block_sort_packed<E>(rec, n_eff, tid, nt, x_key);
+        block_sort_packed<E>(rec, n_eff, nt_ld * E, tid, nt, x_key);
         LA_BCLK(2);
 #pragma unroll
         for (int r = 0; r < E; ++r) {
@@ -615,7 +624,7 @@ __global__ __launch_bounds__(1024) void block_topic_kernel(BlockArgs a) {
         Rec rec[E];
 #pragma unroll
         for (int r = 0; r < E; ++r) {
-            const bool valid = tid < nt_eff && r * nt_eff + tid < P;
+            const bool valid = tid < nt_ld && r * nt_ld + tid < P;
             const uint64_t key = (uint64_t)lag[r] ^ kLagKeyFlip;
             rec[r].hi = valid ? (uint32_t)(key >> 32) : 0xFFFFFFFFu;
             rec[r].lo = valid ? (uint32_t)key : 0xFFFFFFFFu;

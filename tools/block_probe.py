@@ -49,7 +49,10 @@ def run(t, p, c, algo=N.LA_ALGO_AUTO, reps=5, lag_bits=34, offsets=False):
 
 if hasattr(ctx._lib, "la_debug_block_clocks"):          # development build (-DLA_BLOCK_CLOCKS): stage times of workgroup 0
     names = ["loads", "decide", "sort", "slots + out_partition", "greedy rounds", "member ranks out", "-", "-"]
-    for (t, p, c) in [(200, 8000, 16), (200, 8000, 64), (200, 8000, 4), (1000, 2000, 16)]:
+    shapes = [(200, 8000, 16), (200, 8000, 64), (200, 8000, 4), (1000, 2000, 16)]
+    if len(sys.argv) > 1:                               # python tools/block_probe.py T,P,C [T,P,C ..]
+        shapes = [tuple(int(x) for x in a.split(",")) for a in sys.argv[1:]]
+    for (t, p, c) in shapes:
         clk = (ctypes.c_ulonglong * 8)()
         run(t, p, c, reps=1)
         ctx._lib.la_debug_block_clocks(clk, 1)
@@ -59,11 +62,16 @@ if hasattr(ctx._lib, "la_debug_block_clocks"):          # development build (-DL
               ", ".join("%s %.1f" % (n, v / 10 / 100.0) for n, v in zip(names, clk) if n != "-"))
     sys.exit(0)
 
-for (t, p, c) in [(1000, 2000, 100), (5000, 200, 100), (200, 8000, 16), (2000, 1000, 500), (64, 8192, 2048),
-                  (1, 2000, 100), (1, 8192, 2048), (20000, 100, 65), (300, 5000, 3), (1, 100, 65), (1, 1025, 8), (20000, 300, 10)]:
+shapes = [(1000, 2000, 100), (5000, 200, 100), (200, 8000, 16), (2000, 1000, 500), (64, 8192, 2048),
+          (1, 2000, 100), (1, 8192, 2048), (20000, 100, 65), (300, 5000, 3), (1, 100, 65), (1, 1025, 8), (20000, 300, 10)]
+if len(sys.argv) > 1:                                   # python tools/block_probe.py T,P,C [T,P,C ..]
+    shapes = [tuple(int(x) for x in a.split(",")) for a in sys.argv[1:]]
+for (t, p, c) in shapes:
     ms = run(t, p, c) * 1e3
     ms_off = run(t, p, c, offsets=True) * 1e3
     print("T=%6d P=%5d C=%5d : %8.3f ms  %.3e assignments/s; from offsets %8.3f ms" % (t, p, c, ms, t * p / ms * 1e3, ms_off), flush=True)
+if len(sys.argv) > 1:
+    sys.exit(0)
 print("-- P=8000 sweep over C")
 for c in (2000, 300, 100, 64, 16, 4):
     ms = run(200, 8000, c) * 1e3
