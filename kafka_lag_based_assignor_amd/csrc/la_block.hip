@@ -408,6 +408,7 @@ __device__ __forceinline__ void greedy_multi_wave_packed(const BlockArgs& a, con
     constexpr bool kVo = true;                                           // the steps' VALU form (few wavefronts per SIMD)
     const int ntu = n_c / EC;                                            // threads that hold bins (multiple of 64)
     const bool active = tid < ntu;                                       // wavefront-uniform
+    if (!active) return;                                                 // (s_barrier counts the wavefronts that are left)
     const uint32_t idx_mask = (1u << idx_bits) - 1;
     P64 bin[EC];
     uint64_t lag[EC];
@@ -676,14 +677,23 @@ __global__ __launch_bounds__(1024) void block_topic_kernel(BlockArgs a) {
     // Slots 2*idx and 2*idx+1 are updated by the thread that owns pair idx in the network's in-span steps,
     // so the update and the next round's sort are separated by a wavefront fence only.
     if (n_c <= 4 * kWave) {
+        // packed bins when nothing can overflow: the keys are sorted, the first carries the largest lag and
+        // the last the smallest
+        const int64_t lmax = P > 0 ? (int64_t)(s_key[0] ^ kLagKeyFlip) : 0;
+        const int64_t lmin = P > 0 ? (int64_t)(s_key[P - 1] ^ kLagKeyFlip) : 0;
+        const int lag_bits = lmax > 0 ? 64 - __builtin_clzll((unsigned long long)lmax) : 0;
+        const int round_bits = 32 - __builtin_clz((unsigned)((P + C - 1) / C) | 1u);
+        const bool packed = lmin >= 0 && lag_bits + round_bits + idx_bits <= 62;
+        if (packed && n_c > kWave && n_c <= nt && (n_c > 2 * kWave || gridDim.x <= 512)) {
+            // 128 / 256 bins: one per lane on 2 / 4 wavefronts (an exchange through LDS per merge level) instead of 2 / 4 per
+            // lane on one; the other wavefronts leave (greedy_multi_wave_packed), so a round's barriers are among those 2 / 4.
+            // 1 x 8 000 x 256: 0.121 -> 0.101 ms, 1 x 16 000 x 200: 0.268 -> 0.218, 2 000 x 1 000 x 200: 0.086 -> 0.078; with
+            // 128 bins the gain is small (1 x 10 000 x 128: 0.167 -> 0.160) and a launch that fills the CUs loses 4 %, so
+            // there only up to 512 topics.
+            greedy_multi_wave_packed<1>(a, s_key, s_rank, s_tot, p0, c0, P, C, n_c, idx_bits, tid);
+            return;
+        }
         if (tid < kWave) {
-            // packed bins when nothing can overflow: the keys are sorted, the first carries the largest lag and
-            // the last the smallest
-            const int64_t lmax = P > 0 ? (int64_t)(s_key[0] ^ kLagKeyFlip) : 0;
-            const int64_t lmin = P > 0 ? (int64_t)(s_key[P - 1] ^ kLagKeyFlip) : 0;
-            const int lag_bits = lmax > 0 ? 64 - __builtin_clzll((unsigned long long)lmax) : 0;
-            const int round_bits = 32 - __builtin_clz((unsigned)((P + C - 1) / C) | 1u);
-            const bool packed = lmin >= 0 && lag_bits + round_bits + idx_bits <= 62;
 #define LA_ONE_WAVE(EC, L)                                                                              \
     if (packed) greedy_one_wave_packed<EC, L>(a, s_key, s_rank, p0, c0, P, C, idx_bits, tid);           \
     else greedy_one_wave<EC, L>(a, s_key, s_rank, p0, c0, P, C, tid)

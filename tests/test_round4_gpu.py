@@ -280,6 +280,21 @@ def test_calls_leave_the_current_device_alone(ctx, torch_dev):
 from oracle.round_form import round_form  # noqa: E402
 
 
+@pytest.mark.parametrize("topics,p,c", [
+    (1, 513, 3), (3, 2049, 70), (2, 4097, 200), (1, 8193, 128), (2, 10000, 128), (1, 12289, 256), (40, 700, 128), (40, 1500, 256),
+    (600, 300, 128), (600, 300, 200), (5, 9000, 65), (3, 5000, 129),
+])
+def test_block_sort_skips_sentinel_halves_and_small_multi_wave_greedy(ctx, topics, p, c):
+    """Round 4, block path: (i) the records of a topic go to as few wavefronts as hold them and the packed sort skips every
+    merge whose upper half is all sentinels -- partition counts just above a class border (513, 2 049, 4 097, 8 193) and in
+    the middle of one; (ii) 65 .. 256 consumers with packed bins: one bin per lane on 2 / 4 wavefronts, the others leave the
+    workgroup (128 bins only in launches of up to 512 topics: 600 topics take the one-wavefront form).  Mixed lag kinds (the
+    "full" topics do not pack: they take the 96-bit forms of both steps), against the oracle."""
+    w = _batch_of([(p + (i % 3), c - (i % 2)) for i in range(topics)], 1000 * topics + p + c)
+    exp = oracle.assign_flat(w.part_off, w.partition_id, w.lag, w.cons_off, w.cons_rank)
+    _same3(_device_call(ctx, w), exp)
+
+
 def _batch_of(shapes, seed, kinds=None, negative=False):
     """A batch of topics with the given (partitions, consumers) shapes; lags per `kinds` (default: mixed)."""
     rng = np.random.default_rng(seed)
