@@ -691,6 +691,7 @@ __global__ __launch_bounds__(1024) void block_topic_kernel(BlockArgs a) {
             // 128 bins the gain is small (1 x 10 000 x 128: 0.167 -> 0.160) and a launch that fills the CUs loses 4 %, so
             // there only up to 512 topics.
             greedy_multi_wave_packed<1>(a, s_key, s_rank, s_tot, p0, c0, P, C, n_c, idx_bits, tid);
+            LA_BCLK(4);
             return;
         }
         if (tid < kWave) {
