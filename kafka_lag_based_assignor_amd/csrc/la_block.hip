@@ -207,6 +207,81 @@ __device__ __forceinline__ void block_sort_packed(P64 (&rec)[E], int n_eff, int 
     }
 }
 
+// ---- the packed records once more, by digits: an LSD radix sort inside the workgroup -------------------------------------
+// The network above costs 8 (16) records x ~5 VALU x 91 (105) steps per thread whatever the keys are; the records of a topic
+// have lbw + sh significant bits -- 47 for 34-bit lags and 8 191 ids -- i.e. six 8-bit digits.  Per digit, with the records in
+// registers: every wavefront counts its digits in its own 256 counters with RETURNING LDS atomics, whose old values are the
+// record's rank among the wavefront's equal digits (lanes of one instruction are served in lane order: the property
+// la_create tests, LA_FEATURE_ATOMIC_RANK; a wavefront issues its E instructions in order) -> a barrier -> thread d turns the
+// counters of digit d into the wavefronts' first places inside the digit and leaves the digit's total -> a barrier -> one
+// wavefront scans the 256 totals -> a barrier -> every record goes to (digit's first place + its wavefront's + its rank) in
+// region A -> a barrier -> the wavefronts read the result back blocked by wavefront, register-major (consecutive lanes,
+// consecutive words; the order the next digit's ranks are taken in).  The last digit's records stay in region A, by position:
+// the caller reads record i and writes the key of position i into the same word.
+// Only the wavefronts below `live` slots take part (the others hold sentinels: they would sort behind everything); the
+// sentinels inside them (all ones) have digit 255 in every pass.  hist: [live / (64 E)][256] counters (the bins' area, unused
+// until the sort is done), aux: [2][256].
+template <int E>
+__device__ __forceinline__ void block_sort_radix(P64 (&rec)[E], int live, int bits, int tid, int nt, uint64_t* buf,
+                                                 uint32_t* hist, uint32_t* aux) {
+    constexpr int kSpanSlots = kWave * E;
+    const int lane = tid & (kWave - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int nw = (live + kSpanSlots - 1) / kSpanSlots;                 // wavefronts that hold records (a small topic: part of one)
+    const bool act = wave < nw;                                          // wavefront-uniform
+    uint32_t* mine = hist + wave * 256;
+    uint32_t* total = aux;                                               // [256] records per digit, then first place of the digit
+    if (act) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) mine[k * kWave + lane] = 0;
+    }
+    wave_lds_fence();
+    for (int shift = 0; shift < bits; shift += 8) {
+        uint32_t old[E];
+        if (act) {
+#pragma unroll
+            for (int r = 0; r < E; ++r) {
+                const uint32_t d = (uint32_t)(p64_value(rec[r]) >> shift) & 255u;
+                old[r] = atomicAdd(&mine[d], 1u);
+            }
+        }
+        __syncthreads();
+        for (int d = tid; d < 256; d += nt) {                            // digit d: first places of the wavefronts inside it
+            uint32_t run = 0;
+            for (int w = 0; w < nw; ++w) {
+                const uint32_t c = hist[w * 256 + d];
+                hist[w * 256 + d] = run;
+                run += c;
+            }
+            total[d] = run;
+        }
+        __syncthreads();
+        if (wave == 0) {                                                 // exclusive scan of the 256 totals, four per lane
+            const uint4 t = reinterpret_cast<const uint4*>(total)[lane];
+            const uint32_t s = t.x + t.y + t.z + t.w;
+            const uint32_t excl = wave_incl_scan_u32(s) - s;
+            __builtin_amdgcn_wave_barrier();
+            reinterpret_cast<uint4*>(total)[lane] = make_uint4(excl, excl + t.x, excl + t.x + t.y, excl + t.x + t.y + t.z);
+        }
+        __syncthreads();
+        if (act) {
+#pragma unroll
+            for (int r = 0; r < E; ++r) {
+                const uint32_t d = (uint32_t)(p64_value(rec[r]) >> shift) & 255u;
+                buf[total[d] + mine[d] + old[r]] = p64_value(rec[r]);
+            }
+        }
+        __syncthreads();
+        if (act && shift + 8 < bits) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) mine[k * kWave + lane] = 0;       // (read above, before the barrier)
+#pragma unroll
+            for (int r = 0; r < E; ++r) rec[r] = p64_from(buf[wave * kSpanSlots + r * kWave + lane]);
+            // (the next scatter into buf comes three barriers later)
+        }
+    }
+}
+
 // Greedy rounds for up to 256 consumers: one wavefront, bins in registers (EC per lane, slot = lane*EC + r),
 // sorted by the DPP / permlane networks of la_device.h -- no LDS traffic and no barrier between rounds.
 // Slots >= C hold an all-ones sentinel (a real bin's index is < C, so it never equals it).  L = lanes in use
@@ -608,6 +683,23 @@ __global__ __launch_bounds__(1024) void block_topic_kernel(BlockArgs a) {
             const bool valid = tid < nt_ld && r * nt_ld + tid < P;
             rec[r] = p64_from(valid ? (((lag_max - (uint64_t)lag[r]) << sh) | (uint32_t)pid[r]) : ~0ull);
         }
+        if (a.radix_sort && lbw + sh > 0) {
+            uint32_t* aux = reinterpret_cast<uint32_t*>(s_rank + a.nc_cap) + 4;          // [512] behind the OR words
+            block_sort_radix<E>(rec, nt_ld * E, lbw + sh, tid, nt, x_key, reinterpret_cast<uint32_t*>(s_tot), aux);
+            LA_BCLK(2);
+            // the sorted records lie in region A by position: record i becomes the key of position i, in place
+#pragma unroll
+            for (int r = 0; r < E; ++r) {
+                const int i = r * nt + tid;
+                if (i < P) {
+                    const uint64_t v = x_key[i];
+                    const uint64_t lv = lag_max - (v >> sh);
+                    s_key[i] = slots ? (lv << idx_bits) : (lv ^ kLagKeyFlip);
+                    a.out_pid[p0 + i] = (int32_t)((uint32_t)v & id_mask);
+                    if (C == 0) a.out_rank[p0 + i] = -1;                // Main.java:211-214: nobody to assign to
+                }
+            }
+        } else {
         block_sort_packed<E>(rec, n_eff, nt_ld * E, tid, nt, x_key);
         LA_BCLK(2);
 #pragma unroll
@@ -620,6 +712,7 @@ __global__ __launch_bounds__(1024) void block_topic_kernel(BlockArgs a) {
                 a.out_pid[p0 + i] = (int32_t)((uint32_t)v & id_mask);
                 if (C == 0) a.out_rank[p0 + i] = -1;                    // Main.java:211-214: nobody to assign to
             }
+        }
         }
     } else {
         Rec rec[E];
@@ -789,7 +882,14 @@ hipError_t block_launch(BlockArgs a, int cls, hipStream_t stream) {
     a.np_cap = nt * e;
     a.nc_cap = kNc[cls];
     const size_t region_a = (size_t)(e * 8 > kXchg * 12 ? e * 8 : kXchg * 12) * nt + kZeroSlotBytes;
-    const size_t lds = region_a + (size_t)16 * a.nc_cap + 16;
+    const size_t lds = region_a + (size_t)16 * a.nc_cap + 16 + 2048;     // + [2][256] words of the radix sort behind the OR words
+    // which classes sort by digits (LA_BLOCK_RADIX: 0 never -- the network, the form of rounds 1-3 --, 1 the three largest
+    // classes, 2 all of them: the default; needs the atomic ranks).  Same box, ms per call, network / digits:
+    // 1 x 10 000 x 128 0.164 / 0.126, 1 x 16 000 x 200 0.226 / 0.177, 200 x 8 000 x 16 0.147 / 0.124, 64 x 8 192 x 2 048
+    // 0.098 / 0.075, 1 000 x 2 000 x 100 0.089 / 0.072, 5 000 x 200 x 100 0.072 / 0.060, 20 000 x 100 x 65 0.170 / 0.134,
+    // 20 000 x 300 x 10 0.109 / 0.109 (profiles/r04_block_radix.txt)
+    static const int radix_mode = [] { const char* e = getenv("LA_BLOCK_RADIX"); return e ? atoi(e) : 2; }();
+    a.radix_sort = (large_atomic_rank_supported() && (radix_mode >= 2 || (radix_mode == 1 && cls >= 2))) ? 1 : 0;
     static PerDeviceOnce lds_opt_in;
     hipError_t err = lds_opt_in.run([] {
         hipError_t e2 = hipFuncSetAttribute((const void*)block_topic_kernel<8>,

@@ -129,6 +129,8 @@ struct BlockArgs {
     uint32_t* status;
     int32_t reset_latest;
     int32_t np_cap, nc_cap;     // LDS capacity in records / bins, set by the launcher
+    int32_t radix_sort;         // set by the launcher: records that pack into one word are sorted by the workgroup's LSD radix
+                                // sort (block_sort_radix) -- needs ranks from returning LDS atomics (large_atomic_rank_supported)
 };
 
 inline bool block_fits(int64_t p, int64_t c) {

@@ -1013,17 +1013,6 @@ __device__ __forceinline__ SampleLds sample_lds_carve(void* smem, int n) {
     return L;
 }
 
-// inclusive scan over the wavefront through DPP (row shifts, then the row broadcasts of GFX9)
-__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v) {
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, false);   // row_shr:1
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, false);   // row_shr:2
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, false);   // row_shr:4
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, false);   // row_shr:8
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false);   // row_bcast:15 -> rows 1, 3
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false);   // row_bcast:31 -> rows 2, 3
-    return v;
-}
-
 // max over the wavefront, in every lane, without the LDS pipe (DPP + v_permlane*_swap butterflies)
 __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
     v = max(v, shfl_xor<1>(v));

@@ -295,6 +295,35 @@ def test_block_sort_skips_sentinel_halves_and_small_multi_wave_greedy(ctx, topic
     _same3(_device_call(ctx, w), exp)
 
 
+def test_block_sort_forms_in_fresh_processes():
+    """The block path sorts packed records by digits inside the workgroup (block_sort_radix: ranks from returning LDS
+    atomics) and with the bitonic network where the device lacks LA_FEATURE_ATOMIC_RANK or LA_BLOCK_RADIX says so; the
+    choice is made once per process.  Every form, the same topics (all five size classes, partition counts at and between
+    the class borders, packed and 96-bit records), the oracle's result."""
+    import subprocess
+    import sys
+    code = r"""
+import numpy as np, sys
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+from kafka_lag_based_assignor_amd import _native as N
+from oracle import oracle
+import test_round4_gpu as t
+ctx = N.Context(0)
+for topics, p, c in ((3, 100, 65), (2, 512, 3), (2, 513, 70), (2, 2048, 256), (1, 2049, 300), (2, 4096, 1000), (1, 4097, 17),
+                     (1, 8192, 2048), (1, 8193, 5), (1, 10000, 128), (1, 16384, 1024), (300, 130, 70), (7, 1, 65)):
+    w = t._batch_of([(p - (i %% 2), c) for i in range(topics)], 77 * topics + p + c)
+    exp = oracle.assign_flat(w.part_off, w.partition_id, w.lag, w.cons_off, w.cons_rank)
+    t._same3(t._device_call(ctx, w), exp, what=str((topics, p, c)))
+print("ok")
+"""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for mode in ("0", "1", "2"):
+        env = dict(os.environ, LA_BLOCK_RADIX=mode)
+        out = subprocess.run([sys.executable, "-c", code % (root, os.path.join(root, "tests"))], env=env, capture_output=True,
+                             text=True, timeout=900)
+        assert out.returncode == 0 and "ok" in out.stdout, (mode, out.stdout[-1500:], out.stderr[-1500:])
+
+
 def _batch_of(shapes, seed, kinds=None, negative=False):
     """A batch of topics with the given (partitions, consumers) shapes; lags per `kinds` (default: mixed)."""
     rng = np.random.default_rng(seed)
