@@ -515,7 +515,7 @@ __device__ __forceinline__ void greedy_multi_wave_packed(const BlockArgs& a, con
 #pragma unroll
                         for (int r = 0; r < EC; ++r) x[r * ntu + tid] = p64_value(bin[r]);
                     }
-                    __syncthreads();
+                    lds_barrier();        // (LDS traffic only: the round's global stores stay in flight, la_device.h)
                     if (active) {
 #pragma unroll
                         for (int r = 0; r < EC; ++r) {
@@ -527,7 +527,7 @@ __device__ __forceinline__ void greedy_multi_wave_packed(const BlockArgs& a, con
                             bin[r] = p64_from(keep_min ? lo : hi);
                         }
                     }
-                    __syncthreads();
+                    lds_barrier();        // (LDS traffic only: the round's global stores stay in flight, la_device.h)
                 }
                 if (active) {
 #pragma unroll
