@@ -683,16 +683,31 @@ __global__ __launch_bounds__(1024) void block_topic_kernel(BlockArgs a) {
             const bool valid = tid < nt_ld && r * nt_ld + tid < P;
             rec[r] = p64_from(valid ? (((lag_max - (uint64_t)lag[r]) << sh) | (uint32_t)pid[r]) : ~0ull);
         }
-        if (a.radix_sort && lbw + sh > 0) {
+        // (below ~700 partitions the network's few steps are cheaper than six digits of four barriers each: 10 000 x 200 x 100
+        //  0.105 ms against 0.150, 5 000 x 512 x 100 and 4 000 x 700 x 100 even, 3 000 x 1 000 x 100 0.104 against 0.095)
+        if (a.radix_sort && lbw + sh > 0 && (a.radix_sort >= 2 || P >= 768)) {
             uint32_t* aux = reinterpret_cast<uint32_t*>(s_rank + a.nc_cap) + 4;          // [512] behind the OR words
             block_sort_radix<E>(rec, nt_ld * E, lbw + sh, tid, nt, x_key, reinterpret_cast<uint32_t*>(s_tot), aux);
             LA_BCLK(2);
-            // the sorted records lie in region A by position: record i becomes the key of position i, in place
+            // the sorted records lie in region A by position: record i becomes the key of position i, in place.  On the way
+            // every record is compared with the one before it: the ranks of the sort rest on a property of the LDS atomics
+            // that the device was tested for once (la_create), so an order that is not one is an error of the call
+            // (kStatusOrder -> LA_EHIP), never a silently different assignment -- what emit_ids_kernel does for the large path.
+            uint64_t sorted[E];
+            bool bad = false;
+#pragma unroll
+            for (int r = 0; r < E; ++r) {
+                const int i = r * nt + tid;
+                sorted[r] = x_key[i < P ? i : 0];
+                bad |= i > 0 && i < P && x_key[i < P ? i - 1 : 0] > sorted[r];
+            }
+            __syncthreads();                                            // every record is in a register: the keys go over them
+            if (__builtin_amdgcn_ballot_w64(bad) != 0 && (tid & (kWave - 1)) == 0) atomicOr(a.status, kStatusOrder);
 #pragma unroll
             for (int r = 0; r < E; ++r) {
                 const int i = r * nt + tid;
                 if (i < P) {
-                    const uint64_t v = x_key[i];
+                    const uint64_t v = sorted[r];
                     const uint64_t lv = lag_max - (v >> sh);
                     s_key[i] = slots ? (lv << idx_bits) : (lv ^ kLagKeyFlip);
                     a.out_pid[p0 + i] = (int32_t)((uint32_t)v & id_mask);
@@ -883,13 +898,14 @@ hipError_t block_launch(BlockArgs a, int cls, hipStream_t stream) {
     a.nc_cap = kNc[cls];
     const size_t region_a = (size_t)(e * 8 > kXchg * 12 ? e * 8 : kXchg * 12) * nt + kZeroSlotBytes;
     const size_t lds = region_a + (size_t)16 * a.nc_cap + 16 + 2048;     // + [2][256] words of the radix sort behind the OR words
-    // which classes sort by digits (LA_BLOCK_RADIX: 0 never -- the network, the form of rounds 1-3 --, 1 the three largest
-    // classes, 2 all of them: the default; needs the atomic ranks).  Same box, ms per call, network / digits:
-    // 1 x 10 000 x 128 0.164 / 0.126, 1 x 16 000 x 200 0.226 / 0.177, 200 x 8 000 x 16 0.147 / 0.124, 64 x 8 192 x 2 048
-    // 0.098 / 0.075, 1 000 x 2 000 x 100 0.089 / 0.072, 5 000 x 200 x 100 0.072 / 0.060, 20 000 x 100 x 65 0.170 / 0.134,
-    // 20 000 x 300 x 10 0.109 / 0.109 (profiles/r04_block_radix.txt)
+    // which topics sort by digits (LA_BLOCK_RADIX: 0 never -- the network, the form of rounds 1-3 --, 1 only the three largest
+    // classes, 2 every class: the default; topics of fewer than 768 partitions keep the network; needs the atomic ranks).
+    // Same box, ms per call, network / digits: 1 x 10 000 x 128 0.164 / 0.126, 1 x 16 000 x 200 0.226 / 0.177, 200 x 8 000 x 16
+    // 0.147 / 0.124, 64 x 8 192 x 2 048 0.098 / 0.075, 1 000 x 2 000 x 100 0.089 / 0.072, 1 000 x 4 000 x 100 0.190 / 0.153
+    // (profiles/r04_block_radix.txt)
+    // (3: every topic whatever its size -- the test hook that drives small topics through the digits)
     static const int radix_mode = [] { const char* e = getenv("LA_BLOCK_RADIX"); return e ? atoi(e) : 2; }();
-    a.radix_sort = (large_atomic_rank_supported() && (radix_mode >= 2 || (radix_mode == 1 && cls >= 2))) ? 1 : 0;
+    a.radix_sort = (large_atomic_rank_supported() && (radix_mode >= 2 || (radix_mode == 1 && cls >= 2))) ? (radix_mode >= 3 ? 2 : 1) : 0;
     static PerDeviceOnce lds_opt_in;
     hipError_t err = lds_opt_in.run([] {
         hipError_t e2 = hipFuncSetAttribute((const void*)block_topic_kernel<8>,

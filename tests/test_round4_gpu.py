@@ -317,7 +317,7 @@ for topics, p, c in ((3, 100, 65), (2, 512, 3), (2, 513, 70), (2, 2048, 256), (1
 print("ok")
 """
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    for mode in ("0", "1", "2"):
+    for mode in ("0", "1", "2", "3"):                              # 3: topics below the size threshold too
         env = dict(os.environ, LA_BLOCK_RADIX=mode)
         out = subprocess.run([sys.executable, "-c", code % (root, os.path.join(root, "tests"))], env=env, capture_output=True,
                              text=True, timeout=900)
