@@ -242,7 +242,22 @@ __device__ __forceinline__ void block_sort_radix(P64 (&rec)[E], int live, int bi
 #pragma unroll
             for (int r = 0; r < E; ++r) {
                 const uint32_t d = (uint32_t)(p64_value(rec[r]) >> shift) & 255u;
-                old[r] = atomicAdd(&mine[d], 1u);
+                // the lanes that share lane 0's digit take their ranks from ONE atomic (skewed lags: the high digits of nearly
+                // every record are equal, and 64 lanes on one counter are 64 turns); the others as before, after it
+                const uint32_t d0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)d);
+                const uint64_t grp = __builtin_amdgcn_ballot_w64(d == d0);
+                const int cnt = __builtin_popcountll(grp);
+                if (cnt >= 8) {                                              // (wavefront-uniform)
+                    uint32_t base = 0;
+                    if (lane == 0) base = atomicAdd(&mine[d0], (uint32_t)cnt);
+                    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+                    const uint32_t before = (uint32_t)__builtin_popcountll(grp & ((1ull << lane) - 1ull));
+                    uint32_t o = base + before;
+                    if (d != d0) o = atomicAdd(&mine[d], 1u);
+                    old[r] = o;
+                } else {
+                    old[r] = atomicAdd(&mine[d], 1u);
+                }
             }
         }
         __syncthreads();
