@@ -28,6 +28,21 @@ int main(void) {
     const int64_t cons_off[2] = {0, 2};
     const int32_t cons_rank[2] = {0, 1};                        /* "C0" < "C1" under String.compareTo */
 
+    /* what the marshalling loop knows for free (ABI 0.4.0): no lag exceeds the largest end offset (no offset here is negative)
+     * and no partition id exceeds 2.  One-shot: it applies to the next assign call.  Optional -- a call without it is the same
+     * call, with one more (empty) kernel launch per chunk of a large batch. */
+    if (la_version() >= 400) {
+        la_call_hints hints;
+        hints.struct_size = (int32_t)sizeof hints;
+        hints.flags = LA_HINT_BOUNDS;
+        hints.max_lag = 100000;
+        hints.max_partition_id = 2;
+        rc = la_hint_next_call(ctx, &hints);
+        if (rc != LA_OK) {
+            fprintf(stderr, "la_hint_next_call: %d %s\n", rc, la_last_error(ctx));
+            return 1;
+        }
+    }
     /* results stay on the device; every member's list comes back grouped */
     int64_t total[2];
     rc = la_assign_batch(ctx, 1, part_off, partition_id, begin_off, end_off, committed_off, LA_RESET_EARLIEST,

@@ -27,8 +27,10 @@
  *                           assignment on every GPU, one RCCL all-gather over xGMI
  *   la_pack_results_on, la_unpack_results_on, la_allgather_packed, la_wire_format_for
  *                           the same gather in 2 (or 4) bytes per assigned partition instead of 8
+ *   la_hint_next_call       nothing in the reference's arithmetic: what the marshalling loop of readTopicPartitionLags
+ *                           (Main.java:344-356) knows for free -- the largest end offset and partition id it walked past
  *   la_last_phase_times     nothing: measurement hook (radix-sort phase against the HBM roofline)
- *   la_device_features, la_last_pipeline   nothing: diagnostics (what the library found / did)
+ *   la_device_features, la_last_pipeline, la_last_launches   nothing: diagnostics (what the library found / did)
  *
  * Data model (SoA; TopicPartitionLag, Main.java:431-455, flattened):
  *   topic t owns partitions [part_off[t], part_off[t+1]) of the per-partition arrays and
@@ -215,8 +217,10 @@ const char *la_last_error(const la_ctx *ctx);
  *   0.2.1 (201)  rounds 2-3: multi-device contexts, grouped calls, *_on device entry points, la_allgather_results
  *   0.3.0 (300)  round 4: la_wire_format_for / la_pack_results_on / la_unpack_results_on / la_allgather_packed (narrow wire
  *                format of the all-gather), la_assign_batch_sparse / la_assign_batch_grouped_sparse (begin offsets only
- *                where there is no committed offset); every entry point restores the caller's current HIP device */
-#define LA_VERSION 300
+ *                where there is no committed offset); every entry point restores the caller's current HIP device
+ *   0.4.0 (400)  round 5: la_hint_next_call (the caller's bounds on lags and ids reach the host-buffer calls: one tile launch
+ *                instead of two), la_last_launches, la_last_phase_times_sized */
+#define LA_VERSION 400
 int la_version(void);
 
 /* computePartitionLag over n partitions (host buffers).  begin_off may be NULL when
@@ -227,6 +231,32 @@ int la_compute_lag(la_ctx *ctx, int64_t n,
                    const int64_t *begin_off, const int64_t *end_off,
                    const int64_t *committed_off, int32_t reset_mode,
                    int64_t *out_lag);
+
+/* What the caller's marshalling loop knows about the NEXT host-buffer assign call on this context (la_assign_batch, _sparse,
+ * _lags, _grouped, _grouped_sparse) -- the reference's loop (Main.java:344-356) walks every partition's offsets anyway, so the
+ * largest end offset and the largest partition id cost it two compares per partition.  One-shot: the hints apply to the next
+ * such call and are forgotten when it returns, whatever it returns (a call without la_hint_next_call before it has none).
+ *   LA_HINT_BOUNDS  the caller guarantees 0 <= lag <= max_lag for every lag the call computes (the largest end offset will do
+ *                   when no begin / end / committed offset of the batch is negative, which Kafka guarantees: a lag never
+ *                   exceeds its end offset) and 0 <= partition id <= max_partition_id.  The library hands them to its kernels
+ *                   as LA_FLAG_BOUNDS (below): where they prove that every tile's records pack into 64 bits, the tile path
+ *                   is ONE launch per chunk instead of two.  A partition that violates the bounds makes the call fail with
+ *                   LA_EINVAL -- never a silently different result; a caller that is not sure gives no hint.
+ * struct_size = sizeof(la_call_hints) of the caller's header (the struct may grow).  hints == NULL clears pending hints. */
+#define LA_HINT_BOUNDS 1
+typedef struct la_call_hints {
+    int32_t struct_size;
+    int32_t flags;               /* LA_HINT_* */
+    int64_t max_lag;             /* LA_HINT_BOUNDS */
+    int64_t max_partition_id;    /* LA_HINT_BOUNDS */
+} la_call_hints;
+int la_hint_next_call(la_ctx *ctx, const la_call_hints *hints);
+
+/* Kernel launches the last host-buffer call (or the last la_assign_batch_device[_on] call) on this context enqueued -- every
+ * kernel of the library counts, copies and memsets do not.  Diagnostics / tests: a batch of tile-sized topics whose hints prove
+ * that every tile packs reports 1 per chunk (+ 1 per chunk for the consumer-rank check of the copying pipelines).  The counter
+ * behind it is process-wide: exact while no other context of the process is inside a call. */
+int64_t la_last_launches(const la_ctx *ctx);
 
 /* One rebalance: lag from offsets, then sort + greedy per topic.  All pointers are
  * caller-owned host memory, valid for the duration of the call.  N = part_off[T],
@@ -350,6 +380,10 @@ typedef struct la_phase_times {
     int32_t redone;        /* 1: a run of equal lags did not fit the repair and the sort was redone in full     */
 } la_phase_times;
 int la_last_phase_times(la_ctx *ctx, la_phase_times *out);
+/* The same for a caller compiled against any version of this header: writes min(out_size, sizeof(la_phase_times)) bytes.
+ * la_last_phase_times writes the whole struct of THIS header (40 bytes since ABI 0.3.0, 32 before): a shim built against 0.2.x
+ * must check la_version() < 300 before it calls that one, or call this one with its own sizeof. */
+int la_last_phase_times_sized(la_ctx *ctx, void *out, size_t out_size);
 
 /* The context's own (non-blocking) hipStream_t, used by the host-buffer entry points. */
 void *la_stream(la_ctx *ctx);

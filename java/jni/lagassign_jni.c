@@ -139,6 +139,27 @@ Java_com_github_grantneale_kafka_gpu_LagAssignNative_assignBatchGroupedSparse(
                                           (int32_t *)ADDR(env, grouped_partition), (int64_t *)ADDR(env, out_total_lag));
 }
 
+/* la_hint_next_call with LA_HINT_BOUNDS: what the marshalling loop saw -- the largest end offset (or lag) and partition id. */
+JNIEXPORT jint JNICALL
+Java_com_github_grantneale_kafka_gpu_LagAssignNative_hintNextCallBounds(JNIEnv *env, jclass cls, jlong ctx, jlong max_lag,
+                                                                       jlong max_partition_id) {
+    la_call_hints h;
+    (void)env;
+    (void)cls;
+    h.struct_size = (int32_t)sizeof h;
+    h.flags = LA_HINT_BOUNDS;
+    h.max_lag = (int64_t)max_lag;
+    h.max_partition_id = (int64_t)max_partition_id;
+    return la_hint_next_call(CTX(ctx), &h);
+}
+
+JNIEXPORT jlong JNICALL
+Java_com_github_grantneale_kafka_gpu_LagAssignNative_lastLaunches(JNIEnv *env, jclass cls, jlong ctx) {
+    (void)env;
+    (void)cls;
+    return (jlong)la_last_launches(CTX(ctx));
+}
+
 JNIEXPORT jint JNICALL
 Java_com_github_grantneale_kafka_gpu_LagAssignNative_version(JNIEnv *env, jclass cls) {
     (void)env;

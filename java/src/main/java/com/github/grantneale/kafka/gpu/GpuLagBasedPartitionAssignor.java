@@ -46,8 +46,9 @@ import org.slf4j.LoggerFactory;
  *      nothing on a device ever needs another device's topics (DESIGN.md section 5);</li>
  *  <li>there is no pure-Java arithmetic path.  On a native failure (no GPU, a HIP error) the assignor throws
  *      IllegalStateException out of assign() -- which propagates out of KafkaConsumer.poll() on the group leader --
- *      unless {@code lag.assignor.fallback.class} names another ConsumerPartitionAssignor (for instance the reference
- *      class itself) to delegate that rebalance to.  See INTEGRATION.md section 3.</li>
+ *      unless a fallback takes that rebalance over: the ConsumerPartitionAssignor {@code lag.assignor.fallback.class}
+ *      names, or -- when the property is unset -- the reference class itself if it is on the class path (looked up by
+ *      name; nothing of it is linked).  See INTEGRATION.md section 3.</li>
  * </ul>
  */
 public class GpuLagBasedPartitionAssignor implements ConsumerPartitionAssignor, Configurable, AutoCloseable {
@@ -56,6 +57,8 @@ public class GpuLagBasedPartitionAssignor implements ConsumerPartitionAssignor, 
 
     /** Consumer property: FQCN of the ConsumerPartitionAssignor that takes over a rebalance the GPU path failed. */
     public static final String FALLBACK_CLASS_CONFIG = "lag.assignor.fallback.class";
+    /** What takes over when {@link #FALLBACK_CLASS_CONFIG} is unset and this class is on the class path: the reference. */
+    public static final String DEFAULT_FALLBACK_CLASS = "com.github.grantneale.kafka.LagBasedPartitionAssignor";
     /** Consumer property: comma-separated HIP device ids (default: every device of the node). */
     public static final String DEVICES_CONFIG = "lag.assignor.devices";
 
@@ -76,6 +79,7 @@ public class GpuLagBasedPartitionAssignor implements ConsumerPartitionAssignor, 
     private Properties sideConsumerProps;
     private KafkaConsumer<byte[], byte[]> sideConsumer;
     private ConsumerPartitionAssignor fallback;
+    private boolean defaultFallbackTried;
     private Map<String, ?> rawConfigs;
     private final Engine engine = new Engine();
 
@@ -196,6 +200,12 @@ public class GpuLagBasedPartitionAssignor implements ConsumerPartitionAssignor, 
         long nNone = 0;
         int cursor = 0;
         int k = 0;
+        // what this loop sees on its way (the reference's own loop walks the same offsets, LagBasedPartitionAssignor.java:
+        // 344-356): the largest end offset and partition id, and whether anything is negative -- la_hint_next_call's bounds
+        long maxEnd = 0;
+        int maxPartition = 0;
+        boolean anyNegative = false;
+        final boolean trace = LOGGER.isTraceEnabled();        // only the trace path reads the dense begin array
         for (int t = 0; t < nTopics; t++) {
             partOff.put(t, cursor);
             consOff.put(t, k);
@@ -203,14 +213,21 @@ public class GpuLagBasedPartitionAssignor implements ConsumerPartitionAssignor, 
                 final TopicPartition tp = all.get(cursor);
                 final OffsetAndMetadata md = committed.get(tp);
                 final long b = begin.getOrDefault(tp, 0L);
+                final long e = end.getOrDefault(tp, 0L);
                 partitionId.put(cursor, tp.partition());
-                beginOff.put(cursor, b);
-                endOff.put(cursor, end.getOrDefault(tp, 0L));
+                if (trace) {
+                    beginOff.put(cursor, b);
+                }
+                endOff.put(cursor, e);
                 committedOff.put(cursor, md == null ? LagAssignNative.NO_COMMITTED : md.offset());
+                maxEnd = Math.max(maxEnd, e);
+                maxPartition = Math.max(maxPartition, tp.partition());
+                anyNegative |= e < 0 || tp.partition() < 0;
                 if (md == null) {
                     noneIndex.put((int) nNone, cursor);
                     noneBegin.put((int) nNone, b);
                     nNone++;
+                    anyNegative |= b < 0;
                 }
             }
             final int[] ranks = plan.topicRanks.get(t);
@@ -224,8 +241,13 @@ public class GpuLagBasedPartitionAssignor implements ConsumerPartitionAssignor, 
         final String resetMode = groupProps.getProperty(ConsumerConfig.AUTO_OFFSET_RESET_CONFIG, "latest");
         final int reset = resetMode.equalsIgnoreCase("latest") ? LagAssignNative.RESET_LATEST
                                                                : LagAssignNative.RESET_EARLIEST;
-        final boolean trace = LOGGER.isTraceEnabled();
         final Map<String, List<TopicPartition>> lists;
+        if (!anyNegative && n > 0 && engine.hasHints) {
+            // with no negative offset a lag never exceeds its end offset: the bounds prove, for the usual offsets and ids, that
+            // every tile's records pack into 64 bits, and the tile path is one launch per chunk instead of two.  (A refused hint
+            // is no hint; a violated one would fail the call with LA_EINVAL -- it cannot be: the loop above saw every value.)
+            LagAssignNative.hintNextCallBounds(engine.ctx, maxEnd, maxPartition);
+        }
         if (trace) {
             // the trace lines need the ungrouped arrays as well: two native calls
             engine.check(LagAssignNative.assignBatch(engine.ctx, nTopics, engine.partOff.bytes, engine.partitionId.bytes,
@@ -475,6 +497,8 @@ public class GpuLagBasedPartitionAssignor implements ConsumerPartitionAssignor, 
         final Buf groupedTopic = new Buf();
         final Buf groupedPartition = new Buf();
 
+        boolean hasHints;
+
         void open() {
             if (ctx == 0) {
                 // the sparse-begin entry point exists since ABI 0.3.0 (include/lagassign.h: LA_VERSION)
@@ -482,6 +506,7 @@ public class GpuLagBasedPartitionAssignor implements ConsumerPartitionAssignor, 
                 if (version < 300) {
                     throw new NativeAssignException("liblagassign ABI " + version + " is older than the 300 this host binds");
                 }
+                hasHints = version >= 400;                       // la_hint_next_call exists since ABI 0.4.0
                 try {
                     ctx = LagAssignNative.createMulti(devices);  // the shim throws IllegalStateException(la_last_error)
                 } catch (IllegalStateException e) {
@@ -656,9 +681,29 @@ public class GpuLagBasedPartitionAssignor implements ConsumerPartitionAssignor, 
 
     private ConsumerPartitionAssignor fallback() {
         if (fallback == null) {
-            final String cls = groupProps == null ? null : groupProps.getProperty(FALLBACK_CLASS_CONFIG);
+            String cls = groupProps == null ? null : groupProps.getProperty(FALLBACK_CLASS_CONFIG);
             if (cls == null || cls.trim().isEmpty()) {
-                return null;
+                // A drop-in must not break a rebalance on a GPU fault (SURVEY 8b, "errors"): with no class configured, the
+                // reference itself takes over when it is on the class path -- found by name, nothing of it is linked here.
+                if (defaultFallbackTried) {
+                    return null;
+                }
+                defaultFallbackTried = true;
+                try {
+                    final Class<?> found =
+                        Class.forName(DEFAULT_FALLBACK_CLASS, false, GpuLagBasedPartitionAssignor.class.getClassLoader());
+                    if (GpuLagBasedPartitionAssignor.class.isAssignableFrom(found)) {
+                        // the test adapter (java/src/adapter) carries the reference's name and IS this host: no way out there
+                        return null;
+                    }
+                } catch (ClassNotFoundException | LinkageError absent) {
+                    LOGGER.info("{} is unset and {} is not on the class path: a native failure will propagate out of assign()",
+                        FALLBACK_CLASS_CONFIG, DEFAULT_FALLBACK_CLASS);
+                    return null;
+                }
+                LOGGER.info("{} is unset: {} (found on the class path) takes over a rebalance the GPU path fails",
+                    FALLBACK_CLASS_CONFIG, DEFAULT_FALLBACK_CLASS);
+                cls = DEFAULT_FALLBACK_CLASS;
             }
             try {
                 final Object o = Class.forName(cls.trim()).getDeclaredConstructor().newInstance();

@@ -85,6 +85,17 @@ final class LagAssignNative {
                                                ByteBuffer consRank, int nMembers, ByteBuffer memberOff,
                                                ByteBuffer groupedTopic, ByteBuffer groupedPartition, ByteBuffer outTotalLag);
 
+    /**
+     * la_hint_next_call(LA_HINT_BOUNDS): what the marshalling loop saw on its way -- every lag of the NEXT assign call on this
+     * context is in [0, maxLag] (the largest end offset will do when no offset is negative) and every partition id in
+     * [0, maxPartitionId].  One-shot.  The tile path then runs ONE launch per chunk instead of two; a partition outside the
+     * bounds fails that call with LA_EINVAL.  Needs la_version() &gt;= 400.
+     */
+    static native int hintNextCallBounds(long ctx, long maxLag, long maxPartitionId);
+
+    /** la_last_launches: kernel launches of the last call on this context (diagnostics). */
+    static native long lastLaunches(long ctx);
+
     /** la_version of the loaded library: major * 10000 + minor * 100 + patch. */
     static native int version();
 

@@ -28,6 +28,7 @@ LA_FLAG_BOUNDS = 1024
 LA_FEATURE_ATOMIC_RANK = 1
 LA_PIPELINE_ONE_COPY, LA_PIPELINE_LANES, LA_PIPELINE_STREAMS, LA_PIPELINE_ZERO_COPY, LA_PIPELINE_MAPPED = 0, 1, 2, 3, 4
 LA_CREATE_LANES_MASK, LA_CREATE_SPLIT_ALWAYS = 0xF, 0x10
+LA_HINT_BOUNDS = 1
 
 EXPORTED_SYMBOLS = (
     "la_create", "la_destroy", "la_last_error", "la_version", "la_compute_lag",
@@ -39,6 +40,7 @@ EXPORTED_SYMBOLS = (
     "la_allgather_results", "la_assign_batch_grouped",
     "la_wire_format_for", "la_pack_results_on", "la_unpack_results_on", "la_allgather_packed",
     "la_assign_batch_sparse", "la_assign_batch_grouped_sparse",
+    "la_hint_next_call", "la_last_launches", "la_last_phase_times_sized",
 )
 
 _i64p = ctypes.POINTER(ctypes.c_int64)
@@ -67,6 +69,12 @@ class DeviceBatch(ctypes.Structure):
         ("h_part_off", _i64p), ("h_cons_off", _i64p),
         ("max_lag_hint", ctypes.c_int64), ("max_partition_id_hint", ctypes.c_int64),
     ]
+
+
+class CallHints(ctypes.Structure):
+    """struct la_call_hints"""
+    _fields_ = [("struct_size", ctypes.c_int32), ("flags", ctypes.c_int32), ("max_lag", ctypes.c_int64),
+                ("max_partition_id", ctypes.c_int64)]
 
 
 class WireFormat(ctypes.Structure):
@@ -194,6 +202,12 @@ def load() -> ctypes.CDLL:
     L.la_group_by_member_device_on.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int32, ctypes.c_int64,
                                                ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int32,
                                                ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+    L.la_hint_next_call.restype = ctypes.c_int
+    L.la_hint_next_call.argtypes = [ctypes.c_void_p, ctypes.POINTER(CallHints)]
+    L.la_last_launches.restype = ctypes.c_int64
+    L.la_last_launches.argtypes = [ctypes.c_void_p]
+    L.la_last_phase_times_sized.restype = ctypes.c_int
+    L.la_last_phase_times_sized.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]
     _lib = L
     return L
 
@@ -240,6 +254,26 @@ def sparse_begin(begin, committed):
     -- what a marshaller that knows `md == null` hands to la_assign_batch_sparse instead of the dense array."""
     idx = np.flatnonzero(np.asarray(committed) < 0).astype(np.int64)
     return idx, np.ascontiguousarray(np.asarray(begin, dtype=np.int64)[idx])
+
+
+def offset_bounds(begin, end, committed, partition_id, lag=None):
+    """What a marshaller that walks every partition knows for free (Main.java:344-356): (largest end offset, largest partition
+    id) -- a lag never exceeds its end offset when no offset of the batch is negative -- or None when an offset or an id IS
+    negative (then there is nothing to promise).  With `lag` (the precomputed-lags seam): (largest lag, largest id)."""
+    pid = np.asarray(partition_id)
+    if pid.size == 0 or int(pid.min()) < 0:
+        return None
+    if lag is not None:
+        lag = np.asarray(lag)
+        return None if int(lag.min()) < 0 else (int(lag.max()), int(pid.max()))
+    end = np.asarray(end)
+    if int(end.min()) < 0:
+        return None
+    if begin is not None:
+        b = np.asarray(begin)
+        if b.size and int(b.min()) < 0:
+            return None
+    return int(end.max()), int(pid.max())
 
 
 def device_count() -> int:
@@ -325,6 +359,19 @@ class Context:
     def _check(self, rc: int) -> None:
         if rc != LA_OK:
             raise LagAssignError(rc, self._lib.la_last_error(self._h).decode())
+
+    def hint_next_call(self, bounds) -> None:
+        """la_hint_next_call: `bounds` = (max_lag, max_partition_id) the caller guarantees for its NEXT host-buffer assign call
+        (offset_bounds() computes them the way a marshaller would), or None = no hint (clears a pending one)."""
+        if bounds is None:
+            self._check(self._lib.la_hint_next_call(self._h, None))
+            return
+        h = CallHints(ctypes.sizeof(CallHints), LA_HINT_BOUNDS, int(bounds[0]), int(bounds[1]))
+        self._check(self._lib.la_hint_next_call(self._h, ctypes.byref(h)))
+
+    def last_launches(self) -> int:
+        """Kernel launches the last call on this context enqueued (la_last_launches)."""
+        return int(self._lib.la_last_launches(self._h))
 
     # -- host-buffer entry points ------------------------------------------------
     def compute_lag(self, begin, end, committed, reset_mode: int) -> np.ndarray:

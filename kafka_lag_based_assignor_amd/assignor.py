@@ -82,6 +82,12 @@ class LagBasedPartitionAssignor:
         """The same for the last assign_lags() on this thread."""
         return bool(_host().LagBasedPartitionAssignor.last_static_order_exact())
 
+    @staticmethod
+    def last_native_call() -> Dict[str, object]:
+        """What the last native assign call on this thread was given and did: `hinted` (the marshalling loop vouched for
+        bounds: la_hint_next_call), `max_lag` / `max_partition_id`, the library's `pipeline` and kernel `launches`."""
+        return dict(_host().LagBasedPartitionAssignor.last_native_call())
+
     def set_warn(self, fn: Callable[[str], None]) -> None:
         self._impl.set_warn(fn)
 

@@ -34,6 +34,7 @@ la_ctx* shared_ctx_locked() {
 // Whether the list order of the last static assign() on this thread is the modelled HashMap's exact order
 // (false: a bucket of consumersPerTopic reached tree-bin size, which java_compat.hpp does not model).
 thread_local bool t_last_order_exact = true;
+thread_local LagBasedPartitionAssignor::NativeCallStats t_last_native;
 
 void check(la_ctx* ctx, int rc) {
     if (rc == LA_OK) return;
@@ -122,7 +123,33 @@ struct Flat {
     // the beginning offset is read only where a partition has no committed offset (Main.java:384-396): it crosses the
     // boundary as (position, begin) pairs for those partitions alone (la_assign_batch_grouped_sparse)
     std::vector<int64_t> none_index, none_begin;
+    // what the marshalling loop sees on its way (Main.java:344-356 walks every partition's offsets): the largest end offset /
+    // lag and partition id, and whether any offset, lag or id is negative -- la_hint_next_call's bounds
+    int64_t max_value = 0, max_id = 0;
+    bool any_negative = false;
+    void see(int64_t value, int32_t id) {
+        if (value > max_value) max_value = value;
+        if (id > max_id) max_id = id;
+        any_negative |= (value < 0) | (id < 0);
+    }
 };
+
+// The bounds of the next call, when the marshaller can vouch for them: with no negative offset a lag never exceeds its end
+// offset (computePartitionLag, Main.java:376-404: end - committed / end - begin / 0, clamped at 0).  One launch per chunk of
+// tile-sized topics instead of two; a caller that saw a negative value promises nothing.
+void hint_bounds(la_ctx* ctx, const Flat& f) {
+    t_last_native = LagBasedPartitionAssignor::NativeCallStats{};
+    if (f.any_negative || f.pid.empty()) return;
+    la_call_hints h{};
+    h.struct_size = (int32_t)sizeof h;
+    h.flags = LA_HINT_BOUNDS;
+    h.max_lag = f.max_value;
+    h.max_partition_id = f.max_id;
+    if (la_hint_next_call(ctx, &h) != LA_OK) return;          // a refused hint is no hint: the call itself decides
+    t_last_native.hinted = true;
+    t_last_native.max_lag = h.max_lag;
+    t_last_native.max_partition_id = h.max_partition_id;
+}
 
 Assignment run_native(const Plan& plan, const std::vector<const TopicData*>& data, bool offsets_mode,
                       int32_t reset_mode, std::map<std::string, std::map<std::string, int64_t>>* totals_out,
@@ -134,14 +161,18 @@ Assignment run_native(const Plan& plan, const std::vector<const TopicData*>& dat
             f.pid.insert(f.pid.end(), d->partition.begin(), d->partition.end());
             if (offsets_mode) {
                 const int64_t base = (int64_t)f.end.size();
-                for (size_t i = 0; i < d->committed.size(); ++i)
+                for (size_t i = 0; i < d->committed.size(); ++i) {
+                    f.see(d->end[i], d->partition[i]);
                     if (d->committed[i] < 0) {                        // partitionMetadata == null, Main.java:384
                         f.none_index.push_back(base + (int64_t)i);
                         f.none_begin.push_back(d->begin[i]);
+                        f.any_negative |= d->begin[i] < 0;
                     }
+                }
                 f.end.insert(f.end.end(), d->end.begin(), d->end.end());
                 f.committed.insert(f.committed.end(), d->committed.begin(), d->committed.end());
             } else {
+                for (size_t i = 0; i < d->lag.size(); ++i) f.see(d->lag[i], d->partition[i]);
                 f.lag.insert(f.lag.end(), d->lag.begin(), d->lag.end());
             }
         }
@@ -160,6 +191,7 @@ Assignment run_native(const Plan& plan, const std::vector<const TopicData*>& dat
     if (!plan.topics.empty()) {
         std::lock_guard<std::mutex> lock(g_ctx_mutex);       // one lock over both calls: the second reads the first's results
         la_ctx* ctx = shared_ctx_locked();
+        hint_bounds(ctx, f);
         if (offsets_mode) {
             // assign(Cluster, GroupSubscription): both steps in ONE native call -- for a rebalance of ordinary size one
             // upload, one download, one wait (la_assign_batch_grouped_sparse: `begin` only where it is read)
@@ -171,7 +203,14 @@ Assignment run_native(const Plan& plan, const std::vector<const TopicData*>& dat
         } else {
             check(ctx, la_assign_batch_lags(ctx, (int32_t)plan.topics.size(), f.part_off.data(), f.pid.data(), f.lag.data(),
                                             f.cons_off.data(), f.cons_rank.data(), nullptr, nullptr, out_total.data()));
+            t_last_native.pipeline = la_last_pipeline(ctx);
+            t_last_native.launches = la_last_launches(ctx);
             check(ctx, la_group_last_by_member(ctx, n_members, member_off.data(), grouped_topic.data(), grouped_pid.data()));
+            t_last_native.launches += la_last_launches(ctx);
+        }
+        if (offsets_mode) {
+            t_last_native.pipeline = la_last_pipeline(ctx);
+            t_last_native.launches = la_last_launches(ctx);
         }
     }
     // partition id -> the element's own topic string (normally the map key), per topic
@@ -243,6 +282,7 @@ std::vector<std::string> consumersPerTopicOrder(const GroupSubscription& subscri
 }
 
 bool LagBasedPartitionAssignor::lastStaticOrderExact() { return t_last_order_exact; }
+LagBasedPartitionAssignor::NativeCallStats LagBasedPartitionAssignor::lastNativeCall() { return t_last_native; }
 
 LagBasedPartitionAssignor::LagBasedPartitionAssignor() = default;
 LagBasedPartitionAssignor::~LagBasedPartitionAssignor() = default;

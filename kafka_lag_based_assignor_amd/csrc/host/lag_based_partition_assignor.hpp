@@ -110,6 +110,17 @@ class LagBasedPartitionAssignor {
     bool lastOrderExact() const { return last_order_exact_; }
     static bool lastStaticOrderExact();            // same, for the last static assign() on the calling thread
 
+    // What the last native assign call on the calling thread was given and did (diagnostics / tests): whether the marshalling
+    // loop could vouch for bounds (la_hint_next_call: no negative offset, lag or id) and which, the library's pipeline and the
+    // number of kernel launches of the call (la_last_pipeline / la_last_launches).
+    struct NativeCallStats {
+        bool hinted = false;
+        int64_t max_lag = 0, max_partition_id = 0;
+        int pipeline = -1;
+        int64_t launches = 0;
+    };
+    static NativeCallStats lastNativeCall();
+
     // Hook for log lines the reference emits through slf4j (warn on missing metadata, :359).
     std::function<void(const std::string&)> warn = [](const std::string&) {};
 

@@ -98,6 +98,16 @@ PYBIND11_MODULE(_host, m) {
         .def("last_topic_totals", &LagBasedPartitionAssignor::lastTopicTotals)
         .def("last_order_exact", &LagBasedPartitionAssignor::lastOrderExact)
         .def_static("last_static_order_exact", &LagBasedPartitionAssignor::lastStaticOrderExact)
+        .def_static("last_native_call", [] {
+            const auto st = LagBasedPartitionAssignor::lastNativeCall();
+            py::dict d;
+            d["hinted"] = st.hinted;
+            d["max_lag"] = st.max_lag;
+            d["max_partition_id"] = st.max_partition_id;
+            d["pipeline"] = st.pipeline;
+            d["launches"] = st.launches;
+            return d;
+        })
         .def("set_warn", [](LagBasedPartitionAssignor& self, std::function<void(const std::string&)> f) { self.warn = std::move(f); })
         .def("set_debug", [](LagBasedPartitionAssignor& self, std::function<void(const std::string&)> f) { self.debug = std::move(f); })
         .def("assign",

@@ -123,9 +123,23 @@ struct la_ctx {
     size_t zero_copy_bytes = 0;          // calls whose staging layout is at most this large run zero-copy (assign_small_zc)
     int last_shards = 0;                 // shards the last call used
     int32_t last_bounds[65] = {};        // their topic ranges
+    la_call_hints hints{};               // la_hint_next_call: what the caller knows about its next host-buffer assign call
+    bool hints_set = false;              // (one-shot: assign_host takes them and clears the flag)
+    int64_t last_launches = 0;           // kernel launches of the last call (la_last_launches)
 };
 
 namespace {
+
+// Kernel launches between construction and destruction, left in the context for la_last_launches (the outermost span of a
+// call wins: the grouped calls run an assign call inside).
+struct LaunchSpan {
+    la_ctx* ctx;
+    uint64_t at;
+    explicit LaunchSpan(la_ctx* c) : ctx(c), at(la::g_kernel_launches.load(std::memory_order_relaxed)) {}
+    ~LaunchSpan() { if (ctx) ctx->last_launches = (int64_t)(la::g_kernel_launches.load(std::memory_order_relaxed) - at); }
+    LaunchSpan(const LaunchSpan&) = delete;
+    LaunchSpan& operator=(const LaunchSpan&) = delete;
+};
 
 int fail(la_ctx* ctx, int code, const char* fmt, ...) {
     char buf[512];
@@ -575,7 +589,7 @@ int status_error(la_ctx* ctx, uint32_t st) {
     if (st & la::kStatusUnsorted)
         return fail(ctx, LA_EINVAL, "a topic's cons_rank segment is not strictly ascending");
     if (st & la::kStatusBounds)
-        return fail(ctx, LA_EINVAL, "a lag or a partition id lies outside the bounds given with LA_FLAG_BOUNDS");
+        return fail(ctx, LA_EINVAL, "a lag or a partition id lies outside the bounds the caller gave (la_hint_next_call / LA_FLAG_BOUNDS)");
     if (st & la::kStatusSparse)
         return fail(ctx, LA_EINVAL, "none_index must hold ascending positions inside the batch");
     if (st & la::kStatusWire)
@@ -644,7 +658,18 @@ struct HostCall {
     int64_t* g_off = nullptr;
     int32_t *g_topic = nullptr, *g_part = nullptr;
     bool* grouped_done = nullptr;
+    // la_hint_next_call: the caller's bounds on every lag and partition id of the call (LA_FLAG_BOUNDS of every chunk's batch)
+    bool bounded = false;
+    int64_t max_lag = 0, max_id = 0;
 };
+
+// The caller's hints on a chunk's / shard's device batch: bounds that hold for the whole call hold for every part of it.
+void apply_hints(const HostCall& c, la_device_batch& b) {
+    if (!c.bounded) return;
+    b.flags |= LA_FLAG_BOUNDS;
+    b.max_lag_hint = c.max_lag;
+    b.max_partition_id_hint = c.max_id;
+}
 
 struct ShardPlan {
     int32_t t0 = 0, t1 = 0;                 // the shard's topics in the caller's numbering
@@ -823,6 +848,7 @@ int run_lane(la_ctx* ctx, const HostCall& c, Shard& sh, ShardPlan& sp, int lane_
         b.h_part_off = sp.lpo + a;
         b.h_cons_off = sp.lco + a;
         b.flags = LA_FLAG_RAGGED;        // the offsets are on the host anyway: let the dispatcher look at the shapes
+        apply_hints(c, b);
         if (np == 0) {
             // nothing to assign in this chunk; its consumers still report a total of 0
             if (c.out_total && nk)
@@ -961,6 +987,7 @@ int run_shard_async(la_ctx* ctx, const HostCall& c, Shard& sh, ShardPlan& sp) {
         b.h_part_off = sp.lpo + a;
         b.h_cons_off = sp.lco + a;
         b.flags = LA_FLAG_RAGGED;
+        apply_hints(c, b);
         if (np == 0) {
             if (c.out_total && nk) LA_HIP(ctx, hipMemsetAsync((int64_t*)sh.out_total.p + k0, 0, nk * 8, sk));
         } else if (int rc = enqueue_batch(ctx, ln, &b, sk)) {
@@ -1048,6 +1075,7 @@ int run_shard_mapped(la_ctx* ctx, const HostCall& c, Shard& sh, ShardPlan& sp) {
     b.h_part_off = c.part_off + sp.t0;
     b.h_cons_off = c.cons_off + sp.t0;
     b.flags = LA_FLAG_RAGGED;
+    apply_hints(c, b);
     if (sp.n == 0) {
         if (c.out_total && sp.k) LA_HIP(ctx, hipMemsetAsync(mapped_ptr(c.out_total) + sp.K0, 0, (size_t)sp.k * 8, st));
         return LA_OK;
@@ -1190,6 +1218,7 @@ int assign_small_zc(la_ctx* ctx, const HostCall& c, Shard& sh, const SmallLayout
     b.reset_mode = c.reset_mode == LA_RESET_LATEST ? LA_RESET_LATEST : LA_RESET_EARLIEST;
     b.algo = LA_ALGO_AUTO;
     b.flags = LA_FLAG_RAGGED;
+    apply_hints(c, b);
     b.n_partitions = c.shape.n;
     b.n_consumers = c.shape.k;
     b.max_partitions_per_topic = c.shape.max_p;
@@ -1332,6 +1361,7 @@ int assign_small(la_ctx* ctx, const HostCall& c, Shard& sh, const SmallLayout& L
     b.reset_mode = c.reset_mode == LA_RESET_LATEST ? LA_RESET_LATEST : LA_RESET_EARLIEST;
     b.algo = LA_ALGO_AUTO;
     b.flags = LA_FLAG_RAGGED;
+    apply_hints(c, b);
     b.n_partitions = c.shape.n;
     b.n_consumers = c.shape.k;
     b.max_partitions_per_topic = c.shape.max_p;
@@ -1395,10 +1425,17 @@ int assign_host(la_ctx* ctx, int32_t T, const int64_t* part_off, const int32_t* 
                 int64_t* out_total, const HostCall* grouped = nullptr, const HostCall* sparse = nullptr) {
     if (!ctx) return LA_EINVAL;
     ctx->last_valid = false;
+    const bool hinted = ctx->hints_set;                       // one-shot: whatever this call returns, the hints are spent
+    ctx->hints_set = false;
     if (T < 0) return fail(ctx, LA_EINVAL, "n_topics < 0");
     if (T == 0) return LA_OK;
     if (!part_off || !cons_off) return fail(ctx, LA_EINVAL, "null offsets");
     HostCall c;
+    if (hinted && (ctx->hints.flags & LA_HINT_BOUNDS) && ctx->hints.max_lag >= 0 && ctx->hints.max_partition_id >= 0) {
+        c.bounded = true;
+        c.max_lag = ctx->hints.max_lag;
+        c.max_id = ctx->hints.max_partition_id;
+    }
     // offsets are checked here; cons_rank's order on the device (run_lane)
     if (int rc = scan_shape(ctx, T, part_off, cons_off, nullptr, &c.shape)) return rc;
     const Shape& s = c.shape;
@@ -1868,6 +1905,23 @@ LA_API int la_unpack_results_on(la_ctx* ctx, int shard, int64_t n, const void* d
 
 LA_API int la_last_pipeline(const la_ctx* ctx) { return ctx ? ctx->last_pipeline : LA_EINVAL; }
 
+LA_API int64_t la_last_launches(const la_ctx* ctx) { return ctx ? ctx->last_launches : (int64_t)LA_EINVAL; }
+
+LA_API int la_hint_next_call(la_ctx* ctx, const la_call_hints* hints) {
+    if (!ctx) return LA_EINVAL;
+    ctx->hints_set = false;
+    if (!hints) return LA_OK;
+    // the struct may grow: take what the caller's header knows of it (the four fields of ABI 0.4.0 at least)
+    if (hints->struct_size < (int32_t)sizeof(la_call_hints))
+        return fail(ctx, LA_EINVAL, "la_call_hints.struct_size %d is smaller than the %zu bytes of ABI 0.4.0", hints->struct_size,
+                    sizeof(la_call_hints));
+    if ((hints->flags & LA_HINT_BOUNDS) && (hints->max_lag < 0 || hints->max_partition_id < 0))
+        return fail(ctx, LA_EINVAL, "LA_HINT_BOUNDS: max_lag and max_partition_id must be >= 0");
+    ctx->hints = *hints;
+    ctx->hints_set = true;
+    return LA_OK;
+}
+
 LA_API void* la_host_alloc(la_ctx* ctx, size_t bytes) {
     DeviceGuard restore_device;
     if (!ctx || ctx->shards.empty()) return nullptr;
@@ -1889,6 +1943,7 @@ LA_API void la_host_free(la_ctx* ctx, void* p) {
 LA_API int la_compute_lag(la_ctx* ctx, int64_t n, const int64_t* begin_off, const int64_t* end_off,
                           const int64_t* committed_off, int32_t reset_mode, int64_t* out_lag) {
     DeviceGuard restore_device;
+    LaunchSpan span(ctx);
     if (!ctx) return LA_EINVAL;
     try {
         if (n < 0) return fail(ctx, LA_EINVAL, "n < 0");
@@ -1938,6 +1993,7 @@ LA_API int la_assign_batch(la_ctx* ctx, int32_t n_topics, const int64_t* part_of
                            int32_t reset_mode, const int64_t* cons_off, const int32_t* cons_rank,
                            int32_t* out_partition, int32_t* out_member_rank, int64_t* out_total_lag) {
     DeviceGuard restore_device;
+    LaunchSpan span(ctx);
     try {
         return assign_host(ctx, n_topics, part_off, partition_id, begin_off, end_off, committed_off, nullptr,
                            reset_mode, cons_off, cons_rank, out_partition, out_member_rank, out_total_lag);
@@ -1950,6 +2006,7 @@ LA_API int la_assign_batch_lags(la_ctx* ctx, int32_t n_topics, const int64_t* pa
                                 const int64_t* lag, const int64_t* cons_off, const int32_t* cons_rank,
                                 int32_t* out_partition, int32_t* out_member_rank, int64_t* out_total_lag) {
     DeviceGuard restore_device;
+    LaunchSpan span(ctx);
     try {
         if (ctx && !lag && n_topics > 0 && part_off && part_off[n_topics] > 0)
             return fail(ctx, LA_EINVAL, "lag is NULL");
@@ -1963,6 +2020,7 @@ LA_API int la_assign_batch_lags(la_ctx* ctx, int32_t n_topics, const int64_t* pa
 
 LA_API int la_assign_batch_device_on(la_ctx* ctx, int shard, const la_device_batch* batch, void* stream) {
     DeviceGuard restore_device;
+    LaunchSpan span(ctx);
     if (!ctx) return LA_EINVAL;
     try {
         if (shard < 0 || shard >= (int)ctx->shards.size()) return fail(ctx, LA_EINVAL, "shard %d of %d", shard, (int)ctx->shards.size());
@@ -2133,6 +2191,7 @@ LA_API int la_group_by_member(la_ctx* ctx, int32_t n_topics, const int64_t* part
                               const int32_t* out_member_rank, int32_t n_members, int64_t* member_off,
                               int32_t* grouped_topic, int32_t* grouped_partition) {
     DeviceGuard restore_device;
+    LaunchSpan span(ctx);
     if (!ctx) return LA_EINVAL;
     try {
         ctx->last_valid = false;                       // this call reuses the scratch the last results live in
@@ -2218,6 +2277,7 @@ LA_API int la_group_by_member(la_ctx* ctx, int32_t n_topics, const int64_t* part
 LA_API int la_group_last_by_member(la_ctx* ctx, int32_t n_members, int64_t* member_off, int32_t* grouped_topic,
                                    int32_t* grouped_partition) {
     DeviceGuard restore_device;
+    LaunchSpan span(ctx);
     if (!ctx) return LA_EINVAL;
     try {
         if (!ctx->last_valid)
@@ -2264,6 +2324,7 @@ LA_API int la_assign_batch_grouped(la_ctx* ctx, int32_t n_topics, const int64_t*
                                    int64_t* member_off, int32_t* grouped_topic, int32_t* grouped_partition,
                                    int64_t* out_total_lag) {
     DeviceGuard restore_device;
+    LaunchSpan span(ctx);
     if (!ctx) return LA_EINVAL;
     try {
         return assign_grouped(ctx, n_topics, part_off, partition_id, begin_off, end_off, committed_off, reset_mode, cons_off,
@@ -2279,6 +2340,7 @@ LA_API int la_assign_batch_sparse(la_ctx* ctx, int32_t n_topics, const int64_t* 
                                   const int32_t* cons_rank, int32_t* out_partition, int32_t* out_member_rank,
                                   int64_t* out_total_lag) {
     DeviceGuard restore_device;
+    LaunchSpan span(ctx);
     try {
         HostCall sp;
         sp.n_none = n_none; sp.none_index = none_index; sp.none_begin = none_begin;
@@ -2296,6 +2358,7 @@ LA_API int la_assign_batch_grouped_sparse(la_ctx* ctx, int32_t n_topics, const i
                                           int64_t* member_off, int32_t* grouped_topic, int32_t* grouped_partition,
                                           int64_t* out_total_lag) {
     DeviceGuard restore_device;
+    LaunchSpan span(ctx);
     if (!ctx) return LA_EINVAL;
     try {
         HostCall sp;
@@ -2333,6 +2396,15 @@ LA_API int la_last_phase_times(la_ctx* ctx, la_phase_times* out) {
     } catch (...) {
         return fail(ctx, LA_ENOMEM, "exception in la_last_phase_times");
     }
+}
+
+LA_API int la_last_phase_times_sized(la_ctx* ctx, void* out, size_t out_size) {
+    if (!ctx) return LA_EINVAL;
+    if (!out) return fail(ctx, LA_EINVAL, "out is NULL");
+    la_phase_times full{};
+    if (int rc = la_last_phase_times(ctx, &full)) return rc;
+    memcpy(out, &full, out_size < sizeof full ? out_size : sizeof full);
+    return LA_OK;
 }
 
 LA_API int la_sync_on(la_ctx* ctx, int shard, void* stream) {

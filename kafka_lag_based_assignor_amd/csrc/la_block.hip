@@ -708,13 +708,20 @@ __global__ __launch_bounds__(1024) void block_topic_kernel(BlockArgs a) {
             // every record is compared with the one before it: the ranks of the sort rest on a property of the LDS atomics
             // that the device was tested for once (la_create), so an order that is not one is an error of the call
             // (kStatusOrder -> LA_EHIP), never a silently different assignment -- what emit_ids_kernel does for the large path.
+            // A padding sentinel (all ones) and a real record whose lbw + sh bits are all ones (lag 0, id 2^sh - 1) have the
+            // same digits when lbw + sh is a multiple of 8, and the stable sort keeps such ties in (wavefront, register, lane)
+            // order -- a sentinel of wavefront 0 may then stand before that record of wavefront 1 and land at a position < P.
+            // Every position < P belongs to a real record, and the only real records a sentinel can displace are equal to
+            // 2^(lbw+sh) - 1: reading positions < P through the mask of the examined bits puts exactly that value there
+            // (real records have no bit above it).
+            const uint64_t rec_mask = ~0ull >> (64 - (lbw + sh));           // (1 <= lbw + sh <= 63 here)
             uint64_t sorted[E];
             bool bad = false;
 #pragma unroll
             for (int r = 0; r < E; ++r) {
                 const int i = r * nt + tid;
-                sorted[r] = x_key[i < P ? i : 0];
-                bad |= i > 0 && i < P && x_key[i < P ? i - 1 : 0] > sorted[r];
+                sorted[r] = x_key[i < P ? i : 0] & rec_mask;
+                bad |= i > 0 && i < P && (x_key[i < P ? i - 1 : 0] & rec_mask) > sorted[r];
             }
             __syncthreads();                                            // every record is in a register: the keys go over them
             if (__builtin_amdgcn_ballot_w64(bad) != 0 && (tid & (kWave - 1)) == 0) atomicOr(a.status, kStatusOrder);
@@ -930,8 +937,8 @@ hipError_t block_launch(BlockArgs a, int cls, hipStream_t stream) {
                                    160 * 1024);
     });
     if (err != hipSuccess) return err;
-    if (e == 8) hipLaunchKernelGGL(block_topic_kernel<8>, dim3((unsigned)a.n_list), dim3(nt), lds, stream, a);
-    else hipLaunchKernelGGL(block_topic_kernel<16>, dim3((unsigned)a.n_list), dim3(nt), lds, stream, a);
+    if (e == 8) LA_LAUNCH(block_topic_kernel<8>, dim3((unsigned)a.n_list), dim3(nt), lds, stream, a);
+    else LA_LAUNCH(block_topic_kernel<16>, dim3((unsigned)a.n_list), dim3(nt), lds, stream, a);
     return hipGetLastError();
 }
 

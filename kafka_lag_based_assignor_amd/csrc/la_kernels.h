@@ -7,6 +7,16 @@
 
 namespace la {
 
+// Kernel launches of the whole library, counted where they are issued: la_last_launches (lagassign.h) reports the difference
+// over one call -- how a test asserts "one launch" for a batch whose bounds prove that every tile packs.  Process-wide (the
+// lanes of a host-buffer call launch from their own threads), relaxed: a diagnostic, not a synchronisation point.
+inline std::atomic<uint64_t> g_kernel_launches{0};
+#define LA_LAUNCH(...)                                                        \
+    do {                                                                      \
+        ::la::g_kernel_launches.fetch_add(1, std::memory_order_relaxed);      \
+        hipLaunchKernelGGL(__VA_ARGS__);                                      \
+    } while (0)
+
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) applies to the CURRENT device, and a process may hold contexts
 // on several: one bit per device id remembers where a kernel has been opted in (ids >= 32: set on every launch).
 // Calls may come from several host threads (one per shard lane), hence the atomic.

@@ -54,18 +54,18 @@ hipError_t lag_launch(int64_t n, const int64_t* begin, const int64_t* end, const
         const int64_t n2 = n / 2;
         if (n2 > 0) {
             if (reset_latest)
-                hipLaunchKernelGGL(lag_kernel_vec2<true>, dim3(grid_for(n2)), dim3(256), 0, stream, n2,
+                LA_LAUNCH(lag_kernel_vec2<true>, dim3(grid_for(n2)), dim3(256), 0, stream, n2,
                                    (const i64x2*)nullptr, (const i64x2*)end, (const i64x2*)committed,
                                    (i64x2*)out_lag);
             else
-                hipLaunchKernelGGL(lag_kernel_vec2<false>, dim3(grid_for(n2)), dim3(256), 0, stream, n2,
+                LA_LAUNCH(lag_kernel_vec2<false>, dim3(grid_for(n2)), dim3(256), 0, stream, n2,
                                    (const i64x2*)begin, (const i64x2*)end, (const i64x2*)committed,
                                    (i64x2*)out_lag);
         }
         done = n2 * 2;
     }
     if (done < n)
-        hipLaunchKernelGGL(lag_kernel_scalar, dim3(grid_for(n - done)), dim3(256), 0, stream, done, n, begin,
+        LA_LAUNCH(lag_kernel_scalar, dim3(grid_for(n - done)), dim3(256), 0, stream, done, n, begin,
                            end, committed, reset_latest ? 1 : 0, out_lag);
     return hipGetLastError();
 }
@@ -85,7 +85,7 @@ __global__ __launch_bounds__(256) void check_consumers_kernel(int64_t n_topics, 
 hipError_t check_consumers_launch(int64_t n_topics, const int64_t* cons_off, const int32_t* cons_rank,
                                   uint32_t* status, hipStream_t stream) {
     if (n_topics <= 0) return hipSuccess;
-    hipLaunchKernelGGL(check_consumers_kernel, dim3(grid_for(n_topics)), dim3(256), 0, stream, n_topics,
+    LA_LAUNCH(check_consumers_kernel, dim3(grid_for(n_topics)), dim3(256), 0, stream, n_topics,
                        cons_off, cons_rank, status);
     return hipGetLastError();
 }
@@ -102,7 +102,7 @@ __global__ void finish_status_kernel(const uint32_t* d_status, uint32_t* h_flag)
 }
 
 hipError_t finish_status_launch(const uint32_t* d_status, uint32_t* h_flag, hipStream_t stream) {
-    hipLaunchKernelGGL(finish_status_kernel, dim3(1), dim3(64), 0, stream, d_status, h_flag);
+    LA_LAUNCH(finish_status_kernel, dim3(1), dim3(64), 0, stream, d_status, h_flag);
     return hipGetLastError();
 }
 
@@ -128,7 +128,7 @@ __global__ __launch_bounds__(256) void sparse_begin_kernel(int64_t m, const int6
 hipError_t sparse_begin_launch(int64_t m, const int64_t* idx, const int64_t* val, int64_t base, int64_t lo, int64_t hi,
                                int64_t* begin, uint32_t* status, hipStream_t stream) {
     if (m <= 0) return hipSuccess;
-    hipLaunchKernelGGL(sparse_begin_kernel, dim3(grid_for(m)), dim3(256), 0, stream, m, idx, val, base, lo, hi, begin, status);
+    LA_LAUNCH(sparse_begin_kernel, dim3(grid_for(m)), dim3(256), 0, stream, m, idx, val, base, lo, hi, begin, status);
     return hipGetLastError();
 }
 

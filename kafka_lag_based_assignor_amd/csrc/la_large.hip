@@ -2104,10 +2104,10 @@ hipError_t launch_rounds(const LargeArgs& a, const SortBufs& b, int threads, hip
                                    160 * 1024);
     });
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((greedy_rounds_kernel<EC>), dim3(count), dim3(threads), lds, stream, a, b, items, scratch, order);
+    LA_LAUNCH((greedy_rounds_kernel<EC>), dim3(count), dim3(threads), lds, stream, a, b, items, scratch, order);
     if (!items) {
         int grid = (int)((a.n_part + 255) / 256);
-        hipLaunchKernelGGL(map_ranks_kernel, dim3(grid > 2048 ? 2048 : grid), dim3(256), 0, stream, a, (const LargeItem*)nullptr);
+        LA_LAUNCH(map_ranks_kernel, dim3(grid > 2048 ? 2048 : grid), dim3(256), 0, stream, a, (const LargeItem*)nullptr);
     }
     return hipGetLastError();
 }
@@ -2214,7 +2214,7 @@ hipError_t large_init_device() {
         uint32_t h_bad = 1;
         if ((e = hipMalloc((void**)&d_bad, sizeof(uint32_t))) != hipSuccess) return e;
         if ((e = hipMemset(d_bad, 0, sizeof(uint32_t))) == hipSuccess) {
-            hipLaunchKernelGGL(lds_atomic_order_test_kernel, dim3(8), dim3(256), 0, nullptr, d_bad);
+            LA_LAUNCH(lds_atomic_order_test_kernel, dim3(8), dim3(256), 0, nullptr, d_bad);
             e = hipMemcpy(&h_bad, d_bad, sizeof(uint32_t), hipMemcpyDeviceToHost);
         }
         (void)hipFree(d_bad);
@@ -2360,7 +2360,7 @@ static void sort_run_passes(const SortBufs& b, hipStream_t stream, uint32_t* sta
     // wide as the class's largest topic (max_tiles); the plan of all of them is the caller's (one launch over every class).
     // slot0 = kDigits: the redo slots of a keys-first sort (same digits, see tie_repair_kernel).
     if (!items && slot0 == 0)
-        hipLaunchKernelGGL(plan_kernel, dim3(kDigits), dim3(kRadix), 0, stream, b, (const LargeItem*)nullptr, (char*)nullptr);
+        LA_LAUNCH(plan_kernel, dim3(kDigits), dim3(kRadix), 0, stream, b, (const LargeItem*)nullptr, (char*)nullptr);
     if (planned) (void)hipEventRecord(planned, stream);
     for (int d = 0; d < kDigits; ++d) {
         if (!((pass_mask >> d) & 1u)) continue;
@@ -2368,22 +2368,22 @@ static void sort_run_passes(const SortBufs& b, hipStream_t stream, uint32_t* sta
         if (b.tile_state) {
             const dim3 grid(items ? max_tiles : b.n_tiles, items ? count : 1);
             if (b.sweep_threads == 1024) {
-                if (b.atomic_rank) hipLaunchKernelGGL((onesweep_pass_kernel<true, 1024>), grid, dim3(1024), 0, stream, b, p, status, items, scratch);
-                else hipLaunchKernelGGL((onesweep_pass_kernel<false, 1024>), grid, dim3(1024), 0, stream, b, p, status, items, scratch);
+                if (b.atomic_rank) LA_LAUNCH((onesweep_pass_kernel<true, 1024>), grid, dim3(1024), 0, stream, b, p, status, items, scratch);
+                else LA_LAUNCH((onesweep_pass_kernel<false, 1024>), grid, dim3(1024), 0, stream, b, p, status, items, scratch);
             } else if (b.sweep_threads == 512) {
-                if (b.atomic_rank) hipLaunchKernelGGL((onesweep_pass_kernel<true, 512>), grid, dim3(512), 0, stream, b, p, status, items, scratch);
-                else hipLaunchKernelGGL((onesweep_pass_kernel<false, 512>), grid, dim3(512), 0, stream, b, p, status, items, scratch);
+                if (b.atomic_rank) LA_LAUNCH((onesweep_pass_kernel<true, 512>), grid, dim3(512), 0, stream, b, p, status, items, scratch);
+                else LA_LAUNCH((onesweep_pass_kernel<false, 512>), grid, dim3(512), 0, stream, b, p, status, items, scratch);
             } else {
-                if (b.atomic_rank) hipLaunchKernelGGL((onesweep_pass_kernel<true, 256>), grid, dim3(256), 0, stream, b, p, status, items, scratch);
-                else hipLaunchKernelGGL((onesweep_pass_kernel<false, 256>), grid, dim3(256), 0, stream, b, p, status, items, scratch);
+                if (b.atomic_rank) LA_LAUNCH((onesweep_pass_kernel<true, 256>), grid, dim3(256), 0, stream, b, p, status, items, scratch);
+                else LA_LAUNCH((onesweep_pass_kernel<false, 256>), grid, dim3(256), 0, stream, b, p, status, items, scratch);
             }
             continue;
         }
-        hipLaunchKernelGGL(tile_count_kernel, dim3(b.n_tiles < 2048 ? b.n_tiles : 2048), dim3(kSortThreads), 0, stream, b, p);
-        hipLaunchKernelGGL(scan_group_sums_kernel, dim3(b.n_groups), dim3(kRadix), 0, stream, b, p);
-        hipLaunchKernelGGL(scan_offsets_kernel, dim3(b.n_groups), dim3(kRadix), 0, stream, b, p);
-        if (b.atomic_rank) hipLaunchKernelGGL(tile_scatter_kernel<true>, dim3(b.n_tiles), dim3(kSortThreads), 0, stream, b, p);
-        else hipLaunchKernelGGL(tile_scatter_kernel<false>, dim3(b.n_tiles), dim3(kSortThreads), 0, stream, b, p);
+        LA_LAUNCH(tile_count_kernel, dim3(b.n_tiles < 2048 ? b.n_tiles : 2048), dim3(kSortThreads), 0, stream, b, p);
+        LA_LAUNCH(scan_group_sums_kernel, dim3(b.n_groups), dim3(kRadix), 0, stream, b, p);
+        LA_LAUNCH(scan_offsets_kernel, dim3(b.n_groups), dim3(kRadix), 0, stream, b, p);
+        if (b.atomic_rank) LA_LAUNCH(tile_scatter_kernel<true>, dim3(b.n_tiles), dim3(kSortThreads), 0, stream, b, p);
+        else LA_LAUNCH(tile_scatter_kernel<false>, dim3(b.n_tiles), dim3(kSortThreads), 0, stream, b, p);
     }
 }
 
@@ -2400,12 +2400,12 @@ static hipError_t sort_repair_launch(const SortBufs& b, hipStream_t stream, cons
     if (e != hipSuccess) return e;
     int64_t gs = (max_n / 2 + 255) / 256;
     if (gs > 4096) gs = 4096;
-    hipLaunchKernelGGL(tie_scan_kernel, dim3((unsigned)(gs < 1 ? 1 : gs), items ? count : 1), dim3(256), 0, stream, b, items, scratch);
+    LA_LAUNCH(tie_scan_kernel, dim3((unsigned)(gs < 1 ? 1 : gs), items ? count : 1), dim3(256), 0, stream, b, items, scratch);
     int64_t gx = (max_n + kRepairWindow - 1) / kRepairWindow;
     if (gx > 1024) gx = 1024;                                   // (128 KB of LDS each: one per CU at a time; windows grid-stride)
-    hipLaunchKernelGGL(tie_repair_kernel, dim3((unsigned)gx, items ? count : 1), dim3(kRepairThreads),
+    LA_LAUNCH(tie_repair_kernel, dim3((unsigned)gx, items ? count : 1), dim3(kRepairThreads),
                        (size_t)2 * kRepairCap * sizeof(uint64_t), stream, b, items, scratch);
-    hipLaunchKernelGGL(replan_kernel, dim3(items ? count : 1), dim3(64), 0, stream, b, items, scratch);
+    LA_LAUNCH(replan_kernel, dim3(items ? count : 1), dim3(64), 0, stream, b, items, scratch);
     return hipGetLastError();
 }
 
@@ -2436,15 +2436,15 @@ hipError_t large_topic_launch(LargeScratch& scratch, const LargeArgs& a, bool ar
         LargeProfile& pf; bool on; hipStream_t st;
         ~Done() { if (on) (void)hipEventRecord(pf.ev[3], st); }
     } done{pf, profile, stream};
-    hipLaunchKernelGGL(build_keys_kernel, dim3(grid), dim3(256), 0, stream, a, b, (const LargeItem*)nullptr, (char*)nullptr);
-    if (b.samp) hipLaunchKernelGGL(sample_scan_kernel, dim3(256), dim3(256), 0, stream, b, (const LargeItem*)nullptr, (char*)nullptr);
+    LA_LAUNCH(build_keys_kernel, dim3(grid), dim3(256), 0, stream, a, b, (const LargeItem*)nullptr, (char*)nullptr);
+    if (b.samp) LA_LAUNCH(sample_scan_kernel, dim3(256), dim3(256), 0, stream, b, (const LargeItem*)nullptr, (char*)nullptr);
     sort_run_passes(b, stream, a.status, profile ? pf.ev[1] : nullptr);
     if (b.samp) {
         if ((e = sort_repair_launch(b, stream, nullptr, 1, nullptr, n)) != hipSuccess) return e;
         sort_run_passes(b, stream, a.status, nullptr, (1u << kDigits) - 1, nullptr, 1, 0, nullptr, kDigits);
     }
     if (profile) (void)hipEventRecord(pf.ev[2], stream);
-    hipLaunchKernelGGL(emit_ids_kernel, dim3(grid), dim3(256), 0, stream, a, b, (const LargeItem*)nullptr, (char*)nullptr);
+    LA_LAUNCH(emit_ids_kernel, dim3(grid), dim3(256), 0, stream, a, b, (const LargeItem*)nullptr, (char*)nullptr);
     if ((e = hipGetLastError()) != hipSuccess) return e;
     if (a.n_cons == 0) return hipSuccess;
 
@@ -2459,7 +2459,7 @@ hipError_t large_topic_launch(LargeScratch& scratch, const LargeArgs& a, bool ar
                                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
              })) != hipSuccess)
             return e;
-        hipLaunchKernelGGL(greedy_argmin_kernel, dim3(1), dim3(threads), lds, stream, a, b);
+        LA_LAUNCH(greedy_argmin_kernel, dim3(1), dim3(threads), lds, stream, a, b);
         return hipGetLastError();
     }
     int ec = 1, threads = 64;
@@ -2575,9 +2575,9 @@ hipError_t large_topics_launch(LargeScratch& scratch, const LargeArgs* args, int
     b0.atomic_rank = large_atomic_rank_supported();
     b0.keys_first_force = force_keys_first ? 1 : 0;
     uint32_t* status = args[0].status;
-    hipLaunchKernelGGL(build_keys_kernel, dim3(gx, count), dim3(256), 0, stream, a0, b0, d_items, base);
-    if (any_keys_first) hipLaunchKernelGGL(sample_scan_kernel, dim3(64, count), dim3(256), 0, stream, b0, d_items, base);
-    hipLaunchKernelGGL(plan_kernel, dim3(kDigits, count), dim3(kRadix), 0, stream, b0, d_items, base);
+    LA_LAUNCH(build_keys_kernel, dim3(gx, count), dim3(256), 0, stream, a0, b0, d_items, base);
+    if (any_keys_first) LA_LAUNCH(sample_scan_kernel, dim3(64, count), dim3(256), 0, stream, b0, d_items, base);
+    LA_LAUNCH(plan_kernel, dim3(kDigits, count), dim3(kRadix), 0, stream, b0, d_items, base);
     if (profile) (void)hipEventRecord(pf.ev[1], stream);
     for (int first = 0; first < count;) {                          // one set of pass launches per tile class
         const int sweep = lay[(size_t)idx[(size_t)first]].sweep_threads;
@@ -2609,10 +2609,10 @@ hipError_t large_topics_launch(LargeScratch& scratch, const LargeArgs* args, int
         }
     }
     if (profile) (void)hipEventRecord(pf.ev[2], stream);
-    hipLaunchKernelGGL(emit_ids_kernel, dim3(gx, count), dim3(256), 0, stream, a0, b0, d_items, base);
+    LA_LAUNCH(emit_ids_kernel, dim3(gx, count), dim3(256), 0, stream, a0, b0, d_items, base);
     for (const Cls& c : cls)
         if ((e = launch_rounds_class(c.ec, c.threads, a0, b0, stream, d_items, base, d_order + c.first, c.n)) != hipSuccess) return e;
-    if (!cls.empty()) hipLaunchKernelGGL(map_ranks_kernel, dim3(gx, count), dim3(256), 0, stream, a0, d_items);
+    if (!cls.empty()) LA_LAUNCH(map_ranks_kernel, dim3(gx, count), dim3(256), 0, stream, a0, d_items);
     if (profile) (void)hipEventRecord(pf.ev[3], stream);
     return hipGetLastError();
 }
@@ -2678,14 +2678,14 @@ hipError_t huge_topic_launch(LargeScratch& scratch, const LargeArgs& a, hipStrea
     if ((e = hipMemsetAsync(base, 0, lp.zero_bytes, stream)) != hipSuccess) return e;
     int grid = (int)((P + 255) / 256);
     if (grid > 2048) grid = 2048;
-    hipLaunchKernelGGL(build_keys_kernel, dim3(grid), dim3(256), 0, stream, a, bp, (const LargeItem*)nullptr, (char*)nullptr);
-    if (bp.samp) hipLaunchKernelGGL(sample_scan_kernel, dim3(256), dim3(256), 0, stream, bp, (const LargeItem*)nullptr, (char*)nullptr);
+    LA_LAUNCH(build_keys_kernel, dim3(grid), dim3(256), 0, stream, a, bp, (const LargeItem*)nullptr, (char*)nullptr);
+    if (bp.samp) LA_LAUNCH(sample_scan_kernel, dim3(256), dim3(256), 0, stream, bp, (const LargeItem*)nullptr, (char*)nullptr);
     sort_run_passes(bp, stream, a.status);
     if (bp.samp) {
         if ((e = sort_repair_launch(bp, stream, nullptr, 1, nullptr, P)) != hipSuccess) return e;
         sort_run_passes(bp, stream, a.status, nullptr, (1u << kDigits) - 1, nullptr, 1, 0, nullptr, kDigits);
     }
-    hipLaunchKernelGGL(emit_ids_kernel, dim3(grid), dim3(256), 0, stream, a, bp, (const LargeItem*)nullptr, (char*)nullptr);
+    LA_LAUNCH(emit_ids_kernel, dim3(grid), dim3(256), 0, stream, a, bp, (const LargeItem*)nullptr, (char*)nullptr);
     int cgrid = (int)((C + 255) / 256);
     if (cgrid > 1024) cgrid = 1024;
     const int64_t rounds = (P + C - 1) / C;
@@ -2694,7 +2694,7 @@ hipError_t huge_topic_launch(LargeScratch& scratch, const LargeArgs& a, hipStrea
         const SortBufs& next = bins[(r + 1) & 1];
         const int last = r + 1 == rounds;
         if (!last && (e = hipMemsetAsync((char*)next.ctl, 0, lc.zero_bytes, stream)) != hipSuccess) return e;
-        hipLaunchKernelGGL(huge_round_kernel, dim3(cgrid), dim3(256), 0, stream, a, bp, cur, next, r, r == 0 ? 1 : 0, last);
+        LA_LAUNCH(huge_round_kernel, dim3(cgrid), dim3(256), 0, stream, a, bp, cur, next, r, r == 0 ? 1 : 0, last);
         if (!last) sort_run_passes(next, stream, a.status, nullptr, 0xFF0u);       // the 8 digits of the totals; ids stay in order
     }
     return hipGetLastError();
@@ -2860,7 +2860,7 @@ hipError_t group_by_member_launch(LargeScratch& scratch, int64_t n, int32_t n_me
     if (n == 0) return hipMemsetAsync(member_off, 0, sizeof(int64_t) * ((size_t)n_members + 1), stream);
     if (n <= kSmallGroupN && (int64_t)n_members + 2 <= kSmallGroupM && ((int64_t)n_members + 1) < ((int64_t)1 << (kSmallGroupBits + 1)) &&
         !getenv("LA_NO_SMALL_GROUP")) {
-        hipLaunchKernelGGL(group_small_kernel, dim3(1), dim3(1024), 0, stream, (int)n, n_members, n_topics, part_off, out_partition,
+        LA_LAUNCH(group_small_kernel, dim3(1), dim3(1024), 0, stream, (int)n, n_members, n_topics, part_off, out_partition,
                            member_rank, member_off, grouped_topic, grouped_partition, grouped_entry, (const uint32_t*)status,
                            fin_flag);
         if (fin_done) *fin_done = fin_flag != nullptr;
@@ -2870,14 +2870,14 @@ hipError_t group_by_member_launch(LargeScratch& scratch, int64_t n, int32_t n_me
     if ((e = sort_prepare(scratch, n, stream, &b)) != hipSuccess) return e;
     int grid = (int)((n + 255) / 256);
     if (grid > 2048) grid = 2048;
-    hipLaunchKernelGGL(member_keys_kernel, dim3(grid), dim3(256), 0, stream, member_rank, b);
+    LA_LAUNCH(member_keys_kernel, dim3(grid), dim3(256), 0, stream, member_rank, b);
     // key = rank + 1 <= n_members: only its low ceil(bits / 8) digits can differ; the payload (entry index) is ascending.
     // Launching just those passes matters for the small batches a real group leader sends: every skipped pass used to
     // cost four empty launches (~50 launches, ~190 us, for a 100-partition rebalance).
     uint32_t mask = 0;
     for (int d = 0; d < 8 && ((uint64_t)n_members >> (8 * d)) != 0; ++d) mask |= 1u << (4 + d);
     sort_run_passes(b, stream, status, nullptr, mask);
-    hipLaunchKernelGGL(member_emit_kernel, dim3(grid), dim3(256), 0, stream, b, n_members, n_topics, part_off,
+    LA_LAUNCH(member_emit_kernel, dim3(grid), dim3(256), 0, stream, b, n_members, n_topics, part_off,
                        out_partition, member_off, grouped_topic, grouped_partition, grouped_entry, status);
     return hipGetLastError();
 }

@@ -770,28 +770,28 @@ static hipError_t launch_one(const TileArgs& a, int mode, hipStream_t stream) {
     const dim3 b(Cfg::kThreads);
     auto grid = [&](int resident) { return dim3((unsigned)(blocks < resident ? blocks : resident)); };
     if (mode == kModeArgmin) {
-        hipLaunchKernelGGL((wave_tile_wide_kernel<L, E, true>), grid(res_argmin), b, 0, stream, a, 0);
+        LA_LAUNCH((wave_tile_wide_kernel<L, E, true>), grid(res_argmin), b, 0, stream, a, 0);
     } else if (mode == kModeWide) {
-        hipLaunchKernelGGL((wave_tile_wide_kernel<L, E, false>), grid(res_wide), b, 0, stream, a, 0);
+        LA_LAUNCH((wave_tile_wide_kernel<L, E, false>), grid(res_wide), b, 0, stream, a, 0);
     } else {
         if (!a.defer_count || !a.defer_count_next || !a.defer_list) return hipErrorInvalidValue;
         // 32-bit indexing when every byte offset (8-byte arrays) fits 32 bits
         const bool idx32 = a.n_total < ((int64_t)1 << 29) && a.k_total < ((int64_t)1 << 30) && !(a.flags & 1);
         if (idx32 && blocks <= res_inline && !(a.flags & 2)) {
             // the whole batch is resident at once: one kernel with the wide code inline, no second launch
-            hipLaunchKernelGGL((wave_tile_packed_kernel<L, E, uint32_t, true>), dim3((unsigned)blocks), b, 0, stream, a);
+            LA_LAUNCH((wave_tile_packed_kernel<L, E, uint32_t, true>), dim3((unsigned)blocks), b, 0, stream, a);
             return hipGetLastError();
         }
         if (idx32)
-            hipLaunchKernelGGL((wave_tile_packed_kernel<L, E, uint32_t, false>), dim3((unsigned)blocks), b, 0, stream, a);
+            LA_LAUNCH((wave_tile_packed_kernel<L, E, uint32_t, false>), dim3((unsigned)blocks), b, 0, stream, a);
         else
-            hipLaunchKernelGGL((wave_tile_packed_kernel<L, E, int64_t, false>), dim3((unsigned)blocks), b, 0, stream, a);
+            LA_LAUNCH((wave_tile_packed_kernel<L, E, int64_t, false>), dim3((unsigned)blocks), b, 0, stream, a);
         if (a.flags & kTileNoDefer) return hipGetLastError();      // proven: nothing can be deferred, no second launch
         // usually nothing was deferred: every wavefront reads the count and leaves
 #ifdef LA_LAB
         if (getenv("LA_NO_WIDE")) return hipGetLastError();
 #endif
-        hipLaunchKernelGGL((wave_tile_wide_kernel<L, E, false>), grid(res_wide), b, 0, stream, a, 1);
+        LA_LAUNCH((wave_tile_wide_kernel<L, E, false>), grid(res_wide), b, 0, stream, a, 1);
     }
     return hipGetLastError();
 }

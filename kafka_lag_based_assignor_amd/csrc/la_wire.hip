@@ -128,8 +128,8 @@ hipError_t wire_pack_launch(int64_t n, const int32_t* pid, const int32_t* rank, 
     const dim3 grid(wire_grid(n)), block(256);
 #define LA_PACK(W)                                                                                                   \
     do {                                                                                                             \
-        if (vec) hipLaunchKernelGGL((wire_pack_kernel<W, true>), grid, block, 0, stream, n, pid, rank, id_bits, (W*)out, status);   \
-        else hipLaunchKernelGGL((wire_pack_kernel<W, false>), grid, block, 0, stream, n, pid, rank, id_bits, (W*)out, status);      \
+        if (vec) LA_LAUNCH((wire_pack_kernel<W, true>), grid, block, 0, stream, n, pid, rank, id_bits, (W*)out, status);   \
+        else LA_LAUNCH((wire_pack_kernel<W, false>), grid, block, 0, stream, n, pid, rank, id_bits, (W*)out, status);      \
     } while (0)
     if (elem_bytes == 2) LA_PACK(uint16_t);
     else if (elem_bytes == 4) LA_PACK(uint32_t);
@@ -146,8 +146,8 @@ hipError_t wire_unpack_launch(int64_t n, const void* in, int elem_bytes, int id_
     const dim3 grid(wire_grid(n)), block(256);
 #define LA_UNPACK(W)                                                                                                 \
     do {                                                                                                             \
-        if (vec) hipLaunchKernelGGL((wire_unpack_kernel<W, true>), grid, block, 0, stream, n, (const W*)in, id_bits, pid, rank);    \
-        else hipLaunchKernelGGL((wire_unpack_kernel<W, false>), grid, block, 0, stream, n, (const W*)in, id_bits, pid, rank);       \
+        if (vec) LA_LAUNCH((wire_unpack_kernel<W, true>), grid, block, 0, stream, n, (const W*)in, id_bits, pid, rank);    \
+        else LA_LAUNCH((wire_unpack_kernel<W, false>), grid, block, 0, stream, n, (const W*)in, id_bits, pid, rank);       \
     } while (0)
     if (elem_bytes == 2) LA_UNPACK(uint16_t);
     else if (elem_bytes == 4) LA_UNPACK(uint32_t);

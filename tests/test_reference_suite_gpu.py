@@ -153,6 +153,12 @@ def test_plugin_level_assign_with_offsets(mode):
     for t in ("orders", "payments"):
         assigned = {m: sum(l for (tt, p, l) in lags[t] if (tt, p) in got[m]) for m in totals[t]}
         assert totals[t] == assigned
+    # round 5: the marshalling loop vouches for what it saw -- the largest end offset (a failed lookup counts as 0) and the
+    # largest partition id -- through la_hint_next_call; a rebalance this small is one launch for the tiles + one for the lists
+    st = LagBasedPartitionAssignor.last_native_call()
+    assert st["hinted"] and st["max_partition_id"] == 11
+    assert st["max_lag"] == max(end.get((t, p), 0) for t, ps in metadata.items() for p in ps)
+    assert 1 <= st["launches"] <= 2
 
 
 def test_debug_summary_matches_reference_format():

@@ -1,0 +1,165 @@
+"""Round-5 additions, through the C ABI, bit-exact against the oracle."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from kafka_lag_based_assignor_amd import _native as N
+from kafka_lag_based_assignor_amd import synth
+from oracle import oracle
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = N.Context(0)
+    yield c
+    c.close()
+
+
+def _same3(got, exp, what=""):
+    for g, e, name in zip(got, exp, ("partition order", "member", "totals")):
+        np.testing.assert_array_equal(g, e, err_msg="%s %s" % (name, what))
+
+
+# ---- block_sort_radix, a padding sentinel against the record whose examined bits are all ones ------------
+def test_block_radix_sentinel_against_all_ones_record_in_fresh_process():
+    """The workgroup's digit sort pads with all-ones sentinels and looks at ceil((lbw + sh) / 8) digits.  When lbw + sh is a
+    multiple of 8, the record (lag 0, id 2^sh - 1) has the sentinel's digits; a sentinel of an earlier wavefront may then sort
+    before it.  P is not a multiple of 64 x 8, the special record sits in the second wavefront, lbw + sh in {8, 16, 24}; every
+    topic through the digits (LA_BLOCK_RADIX=3, read once per process), against the oracle."""
+    code = r"""
+import numpy as np, sys
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+from kafka_lag_based_assignor_amd import _native as N, synth
+from oracle import oracle
+import test_round4_gpu as t
+ctx = N.Context(0)
+rng = np.random.default_rng(5)
+for P, C, sh, lbw in ((924, 65, 10, 6), (924, 70, 10, 14), (924, 65, 4, 4), (1500, 3, 11, 5), (3000, 100, 12, 12), (9000, 8, 14, 10),
+                      (924, 65, 10, 7)):
+    for at in (64, 100, 127, P - 1):
+        ids = rng.permutation((1 << sh) - 1)[:P] if (1 << sh) - 1 >= P else rng.integers(0, (1 << sh) - 1, P)
+        ids = ids.astype(np.int32)
+        lag = rng.integers(0, 1 << lbw, P).astype(np.int64)
+        lag[0] = (1 << lbw) - 1                       # the OR of the lags has lbw bits
+        ids[at] = (1 << sh) - 1                       # the record whose lbw + sh bits are all ones ...
+        lag[at] = 0                                   # ... : lag_max - 0 = all ones, id all ones
+        part_off = np.array([0, P], np.int64); cons_off = np.array([0, C], np.int64)
+        ranks = np.arange(C, dtype=np.int32) * 2
+        w = synth.Workload("s", 1, part_off, ids, np.zeros(P, np.int64), lag.copy(), np.zeros(P, np.int64), lag, cons_off, ranks, P, C)
+        exp = oracle.assign_flat(part_off, ids, lag, cons_off, ranks)
+        t._same3(t._device_call(ctx, w), exp, what=str((P, C, sh, lbw, at)))
+print("ok")
+"""
+    env = dict(os.environ, LA_BLOCK_RADIX="3")
+    out = subprocess.run([sys.executable, "-c", code % (ROOT, os.path.join(ROOT, "tests"))], env=env, capture_output=True,
+                         text=True, timeout=900)
+    assert out.returncode == 0 and "ok" in out.stdout, (out.stdout[-1500:], out.stderr[-1500:])
+
+
+# ---- la_hint_next_call: the caller's bounds reach the host-buffer entry points -------------------------
+def _pinned_copy(ctx, arrays):
+    out = []
+    for a in arrays:
+        if a is None or isinstance(a, int):
+            out.append(a)
+        else:
+            p = ctx.host_alloc(a.shape, a.dtype)
+            p[...] = a
+            out.append(p)
+    return out
+
+
+def test_hinted_host_call_is_one_tile_launch_per_chunk(ctx):
+    """A batch too large to be resident at once (40 000 x 256 x 32: the inline single-launch form of small batches does not
+    apply) through la_assign_batch on pinned, mapped arrays: without a hint the tile path is two launches (packed records +
+    the wide-record kernel over an empty list), with the marshaller's bounds ONE; + one launch for the consumer-rank check.
+    Same results either way, equal to the device-resident path's; the hint is one-shot."""
+    w = synth.make_uniform("hint", 31, 40000, 256, 32, "zipf")
+    a = (w.part_off, w.partition_id, w.begin, w.end, w.committed, N.LA_RESET_EARLIEST, w.cons_off, w.cons_rank)
+    pa = _pinned_copy(ctx, a)
+    pout = (ctx.host_alloc((w.n_partitions,), np.int32), ctx.host_alloc((w.n_partitions,), np.int32),
+            ctx.host_alloc((w.cons_rank.size,), np.int64))
+    bounds = N.offset_bounds(w.begin, w.end, w.committed, w.partition_id)
+    assert bounds is not None
+    ref = [x.copy() for x in ctx.assign_batch(*pa, out=pout)]
+    assert ctx.last_pipeline() == N.LA_PIPELINE_MAPPED
+    plain = ctx.last_launches()
+    ctx.hint_next_call(bounds)
+    got = [x.copy() for x in ctx.assign_batch(*pa, out=pout)]
+    hinted = ctx.last_launches()
+    assert (plain, hinted) == (3, 2), (plain, hinted)
+    _same3(got, ref, "hinted")
+    ctx.assign_batch(*pa, out=pout)                                # one-shot: the next call has no hint again
+    assert ctx.last_launches() == plain
+    # pageable arrays: chunks over the lanes.  A chunk that is resident at once takes the inline single-launch form with or
+    # without bounds, so the hint can only ever remove launches
+    ctx.assign_batch(*a, out=tuple(np.empty_like(x) for x in ref))
+    plain_l = ctx.last_launches()
+    assert ctx.last_pipeline() == N.LA_PIPELINE_LANES
+    ctx.hint_next_call(bounds)
+    got = ctx.assign_batch(*a, out=tuple(np.empty_like(x) for x in ref))
+    assert ctx.last_launches() <= plain_l
+    _same3(got, ref, "hinted, lanes")
+    # the oracle on a slice of the batch (the whole batch through the device path is covered elsewhere)
+    t = 500
+    p1, k1 = int(w.part_off[t]), int(w.cons_off[t])
+    lag = oracle.compute_lags(w.begin[:p1], w.end[:p1], w.committed[:p1], False)
+    e = oracle.assign_flat(w.part_off[:t + 1], w.partition_id[:p1], lag, w.cons_off[:t + 1], w.cons_rank[:k1])
+    _same3((ref[0][:p1], ref[1][:p1], ref[2][:k1]), e, "oracle slice")
+
+
+def test_violated_hint_is_einval_never_a_different_result(ctx):
+    """The kernels decide per wavefront, from the data, whether a tile's records pack; the bounds only prove that the
+    wide-record launch behind them has nothing to do.  A tile that does NOT pack although the bounds said it would (an end
+    offset of 2^56 under a promise of 2^31) is reported as LA_EINVAL; a bound that is wrong but harmless changes nothing."""
+    w = synth.make_uniform("hint", 32, 40000, 256, 32, "zipf")
+    end = w.end.copy()
+    end[123457] = 1 << 56                                          # one partition with a lag of ~2^56: its tile needs wide records
+    a = (w.part_off, w.partition_id, w.begin, end, w.committed, N.LA_RESET_EARLIEST, w.cons_off, w.cons_rank)
+    pa = _pinned_copy(ctx, a)
+    good = [x.copy() for x in ctx.assign_batch(*pa)]               # no hint: the tile goes through the wide-record kernel
+    assert ctx.last_pipeline() == N.LA_PIPELINE_MAPPED and ctx.last_launches() == 3
+    t = 123457 // 256
+    p0, p1, k0, k1 = t * 256, (t + 2) * 256, t * 32, (t + 2) * 32
+    lag = oracle.compute_lags(w.begin[p0:p1], end[p0:p1], w.committed[p0:p1], False)
+    e = oracle.assign_flat(w.part_off[t:t + 3] - p0, w.partition_id[p0:p1], lag, w.cons_off[t:t + 3] - k0, w.cons_rank[k0:k1])
+    _same3((good[0][p0:p1], good[1][p0:p1], good[2][k0:k1]), e, "oracle on the wide tile and its neighbour")
+    ctx.hint_next_call(((1 << 31), 255))                           # the promise the data breaks
+    with pytest.raises(N.LagAssignError) as ei:
+        ctx.assign_batch(*pa)
+    assert ei.value.code == N.LA_EINVAL and "bounds" in str(ei.value)
+    _same3(ctx.assign_batch(*pa), good, "after the failure, no hint")
+    ctx.hint_next_call(N.offset_bounds(w.begin, end, w.committed, w.partition_id))   # the honest bounds prove nothing here:
+    _same3(ctx.assign_batch(*pa), good, "honest bounds")                             # two launches, same result
+    assert ctx.last_launches() == 3
+    ctx.hint_next_call(((1 << 57), 100))                           # wrong about the ids, harmless: every tile still packs or defers
+    _same3(ctx.assign_batch(*pa), good, "harmless wrong bound")
+    with pytest.raises(N.LagAssignError):
+        ctx.hint_next_call((-1, 5))
+
+
+def test_grouped_and_sparse_calls_take_the_hint(ctx):
+    w = synth.make_uniform("hint", 33, 40000, 256, 32, "zipf")
+    idx, val = N.sparse_begin(w.begin, w.committed)
+    n_members = int(w.cons_rank.max()) + 1
+    bounds = N.offset_bounds(w.begin, w.end, w.committed, w.partition_id)
+    base = ctx.assign_batch_grouped_sparse(w.part_off, w.partition_id, w.end, w.committed, N.LA_RESET_EARLIEST, idx, val,
+                                           w.cons_off, w.cons_rank, n_members)
+    plain = ctx.last_launches()
+    ctx.hint_next_call(bounds)
+    got = ctx.assign_batch_grouped_sparse(w.part_off, w.partition_id, w.end, w.committed, N.LA_RESET_EARLIEST, idx, val,
+                                          w.cons_off, w.cons_rank, n_members)
+    assert ctx.last_launches() < plain
+    for g, e in zip(got, base):
+        np.testing.assert_array_equal(g, e)
+    lag = oracle.compute_lags(w.begin, w.end, w.committed, False)
+    ctx.hint_next_call(N.offset_bounds(None, None, None, w.partition_id, lag=lag))
+    r = ctx.assign_batch_lags(w.part_off, w.partition_id, lag, w.cons_off, w.cons_rank)
+    e = ctx.assign_batch(w.part_off, w.partition_id, w.begin, w.end, w.committed, N.LA_RESET_EARLIEST, w.cons_off, w.cons_rank)
+    _same3(r, e, "lags entry with a hint")
