@@ -106,6 +106,10 @@ def parse_args():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the cpu_baseline leg (rank 0, N=1)")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the oracle legs (parity check, cpu_baseline, host_boundary)")
     ap.add_argument("--no-sort-phase", action="store_true", help="skip the sort_phase leg of the default line")
+    ap.add_argument("--rotate", type=int, default=3,
+                    help="distinct resident copies of the batch (inputs AND result buffers) the steps rotate over, so that no "
+                         "step finds its bytes in the 256 MiB Infinity Cache because the previous step left them there: 3 x 950 MB "
+                         "at the target (1 = the round 1-4 form: every step on the same buffers)")
     ap.add_argument("--no-live-traffic", action="store_true",
                     help="roofline.traffic from the committed PMC summary instead of two rocprofv3 child passes in this run")
     return ap.parse_args()
@@ -191,8 +195,9 @@ class DeviceShard:
         self._N = N
         self.batch = self.make_batch(latest, algo, flags)
 
-    def make_batch(self, latest, algo="auto", flags=0):
-        """A la_device_batch over this shard's resident arrays (`latest`: auto.offset.reset=latest, `begin` not even passed)."""
+    def make_batch(self, latest, algo="auto", flags=0, bounds=True):
+        """A la_device_batch over this shard's resident arrays (`latest`: auto.offset.reset=latest, `begin` not even passed;
+        bounds=False: without LA_FLAG_BOUNDS, the two-launch form of the tile path)."""
         N = self._N
         b = N.DeviceBatch()
         b.n_topics = self.t1 - self.t0
@@ -217,7 +222,7 @@ class DeviceShard:
         if b.max_partitions_per_topic > 1024 or b.max_consumers_per_topic > 64:
             b.h_part_off = self.h_part_off.ctypes.data_as(ctypes.POINTER(ctypes.c_int64))
             b.h_cons_off = self.h_cons_off.ctypes.data_as(ctypes.POINTER(ctypes.c_int64))
-        if self.bounds is not None and not os.environ.get("LA_BENCH_NO_BOUNDS"):
+        if bounds and self.bounds is not None and not os.environ.get("LA_BENCH_NO_BOUNDS"):
             # what a marshaller knows without looking at a lag: the largest end offset (no lag exceeds it) and the largest
             # partition id.  When they prove that every tile packs, the tile path is ONE launch (LA_FLAG_BOUNDS)
             b.flags |= N.LA_FLAG_BOUNDS
@@ -596,10 +601,18 @@ def main():
         n_total = w.n_partitions
         gather = True
     else:
+        t0, t1 = 0, T
         sh = DeviceShard(torch, N, dev, w, 0, T, latest, args.algo)
         counts = [sh.n] * world
         n_total = world * sh.n
         gather = bool(args.gather and use_dist)
+    # The steps ROTATE over `--rotate` distinct resident copies of the (shard of the) batch -- inputs and result buffers at
+    # different addresses, the same values -- so that what a step reads was last touched two steps (1.9 GB of traffic) ago and
+    # cannot sit in the 256 MiB Infinity Cache (MI355X_MICROARCH.md: cache hits appear inside FETCH_SIZE).
+    # sets[0] is `sh`: parity, lag_ratio and the host legs read its buffers, which hold the same assignment as every copy's.
+    rot = max(1, int(args.rotate))
+    sets = [sh] + [DeviceShard(torch, N, dev, w, t0, t1, latest, args.algo, out_cap=(sh.cap if strong else None))
+                   for _ in range(rot - 1)]
     cap = sh.cap
     do_gather = gather and use_dist
     n_part = sh.n
@@ -625,10 +638,11 @@ def main():
             gathered = torch.empty(world * 2 * cap, device=dev, dtype=torch.int32)     # [world][2][cap]
     gather_bytes_per_rank = (cap * fmt.elem_bytes if packed else 2 * cap * 4) if do_gather else 0
 
-    def gather_step(trio=None):
-        """pack -> THE collective of a step -> unpack; trio[2..4] are recorded behind each phase when given."""
+    def gather_step(cur, trio=None):
+        """pack -> THE collective of a step -> unpack, on the results of the copy `cur` the step's kernels just wrote;
+        trio[2..4] are recorded behind each phase when given."""
         if packed:
-            ctx.pack_results(n_part, sh.out_pid.data_ptr(), sh.out_rank.data_ptr(), fmt, wire_send.data_ptr(), stream)
+            ctx.pack_results(n_part, cur.out_pid.data_ptr(), cur.out_rank.data_ptr(), fmt, wire_send.data_ptr(), stream)
             if trio:
                 trio[2].record()
             all_gather(wire_recv, wire_send)
@@ -642,15 +656,24 @@ def main():
         else:
             if trio:
                 trio[2].record()
-            all_gather(gathered, sh.out2)
+            all_gather(gathered, cur.out2)
             if trio:
                 trio[3].record()
                 trio[4].record()
 
+    step_no = [0]
+
+    def next_set():
+        """the copy of the batch the next step works on: the copies in turn"""
+        i = step_no[0] % rot
+        step_no[0] += 1
+        return sets[i]
+
     def step():
-        ctx.assign_batch_device(b, stream)
+        cur = next_set()
+        ctx.assign_batch_device(cur.batch, stream)
         if do_gather:
-            gather_step()
+            gather_step(cur)
 
     def barrier():
         torch.cuda.synchronize()
@@ -692,10 +715,11 @@ def main():
             step()
         else:
             trio[0].record()
-            ctx.assign_batch_device(b, stream)
+            cur = next_set()
+            ctx.assign_batch_device(cur.batch, stream)
             trio[1].record()
             if do_gather:
-                gather_step(trio)
+                gather_step(cur, trio)
     barrier()
     elapsed = time.perf_counter() - t0c
     ctx.sync(stream)
@@ -796,6 +820,26 @@ def main():
                 "algorithmic_bytes_per_launch": bpp * n_part,
                 # the same bytes over the time of ONE call after a second of idle: the regime a real rebalance lives in
                 "frac_cold": round(bpp * n_part / (cold_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+    roofline["frac_rotating"] = roofline["frac"] if rot > 1 else None
+    roofline["rotation"] = {"sets": rot, "bytes_resident": int(rot * (bpp * n_part + 8 * sh.k)),
+                            "what": "the timed steps rotate over %d distinct resident copies of the batch (inputs and result buffers): "
+                                    "`frac` / `frac_rotating` cannot owe anything to the 256 MiB Infinity Cache holding a previous "
+                                    "step's bytes; frac_same_buffers is the round 1-4 form (every step on ONE copy)" % rot}
+    if world == 1 and not args.no_cpu_baseline:
+        try:
+            sms, scalls = timed_calls(torch, ctx, sh.batch, stream, settle_ms=60.0)
+            roofline["same_buffers_ms"] = round(sms, 4)
+            roofline["frac_same_buffers"] = round(bpp * n_part / (sms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+            if sh.bounds is not None:
+                # the same batch without the marshaller's bounds: packed-record kernel + the wide-record kernel over its (empty)
+                # deferred list -- what a caller that gives no hint (la_hint_next_call / LA_FLAG_BOUNDS) gets
+                nms, ncalls = timed_calls(torch, ctx, sh.make_batch(latest, args.algo, bounds=False), stream, settle_ms=60.0)
+                roofline["no_bounds_ms"] = round(nms, 4)
+                roofline["no_bounds_frac"] = round(bpp * n_part / (nms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+            ctx.assign_batch_device(b, stream)
+            ctx.sync(stream)
+        except Exception as exc:  # noqa: BLE001 -- a reported extra
+            roofline["same_buffers_error"] = str(exc)
     if world > 1 or do_gather:
         roofline["per_rank_kernel_ms"] = [round(float(x), 4) for x in per_rank[:world]]
         roofline["per_rank_gather_ms"] = [round(float(x), 4) for x in per_rank[world:]]
@@ -876,12 +920,16 @@ def main():
             try:
                 mode = N.LA_RESET_LATEST if latest else N.LA_RESET_EARLIEST
                 a = (w.part_off, w.partition_id, None if latest else w.begin, w.end, w.committed, mode, w.cons_off, w.cons_rank)
+                # what the Java / C++ hosts' marshalling loops hand over before every assign call (la_hint_next_call): the largest
+                # end offset and partition id they walked past.  One-shot, so it is repeated before each timed call.
+                hb = N.offset_bounds(None if latest else w.begin, w.end, w.committed, w.partition_id)
                 reuse = ctx.assign_batch(*a)            # result buffers are the caller's and reused (a Java host's direct
                 for o in reuse:                         # ByteBuffers): the first call touches them, the next are timed
                     o.fill(0)
                 times = []
                 for _ in range(3):
                     c0 = time.perf_counter()
+                    ctx.hint_next_call(hb)
                     hp, hm, ht = ctx.assign_batch(*a, out=reuse)
                     times.append(time.perf_counter() - c0)
                 dt = min(times)
@@ -898,10 +946,19 @@ def main():
                 ptimes = []
                 for _ in range(4):
                     c0 = time.perf_counter()
+                    ctx.hint_next_call(hb)
                     pp, pm, pt = ctx.assign_batch(*pa, out=pout)
                     ptimes.append(time.perf_counter() - c0)
                 pdt = min(ptimes[1:])
                 pinned_pipe = ctx.last_pipeline()
+                pinned_launches = ctx.last_launches()
+                # the same call without the hint (the tile path's second, empty launch is back)
+                utimes = []
+                for _ in range(3):
+                    c0 = time.perf_counter()
+                    ctx.assign_batch(*pa, out=pout)
+                    utimes.append(time.perf_counter() - c0)
+                unhinted_ms, unhinted_launches = min(utimes[1:]) * 1e3, ctx.last_launches()
                 pinned_ok = bool(np.array_equal(pp, ref_p) and np.array_equal(pm, ref_m)) and \
                     pinned_pipe in (N.LA_PIPELINE_STREAMS, N.LA_PIPELINE_MAPPED)
                 # ... and the round-3 form on the same arrays: three copy streams (LA_NO_MAPPED_PIPELINE)
@@ -910,6 +967,7 @@ def main():
                     s3 = []
                     for _ in range(3):
                         c0 = time.perf_counter()
+                        ctx.hint_next_call(hb)
                         ctx.assign_batch(*pa, out=pout)
                         s3.append(time.perf_counter() - c0)
                     streams_ms = min(s3[1:]) * 1e3 if ctx.last_pipeline() == N.LA_PIPELINE_STREAMS else None
@@ -926,6 +984,7 @@ def main():
                     stimes = []
                     for _ in range(4):
                         c0 = time.perf_counter()
+                        ctx.hint_next_call(hb)
                         sp_, sm_, st_ = ctx.assign_batch_sparse(pa[0], pa[1], pa[3], pa[4], mode, p_idx, p_val, pa[6], pa[7], out=pout)
                         stimes.append(time.perf_counter() - c0)
                     sparse_ms = min(stimes[1:])
@@ -939,6 +998,7 @@ def main():
                 gtimes = []
                 for _ in range(3):
                     c0 = time.perf_counter()
+                    ctx.hint_next_call(hb)
                     ctx.assign_batch(*pa, keep_on_device=True, want_totals=False)
                     g_off, g_t, g_p = ctx.group_last_by_member(w.n_partitions, n_members, out=gout)
                     gtimes.append(time.perf_counter() - c0)
@@ -953,6 +1013,12 @@ def main():
                 host_leg = {"ms": round(dt * 1e3, 2), "value": round(w.n_partitions / dt, 1), "unit": "partition-assignments/sec",
                             "pinned_ms": round(pdt * 1e3, 2), "pinned_value": round(w.n_partitions / pdt, 1),
                             "pinned_ms_all": [round(x * 1e3, 2) for x in ptimes], "pinned_bit_exact_and_three_streams": pinned_ok,
+                            "hint": ({"max_end_offset": hb[0], "max_partition_id": hb[1], "pinned_launches": pinned_launches,
+                                      "pinned_unhinted_ms": round(unhinted_ms, 2), "pinned_unhinted_launches": unhinted_launches,
+                                      "what": "every timed call of this block is preceded by la_hint_next_call with what a marshalling "
+                                              "loop knows (largest end offset, largest partition id), as the Java and C++ hosts do: "
+                                              "the tile path is one launch; pinned_unhinted_* = the same call without it"}
+                                     if hb else None),
                             "pinned_pipeline": {2: "three copy streams", 4: "mapped: the kernels read / write the pinned arrays in place, no copies"}.get(pinned_pipe, pinned_pipe),
                             "pinned_three_streams_ms": round(streams_ms, 2) if streams_ms else None,
                             "sparse_begin_ms": round(sparse_ms * 1e3, 2) if sparse_ms else None,
@@ -1005,7 +1071,10 @@ def main():
     sort_phase = None
     if not args.no_sort_phase:                                  # rank 0 (the other ranks wait at the closing barrier)
         try:
-            del sh.d                                             # the batch is done with: make room
+            for x in sets:
+                if hasattr(x, "d"):
+                    del x.d                                      # the batch is done with: make room
+            del sets[1:]
             torch.cuda.empty_cache()
             sp = run_sort_phase(torch, N, ctx, dev, SORT_PHASE_PARTITIONS, 5, stream, args.sort_form,
                                 live=world == 1 and not args.no_live_traffic and not args.no_cpu_baseline)
@@ -1071,7 +1140,7 @@ def main():
                                             "packs into 64-bit records, so the tile path is ONE launch per step (no empty wide-record launch "
                                             "behind it); a violated bound is LA_EINVAL, never a different result"}
                                    if (sh.bounds is not None and not os.environ.get("LA_BENCH_NO_BOUNDS")) else None),
-                   "settle_ms": args.settle_ms, "settle_steps": settle_steps},
+                   "rotate": rot, "settle_ms": args.settle_ms, "settle_steps": settle_steps},
         "roofline": roofline,
         "cold_call_ms": cold["ms"],
         "cold_call": cold,
