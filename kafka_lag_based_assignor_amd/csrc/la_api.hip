@@ -21,6 +21,7 @@
 #include <vector>
 
 #include "la_kernels.h"
+#include "la_group_small.h"
 
 #define LA_API extern "C" __attribute__((visibility("default")))
 
@@ -73,6 +74,10 @@ struct Lane {
     } stage[4];
     unsigned stage_next = 0;
     la::LargeScratch large;              // scratch of the large-topic path and of la_group_by_member
+    // a zero-copy small call asks the dispatcher to hang its tail (lists + completion word, la::TileTail) on the batch's tile
+    // launch; honoured only when the batch IS one single-launch tile kernel -- tail_done says whether it was
+    la::TileTail tail{};
+    bool tail_wanted = false, tail_done = false;
     std::vector<uint8_t> topic_class;    // host scratch of the dispatcher: path / class of every topic
     std::vector<int64_t> host_offsets;   // offsets fetched from the device when the caller gave no host copy
 };
@@ -525,7 +530,9 @@ int enqueue_batch(la_ctx* ctx, Lane& ln, const la_device_batch* b, hipStream_t s
         if (proven(b->max_partitions_per_topic, b->max_consumers_per_topic)) a.flags |= la::kTileNoDefer;
         next_counters(a);
         LA_HIP(ctx, counter_err);
-        LA_HIP(ctx, la::wave_tile_launch(a, b->max_partitions_per_topic, b->max_consumers_per_topic, tile_mode, stream));
+        if (ln.tail_wanted && tile_mode == 0) a.tail = ln.tail;           // the batch is this one launch
+        LA_HIP(ctx, la::wave_tile_launch(a, b->max_partitions_per_topic, b->max_consumers_per_topic, tile_mode, stream,
+                                         &ln.tail_done));
         return LA_OK;
     }
     la_device_batch with_host;
@@ -571,7 +578,9 @@ int enqueue_batch(la_ctx* ctx, Lane& ln, const la_device_batch* b, hipStream_t s
         if (proven(plan.tile_mp, plan.tile_mc)) run.flags |= la::kTileNoDefer;
         next_counters(run);
         LA_HIP(ctx, counter_err);
-        LA_HIP(ctx, la::wave_tile_launch(run, plan.tile_mp, plan.tile_mc, tile_mode, stream));
+        // (a tail only when nothing else of the batch runs behind this launch)
+        if (ln.tail_wanted && tile_mode == 0 && plan.n_block_all == 0 && plan.n_large == 0) run.tail = ln.tail;
+        LA_HIP(ctx, la::wave_tile_launch(run, plan.tile_mp, plan.tile_mc, tile_mode, stream, &ln.tail_done));
     }
     if (plan.n_block_all > 0)
         if (int rc = launch_block_topics(ctx, ln, b, plan, d_lists, stream)) return rc;
@@ -1238,9 +1247,32 @@ int assign_small_zc(la_ctx* ctx, const HostCall& c, Shard& sh, const SmallLayout
     b.d_out_total_lag = c.out_total ? (int64_t*)(m + L.ot) : nullptr;
     b.h_part_off = c.part_off;
     b.h_cons_off = c.cons_off;
+    // ONE launch for the whole rebalance where the batch is one resident tile launch: its last workgroup builds the lists (up
+    // to kSmallGroupN entries) and stores the completion word -- otherwise the grouping / finishing launches below
+    const bool one_wg_lists = !grouped || (c.shape.n <= la::kSmallGroupN && (int64_t)c.g_members + 2 <= la::kTailGroupM);
+    static const bool no_tail = getenv("LA_NO_FUSED_TAIL") != nullptr;                 // (A/B hook)
+    ln.tail_done = false;
+    ln.tail_wanted = one_wg_lists && !no_tail && k <= kSmallHostCheck;
+    if (ln.tail_wanted) {
+        ln.tail = la::TileTail{};
+        ln.tail.enabled = 1;
+        ln.tail.n_members = grouped ? c.g_members : 0;
+        ln.tail.n = (int32_t)c.shape.n;
+        ln.tail.n_topics = c.T;
+        ln.tail.part_off = (const int64_t*)(m + L.po);
+        ln.tail.out_pid = b.d_out_partition;
+        ln.tail.out_rank = b.d_out_member_rank;
+        ln.tail.member_off = grouped ? (int64_t*)(m + L.goff) : nullptr;
+        ln.tail.grouped_topic = grouped && c.g_topic ? (int32_t*)(m + L.gt) : nullptr;
+        ln.tail.grouped_partition = grouped ? (int32_t*)(m + L.gp) : nullptr;
+        ln.tail.counter = ln.d_status + 24;
+        ln.tail.fin_flag = (uint32_t*)(m + L.status);
+    }
     int rc = enqueue_batch(ctx, ln, &b, st);
-    bool finished = false;                                               // (the one-workgroup grouping also finishes the call)
-    if (rc == LA_OK && grouped) {
+    ln.tail_wanted = false;
+    bool finished = ln.tail_done;                                        // (the one-workgroup grouping also finishes the call)
+    ln.tail_done = false;
+    if (rc == LA_OK && grouped && !finished) {
         const hipError_t e = la::group_by_member_launch(ln.large, c.shape.n, c.g_members, c.T, (const int64_t*)(m + L.po),
                                                         (const int32_t*)(d + L.op), (const int32_t*)(d + L.orank),
                                                         (int64_t*)(m + L.goff), c.g_topic ? (int32_t*)(m + L.gt) : nullptr,
@@ -1253,6 +1285,11 @@ int assign_small_zc(la_ctx* ctx, const HostCall& c, Shard& sh, const SmallLayout
         if (e != hipSuccess) rc = fail(ctx, LA_EHIP, "finish launch: %s", hipGetErrorString(e));
     }
     if (rc != LA_OK) {
+        // nothing of this call stays in flight or behind: kernels already enqueued may have OR-ed bits into the lane's status word
+        // (and counted themselves done on the tail's counter) -- the next call must not inherit them
+        (void)hipStreamSynchronize(st);
+        (void)hipMemsetAsync(ln.d_status, 0, sizeof(uint32_t), st);
+        (void)hipMemsetAsync(ln.d_status + 24, 0, sizeof(uint32_t), st);
         (void)hipStreamSynchronize(st);
         return rc;
     }
@@ -1264,7 +1301,11 @@ int assign_small_zc(la_ctx* ctx, const HostCall& c, Shard& sh, const SmallLayout
         if ((spins & 0xFFFu) == 0xFFFu) {
             const hipError_t q = hipStreamQuery(st);
             if (q == hipSuccess) { f = *flag; if (f & 0x80000000u) break; LA_HIP(ctx, hipStreamSynchronize(st)); f = *flag | 0x80000000u; break; }
-            if (q != hipErrorNotReady) return fail(ctx, LA_EHIP, "zero-copy call: %s", hipGetErrorString(q));
+            if (q != hipErrorNotReady) {
+                (void)hipMemsetAsync(ln.d_status, 0, sizeof(uint32_t), st);          // (best effort after a stream error)
+                (void)hipMemsetAsync(ln.d_status + 24, 0, sizeof(uint32_t), st);
+                return fail(ctx, LA_EHIP, "zero-copy call: %s", hipGetErrorString(q));
+            }
         }
     }
     std::atomic_thread_fence(std::memory_order_acquire);

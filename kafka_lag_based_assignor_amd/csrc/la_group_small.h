@@ -1,0 +1,156 @@
+// la_group_small.h -- every member's list for what a real rebalance is: up to a few thousand entries, ONE workgroup.
+//
+// The wrap step of the reference (every member's list is created at Main.java:171-174 and appended to at :264, topic by topic,
+// inside a topic in assignment order) as a stable counting sort in LDS, LINEAR in n.  Device code shared by
+//   * group_small_kernel (la_large.hip): the one-workgroup form of la_group_by_member, 1 024 threads;
+//   * the tail of the single-launch tile kernel (la_wave_tile_impl.h): the LAST workgroup of a small rebalance's one launch
+//     builds the lists and finishes the call, 256 threads.
+//
+// member_keys + plan + one or two radix passes + emit are five dependent launches (~25 us, 84 us for 2 000 entries) for a job one
+// workgroup does in a few microseconds (round 3's form placed an entry by walking all entries before it: n^2 / 2 compares, hence
+// its 1 024-entry limit):
+//   1. count the entries of every group (group = member rank + 1; 0 = topics without consumers), exclusive scan -> cursors;
+//   2. chunks of 64 consecutive entries, chunk c to wavefront c % (NT / 64): inside a chunk every lane finds its peers (the lanes
+//      with the same group: one ballot per group-id bit) -- its rank among them and, for the first of them, their number;
+//   3. the chunks take their places IN ORDER: wavefront-ordered hand-over -- a wavefront's turn waits until `turn` says its
+//      predecessor has advanced the cursors, its group leaders advance them by their peers' counts (one LDS atomic per chunk,
+//      back to back), it passes the turn on.  Turn t - 1 belongs to another wavefront of the same workgroup that waits for
+//      nothing later: no deadlock; the ordered section is a few atomic instructions per chunk.
+// Stable by construction (chunk order, then lane order), no reliance on how colliding lanes of an atomic are served.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "la_device.h"
+
+namespace la {
+
+constexpr int kSmallGroupN = 2560;       // entries.  Measured on one box, device-resident, back to back (tools/group_probe.py,
+                                         // profiles/r04_group_probe.txt): this kernel 4.0 us at 100 entries, 9 at 1 000, 14.8 at 2 000, 26 at
+                                         // 4 096 (its chunks' global loads and topic searches are dependent round trips, 16 chunks deep per
+                                         // wavefront at 16 384: 90-100 us), the radix form 17-23 us whatever the size: beyond ~2 500 entries
+                                         // the five launches win
+constexpr int kSmallGroupM = 8192;       // groups (members + 2) of the 1 024-thread kernel
+constexpr int kSmallGroupBits = 13;      // bits of a group id
+constexpr int kTailGroupM = 2048;        // groups (members + 2) the tile kernel's tail holds (8 KB of LDS beside the tiles' slices)
+
+// A TURN is kSub consecutive chunks of one wavefront: their ranks are found first, side by side; inside the turn the wavefront's
+// cursor atomics go out back to back (LDS executes one wavefront's operations in order), so the ordered hand-over -- ~0.4 us per
+// turn -- is paid once per kSub * 64 entries.  kSub = 1 is what runs (every wavefront gets work); 4 was measured 2-3 us slower at
+// every size the kernel is used for (lab builds with -DLA_GROUP_SUB=4).
+template <int kSub, int NT>
+__device__ __forceinline__ void group_small_place(int n, uint32_t G, int64_t n_topics, const int64_t* part_off, const int32_t* out_partition,
+                                                  const int32_t* member_rank, int32_t* grouped_topic, int32_t* grouped_partition,
+                                                  int32_t* grouped_entry, uint32_t* start, uint32_t* turn_p, int lane, int wave) {
+    uint32_t& turn = *turn_p;
+    const uint64_t below = ((uint64_t)1 << lane) - 1;
+    const int n_turns = (n + kSub * kWave - 1) / (kSub * kWave);
+    for (int turn_i = wave; turn_i < n_turns; turn_i += NT / kWave) {
+        uint32_t gi[kSub], rank[kSub], cnt[kSub], first[kSub];
+        int leader[kSub];
+        int32_t part[kSub], topic[kSub];
+        bool valid[kSub];
+#pragma unroll
+        for (int u = 0; u < kSub; ++u) {
+            const int i = (turn_i * kSub + u) * kWave + lane;
+            valid[u] = i < n;
+            gi[u] = 0;
+            part[u] = 0;
+            if (valid[u]) {
+                gi[u] = (uint32_t)(member_rank[i] + 1);
+                gi[u] = gi[u] < G ? gi[u] : G;
+                part[u] = out_partition ? out_partition[i] : 0;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < kSub; ++u) {
+            uint64_t peers = __ballot(valid[u]);
+#pragma unroll
+            for (int bit = 0; bit < kSmallGroupBits + 1; ++bit) {       // (G itself may need one bit more than G - 1)
+                const bool one = (gi[u] >> bit) & 1u;
+                const uint64_t bal = __ballot(one);
+                peers &= one ? bal : ~bal;
+            }
+            rank[u] = (uint32_t)__popcll(peers & below);
+            cnt[u] = (uint32_t)__popcll(peers);
+            leader[u] = __ffsll((unsigned long long)peers) - 1;
+            topic[u] = 0;
+            if (valid[u] && grouped_topic) {
+                const int64_t i = (int64_t)(turn_i * kSub + u) * kWave + lane;
+                int64_t lo = 0, hi = n_topics;                         // largest t with part_off[t] <= i
+                while (hi - lo > 1) {
+                    const int64_t mid = (lo + hi) >> 1;
+                    if (part_off[mid] <= i) lo = mid; else hi = mid;
+                }
+                topic[u] = (int32_t)lo;
+            }
+        }
+        // the ordered section: wait for the turn before this one, advance the cursors, pass the turn on
+        while (__hip_atomic_load(&turn, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != (uint32_t)turn_i) __builtin_amdgcn_s_sleep(1);
+#pragma unroll
+        for (int u = 0; u < kSub; ++u) {
+            first[u] = 0;
+            if (valid[u] && lane == leader[u]) first[u] = atomicAdd(&start[gi[u]], cnt[u]);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (lane == 0) __hip_atomic_store(&turn, (uint32_t)turn_i + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+#pragma unroll
+        for (int u = 0; u < kSub; ++u) {
+            const uint32_t f = (uint32_t)__shfl((int)first[u], leader[u] < 0 ? 0 : leader[u]);
+            if (valid[u]) {
+                const int i = (turn_i * kSub + u) * kWave + lane;
+                const uint32_t pos = f + rank[u];
+                if (grouped_entry) grouped_entry[pos] = i;
+                if (grouped_partition) grouped_partition[pos] = part[u];
+                if (grouped_topic) grouped_topic[pos] = topic[u];
+            }
+        }
+    }
+}
+
+// The whole grouping by one workgroup of NT threads (every thread of it calls this).  start: [M] words of LDS, wsum: [NT / 64],
+// turn: one word.  Needs n_members + 2 <= M and n_members + 1 < 2^(kSmallGroupBits + 1).
+template <int NT, int M, int kSub = 1>
+__device__ __forceinline__ void group_small_body(int n, int32_t n_members, int64_t n_topics, const int64_t* part_off,
+                                                 const int32_t* out_partition, const int32_t* member_rank, int64_t* member_off,
+                                                 int32_t* grouped_topic, int32_t* grouped_partition, int32_t* grouped_entry,
+                                                 uint32_t* start, uint32_t* wsum, uint32_t* turn) {
+    static_assert(M % NT == 0 && NT % kWave == 0, "M counters over NT threads");
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t G = (uint32_t)n_members + 1;                      // a rank >= n_members (out of contract) sorts behind every
+                                                                       // member, as in member_emit_kernel: member_off[n_members]
+    for (int k = tid; k < M; k += NT) start[k] = 0;                   // is then where such entries start
+    if (tid == 0) *turn = 0;
+    __syncthreads();
+    for (int i = tid; i < n; i += NT) {
+        uint32_t gi = (uint32_t)(member_rank[i] + 1);
+        gi = gi < G ? gi : G;
+        atomicAdd(&start[gi], 1u);
+    }
+    __syncthreads();
+    // exclusive scan over the M counts: M / NT per thread, a wavefront scan, the wavefronts' sums
+    constexpr int PER = M / NT;
+    uint32_t c[PER], run = 0;
+#pragma unroll
+    for (int r = 0; r < PER; ++r) { c[r] = start[PER * tid + r]; run += c[r]; }
+    uint32_t incl = run;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t y = __shfl_up(incl, o);
+        if (lane >= o) incl += y;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    uint32_t base = incl - run;
+    for (int w = 0; w < wave; ++w) base += wsum[w];
+#pragma unroll
+    for (int r = 0; r < PER; ++r) { start[PER * tid + r] = base; base += c[r]; }
+    __syncthreads();
+    // member r's list starts where the groups 0 .. r end; positions before member_off[0] belong to topics without consumers
+    for (int k = tid; k <= n_members; k += NT) member_off[k] = (int64_t)start[k + 1];
+    __syncthreads();                                                    // (the cursors move from here on)
+    group_small_place<kSub, NT>(n, G, n_topics, part_off, out_partition, member_rank, grouped_topic, grouped_partition, grouped_entry,
+                                start, turn, lane, wave);
+}
+
+}  // namespace la

@@ -59,6 +59,26 @@ constexpr int64_t kTileMaxPartitions = 1024;   // 64 lanes x 16 records
 constexpr int64_t kTileMaxConsumers = 64;      // one consumer bin per lane
 constexpr int64_t kLargeMaxConsumers = 8192;   // large path: 8 bins per thread x 1024 threads
 
+// The tail of a small rebalance's ONE launch (tile kernel, single-launch form: the whole batch resident at once).  Every
+// workgroup counts itself done on `counter`; the last one builds every member's list from the results the others wrote
+// (group_small_body, la_group_small.h; skipped when member_off is null: an ungrouped call) and stores `done | status` where the
+// calling thread is spinning -- assignment, lists and completion in one launch instead of three (Main.java:147-156).
+struct TileTail {
+    int32_t enabled;            // 0: no tail (every launch but a zero-copy small call's)
+    int32_t n_members;
+    int32_t n;                  // entries (partitions of the batch), <= kSmallGroupN when the lists are wanted
+    int32_t pad_;
+    int64_t n_topics;
+    const int64_t* part_off;    // of the WHOLE batch, from topic 0 (what grouped_topic indexes)
+    const int32_t* out_pid;     // the launch's own results
+    const int32_t* out_rank;
+    int64_t* member_off;        // null: no lists
+    int32_t* grouped_topic;     // may be null
+    int32_t* grouped_partition;
+    uint32_t* counter;          // device word, zero between calls (the last workgroup resets it)
+    uint32_t* fin_flag;         // host word (coherent, mapped)
+};
+
 // Arguments of the fused wave-tile kernel (all device pointers).
 struct TileArgs {
     int64_t n_topics;
@@ -85,6 +105,7 @@ struct TileArgs {
     int32_t* defer_count;
     int32_t* defer_count_next;
     int32_t* defer_list;
+    TileTail tail;              // honoured by the single-launch form only (wave_tile_launch says whether it was)
 };
 
 // bytes of defer_list a launch over n_topics topics may need (one tile holds >= 1 topic)
@@ -97,7 +118,9 @@ void wave_tile_pick(int64_t max_p, int64_t max_c, int* L, int* E);
 // true when ids in [0, max_id] and lags in [0, max_lag] pack into 64-bit records in every tile of the shape the launch would pick
 bool wave_tile_always_packs(int64_t max_p, int64_t max_c, int64_t max_lag, int64_t max_id);
 // mode: 0 = rounds, record format picked per wavefront; 1 = rounds, wide records forced; 2 = literal argmin
-hipError_t wave_tile_launch(TileArgs a, int64_t max_p, int64_t max_c, int mode, hipStream_t stream);
+// *tail_done (may be null) <- true when a.tail.enabled and the launch was the single-launch form, whose last workgroup runs
+// the tail; otherwise the caller finishes the call with its own launches.
+hipError_t wave_tile_launch(TileArgs a, int64_t max_p, int64_t max_c, int mode, hipStream_t stream, bool* tail_done = nullptr);
 
 // Elementwise lag: out_lag[i] = computePartitionLag(...)   (Main.java:376-404)
 hipError_t lag_launch(int64_t n, const int64_t* begin, const int64_t* end, const int64_t* committed,

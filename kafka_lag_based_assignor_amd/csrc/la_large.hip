@@ -25,6 +25,7 @@
 #include "la_kernels.h"
 #include "la_device.h"
 #include "la_sort64.h"
+#include "la_group_small.h"
 
 #include <algorithm>
 #include <type_traits>
@@ -2700,100 +2701,7 @@ hipError_t huge_topic_launch(LargeScratch& scratch, const LargeArgs& a, hipStrea
     return hipGetLastError();
 }
 
-// ---- the same grouping for what a real rebalance is: up to a few thousand entries, ONE workgroup ---------------------------
-// member_keys + plan + one or two radix passes + emit are five dependent launches (~25 us, 84 us for 2 000 entries) for a job one
-// workgroup does in a few microseconds: a stable counting sort in LDS, LINEAR in n (round 3's form placed an entry by walking
-// all entries before it: n^2 / 2 compares, hence its 1 024-entry limit).
-//   1. count the entries of every group (group = member rank + 1; 0 = topics without consumers), exclusive scan -> cursors;
-//   2. chunks of 64 consecutive entries, chunk c to wavefront c % 16: inside a chunk every lane finds its peers (the lanes with
-//      the same group: one ballot per group-id bit) -- its rank among them and, for the first of them, their number;
-//   3. the chunks take their places IN ORDER: wavefront-ordered hand-over -- a wavefront's turn (four consecutive chunks) waits
-//      until `turn` says its predecessor has advanced the cursors, its group leaders advance them by their peers' counts (one
-//      LDS atomic per chunk, back to back), it passes the turn on.  Turn t - 1 belongs to another wavefront of the same
-//      workgroup that waits for nothing later: no deadlock; the ordered section is four atomic instructions per 256 entries.
-// Stable by construction (chunk order, then lane order), no reliance on how colliding lanes of an atomic are served.
-constexpr int kSmallGroupN = 2560;       // entries.  Measured on one box, device-resident, back to back (tools/group_probe.py,
-                                         // profiles/r04_group_probe.txt): this kernel 4.0 us at 100 entries, 9 at 1 000, 14.8 at 2 000, 26 at
-                                         // 4 096 (its chunks' global loads and topic searches are dependent round trips, 16 chunks deep per
-                                         // wavefront at 16 384: 90-100 us), the radix form 17-23 us whatever the size: beyond ~2 500 entries
-                                         // the five launches win
-constexpr int kSmallGroupM = 8192;       // groups (members + 2)
-constexpr int kSmallGroupBits = 13;      // bits of a group id
-
-// A TURN is kSub consecutive chunks of one wavefront: their ranks are found first, side by side; inside the turn the wavefront's
-// cursor atomics go out back to back (LDS executes one wavefront's operations in order), so the ordered hand-over -- ~0.4 us per
-// turn -- is paid once per kSub * 64 entries.  kSub = 1 is what runs (every wavefront gets work); 4 was measured 2-3 us slower at
-// every size the kernel is used for (lab builds with -DLA_GROUP_SUB=4).
-template <int kSub>
-__device__ __forceinline__ void group_small_place(int n, uint32_t G, int64_t n_topics, const int64_t* part_off, const int32_t* out_partition,
-                                                  const int32_t* member_rank, int32_t* grouped_topic, int32_t* grouped_partition,
-                                                  int32_t* grouped_entry, uint32_t* start, uint32_t* turn_p, int lane, int wave) {
-    uint32_t& turn = *turn_p;
-    const uint64_t below = ((uint64_t)1 << lane) - 1;
-    const int n_turns = (n + kSub * kWave - 1) / (kSub * kWave);
-    for (int turn_i = wave; turn_i < n_turns; turn_i += 1024 / kWave) {
-        uint32_t gi[kSub], rank[kSub], cnt[kSub], first[kSub];
-        int leader[kSub];
-        int32_t part[kSub], topic[kSub];
-        bool valid[kSub];
-#pragma unroll
-        for (int u = 0; u < kSub; ++u) {
-            const int i = (turn_i * kSub + u) * kWave + lane;
-            valid[u] = i < n;
-            gi[u] = 0;
-            part[u] = 0;
-            if (valid[u]) {
-                gi[u] = (uint32_t)(member_rank[i] + 1);
-                gi[u] = gi[u] < G ? gi[u] : G;
-                part[u] = out_partition ? out_partition[i] : 0;
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < kSub; ++u) {
-            uint64_t peers = __ballot(valid[u]);
-#pragma unroll
-            for (int bit = 0; bit < kSmallGroupBits + 1; ++bit) {       // (G itself may need one bit more than G - 1)
-                const bool one = (gi[u] >> bit) & 1u;
-                const uint64_t bal = __ballot(one);
-                peers &= one ? bal : ~bal;
-            }
-            rank[u] = (uint32_t)__popcll(peers & below);
-            cnt[u] = (uint32_t)__popcll(peers);
-            leader[u] = __ffsll((unsigned long long)peers) - 1;
-            topic[u] = 0;
-            if (valid[u] && grouped_topic) {
-                const int64_t i = (int64_t)(turn_i * kSub + u) * kWave + lane;
-                int64_t lo = 0, hi = n_topics;                         // largest t with part_off[t] <= i
-                while (hi - lo > 1) {
-                    const int64_t mid = (lo + hi) >> 1;
-                    if (part_off[mid] <= i) lo = mid; else hi = mid;
-                }
-                topic[u] = (int32_t)lo;
-            }
-        }
-        // the ordered section: wait for the turn before this one, advance the cursors, pass the turn on
-        while (__hip_atomic_load(&turn, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != (uint32_t)turn_i) __builtin_amdgcn_s_sleep(1);
-#pragma unroll
-        for (int u = 0; u < kSub; ++u) {
-            first[u] = 0;
-            if (valid[u] && lane == leader[u]) first[u] = atomicAdd(&start[gi[u]], cnt[u]);
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        if (lane == 0) __hip_atomic_store(&turn, (uint32_t)turn_i + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-#pragma unroll
-        for (int u = 0; u < kSub; ++u) {
-            const uint32_t f = (uint32_t)__shfl((int)first[u], leader[u] < 0 ? 0 : leader[u]);
-            if (valid[u]) {
-                const int i = (turn_i * kSub + u) * kWave + lane;
-                const uint32_t pos = f + rank[u];
-                if (grouped_entry) grouped_entry[pos] = i;
-                if (grouped_partition) grouped_partition[pos] = part[u];
-                if (grouped_topic) grouped_topic[pos] = topic[u];
-            }
-        }
-    }
-}
-
+// ---- the same grouping for what a real rebalance is: up to a few thousand entries, ONE workgroup (la_group_small.h) ---------
 __global__ __launch_bounds__(1024) void group_small_kernel(int n, int32_t n_members, int64_t n_topics, const int64_t* part_off,
                                                            const int32_t* out_partition, const int32_t* member_rank,
                                                            int64_t* member_off, int32_t* grouped_topic,
@@ -2802,51 +2710,19 @@ __global__ __launch_bounds__(1024) void group_small_kernel(int n, int32_t n_memb
     __shared__ uint32_t start[kSmallGroupM];          // counts, then the groups' cursors
     __shared__ uint32_t wsum[1024 / kWave];
     __shared__ uint32_t turn;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const uint32_t G = (uint32_t)n_members + 1;                      // a rank >= n_members (out of contract) sorts behind every
-                                                                       // member, as in member_emit_kernel: member_off[n_members]
-    for (int k = tid; k < kSmallGroupM; k += 1024) start[k] = 0;      // is then where such entries start
-    if (tid == 0) turn = 0;
-    __syncthreads();
-    for (int i = tid; i < n; i += 1024) {
-        uint32_t gi = (uint32_t)(member_rank[i] + 1);
-        gi = gi < G ? gi : G;
-        atomicAdd(&start[gi], 1u);
-    }
-    __syncthreads();
-    // exclusive scan over the kSmallGroupM counts: eight per thread, a wavefront scan, the wavefronts' sums
-    constexpr int PER = kSmallGroupM / 1024;
-    uint32_t c[PER], run = 0;
-#pragma unroll
-    for (int r = 0; r < PER; ++r) { c[r] = start[PER * tid + r]; run += c[r]; }
-    uint32_t incl = run;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const uint32_t y = __shfl_up(incl, o);
-        if (lane >= o) incl += y;
-    }
-    if (lane == 63) wsum[wave] = incl;
-    __syncthreads();
-    uint32_t base = incl - run;
-    for (int w = 0; w < wave; ++w) base += wsum[w];
-#pragma unroll
-    for (int r = 0; r < PER; ++r) { start[PER * tid + r] = base; base += c[r]; }
-    __syncthreads();
-    // member r's list starts where the groups 0 .. r end; positions before member_off[0] belong to topics without consumers
-    for (int k = tid; k <= n_members; k += 1024) member_off[k] = (int64_t)start[k + 1];
-    __syncthreads();                                                    // (the cursors move from here on)
 #ifdef LA_GROUP_SUB                                   // (lab builds: tools/group_probe.py compares the forms on one box)
-    if (LA_GROUP_SUB == 4)
-        group_small_place<4>(n, G, n_topics, part_off, out_partition, member_rank, grouped_topic, grouped_partition, grouped_entry, start, &turn, lane, wave);
-    else
+    group_small_body<1024, kSmallGroupM, LA_GROUP_SUB>(n, n_members, n_topics, part_off, out_partition, member_rank, member_off,
+                                                       grouped_topic, grouped_partition, grouped_entry, start, wsum, &turn);
+#else
+    group_small_body<1024, kSmallGroupM>(n, n_members, n_topics, part_off, out_partition, member_rank, member_off, grouped_topic,
+                                         grouped_partition, grouped_entry, start, wsum, &turn);
 #endif
-        group_small_place<1>(n, G, n_topics, part_off, out_partition, member_rank, grouped_topic, grouped_partition, grouped_entry, start, &turn, lane, wave);
     if (fin_flag) {
         // the last launch of a zero-copy call (la_api.hip, assign_small_zc): this ONE workgroup's stores into the host's memory
         // are out, then `done | status` goes where the calling thread is spinning -- no separate finishing launch
         __threadfence_system();
         __syncthreads();
-        if (tid == 0) __hip_atomic_store(fin_flag, 0x80000000u | *fin_status, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (threadIdx.x == 0) __hip_atomic_store(fin_flag, 0x80000000u | *fin_status, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 

@@ -5,10 +5,10 @@
 
 namespace la {
 
-hipError_t wave_tile_launch_l8(int e, const TileArgs& a, int mode, hipStream_t stream);
-hipError_t wave_tile_launch_l16(int e, const TileArgs& a, int mode, hipStream_t stream);
-hipError_t wave_tile_launch_l32(int e, const TileArgs& a, int mode, hipStream_t stream);
-hipError_t wave_tile_launch_l64(int e, const TileArgs& a, int mode, hipStream_t stream);
+hipError_t wave_tile_launch_l8(int e, const TileArgs& a, int mode, hipStream_t stream, bool* tail_done);
+hipError_t wave_tile_launch_l16(int e, const TileArgs& a, int mode, hipStream_t stream, bool* tail_done);
+hipError_t wave_tile_launch_l32(int e, const TileArgs& a, int mode, hipStream_t stream, bool* tail_done);
+hipError_t wave_tile_launch_l64(int e, const TileArgs& a, int mode, hipStream_t stream, bool* tail_done);
 
 static int pow2ceil(int64_t x) {
     int p = 1;
@@ -44,16 +44,17 @@ bool wave_tile_always_packs(int64_t max_p, int64_t max_c, int64_t max_lag, int64
     return sh < 32 && lbw <= lim;
 }
 
-hipError_t wave_tile_launch(TileArgs a, int64_t max_p, int64_t max_c, int mode, hipStream_t stream) {
+hipError_t wave_tile_launch(TileArgs a, int64_t max_p, int64_t max_c, int mode, hipStream_t stream, bool* tail_done) {
     int L, E;
+    if (tail_done) *tail_done = false;
     if (a.n_total <= 0) return hipSuccess;
     if (max_p > a.n_total) max_p = a.n_total;      // no topic holds more than the batch (E >= 2 needs 2 elements)
     wave_tile_pick(max_p, max_c, &L, &E);
     switch (L) {
-        case 8: return wave_tile_launch_l8(E, a, mode, stream);
-        case 16: return wave_tile_launch_l16(E, a, mode, stream);
-        case 32: return wave_tile_launch_l32(E, a, mode, stream);
-        default: return wave_tile_launch_l64(E, a, mode, stream);
+        case 8: return wave_tile_launch_l8(E, a, mode, stream, tail_done);
+        case 16: return wave_tile_launch_l16(E, a, mode, stream, tail_done);
+        case 32: return wave_tile_launch_l32(E, a, mode, stream, tail_done);
+        default: return wave_tile_launch_l64(E, a, mode, stream, tail_done);
     }
 }
 

@@ -46,6 +46,7 @@
 #include "la_device.h"
 #include "la_sort64.h"
 #include "la_sort32.h"
+#include "la_group_small.h"
 #ifdef LA_LAB
 #include <cstdio>
 #include <cstdlib>
@@ -643,6 +644,35 @@ __device__ __forceinline__ void packed_tile(const TileArgs& a, const TopicDescT<
     }
 }
 
+// ---- the tail of a small rebalance's one launch (TileTail, la_kernels.h) --------------------------------------------------
+// Called by every thread of every workgroup of the single-launch form once its tiles' results are stored.  Release (the
+// results, device- and host-visible), count the workgroup done; the LAST one acquires, builds every member's list from all
+// workgroups' results (one workgroup's job below kSmallGroupN entries) and stores `done | status` into the host's word.
+__device__ __forceinline__ void tile_tail(const TileTail& t, const uint32_t* status) {
+    __shared__ uint32_t s_start[kTailGroupM];
+    __shared__ uint32_t s_wsum[LA_WPB];
+    __shared__ uint32_t s_turn, s_last;
+    __threadfence_system();                                   // this thread's result stores (to HBM or into the host's arrays)
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t done = __hip_atomic_fetch_add(t.counter, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = done == gridDim.x - 1 ? 1u : 0u;
+    }
+    __syncthreads();
+    if (!s_last) return;                                      // (workgroup-uniform)
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");        // the other workgroups' results
+    if (threadIdx.x == 0) __hip_atomic_store(t.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // the next call's count
+    if (t.member_off)
+        group_small_body<kWave * LA_WPB, kTailGroupM>(t.n, t.n_members, t.n_topics, t.part_off, t.out_pid, t.out_rank, t.member_off,
+                                                      t.grouped_topic, t.grouped_partition, nullptr, s_start, s_wsum, &s_turn);
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t st = __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(t.fin_flag, 0x80000000u | st, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
 // ---- kernel 1: packed records -------------------------------------------------------------------------
 // One tile per wavefront.  Loads (all issued back to back) -> lags -> format decision -> 32-bit key sort ->
 // greedy rounds -> stores.  A tile whose records do not fit the packed format is appended to the deferred
@@ -675,7 +705,16 @@ __global__ __launch_bounds__(256) LA_WPE_ATTR void wave_tile_packed_kernel(TileA
     // The single-launch form has no wide kernel behind it to zero the counter of the NEXT launch (the pair
     // alternates per launch, la_api.hip): do it here, or a later deferring launch would start counting at
     // whatever an earlier one left there and re-run a stale list.  Idle by stream order, like in the wide kernel.
-    if constexpr (INLINE_WIDE) if (blockIdx.x == 0 && threadIdx.x == 0) *a.defer_count_next = 0;
+    if constexpr (INLINE_WIDE) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) *a.defer_count_next = 0;
+        // the single-launch form may carry a tail (a small rebalance's lists and completion word): every wavefront stays to the end
+        if (tile < n_tiles) {
+            const TopicDescT<IDX> cur = load_desc<L, E, IDX>(a, tile, n_tiles, grp, gl);
+            packed_tile<L, E, IDX, true, false>(a, cur, slice, rank_tab, tile, gl, lane);
+        }
+        if (a.tail.enabled) tile_tail(a.tail, a.status);                 // (kernel-uniform)
+        return;
+    }
     if (tile >= n_tiles) return;
     const TopicDescT<IDX> cur = load_desc<L, E, IDX>(a, tile, n_tiles, grp, gl);
     // every topic of this wavefront fills its tile exactly: the form without clamps, validity selects and sentinels
@@ -738,7 +777,10 @@ static hipError_t resident_blocks(K kernel, int threads, int* out) {
 }
 
 template <int L, int E>
-static hipError_t launch_one(const TileArgs& a, int mode, hipStream_t stream) {
+static hipError_t launch_one(const TileArgs& a_in, int mode, hipStream_t stream, bool* tail_done) {
+    TileArgs a = a_in;
+    const bool want_tail = a.tail.enabled != 0;
+    a.tail.enabled = 0;                                          // only the single-launch form below turns it back on
     using Cfg = TileCfg<L, E>;
     const int64_t blocks = (a.n_topics + Cfg::kTopicsPerBlock - 1) / Cfg::kTopicsPerBlock;
     if (blocks <= 0) return hipSuccess;
@@ -779,6 +821,10 @@ static hipError_t launch_one(const TileArgs& a, int mode, hipStream_t stream) {
         const bool idx32 = a.n_total < ((int64_t)1 << 29) && a.k_total < ((int64_t)1 << 30) && !(a.flags & 1);
         if (idx32 && blocks <= res_inline && !(a.flags & 2)) {
             // the whole batch is resident at once: one kernel with the wide code inline, no second launch
+            if (want_tail && tail_done) {
+                a.tail.enabled = 1;
+                *tail_done = true;
+            }
             LA_LAUNCH((wave_tile_packed_kernel<L, E, uint32_t, true>), dim3((unsigned)blocks), b, 0, stream, a);
             return hipGetLastError();
         }
@@ -797,13 +843,13 @@ static hipError_t launch_one(const TileArgs& a, int mode, hipStream_t stream) {
 }
 
 template <int L>
-static inline hipError_t launch_l(int e, const TileArgs& a, int mode, hipStream_t stream) {
+static inline hipError_t launch_l(int e, const TileArgs& a, int mode, hipStream_t stream, bool* tail_done) {
     switch (e) {
-        case 1: return launch_one<L, 1>(a, mode, stream);
-        case 2: return launch_one<L, 2>(a, mode, stream);
-        case 4: return launch_one<L, 4>(a, mode, stream);
-        case 8: return launch_one<L, 8>(a, mode, stream);
-        default: return launch_one<L, 16>(a, mode, stream);
+        case 1: return launch_one<L, 1>(a, mode, stream, tail_done);
+        case 2: return launch_one<L, 2>(a, mode, stream, tail_done);
+        case 4: return launch_one<L, 4>(a, mode, stream, tail_done);
+        case 8: return launch_one<L, 8>(a, mode, stream, tail_done);
+        default: return launch_one<L, 16>(a, mode, stream, tail_done);
     }
 }
 

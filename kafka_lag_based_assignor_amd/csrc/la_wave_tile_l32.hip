@@ -2,5 +2,7 @@
 #include "la_wave_tile_impl.h"
 
 namespace la {
-hipError_t wave_tile_launch_l32(int e, const TileArgs& a, int mode, hipStream_t stream) { return launch_l<32>(e, a, mode, stream); }
+hipError_t wave_tile_launch_l32(int e, const TileArgs& a, int mode, hipStream_t stream, bool* tail_done) {
+    return launch_l<32>(e, a, mode, stream, tail_done);
+}
 }  // namespace la
