@@ -54,8 +54,8 @@
  *
  * Threading: a la_ctx is single-threaded for its CALLER (one per assignor instance, like
  * the reference's own non-thread-safe state, Main.java:89); inside a host-buffer call the
- * library runs one short-lived host thread per lane of every shard and joins them before
- * it returns.  No global mutable state.
+ * library runs one host thread per lane of every shard (threads of the context, parked between calls; since ABI 0.4.0 -- spawned and
+ * joined per call before) and returns when they are done.  No global mutable state.
  * Errors: every function returns LA_OK or a negative code and never throws or aborts;
  * la_last_error() gives the text.  There is NO CPU fallback in this library: without a
  * usable gfx950 device la_create fails and the caller (the Java host) decides.
@@ -186,7 +186,7 @@ int la_last_shard_bounds(const la_ctx *ctx, int32_t *bounds, int32_t capacity);
 /* How the last la_assign_batch / la_assign_batch_lags call moved its data (diagnostics, tests):
  *   LA_PIPELINE_ZERO_COPY the call a real rebalance is: kernels read and write host memory in place, no copy, no stream wait
  *   LA_PIPELINE_ONE_COPY  a small batch: one H2D and one D2H of a staging buffer
- *   LA_PIPELINE_LANES     chunks over the shard's lanes, one short-lived host thread per lane (pageable caller arrays:
+ *   LA_PIPELINE_LANES     chunks over the shard's lanes, one host thread of the context per lane (pageable caller arrays:
  *                         their copies block the issuing thread)
  *   LA_PIPELINE_STREAMS   every array of the call is pinned but not device-mapped (hipHostRegister without the mapped flag;
  *                         LA_NO_MAPPED_PIPELINE=1): no threads; all H2D copies in order on one stream, kernels on a second, D2H

@@ -10,7 +10,7 @@ sys.path.insert(0, ROOT)
 from kafka_lag_based_assignor_amd import _native as N, synth
 from oracle import oracle
 
-PIPE = {0: "one copy", 1: "lanes", 2: "streams", 3: "zero copy"}
+PIPE = {0: "one copy", 1: "lanes", 2: "streams", 3: "zero copy", 4: "mapped"}
 
 
 def med(f, reps):
@@ -46,9 +46,35 @@ def main():
             e = oracle.assign_flat(w.part_off, w.partition_id, lag, w.cons_off, w.cons_rank)
             return e, np.argsort(e[1], kind="stable")
         t_cpu, _ = med(cpu, max(5, reps // 10))
+        # the same calls on pinned arrays from la_host_alloc -- what the Java host's direct ByteBuffers are made of -- with the
+        # marshaller's bounds hinted before every call (la_hint_next_call), results into pinned arrays as well
+        pa = [x if isinstance(x, int) else ctx.host_alloc(x.shape, x.dtype) for x in a]
+        for dst, src in zip(pa, a):
+            if not isinstance(src, int):
+                dst[...] = src
+        pout = tuple(ctx.host_alloc(o.shape, o.dtype) for o in out)
+        gout = (ctx.host_alloc((c + 1,), np.int64), ctx.host_alloc((w.n_partitions,), np.int32), ctx.host_alloc((w.n_partitions,), np.int32))
+        hb = N.offset_bounds(w.begin, w.end, w.committed, w.partition_id)
+
+        def pinned():
+            ctx.hint_next_call(hb)
+            return ctx.assign_batch(*pa, out=pout)
+
+        def pinned_grouped():
+            ctx.hint_next_call(hb)
+            ctx.assign_batch(*pa, keep_on_device=True)
+            return ctx.group_last_by_member(w.n_partitions, c, out=gout)
+        for _ in range(5):
+            pinned()
+        t_pin, got_p = med(pinned, reps)
+        pipe_p, launches_p = ctx.last_pipeline(), ctx.last_launches()
+        t_pin_g, got_pg = med(pinned_grouped, reps // 3)
+        same = same and all(np.array_equal(x, y) for x, y in zip(got_p, out)) and all(np.array_equal(x, y) for x, y in zip(got_pg, ref))
         print("%6d topics x %4d partitions x %3d consumers (%8d partitions) [%s]: assign %.1f us; assign + group_last %.1f us; "
-              "assign_batch_grouped %.1f us (sparse begin %.1f us; same lists: %s); C oracle + sort by member on one core %.1f us"
-              % (t, p, c, w.n_partitions, PIPE.get(pipe, pipe), t_assign, t_two, t_grouped, t_sparse, same, t_cpu))
+              "assign_batch_grouped %.1f us (sparse begin %.1f us; same lists: %s); pinned arrays [%s, %d launches]: assign %.1f us, "
+              "assign + group_last %.1f us; C oracle + sort by member on one core %.1f us"
+              % (t, p, c, w.n_partitions, PIPE.get(pipe, pipe), t_assign, t_two, t_grouped, t_sparse, same, PIPE.get(pipe_p, pipe_p),
+                 launches_p, t_pin, t_pin_g, t_cpu))
     ctx.close()
 
 
