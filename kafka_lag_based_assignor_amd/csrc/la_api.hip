@@ -727,6 +727,7 @@ void plan_ranges(const int64_t* po, int32_t t_begin, int32_t t_end, int parts, i
 constexpr int kMaxShards = 64;
 constexpr int64_t kMinShardPartitions = 1 << 16;   // below this a second device costs more than it saves
 constexpr int64_t kMinChunkPartitions = 1 << 19;   // a chunk's copies must be long enough to hide a kernel
+constexpr int64_t kMidChunkPartitions = 1 << 17;   // pageable arrays: from two such chunks on, a mid-size shard runs on two lanes
 constexpr int kMaxChunks = 64;
 
 // One host-buffer assign call (all pointers are the caller's host arrays).
@@ -834,7 +835,12 @@ int prepare_shard(la_ctx* ctx, const HostCall& c, Shard& sh, ShardPlan& sp) {
         //  first byte moves, whatever they carry)
         if (ctx->chunk_partitions <= 0 && ctx->last_pipeline == 2)
             target = ((int64_t)28 << 20) / (c.lag ? 12 : (c.use_begin && !c.sparse ? 28 : 20));
-        const int64_t want = (sp.n + target - 1) / target;
+        int64_t want = (sp.n + target - 1) / target;
+        // pageable arrays, a mid-size shard (one chunk by the rule above): every copy of a pageable array costs its issuing thread
+        // ~25 us before the first byte moves, whatever it carries, and a chunk is ten of them -- two lanes side by side still
+        // halve the bytes behind each (256 000 partitions: 386 -> 326 us), more chunks than that lose (4: 421 us, 8: 501;
+        // profiles/r05_b_latency_chunks.txt).  The lanes' threads are parked in the context, so the second one costs a wake-up.
+        if (ctx->chunk_partitions <= 0 && ctx->last_pipeline == 1 && want == 1 && sp.n >= 2 * kMidChunkPartitions) want = 2;
         n_chunks = (int)(want < 1 ? 1 : (want > kMaxChunks ? kMaxChunks : want));
         if (n_chunks > Ts) n_chunks = Ts > 0 ? Ts : 1;
     }

@@ -25,6 +25,7 @@
 #include "la_device.h"
 #include "la_kernels.h"
 #include "la_sort64.h"
+#include "la_sort32.h"
 
 namespace la {
 
@@ -412,6 +413,109 @@ __device__ __forceinline__ void greedy_one_wave_packed(const BlockArgs& a, const
         for (int r = 0; r < EC; ++r) {
             const uint64_t v = p64_value(bin[r]);
             if (v != kRoundSentinel) a.out_total[c0 + ((uint32_t)v & idx_mask)] = (int64_t)(v >> idx_bits);
+        }
+    }
+}
+
+// ---- greedy rounds for 65 .. 256 consumers on ONE wavefront, the bins ordered through 32-bit keys -----------------------------
+// The chain of ceil(P / C) dependent rounds is what a single-topic call waits for (BASELINE config 2: 10 000 x 128, 79 rounds),
+// and a round of the forms above is a full network over 64-bit bins: 28 steps x ~8 issue slots for 128 bins, on two wavefronts
+// with an LDS exchange and two barriers, 0.93 us.  Here the bins do not move at all:
+//   * totals live in LDS by consumer position (s_tot[e]); what is sorted is one 32-bit key per bin,
+//         key = (((total - base) >> drop) << idx_bits) | e,
+//     through the 2-VALU steps of la_sort32.h (a DPP move + v_med3_u32), EC keys per lane;
+//   * sorted position s then reads its bin's total, adds the lag of the round's s-th partition (Main.java:265), writes it back,
+//     leaves the winner's position e in the low word of the partition's slot (member ranks and the global stores are the
+//     workgroup's business after the last round, coalesced) and forms the bin's next key.
+// Why 32 bits are enough.  Lags are non-negative here (the packed condition), and the round form gives
+//     spread after a round <= max(spread before, spread of the round's lags) <= the largest lag          (t asc + l desc)
+// so with base = the smallest total BEFORE the round's adds (sorted position 0: wavefront-uniform) every new total lies in
+// [base, base + 2 * lmax): lag_bits + 1 bits, of which the key keeps the top 31 - idx_bits.  The truncation is monotone: when no
+// two neighbours of the sorted keys share their truncated total, the order IS the order of (total, e) -- (assigned lag, memberId)
+// of Main.java:253-259.  When some do (ties of the full totals included) and bits were dropped, that one round is ordered again
+// by the exact 64-bit network on (total << idx_bits) | e; with drop == 0 the key is exact and e breaks the ties as the reference
+// does.  Uniform 40-bit lags over 128 bins: a shared truncated total about once in 4 000 rounds.
+template <int EC>
+__device__ __forceinline__ void greedy_one_wave_key32(const BlockArgs& a, uint64_t* s_key, uint64_t* s_tot, int64_t c0, int P, int C,
+                                                      int idx_bits, int lag_bits, int lane) {
+    constexpr int kBins = kWave * EC;
+    const uint32_t idx_mask = (1u << idx_bits) - 1;
+    const int keep = 31 - idx_bits;
+    const int drop = lag_bits + 1 > keep ? lag_bits + 1 - keep : 0;                    // wavefront-uniform
+    const int rounds = (P + C - 1) / C;
+    uint32_t key[EC];
+#pragma unroll
+    for (int r = 0; r < EC; ++r) {
+        const int e = lane * EC + r;
+        key[r] = e < C ? (uint32_t)e : 0xFFFFFFFFu;                                    // round 0: totals 0, positions ascending
+        s_tot[e] = 0;
+    }
+    if (lane == 0) s_tot[kBins] = 0;                                                   // where the sentinels' traffic goes
+    wave_lds_fence();
+    uint64_t lag[EC];
+#pragma unroll
+    for (int r = 0; r < EC; ++r) {
+        const int s = lane * EC + r;
+        lag[r] = s_key[(s < C && s < P) ? s : P] ^ kLagKeyFlip;                        // s_key[P] holds "lag 0" (see the caller)
+    }
+    for (int q = 0; q < rounds; ++q) {
+        uint64_t next[EC];
+#pragma unroll
+        for (int r = 0; r < EC; ++r) {                                                 // next round's lags: off the chain
+            const int s = lane * EC + r, g = (q + 1) * C + s;
+            next[r] = s_key[(s < C && g < P) ? g : P] ^ kLagKeyFlip;
+        }
+        if (q > 0) bitonic_sort_tile_u32<kWave, EC>(key);
+        uint32_t e[EC];
+        uint64_t tot[EC];
+#pragma unroll
+        for (int r = 0; r < EC; ++r) {
+            e[r] = key[r] == 0xFFFFFFFFu ? (uint32_t)kBins : (key[r] & idx_mask);
+            tot[r] = s_tot[e[r]];
+        }
+        if (q > 0 && drop > 0) {
+            // neighbours that share their truncated total: the keys cannot tell which of the two bins is smaller
+            bool tie = false;
+#pragma unroll
+            for (int r = 0; r + 1 < EC; ++r) tie |= key[r + 1] != 0xFFFFFFFFu && ((key[r] ^ key[r + 1]) >> idx_bits) == 0;
+            asm volatile("s_nop 1" : "+v"(key[0]));                    // (written by the network's last block: a DPP read follows)
+            const uint32_t up = (uint32_t)__builtin_amdgcn_update_dpp((int)0xFFFFFFFFu, (int)key[0], 0x130, 0xF, 0xF, false);   // wave_shl:1
+            tie |= lane != kWave - 1 && up != 0xFFFFFFFFu && ((key[EC - 1] ^ up) >> idx_bits) == 0;
+            if (__builtin_amdgcn_ballot_w64(tie) != 0) {                               // rare: this round by the exact network
+                P64 bin[EC];
+#pragma unroll
+                for (int r = 0; r < EC; ++r) bin[r] = p64_from(e[r] == (uint32_t)kBins ? kRoundSentinel : ((tot[r] << idx_bits) | e[r]));
+#pragma unroll
+                for (int r = 0; r < EC; ++r) asm volatile("s_nop 1" : "+v"(bin[r].lo), "+v"(bin[r].hi));
+                bitonic_sort_tile_p64<kWave, EC, true>(bin);
+#pragma unroll
+                for (int r = 0; r < EC; ++r) {
+                    const uint64_t v = p64_value(bin[r]);
+                    e[r] = v == kRoundSentinel ? (uint32_t)kBins : ((uint32_t)v & idx_mask);
+                    tot[r] = v == kRoundSentinel ? 0 : (v >> idx_bits);
+                }
+            }
+        }
+        // the smallest total before the adds: sorted position 0 (lane 0, register 0)
+        const uint64_t base = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(tot[0] >> 32)) << 32) |
+                              (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)tot[0]);
+#pragma unroll
+        for (int r = 0; r < EC; ++r) {
+            const int s = lane * EC + r, g = q * C + s;
+            const bool live = e[r] != (uint32_t)kBins;
+            const uint64_t nt = tot[r] + lag[r];                                       // Main.java:265 (lag 0 past the topic's end)
+            s_tot[e[r]] = live ? nt : 0;
+            if (s < C && g < P) reinterpret_cast<uint32_t*>(s_key + g)[0] = e[r];      // the winner, where its lag was
+            key[r] = live ? ((uint32_t)((nt - base) >> drop) << idx_bits) | e[r] : 0xFFFFFFFFu;
+            lag[r] = next[r];
+        }
+        wave_lds_fence();
+    }
+    if (a.out_total) {
+#pragma unroll
+        for (int r = 0; r < EC; ++r) {
+            const int e = lane * EC + r;
+            if (e < C) a.out_total[c0 + e] = (int64_t)s_tot[e];
         }
     }
 }
@@ -814,6 +918,22 @@ __global__ __launch_bounds__(1024) void block_topic_kernel(BlockArgs a) {
         const int lag_bits = lmax > 0 ? 64 - __builtin_clzll((unsigned long long)lmax) : 0;
         const int round_bits = 32 - __builtin_clz((unsigned)((P + C - 1) / C) | 1u);
         const bool packed = lmin >= 0 && lag_bits + round_bits + idx_bits <= 62;
+        if (packed && n_c > kWave && a.key32_greedy) {
+            // 128 / 256 bins: ONE wavefront, the bins stay where they are (LDS), the order comes from 32-bit keys
+            if (tid == 0) s_key[P] = kLagKeyFlip;                       // "lag 0" for idle slots and rounds past the topic
+            __syncthreads();
+            if (tid < kWave) {
+                if (n_c == 2 * kWave) greedy_one_wave_key32<2>(a, s_key, s_tot, c0, P, C, idx_bits, lag_bits, tid);
+                else greedy_one_wave_key32<4>(a, s_key, s_tot, c0, P, C, idx_bits, lag_bits, tid);
+            }
+            __syncthreads();
+            LA_BCLK(4);
+            // the winners (consumer positions, low word of each slot) -> member ranks, every wavefront, coalesced
+            const uint32_t* won = reinterpret_cast<const uint32_t*>(s_key);
+            for (int i = tid; i < P; i += nt) a.out_rank[p0 + i] = s_rank[won[2 * i]];
+            LA_BCLK(5);
+            return;
+        }
         if (packed && n_c > kWave && n_c <= nt && (n_c > 2 * kWave || gridDim.x <= 512)) {
             // 128 / 256 bins: one per lane on 2 / 4 wavefronts (an exchange through LDS per merge level) instead of 2 / 4 per
             // lane on one; the other wavefronts leave (greedy_multi_wave_packed), so a round's barriers are among those 2 / 4.
@@ -928,6 +1048,9 @@ hipError_t block_launch(BlockArgs a, int cls, hipStream_t stream) {
     // (3: every topic whatever its size -- the test hook that drives small topics through the digits)
     static const int radix_mode = [] { const char* e = getenv("LA_BLOCK_RADIX"); return e ? atoi(e) : 2; }();
     a.radix_sort = (large_atomic_rank_supported() && (radix_mode >= 2 || (radix_mode == 1 && cls >= 2))) ? (radix_mode >= 3 ? 2 : 1) : 0;
+    // LA_BLOCK_KEY32=0: the 65 .. 256-bin greedy of rounds 3-4 (64-bit bins through the networks) instead of the 32-bit-key form (A/B, tests)
+    static const int key32_mode = [] { const char* e = getenv("LA_BLOCK_KEY32"); return e ? atoi(e) : 1; }();
+    a.key32_greedy = key32_mode;
     static PerDeviceOnce lds_opt_in;
     hipError_t err = lds_opt_in.run([] {
         hipError_t e2 = hipFuncSetAttribute((const void*)block_topic_kernel<8>,

@@ -38,10 +38,12 @@ constexpr int kTailGroupM = 2048;        // groups (members + 2) the tile kernel
 // cursor atomics go out back to back (LDS executes one wavefront's operations in order), so the ordered hand-over -- ~0.4 us per
 // turn -- is paid once per kSub * 64 entries.  kSub = 1 is what runs (every wavefront gets work); 4 was measured 2-3 us slower at
 // every size the kernel is used for (lab builds with -DLA_GROUP_SUB=4).
+// topic_of (may be null): the topic of every entry, already worked out (LDS); otherwise a binary search over part_off per entry.
 template <int kSub, int NT>
 __device__ __forceinline__ void group_small_place(int n, uint32_t G, int64_t n_topics, const int64_t* part_off, const int32_t* out_partition,
                                                   const int32_t* member_rank, int32_t* grouped_topic, int32_t* grouped_partition,
-                                                  int32_t* grouped_entry, uint32_t* start, uint32_t* turn_p, int lane, int wave) {
+                                                  int32_t* grouped_entry, uint32_t* start, uint32_t* turn_p, int lane, int wave,
+                                                  const int32_t* topic_of = nullptr) {
     uint32_t& turn = *turn_p;
     const uint64_t below = ((uint64_t)1 << lane) - 1;
     const int n_turns = (n + kSub * kWave - 1) / (kSub * kWave);
@@ -75,7 +77,9 @@ __device__ __forceinline__ void group_small_place(int n, uint32_t G, int64_t n_t
             cnt[u] = (uint32_t)__popcll(peers);
             leader[u] = __ffsll((unsigned long long)peers) - 1;
             topic[u] = 0;
-            if (valid[u] && grouped_topic) {
+            if (valid[u] && grouped_topic && topic_of) {
+                topic[u] = topic_of[(turn_i * kSub + u) * kWave + lane];
+            } else if (valid[u] && grouped_topic) {
                 const int64_t i = (int64_t)(turn_i * kSub + u) * kWave + lane;
                 int64_t lo = 0, hi = n_topics;                         // largest t with part_off[t] <= i
                 while (hi - lo > 1) {
@@ -151,6 +155,91 @@ __device__ __forceinline__ void group_small_body(int n, int32_t n_members, int64
     __syncthreads();                                                    // (the cursors move from here on)
     group_small_place<kSub, NT>(n, G, n_topics, part_off, out_partition, member_rank, grouped_topic, grouped_partition, grouped_entry,
                                 start, turn, lane, wave);
+}
+
+// ---- the same with the inputs staged in LDS first ---------------------------------------------------------------------------
+// The chunks of the placement above are DEPENDENT round trips per wavefront: the loads of a chunk's ranks and partition ids
+// (one trip to HBM each) and a binary search over part_off per entry -- log2(T) trips, to HOST memory over PCIe (~1.5 us each)
+// in a zero-copy call -- eight chunks deep per wavefront in the 256-thread tail: 20 us for 2 000 entries.  Here every global
+// input is read ONCE, coalesced, all loads of a thread issued back to back: ranks and ids into LDS, and the topic of every
+// entry from ONE pass over part_off -- +1 at every topic's first position, an inclusive scan (topic of entry i = the number of
+// topic starts at or before i, minus one: the largest t with part_off[t] <= i, empty topics included).  The placement then
+// runs on LDS.  s_rank / s_part / s_topic: [cap] words each, n <= cap.
+template <int NT, int M>
+__device__ __forceinline__ void group_small_body_staged(int n, int32_t n_members, int64_t n_topics, const int64_t* part_off,
+                                                        const int32_t* out_partition, const int32_t* member_rank, int64_t* member_off,
+                                                        int32_t* grouped_topic, int32_t* grouped_partition, int32_t* grouped_entry,
+                                                        uint32_t* start, uint32_t* wsum, uint32_t* turn, int32_t* s_rank,
+                                                        int32_t* s_part, int32_t* s_topic) {
+    static_assert(M % NT == 0 && NT % kWave == 0, "M counters over NT threads");
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t G = (uint32_t)n_members + 1;
+    for (int k = tid; k < M; k += NT) start[k] = 0;
+    for (int i = tid; i < n; i += NT) s_topic[i] = 0;
+    if (tid == 0) *turn = 0;
+    __syncthreads();
+    for (int i = tid; i < n; i += NT) {                               // (independent loads: they go out back to back)
+        s_rank[i] = member_rank[i];
+        s_part[i] = out_partition ? out_partition[i] : 0;
+    }
+    if (grouped_topic)
+        for (int64_t t = tid; t < n_topics; t += NT) {                // topic t starts at part_off[t]; one at or beyond n holds nothing
+            const int64_t at = part_off[t];
+            if (at >= 0 && at < n) atomicAdd((uint32_t*)&s_topic[at], 1u);
+        }
+    __syncthreads();
+    for (int i = tid; i < n; i += NT) {
+        uint32_t gi = (uint32_t)(s_rank[i] + 1);
+        gi = gi < G ? gi : G;
+        atomicAdd(&start[gi], 1u);
+    }
+    // inclusive scan of the topic starts over the n entries, in blocks of NT * PERT consecutive entries per pass
+    if (grouped_topic) {
+        uint32_t carry = 0;
+        for (int base = 0; base < n; base += NT) {
+            const int i = base + tid;
+            const uint32_t v = i < n ? (uint32_t)s_topic[i] : 0u;
+            uint32_t incl = v;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const uint32_t y = __shfl_up(incl, o);
+                if (lane >= o) incl += y;
+            }
+            if (lane == 63) wsum[wave] = incl;
+            __syncthreads();
+            uint32_t before = carry;
+            for (int w = 0; w < wave; ++w) before += wsum[w];
+            uint32_t all = 0;
+            for (int w = 0; w < NT / kWave; ++w) all += wsum[w];
+            if (i < n) s_topic[i] = (int32_t)(before + incl) - 1;
+            carry += all;
+            __syncthreads();
+        }
+    } else {
+        __syncthreads();
+    }
+    // exclusive scan over the M counts: M / NT per thread, a wavefront scan, the wavefronts' sums
+    constexpr int PER = M / NT;
+    uint32_t c[PER], run = 0;
+#pragma unroll
+    for (int r = 0; r < PER; ++r) { c[r] = start[PER * tid + r]; run += c[r]; }
+    uint32_t incl = run;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t y = __shfl_up(incl, o);
+        if (lane >= o) incl += y;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    uint32_t base = incl - run;
+    for (int w = 0; w < wave; ++w) base += wsum[w];
+#pragma unroll
+    for (int r = 0; r < PER; ++r) { start[PER * tid + r] = base; base += c[r]; }
+    __syncthreads();
+    for (int k = tid; k <= n_members; k += NT) member_off[k] = (int64_t)start[k + 1];
+    __syncthreads();                                                    // (the cursors move from here on)
+    group_small_place<1, NT>(n, G, n_topics, part_off, s_part, s_rank, grouped_topic, grouped_partition, grouped_entry, start, turn,
+                             lane, wave, s_topic);
 }
 
 }  // namespace la

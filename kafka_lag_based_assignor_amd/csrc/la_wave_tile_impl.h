@@ -650,6 +650,7 @@ __device__ __forceinline__ void packed_tile(const TileArgs& a, const TopicDescT<
 // workgroups' results (one workgroup's job below kSmallGroupN entries) and stores `done | status` into the host's word.
 __device__ __forceinline__ void tile_tail(const TileTail& t, const uint32_t* status) {
     __shared__ uint32_t s_start[kTailGroupM];
+    __shared__ int32_t s_in[3 * kSmallGroupN];                // ranks, ids, topics of the entries (group_small_body_staged)
     __shared__ uint32_t s_wsum[LA_WPB];
     __shared__ uint32_t s_turn, s_last;
     __threadfence_system();                                   // this thread's result stores (to HBM or into the host's arrays)
@@ -663,8 +664,9 @@ __device__ __forceinline__ void tile_tail(const TileTail& t, const uint32_t* sta
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");        // the other workgroups' results
     if (threadIdx.x == 0) __hip_atomic_store(t.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // the next call's count
     if (t.member_off)
-        group_small_body<kWave * LA_WPB, kTailGroupM>(t.n, t.n_members, t.n_topics, t.part_off, t.out_pid, t.out_rank, t.member_off,
-                                                      t.grouped_topic, t.grouped_partition, nullptr, s_start, s_wsum, &s_turn);
+        group_small_body_staged<kWave * LA_WPB, kTailGroupM>(t.n, t.n_members, t.n_topics, t.part_off, t.out_pid, t.out_rank,
+                                                             t.member_off, t.grouped_topic, t.grouped_partition, nullptr, s_start,
+                                                             s_wsum, &s_turn, s_in, s_in + kSmallGroupN, s_in + 2 * kSmallGroupN);
     __threadfence_system();
     __syncthreads();
     if (threadIdx.x == 0) {

@@ -154,3 +154,80 @@ def test_lsd_passes_with_counter_ranks_are_a_stable_sort(kind, group):
     low = keys & np.uint64((1 << 48) - 1)
     order = np.argsort(low, kind="stable")
     assert np.array_equal(cur_t, tag[order])
+
+
+# ---- round 5: the block path's greedy through 32-bit keys (la_block.hip, greedy_one_wave_key32) -----------------------------------
+def _key32_greedy_model(lags_sorted_desc, C, n_c):
+    """Numpy restatement of greedy_one_wave_key32: bins stay in place, one 32-bit key per bin
+    ((total - base) >> drop) << idx_bits | e with base = the smallest total before the round's adds; a round whose sorted keys
+    hold two neighbours with the same truncated total (and drop > 0) is ordered again exactly.  Returns (winner per sorted
+    partition, totals, number of exact re-orderings, largest key field seen)."""
+    P = len(lags_sorted_desc)
+    idx_bits = int(np.log2(n_c))                                # n_c: the power of two the bins' network spans
+    lmax = int(lags_sorted_desc[0]) if P else 0
+    lag_bits = lmax.bit_length()
+    keep = 31 - idx_bits
+    drop = max(0, lag_bits + 1 - keep)
+    tot = [0] * C
+    order = list(range(C))                                      # round 0: positions ascending
+    won = [0] * P
+    redone, field_max = 0, 0
+    keys = None
+    for q in range((P + C - 1) // C):
+        if q > 0:
+            order = [k & ((1 << idx_bits) - 1) for k in sorted(keys)]
+            if drop > 0 and any((keys_sorted_a >> idx_bits) == (keys_sorted_b >> idx_bits)
+                                for keys_sorted_a, keys_sorted_b in zip(sorted(keys)[:-1], sorted(keys)[1:])):
+                order = sorted(range(C), key=lambda e: (tot[e], e))
+                redone += 1
+        base = tot[order[0]]
+        assert base == min(tot)
+        keys = []
+        for s, e in enumerate(order):
+            g = q * C + s
+            if g < P:
+                tot[e] += int(lags_sorted_desc[g])
+                won[g] = e
+            field = (tot[e] - base) >> drop
+            assert 0 <= field < (1 << keep), (field, keep)
+            field_max = max(field_max, field)
+            keys.append((field << idx_bits) | e)
+    return won, tot, redone, field_max
+
+
+@pytest.mark.parametrize("P,C,kind,seed", [(10000, 128, "u40", 1), (3000, 100, "u40", 2), (5000, 256, "pareto", 3), (2000, 70, "zero", 4),
+                                          (4000, 130, "ties", 5), (9000, 200, "u20", 6), (700, 256, "u40", 7), (100, 128, "u40", 8),
+                                          (6000, 128, "u55", 9), (1000, 65, "small", 10)])
+def test_key32_greedy_model_equals_the_literal_oracle(P, C, kind, seed):
+    """The order the 32-bit keys give (with the exact re-ordering of tied rounds) is the reference's (total lag, memberId) order:
+    same winners, same totals as the literal per-step min (oracle/lag_oracle.c) -- and the key field never leaves its bits, the
+    bound the kernel's `drop` rests on (spread of the totals <= the largest lag under the round form)."""
+    from oracle import oracle
+    rng = np.random.default_rng(seed)
+    if kind == "u40":
+        lag = rng.integers(0, 1 << 40, P)
+    elif kind == "u55":
+        lag = rng.integers(0, 1 << 48, P)
+    elif kind == "u20":
+        lag = rng.integers(0, 1 << 20, P)
+    elif kind == "small":
+        lag = rng.integers(0, 50, P)
+    elif kind == "zero":
+        lag = np.zeros(P, np.int64)
+    elif kind == "ties":
+        lag = rng.integers(0, 7, P) * (1 << 30)
+    else:
+        lag = np.floor(np.minimum(float(1 << 40), 1000.0 * (1.0 - rng.random(P)) ** (-1.0 / 1.5))).astype(np.int64)
+    lag = np.asarray(lag, np.int64)
+    pid = rng.permutation(P).astype(np.int32)
+    part_off, cons_off = np.array([0, P], np.int64), np.array([0, C], np.int64)
+    ranks = np.arange(C, dtype=np.int32)
+    e_pid, e_rank, e_tot = oracle.assign_flat(part_off, pid, lag, cons_off, ranks)
+    lag_of = dict(zip(pid.tolist(), lag.tolist()))
+    sorted_lags = np.array([lag_of[p] for p in e_pid.tolist()], np.int64)      # the oracle's own sort: (lag desc, id asc)
+    n_c = 1 << max(0, (C - 1).bit_length())
+    won, tot, redone, field_max = _key32_greedy_model(sorted_lags, C, n_c)
+    np.testing.assert_array_equal(np.array(won, np.int32), e_rank)
+    np.testing.assert_array_equal(np.array(tot, np.int64), e_tot)
+    if kind in ("zero", "small"):
+        assert redone == 0                                                      # drop == 0: the key is exact, ties included

@@ -246,3 +246,60 @@ print("ok")
     out = subprocess.run([sys.executable, "-c", code % (ROOT, os.path.join(ROOT, "tests"))], env=env, capture_output=True,
                          text=True, timeout=600)
     assert out.returncode == 0 and "ok" in out.stdout, (out.stdout[-1500:], out.stderr[-1500:])
+
+
+# ---- block path: 65 .. 256 consumers, the greedy's bins ordered through 32-bit keys -------------------------
+def _one_topic(P, C, lag, seed):
+    rng = np.random.default_rng(seed)
+    pid = rng.permutation(P).astype(np.int32)
+    ranks = np.sort(rng.choice(3 * C + 5, C, replace=False)).astype(np.int32)
+    lag = np.asarray(lag, np.int64)
+    return synth.Workload("k32", 1, np.array([0, P], np.int64), pid, np.zeros(P, np.int64), lag.copy(), np.zeros(P, np.int64), lag,
+                          np.array([0, C], np.int64), ranks, P, C)
+
+
+@pytest.mark.parametrize("P,C", [(10000, 128), (1100, 65), (2049, 100), (4097, 129), (8193, 200), (16384, 256), (300, 70), (5000, 255)])
+@pytest.mark.parametrize("kind", ["u40", "bigties", "zero", "pareto", "u20", "nearties"])
+def test_block_greedy_through_32_bit_keys(ctx, P, C, kind):
+    """greedy_one_wave_key32 against the literal oracle: uniform 40-bit lags (bits dropped from the key, shared truncated totals
+    rare), many EQUAL large lags (every round meets tied totals with bits dropped: the exact re-ordering runs), lags that differ
+    only below the dropped bits, all-zero and small lags (drop == 0: the key is exact, memberId breaks the ties), a Pareto tail."""
+    import test_round4_gpu as t4
+    rng = np.random.default_rng(P + C)
+    if kind == "u40":
+        lag = rng.integers(0, 1 << 40, P)
+    elif kind == "bigties":
+        lag = (1 << 39) + rng.integers(0, 3, P) * (1 << 20)
+    elif kind == "nearties":
+        lag = (1 << 41) + rng.integers(0, 64, P)
+    elif kind == "zero":
+        lag = np.zeros(P, np.int64)
+    elif kind == "u20":
+        lag = rng.integers(0, 1 << 20, P)
+    else:
+        lag = np.floor(np.minimum(float(1 << 40), 1000.0 * (1.0 - rng.random(P)) ** (-1.0 / 1.5))).astype(np.int64)
+    w = _one_topic(P, C, lag, P * 7 + C)
+    exp = oracle.assign_flat(w.part_off, w.partition_id, w.lag, w.cons_off, w.cons_rank)
+    _same3(t4._device_call(ctx, w), exp, "%s %d x %d" % (kind, P, C))
+
+
+def test_block_greedy_forms_agree_in_a_fresh_process():
+    """LA_BLOCK_KEY32=0 (the 64-bit bins through the networks, rounds 3-4) gives what the 32-bit-key form gives."""
+    code = r"""
+import numpy as np, sys
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+from kafka_lag_based_assignor_amd import _native as N
+from oracle import oracle
+import test_round4_gpu as t4, test_round5_gpu as t5
+ctx = N.Context(0)
+rng = np.random.default_rng(3)
+for (P, C) in ((10000, 128), (3000, 200), (16000, 256), (1500, 66)):
+    w = t5._one_topic(P, C, rng.integers(0, 1 << 40, P), P + C)
+    exp = oracle.assign_flat(w.part_off, w.partition_id, w.lag, w.cons_off, w.cons_rank)
+    t4._same3(t4._device_call(ctx, w), exp, what=str((P, C)))
+print("ok")
+"""
+    env = dict(os.environ, LA_BLOCK_KEY32="0")
+    out = subprocess.run([sys.executable, "-c", code % (ROOT, os.path.join(ROOT, "tests"))], env=env, capture_output=True,
+                         text=True, timeout=600)
+    assert out.returncode == 0 and "ok" in out.stdout, (out.stdout[-1500:], out.stderr[-1500:])
