@@ -26,6 +26,7 @@
 #include "la_kernels.h"
 #include "la_sort64.h"
 #include "la_sort32.h"
+#include "la_sort32_net.h"
 
 namespace la {
 
@@ -423,7 +424,10 @@ __device__ __forceinline__ void greedy_one_wave_packed(const BlockArgs& a, const
 // with an LDS exchange and two barriers, 0.93 us.  Here the bins do not move at all:
 //   * totals live in LDS by consumer position (s_tot[e]); what is sorted is one 32-bit key per bin,
 //         key = (((total - base) >> drop) << idx_bits) | e,
-//     through the 2-VALU steps of la_sort32.h (a DPP move + v_med3_u32), EC keys per lane;
+//     through 2-VALU steps (a DPP move + v_med3_u32), EC keys per lane, the whole network ONE generated asm statement
+//     (la_sort32_net.h, tools/gen_sort32_net.py: 155 issue slots for 128 keys, 313 for 256 -- the same sort strung together
+//     from la_sort32.h's per-step blocks came out at ~300 / ~450 with the pads each block carries for its worst case, and the
+//     chain of rounds of a lone wavefront is a count of issue slots);
 //   * sorted position s then reads its bin's total, adds the lag of the round's s-th partition (Main.java:265), writes it back,
 //     leaves the winner's position e in the low word of the partition's slot (member ranks and the global stores are the
 //     workgroup's business after the last round, coalesced) and forms the bin's next key.
@@ -444,6 +448,8 @@ __device__ __forceinline__ void greedy_one_wave_key32(const BlockArgs& a, uint64
     const int drop = lag_bits + 1 > keep ? lag_bits + 1 - keep : 0;                    // wavefront-uniform
     const int rounds = (P + C - 1) / C;
     uint32_t key[EC];
+    uint32_t dirs[6];
+    sort_net_dirs(lane, dirs);
 #pragma unroll
     for (int r = 0; r < EC; ++r) {
         const int e = lane * EC + r;
@@ -465,7 +471,10 @@ __device__ __forceinline__ void greedy_one_wave_key32(const BlockArgs& a, uint64
             const int s = lane * EC + r, g = (q + 1) * C + s;
             next[r] = s_key[(s < C && g < P) ? g : P] ^ kLagKeyFlip;
         }
-        if (q > 0) bitonic_sort_tile_u32<kWave, EC>(key);
+        if (q > 0) {
+            if constexpr (EC == 2) sort_net_u32_e2(key, dirs);
+            else sort_net_u32_e4(key, dirs);
+        }
         uint32_t e[EC];
         uint64_t tot[EC];
 #pragma unroll

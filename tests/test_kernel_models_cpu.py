@@ -231,3 +231,51 @@ def test_key32_greedy_model_equals_the_literal_oracle(P, C, kind, seed):
     np.testing.assert_array_equal(np.array(tot, np.int64), e_tot)
     if kind in ("zero", "small"):
         assert redone == 0                                                      # drop == 0: the key is exact, ties included
+
+
+def test_generated_sort_networks_sort_in_the_lane_level_simulator_and_are_current():
+    """la_sort32_net.h is generated (tools/gen_sort32_net.py): the committed header is what the generator emits today, and the
+    instruction streams -- DPP moves, v_permlane*_swap, v_med3_u32 with data-driven direction -- sort 64 / 128 / 256 keys in a
+    lane-level simulator of exactly those instructions (random keys, heavy duplicates, all-ones sentinels, reversed input)."""
+    import importlib.util
+    import os
+    import random
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("gen_sort32_net", os.path.join(root, "tools", "gen_sort32_net.py"))
+    g = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(g)
+    header = os.path.join(root, "kafka_lag_based_assignor_amd", "csrc", "la_sort32_net.h")
+    before = open(header).read()
+    subprocess.check_call([sys.executable, os.path.join(root, "tools", "gen_sort32_net.py")], stdout=subprocess.DEVNULL)
+    assert open(header).read() == before, "la_sort32_net.h is stale: run tools/gen_sort32_net.py"
+    random.seed(7)
+    for E in (1, 2, 4):
+        ins = g.gen(E)
+        n = 64 * E
+        for trial in range(24):
+            kind = trial % 4
+            if kind == 0:
+                keys = [random.getrandbits(32) for _ in range(n)]
+            elif kind == 1:
+                keys = [random.randrange(5) for _ in range(n)]
+            elif kind == 2:
+                live = random.randrange(n + 1)
+                keys = [random.getrandbits(31) for _ in range(live)] + [0xFFFFFFFF] * (n - live)
+                random.shuffle(keys)
+            else:
+                keys = list(range(n))[::-1]
+            assert g.simulate(E, keys, ins) == sorted(keys), (E, trial)
+        # the hazard rule the scheduler keeps: >= 2 issue slots between a VALU write of a register and a DPP / permlane read of it
+        last = {}
+        for i, text in enumerate(ins):
+            ops = [t.rstrip(",") for t in text.split() if t.startswith("%[")]
+            if text.startswith(("v_mov_b32_dpp", "v_permlane")):
+                reads = ops[1:] if text.startswith("v_mov_b32_dpp") else ops
+                for r in reads:
+                    assert r not in last or i - last[r] - 1 + sum(
+                        int(x.split()[1]) for x in ins[last[r] + 1:i] if x.startswith("s_nop")) >= 2, (E, i, text)
+            if not text.startswith("s_nop"):
+                for r in (ops[:2] if text.startswith("v_permlane") else ops[:1]):
+                    last[r] = i
