@@ -422,110 +422,158 @@ __device__ __forceinline__ void greedy_one_wave_packed(const BlockArgs& a, const
 // The chain of ceil(P / C) dependent rounds is what a single-topic call waits for (BASELINE config 2: 10 000 x 128, 79 rounds),
 // and a round of the forms above is a full network over 64-bit bins: 28 steps x ~8 issue slots for 128 bins, on two wavefronts
 // with an LDS exchange and two barriers, 0.93 us.  Here the bins do not move at all:
-//   * totals live in LDS by consumer position (s_tot[e]); what is sorted is one 32-bit key per bin,
-//         key = (((total - base) >> drop) << idx_bits) | e,
-//     through 2-VALU steps (a DPP move + v_med3_u32), EC keys per lane, the whole network ONE generated asm statement
-//     (la_sort32_net.h, tools/gen_sort32_net.py: 155 issue slots for 128 keys, 313 for 256 -- the same sort strung together
-//     from la_sort32.h's per-step blocks came out at ~300 / ~450 with the pads each block carries for its worst case, and the
-//     chain of rounds of a lone wavefront is a count of issue slots);
-//   * sorted position s then reads its bin's total, adds the lag of the round's s-th partition (Main.java:265), writes it back,
-//     leaves the winner's position e in the low word of the partition's slot (member ranks and the global stores are the
-//     workgroup's business after the last round, coalesced) and forms the bin's next key.
-// Why 32 bits are enough.  Lags are non-negative here (the packed condition), and the round form gives
-//     spread after a round <= max(spread before, spread of the round's lags) <= the largest lag          (t asc + l desc)
-// so with base = the smallest total BEFORE the round's adds (sorted position 0: wavefront-uniform) every new total lies in
-// [base, base + 2 * lmax): lag_bits + 1 bits, of which the key keeps the top 31 - idx_bits.  The truncation is monotone: when no
-// two neighbours of the sorted keys share their truncated total, the order IS the order of (total, e) -- (assigned lag, memberId)
-// of Main.java:253-259.  When some do (ties of the full totals included) and bits were dropped, that one round is ordered again
-// by the exact 64-bit network on (total << idx_bits) | e; with drop == 0 the key is exact and e breaks the ties as the reference
-// does.  Uniform 40-bit lags over 128 bins: a shared truncated total about once in 4 000 rounds.
+//   * every bin has a HOME -- consumer position e in register e % EC of lane e / EC -- where its total lives and where its key
+//         key = (((total - floor) >> drop) << idx_bits) | e
+//     is formed; the keys (any order going in) are sorted by ONE generated asm statement of 2-VALU steps (a DPP move +
+//     v_med3_u32; la_sort32_net.h, tools/gen_sort32_net.py: 155 issue slots for 128 keys, 313 for 256 -- strung together from
+//     la_sort32.h's per-step blocks the same sort came out at ~300 / ~450 with the pads each block carries for its worst case,
+//     and the chain of rounds of a lone wavefront is a count of issue slots);
+//   * sorted position i knows which bin stands there (the key's low bits): it hands that bin the lag of the round's i-th
+//     partition through LDS -- a PERMUTATION write (every slot of `hand` written exactly once: idle positions and idle bins
+//     pair up with lag 0), read back linearly by the homes -- and leaves the winner's position in the low word of the
+//     partition's slot (member ranks and the global stores are the workgroup's business after the last round, coalesced);
+//   * home: total += lag (Main.java:265), next key.  (The first form of this function kept the totals in LDS, gathered and
+//     scattered by the sorted positions: two random 64-bit accesses and a read -> add -> write chain per round -- 0.43 us of a
+//     0.71 us round, 1.9 us with the idle bins of a 200-consumer topic all hitting one slot.)
+// Why 32 bits are enough.  Lags are non-negative here (the packed condition), every bin takes exactly one partition per full
+// round, and the rounds are consecutive ranges of the DESCENDING lag list: with floor_q = the sum of the smallest lag of every
+// full round so far (the round's last partition; wavefront-uniform, one broadcast LDS read per round off the chain),
+//     0 <= total_e - floor_q = sum over rounds (lag_e,r - min_r) <= sum over rounds (max_r - min_r) <= lag_first - lag_last
+// i.e. lag_bits bits, of which the key keeps the top 31 - idx_bits.  The truncation is monotone: when no two neighbours of the
+// sorted keys share their truncated total, the order IS the order of (total, e) -- (assigned lag, memberId) of Main.java:253-259.
+// When some do (ties of the full totals included) and bits were dropped, that one round is ordered again by the exact 64-bit
+// network on (total << idx_bits) | e; with drop == 0 the key is exact and e breaks the ties as the reference does.  Uniform
+// 40-bit lags over 128 bins: a shared truncated total about once in 8 000 rounds.
 template <int EC>
-__device__ __forceinline__ void greedy_one_wave_key32(const BlockArgs& a, uint64_t* s_key, uint64_t* s_tot, int64_t c0, int P, int C,
-                                                      int idx_bits, int lag_bits, int lane) {
-    constexpr int kBins = kWave * EC;
+__device__ __forceinline__ void greedy_one_wave_key32(const BlockArgs& a, uint64_t* s_key, uint64_t* hand, uint32_t* scratch, int64_t c0,
+                                                      int P_in, int C_in, int idx_bits_in, int lag_bits_in, int lane) {
+    constexpr uint32_t kIdle = 0x80000000u;                                            // an idle bin's key: | e, above every real key
+    // wavefront-uniform by construction; said so to the compiler (values that came through LDS look divergent to it, and a
+    // "divergent" shift count or loop bound turns into exec-mask branches around every use)
+    const int P = __builtin_amdgcn_readfirstlane(P_in), C = __builtin_amdgcn_readfirstlane(C_in);
+    const int idx_bits = __builtin_amdgcn_readfirstlane(idx_bits_in), lag_bits = __builtin_amdgcn_readfirstlane(lag_bits_in);
     const uint32_t idx_mask = (1u << idx_bits) - 1;
     const int keep = 31 - idx_bits;
-    const int drop = lag_bits + 1 > keep ? lag_bits + 1 - keep : 0;                    // wavefront-uniform
+    const int drop = lag_bits > keep ? lag_bits - keep : 0;
+    const uint32_t tie_lim = 1u << idx_bits;
     const int rounds = (P + C - 1) / C;
-    uint32_t key[EC];
     uint32_t dirs[6];
     sort_net_dirs(lane, dirs);
+    uint32_t key[EC];
+    uint64_t tot[EC];                                                                  // of the bins whose home this lane is
+    bool mine[EC];
 #pragma unroll
     for (int r = 0; r < EC; ++r) {
         const int e = lane * EC + r;
-        key[r] = e < C ? (uint32_t)e : 0xFFFFFFFFu;                                    // round 0: totals 0, positions ascending
-        s_tot[e] = 0;
+        mine[r] = e < C;
+        key[r] = (mine[r] ? 0u : kIdle) | (uint32_t)e;                                 // round 0: totals 0, positions ascending
+        tot[r] = 0;
     }
-    if (lane == 0) s_tot[kBins] = 0;                                                   // where the sentinels' traffic goes
-    wave_lds_fence();
+    uint64_t floor_sum = 0;                                                            // (the same value in every lane)
+    // slot P holds "lag 0" for idle positions and rounds past the topic; the winner words nobody reads go to scratch[i], a
+    // word per position (one shared dummy word would make every idle position of a round hit the same LDS address)
+    char* const key_bytes = reinterpret_cast<char*>(s_key);
     uint64_t lag[EC];
+    uint32_t won_at[EC], idle_at[EC];                                                  // byte offsets from s_key
 #pragma unroll
     for (int r = 0; r < EC; ++r) {
-        const int s = lane * EC + r;
-        lag[r] = s_key[(s < C && s < P) ? s : P] ^ kLagKeyFlip;                        // s_key[P] holds "lag 0" (see the caller)
+        const int i = lane * EC + r;
+        const bool live = i < C && i < P;
+        idle_at[r] = (uint32_t)(reinterpret_cast<char*>(scratch + i) - key_bytes);
+        lag[r] = s_key[live ? i : P] ^ kLagKeyFlip;
+        won_at[r] = live ? (uint32_t)i * 8u : idle_at[r];
     }
+    uint64_t round_min = s_key[C <= P ? C - 1 : P] ^ kLagKeyFlip;                      // a partial round adds nothing to the floor
     for (int q = 0; q < rounds; ++q) {
         uint64_t next[EC];
+        uint32_t next_at[EC];
 #pragma unroll
         for (int r = 0; r < EC; ++r) {                                                 // next round's lags: off the chain
-            const int s = lane * EC + r, g = (q + 1) * C + s;
-            next[r] = s_key[(s < C && g < P) ? g : P] ^ kLagKeyFlip;
+            const int i = lane * EC + r, g = (q + 1) * C + i;
+            const bool live = i < C && g < P;
+            next[r] = s_key[live ? g : P] ^ kLagKeyFlip;
+            next_at[r] = live ? (uint32_t)g * 8u : idle_at[r];
         }
+        const int last_next = (q + 2) * C - 1;
+        const uint64_t next_min = s_key[last_next < P ? last_next : P] ^ kLagKeyFlip;  // (slot P: "lag 0"; one broadcast read)
+#ifdef LA_BLOCK_CLOCKS
+        const unsigned long long kclk0 = wall_clock64();
+#endif
         if (q > 0) {
             if constexpr (EC == 2) sort_net_u32_e2(key, dirs);
             else sort_net_u32_e4(key, dirs);
         }
+#ifdef LA_BLOCK_CLOCKS
+        asm volatile("" : "+v"(key[0]));
+        const unsigned long long kclk1 = wall_clock64();
+#endif
         uint32_t e[EC];
-        uint64_t tot[EC];
+#pragma unroll
+        for (int r = 0; r < EC; ++r) e[r] = key[r] & idx_mask;
+        // sorted position i = lane * EC + r: its partition's lag to the bin that stands there, the bin's position to the partition.
+        // Written BEFORE the order is known to be exact: every slot of `hand` and every live winner word is written by every
+        // round's hand-over, so the rare re-ordered round simply writes them again -- and the tie check below (a ballot and a
+        // branch: a VALU -> SALU hop) runs while these stores are on their way instead of in front of them.
 #pragma unroll
         for (int r = 0; r < EC; ++r) {
-            e[r] = key[r] == 0xFFFFFFFFu ? (uint32_t)kBins : (key[r] & idx_mask);
-            tot[r] = s_tot[e[r]];
+            hand[e[r]] = lag[r];
+            *reinterpret_cast<uint32_t*>(key_bytes + won_at[r]) = e[r];
         }
         if (q > 0 && drop > 0) {
-            // neighbours that share their truncated total: the keys cannot tell which of the two bins is smaller
+            // neighbours that share their truncated total: the keys cannot tell which of the two bins is smaller.  (Idle bins
+            // differ from every real key in the top bit and from each other nowhere above the position: they sit behind
+            // the C real keys, where a "tie" among them is of no consequence -- but must not be reported: compare real keys only.)
             bool tie = false;
 #pragma unroll
-            for (int r = 0; r + 1 < EC; ++r) tie |= key[r + 1] != 0xFFFFFFFFu && ((key[r] ^ key[r + 1]) >> idx_bits) == 0;
+            for (int r = 0; r + 1 < EC; ++r) tie |= (key[r] ^ key[r + 1]) < tie_lim && (int32_t)key[r + 1] >= 0;
             asm volatile("s_nop 1" : "+v"(key[0]));                    // (written by the network's last block: a DPP read follows)
-            const uint32_t up = (uint32_t)__builtin_amdgcn_update_dpp((int)0xFFFFFFFFu, (int)key[0], 0x130, 0xF, 0xF, false);   // wave_shl:1
-            tie |= lane != kWave - 1 && up != 0xFFFFFFFFu && ((key[EC - 1] ^ up) >> idx_bits) == 0;
+            const uint32_t up = (uint32_t)__builtin_amdgcn_update_dpp((int)kIdle, (int)key[0], 0x130, 0xF, 0xF, false);   // wave_shl:1
+            tie |= (key[EC - 1] ^ up) < tie_lim && (int32_t)up >= 0;
             if (__builtin_amdgcn_ballot_w64(tie) != 0) {                               // rare: this round by the exact network
                 P64 bin[EC];
 #pragma unroll
-                for (int r = 0; r < EC; ++r) bin[r] = p64_from(e[r] == (uint32_t)kBins ? kRoundSentinel : ((tot[r] << idx_bits) | e[r]));
+                for (int r = 0; r < EC; ++r)
+                    bin[r] = p64_from(mine[r] ? ((tot[r] << idx_bits) | (uint32_t)(lane * EC + r)) : (kRoundSentinel - idx_mask + (uint32_t)(lane * EC + r)));
 #pragma unroll
                 for (int r = 0; r < EC; ++r) asm volatile("s_nop 1" : "+v"(bin[r].lo), "+v"(bin[r].hi));
                 bitonic_sort_tile_p64<kWave, EC, true>(bin);
+                wave_lds_fence();
 #pragma unroll
                 for (int r = 0; r < EC; ++r) {
-                    const uint64_t v = p64_value(bin[r]);
-                    e[r] = v == kRoundSentinel ? (uint32_t)kBins : ((uint32_t)v & idx_mask);
-                    tot[r] = v == kRoundSentinel ? 0 : (v >> idx_bits);
+                    e[r] = bin[r].lo & idx_mask;
+                    hand[e[r]] = lag[r];
+                    *reinterpret_cast<uint32_t*>(key_bytes + won_at[r]) = e[r];
                 }
             }
         }
-        // the smallest total before the adds: sorted position 0 (lane 0, register 0)
-        const uint64_t base = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(tot[0] >> 32)) << 32) |
-                              (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)tot[0]);
+        wave_lds_fence();
+        floor_sum += round_min;
+        uint64_t got[EC];
+#pragma unroll
+        for (int r = 0; r < EC; ++r) got[r] = hand[lane * EC + r];                     // (all reads out before the first use)
 #pragma unroll
         for (int r = 0; r < EC; ++r) {
-            const int s = lane * EC + r, g = q * C + s;
-            const bool live = e[r] != (uint32_t)kBins;
-            const uint64_t nt = tot[r] + lag[r];                                       // Main.java:265 (lag 0 past the topic's end)
-            s_tot[e[r]] = live ? nt : 0;
-            if (s < C && g < P) reinterpret_cast<uint32_t*>(s_key + g)[0] = e[r];      // the winner, where its lag was
-            key[r] = live ? ((uint32_t)((nt - base) >> drop) << idx_bits) | e[r] : 0xFFFFFFFFu;
+            tot[r] += got[r];                                                          // Main.java:265 (idle bins and late rounds: + 0)
+            const uint32_t field = (uint32_t)((tot[r] - floor_sum) >> drop);
+            key[r] = (mine[r] ? (field << idx_bits) : kIdle) | (uint32_t)(lane * EC + r);     // (the keys start every round at home)
             lag[r] = next[r];
+            won_at[r] = next_at[r];
         }
+        round_min = next_min;
         wave_lds_fence();
+#ifdef LA_BLOCK_CLOCKS
+        if (lane == 0 && blockIdx.x == 0) {
+            asm volatile("" : "+v"(key[0]));
+            const unsigned long long kclk2 = wall_clock64();
+            g_block_clocks[6] += kclk1 - kclk0;                                        // the network
+            g_block_clocks[7] += kclk2 - kclk1;                                        // the rest of the round
+        }
+#endif
     }
     if (a.out_total) {
 #pragma unroll
-        for (int r = 0; r < EC; ++r) {
-            const int e = lane * EC + r;
-            if (e < C) a.out_total[c0 + e] = (int64_t)s_tot[e];
-        }
+        for (int r = 0; r < EC; ++r)
+            if (mine[r]) a.out_total[c0 + lane * EC + r] = (int64_t)tot[r];
     }
 }
 
@@ -927,13 +975,15 @@ __global__ __launch_bounds__(1024) void block_topic_kernel(BlockArgs a) {
         const int lag_bits = lmax > 0 ? 64 - __builtin_clzll((unsigned long long)lmax) : 0;
         const int round_bits = 32 - __builtin_clz((unsigned)((P + C - 1) / C) | 1u);
         const bool packed = lmin >= 0 && lag_bits + round_bits + idx_bits <= 62;
-        if (packed && n_c > kWave && a.key32_greedy) {
+        // (256 bins: four keys per lane on one wavefront lose to one bin per lane on four -- 1 x 8 000 x 256 0.095 against 0.086 ms,
+        //  1 x 16 000 x 200 0.225 against 0.185; 128 bins: 1 x 10 000 x 128 0.109 against 0.130.  LA_BLOCK_KEY32=2 runs both here)
+        if (packed && n_c > kWave && a.key32_greedy && (n_c == 2 * kWave || a.key32_greedy >= 2)) {
             // 128 / 256 bins: ONE wavefront, the bins stay where they are (LDS), the order comes from 32-bit keys
-            if (tid == 0) s_key[P] = kLagKeyFlip;                       // "lag 0" for idle slots and rounds past the topic
+            if (tid == 0) s_key[P] = kLagKeyFlip;                       // "lag 0" for idle slots and rounds past the topic (P + 1: scratch)
             __syncthreads();
             if (tid < kWave) {
-                if (n_c == 2 * kWave) greedy_one_wave_key32<2>(a, s_key, s_tot, c0, P, C, idx_bits, lag_bits, tid);
-                else greedy_one_wave_key32<4>(a, s_key, s_tot, c0, P, C, idx_bits, lag_bits, tid);
+                if (n_c == 2 * kWave) greedy_one_wave_key32<2>(a, s_key, s_tot, s_idx, c0, P, C, idx_bits, lag_bits, tid);
+                else greedy_one_wave_key32<4>(a, s_key, s_tot, s_idx, c0, P, C, idx_bits, lag_bits, tid);
             }
             __syncthreads();
             LA_BCLK(4);

@@ -158,37 +158,39 @@ def test_lsd_passes_with_counter_ranks_are_a_stable_sort(kind, group):
 
 # ---- round 5: the block path's greedy through 32-bit keys (la_block.hip, greedy_one_wave_key32) -----------------------------------
 def _key32_greedy_model(lags_sorted_desc, C, n_c):
-    """Numpy restatement of greedy_one_wave_key32: bins stay in place, one 32-bit key per bin
-    ((total - base) >> drop) << idx_bits | e with base = the smallest total before the round's adds; a round whose sorted keys
-    hold two neighbours with the same truncated total (and drop > 0) is ordered again exactly.  Returns (winner per sorted
-    partition, totals, number of exact re-orderings, largest key field seen)."""
+    """Numpy restatement of greedy_one_wave_key32: bins stay at home, one 32-bit key per bin
+    ((total - floor) >> drop) << idx_bits | e with floor = the sum of the smallest lag of every full round so far; a round whose
+    sorted keys hold two neighbours with the same truncated total (and drop > 0) is ordered again exactly.  Returns (winner per
+    sorted partition, totals, number of exact re-orderings, largest key field seen)."""
     P = len(lags_sorted_desc)
     idx_bits = int(np.log2(n_c))                                # n_c: the power of two the bins' network spans
     lmax = int(lags_sorted_desc[0]) if P else 0
     lag_bits = lmax.bit_length()
     keep = 31 - idx_bits
-    drop = max(0, lag_bits + 1 - keep)
+    drop = max(0, lag_bits - keep)
     tot = [0] * C
-    order = list(range(C))                                      # round 0: positions ascending
     won = [0] * P
     redone, field_max = 0, 0
-    keys = None
+    keys = list(range(C))                                       # round 0: totals 0, positions ascending
+    floor = 0
     for q in range((P + C - 1) // C):
-        if q > 0:
-            order = [k & ((1 << idx_bits) - 1) for k in sorted(keys)]
-            if drop > 0 and any((keys_sorted_a >> idx_bits) == (keys_sorted_b >> idx_bits)
-                                for keys_sorted_a, keys_sorted_b in zip(sorted(keys)[:-1], sorted(keys)[1:])):
-                order = sorted(range(C), key=lambda e: (tot[e], e))
-                redone += 1
-        base = tot[order[0]]
-        assert base == min(tot)
-        keys = []
+        sk = sorted(keys)
+        order = [k & ((1 << idx_bits) - 1) for k in sk]
+        if q > 0 and drop > 0 and any((a >> idx_bits) == (b >> idx_bits) for a, b in zip(sk[:-1], sk[1:])):
+            order = sorted(range(C), key=lambda e: (tot[e], e))
+            redone += 1
         for s, e in enumerate(order):
             g = q * C + s
             if g < P:
                 tot[e] += int(lags_sorted_desc[g])
                 won[g] = e
-            field = (tot[e] - base) >> drop
+        if (q + 1) * C - 1 < P:                                 # a full round: every bin took at least its smallest lag
+            floor += int(lags_sorted_desc[(q + 1) * C - 1])
+        keys = []
+        for e in range(C):
+            rel = tot[e] - floor
+            assert 0 <= rel < (1 << max(lag_bits, 1)) or (lag_bits == 0 and rel == 0), (rel, lag_bits)
+            field = rel >> drop
             assert 0 <= field < (1 << keep), (field, keep)
             field_max = max(field_max, field)
             keys.append((field << idx_bits) | e)

@@ -284,7 +284,8 @@ def test_block_greedy_through_32_bit_keys(ctx, P, C, kind):
 
 
 def test_block_greedy_forms_agree_in_a_fresh_process():
-    """LA_BLOCK_KEY32=0 (the 64-bit bins through the networks, rounds 3-4) gives what the 32-bit-key form gives."""
+    """LA_BLOCK_KEY32=0 (the 64-bit bins through the networks, rounds 3-4) and =2 (32-bit keys for 256 bins too) give what the
+    default gives: the oracle's assignment.  With bigties / nearties lags the exact re-ordering of tied rounds runs in mode 2."""
     code = r"""
 import numpy as np, sys
 sys.path.insert(0, %r); sys.path.insert(0, %r)
@@ -294,12 +295,14 @@ import test_round4_gpu as t4, test_round5_gpu as t5
 ctx = N.Context(0)
 rng = np.random.default_rng(3)
 for (P, C) in ((10000, 128), (3000, 200), (16000, 256), (1500, 66)):
-    w = t5._one_topic(P, C, rng.integers(0, 1 << 40, P), P + C)
-    exp = oracle.assign_flat(w.part_off, w.partition_id, w.lag, w.cons_off, w.cons_rank)
-    t4._same3(t4._device_call(ctx, w), exp, what=str((P, C)))
+    for lag in (rng.integers(0, 1 << 40, P), (1 << 39) + rng.integers(0, 3, P) * (1 << 20), (1 << 41) + rng.integers(0, 64, P)):
+        w = t5._one_topic(P, C, lag, P + C)
+        exp = oracle.assign_flat(w.part_off, w.partition_id, w.lag, w.cons_off, w.cons_rank)
+        t4._same3(t4._device_call(ctx, w), exp, what=str((P, C)))
 print("ok")
 """
-    env = dict(os.environ, LA_BLOCK_KEY32="0")
-    out = subprocess.run([sys.executable, "-c", code % (ROOT, os.path.join(ROOT, "tests"))], env=env, capture_output=True,
-                         text=True, timeout=600)
-    assert out.returncode == 0 and "ok" in out.stdout, (out.stdout[-1500:], out.stderr[-1500:])
+    for mode in ("0", "2"):                                        # 2: the 32-bit-key form for 256 bins as well (default: 128 only)
+        env = dict(os.environ, LA_BLOCK_KEY32=mode)
+        out = subprocess.run([sys.executable, "-c", code % (ROOT, os.path.join(ROOT, "tests"))], env=env, capture_output=True,
+                             text=True, timeout=600)
+        assert out.returncode == 0 and "ok" in out.stdout, (mode, out.stdout[-1500:], out.stderr[-1500:])
