@@ -89,8 +89,10 @@ def parse_args():
                          "the north star's multi-GPU workload), weak at one rank")
     ap.add_argument("--gather", action="store_true",
                     help="weak scaling: also all-gather the packed result buffer (RCCL) in the timed region; strong scaling always does")
-    ap.add_argument("--wire", choices=["packed", "int32"], default="packed",
-                    help="what the all-gather moves: packed = the narrow wire format (2 B per partition at the target), "
+    ap.add_argument("--wire", choices=["fused", "packed", "int32"], default="fused",
+                    help="what the all-gather moves: fused (default) = the narrow wire format written by the assignment kernels "
+                         "themselves (LA_FLAG_WIRE_OUT: no pack launch; falls back to `packed` where the batch is not eligible), "
+                         "packed = the narrow wire format (2 B per partition at the target) from la_pack_results_on, "
                          "int32 = the two int32 result arrays as one [2, cap] buffer (8 B per partition)")
     ap.add_argument("--unpack", action="store_true",
                     help="packed wire: also expand the gathered map into the two int32 arrays on every rank inside the step "
@@ -227,6 +229,20 @@ class DeviceShard:
             # partition id.  When they prove that every tile packs, the tile path is ONE launch (LA_FLAG_BOUNDS)
             b.flags |= N.LA_FLAG_BOUNDS
             b.max_lag_hint, b.max_partition_id_hint = self.bounds
+        return b
+
+    def make_wire_batch(self, latest, algo, fmt, d_wire):
+        """The same batch with LA_FLAG_WIRE_OUT: the kernels write wire elements ((rank + 1) << id_bits | id) into d_wire instead of
+        the two int32 arrays.  None where the library would refuse (no bounds, shapes beyond a tile, wide format)."""
+        N = self._N
+        if self.bounds is None or fmt is None or int(fmt.elem_bytes) not in (2, 4) or self.max_p > 1024 or self.max_c > 64 or algo != "auto":
+            return None
+        b = self.make_batch(latest, algo)
+        if not (b.flags & N.LA_FLAG_BOUNDS):
+            return None
+        b.flags |= N.LA_FLAG_WIRE_OUT
+        b.d_out_wire = d_wire
+        b.wire_elem_bytes, b.wire_id_bits = int(fmt.elem_bytes), int(fmt.id_bits)
         return b
 
 
@@ -621,8 +637,9 @@ def main():
     # element per assigned partition, ((member rank + 1) << id_bits) | partition id, 2 bytes at the target and at cfg4 (the
     # library picks the width from the largest id and the member count: la_wire_format_for); int32: the two result arrays as
     # one [2, cap] int32 buffer (8 B per partition, round 3's form).
-    packed = do_gather and args.wire == "packed"
+    packed = do_gather and args.wire in ("packed", "fused")
     unpack = packed and args.unpack and not args.no_unpack
+    fused = False
     fmt = None
     if do_gather:
         max_id = int(w.partition_id.max()) if w.partition_id.size and int(w.partition_id.min()) >= 0 else -1
@@ -637,12 +654,22 @@ def main():
         else:
             gathered = torch.empty(world * 2 * cap, device=dev, dtype=torch.int32)     # [world][2][cap]
     gather_bytes_per_rank = (cap * fmt.elem_bytes if packed else 2 * cap * 4) if do_gather else 0
+    if packed and args.wire == "fused":
+        # the assignment kernels write the wire elements themselves, straight into the gather's send buffer: no pack launch.
+        # Every rank must agree (a rank whose shard is not eligible would make the step's shape differ): all or none.
+        for x in sets:
+            x.batch_wire = x.make_wire_batch(latest, args.algo, fmt, wire_send.data_ptr())
+        ok = torch.tensor([1.0 if all(x.batch_wire is not None for x in sets) else 0.0], device="cpu" if backend == "gloo" else dev)
+        if use_dist and world > 1:
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        fused = bool(ok.item() == 1.0)
 
     def gather_step(cur, trio=None):
         """pack -> THE collective of a step -> unpack, on the results of the copy `cur` the step's kernels just wrote;
         trio[2..4] are recorded behind each phase when given."""
         if packed:
-            ctx.pack_results(n_part, cur.out_pid.data_ptr(), cur.out_rank.data_ptr(), fmt, wire_send.data_ptr(), stream)
+            if not fused:
+                ctx.pack_results(n_part, cur.out_pid.data_ptr(), cur.out_rank.data_ptr(), fmt, wire_send.data_ptr(), stream)
             if trio:
                 trio[2].record()
             all_gather(wire_recv, wire_send)
@@ -671,7 +698,7 @@ def main():
 
     def step():
         cur = next_set()
-        ctx.assign_batch_device(cur.batch, stream)
+        ctx.assign_batch_device(cur.batch_wire if fused else cur.batch, stream)
         if do_gather:
             gather_step(cur)
 
@@ -716,13 +743,18 @@ def main():
         else:
             trio[0].record()
             cur = next_set()
-            ctx.assign_batch_device(cur.batch, stream)
+            ctx.assign_batch_device(cur.batch_wire if fused else cur.batch, stream)
             trio[1].record()
             if do_gather:
                 gather_step(cur, trio)
     barrier()
     elapsed = time.perf_counter() - t0c
     ctx.sync(stream)
+    if fused:
+        # the timed steps wrote wire elements only: one plain call, so that the two int32 result arrays (and the totals) of
+        # sets[0] hold the same assignment for the legs below that read them
+        ctx.assign_batch_device(b, stream)
+        ctx.sync(stream)
 
     # HIP-event durations on the stream the work runs on: the assign launch (the kernels of one step), then pack, the
     # collective, unpack
@@ -840,6 +872,35 @@ def main():
             ctx.sync(stream)
         except Exception as exc:  # noqa: BLE001 -- a reported extra
             roofline["same_buffers_error"] = str(exc)
+    if world == 1 and not do_gather and not args.no_cpu_baseline and uniform:
+        # what the N > 1 step's kernels cost with and without the fused wire output, measurable on one GPU: assignment + pack
+        # (two int32 arrays written, read again, 2 B written) against the assignment kernels writing the wire elements themselves
+        try:
+            max_id = int(w.partition_id.max()) if w.partition_id.size and int(w.partition_id.min()) >= 0 else -1
+            fmt1 = N.wire_format_for(max_id, int(w.cons_rank.max()) + 1 if w.cons_rank.size else 0)
+            wbuf = torch.zeros(max(n_part, 1) * int(fmt1.elem_bytes), device=dev, dtype=torch.uint8)
+            bw = sh.make_wire_batch(latest, args.algo, fmt1, wbuf.data_ptr())
+            if bw is not None:
+                fms, fcalls = timed_calls(torch, ctx, bw, stream, settle_ms=60.0)
+                got_w = wbuf.clone()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                for _ in range(20):
+                    ctx.assign_batch_device(b, stream)
+                    ctx.pack_results(n_part, sh.out_pid.data_ptr(), sh.out_rank.data_ptr(), fmt1, wbuf.data_ptr(), stream)
+                ctx.sync(stream)
+                e0.record()
+                for _ in range(fcalls):
+                    ctx.assign_batch_device(b, stream)
+                    ctx.pack_results(n_part, sh.out_pid.data_ptr(), sh.out_rank.data_ptr(), fmt1, wbuf.data_ptr(), stream)
+                e1.record()
+                ctx.sync(stream)
+                roofline["wire_out"] = {"fused_ms": round(fms, 4), "kernels_plus_pack_ms": round(float(e0.elapsed_time(e1)) / fcalls, 4),
+                                        "elem_bytes": int(fmt1.elem_bytes), "id_bits": int(fmt1.id_bits),
+                                        "same_wire_bytes": bool(torch.equal(got_w, wbuf)),
+                                        "what": "the kernels of one N > 1 step on this GPU's batch: LA_FLAG_WIRE_OUT (the assignment kernels "
+                                                "write the all-gather's 2-byte elements themselves) against assignment + la_pack_results_on"}
+        except Exception as exc:  # noqa: BLE001 -- a reported extra
+            roofline["wire_out"] = {"error": str(exc)}
     if world > 1 or do_gather:
         roofline["per_rank_kernel_ms"] = [round(float(x), 4) for x in per_rank[:world]]
         roofline["per_rank_gather_ms"] = [round(float(x), 4) for x in per_rank[world:]]
@@ -1119,15 +1180,21 @@ def main():
                    "topics_on_rank0": int(b.n_topics), "gather": bool(do_gather), "algo": args.algo,
                    "collectives_per_step": 1 if do_gather else 0,
                    "collective": (("ONE all_gather_into_tensor of %d wire elements of %d bytes per rank (((member rank + 1) << %d) | "
-                                   "partition id; la_pack_results_on before it%s), inside the timed region: %.4f ms by HIP events "
+                                   "partition id; %s%s), inside the timed region: %.4f ms by HIP events "
                                    "(max over ranks)" % (cap, fmt.elem_bytes, fmt.id_bits,
+                                                         "written by the assignment kernels themselves (LA_FLAG_WIRE_OUT)" if fused else
+                                                         "la_pack_results_on before it",
                                                          ", la_unpack_results_on over the gathered map after it" if unpack else
                                                          "; the gathered map stays in the wire format", gather_ms_max))
                                   if packed else
                                   ("ONE all_gather_into_tensor of the [2, %d] int32 result buffer (partition order | member "
                                    "rank) per step, inside the timed region: %.4f ms by HIP events (max over ranks)"
                                    % (cap, gather_ms_max))) if do_gather else None,
-                   "wire": ({"format": args.wire, "elem_bytes": int(fmt.elem_bytes) if packed else 8, "id_bits": int(fmt.id_bits) if packed else None,
+                   "wire": ({"format": "fused" if fused else ("packed" if packed else args.wire), "requested": args.wire,
+                             "pack_launch": bool(packed and not fused),
+                             "produced_by": ("the assignment kernels themselves (LA_FLAG_WIRE_OUT)" if fused else
+                                             ("la_pack_results_on behind the assignment kernels" if packed else "no packing: two int32 arrays")),
+                             "elem_bytes": int(fmt.elem_bytes) if packed else 8, "id_bits": int(fmt.id_bits) if packed else None,
                              "gather_bytes_per_rank": int(gather_bytes_per_rank), "unpacked_in_step": bool(unpack),
                              "pack_ms": round(pack_ms_max, 4), "gather_ms": round(gather_ms_max, 4), "unpack_ms": round(unpack_ms_max, 4),
                              "unpack_ms_source": ("inside the step" if unpack else "rank 0, 10 back-to-back expansions after the timed region") if packed else None,

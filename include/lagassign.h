@@ -129,6 +129,14 @@ extern "C" {
                                  * pack into 64 bits, the tile path drops its second launch (the wide-record kernel over the list of     *
                                  * deferred tiles, empty in that case): one launch per batch instead of two.  A partition that violates  *
                                  * the bounds is reported by la_sync as LA_EINVAL -- never a silently different result.                  */
+#define LA_FLAG_WIRE_OUT    4096 /* d_out_wire / wire_elem_bytes / wire_id_bits below are valid (since ABI 0.4.0): the results leave the kernels     *
+                                 * in the narrow wire format of the multi-GPU all-gather (la_wire_format_for, below) -- one element of 2 or 4 bytes  *
+                                 * per assigned partition, ((member rank + 1) << id_bits) | partition id, in assignment order -- INSTEAD of the two   *
+                                 * int32 arrays (d_out_partition / d_out_member_rank are not written and may be NULL): what la_pack_results_on        *
+                                 * would produce from them, without the 8 B written and read again per partition.  For the batches the gather is     *
+                                 * for: every topic tile-sized (shape hint within 1024 x 64, no LA_FLAG_RAGGED), LA_FLAG_BOUNDS proving that every    *
+                                 * tile packs, fewer than 2^29 partitions; anything else is LA_EINVAL (run the batch without the flag and pack).     *
+                                 * A pair that does not fit the format is reported by la_sync as LA_EINVAL.  d_out_total_lag is written as usual.     */
 #define LA_FLAG_SERIAL_LARGE 512 /* large path: the batch's large topics one after another (round 3's form) instead of side by   *
                                  * side in shared launches (test hook / A-B)                                            */
 
@@ -341,6 +349,10 @@ typedef struct la_device_batch {
     /* with LA_FLAG_BOUNDS (since ABI 0.3.0; ignored without the flag) */
     int64_t max_lag_hint;            /* upper bound of every lag of the batch, >= 0                */
     int64_t max_partition_id_hint;   /* upper bound of every partition id, >= 0                    */
+    /* with LA_FLAG_WIRE_OUT (since ABI 0.4.0; ignored without the flag) */
+    void   *d_out_wire;              /* [N] elements of wire_elem_bytes each, element-aligned      */
+    int32_t wire_elem_bytes;         /* 2 or 4 (la_wire_format.elem_bytes)                         */
+    int32_t wire_id_bits;            /* la_wire_format.id_bits                                     */
 } la_device_batch;
 
 /* Enqueues the whole batch on `stream` and returns without waiting.  `stream` is a

@@ -25,6 +25,7 @@ LA_FLAG_NO_RUN_MERGE = 256
 LA_FLAG_NO_MOVED_SORT = 2048
 LA_FLAG_SERIAL_LARGE = 512
 LA_FLAG_BOUNDS = 1024
+LA_FLAG_WIRE_OUT = 4096
 LA_FEATURE_ATOMIC_RANK = 1
 LA_PIPELINE_ONE_COPY, LA_PIPELINE_LANES, LA_PIPELINE_STREAMS, LA_PIPELINE_ZERO_COPY, LA_PIPELINE_MAPPED = 0, 1, 2, 3, 4
 LA_CREATE_LANES_MASK, LA_CREATE_SPLIT_ALWAYS = 0xF, 0x10
@@ -68,6 +69,7 @@ class DeviceBatch(ctypes.Structure):
         ("d_out_total_lag", ctypes.c_void_p),
         ("h_part_off", _i64p), ("h_cons_off", _i64p),
         ("max_lag_hint", ctypes.c_int64), ("max_partition_id_hint", ctypes.c_int64),
+        ("d_out_wire", ctypes.c_void_p), ("wire_elem_bytes", ctypes.c_int32), ("wire_id_bits", ctypes.c_int32),
     ]
 
 

@@ -538,7 +538,22 @@ int enqueue_batch(la_ctx* ctx, Lane& ln, const la_device_batch* b, hipStream_t s
     if (b->n_topics == 0) return LA_OK;
     if (!b->d_part_off || !b->d_cons_off) return fail(ctx, LA_EINVAL, "null offsets");
     // (a batch whose topics have no partitions at all has nothing to write: its [0]-sized outputs may be anything)
-    if (b->n_partitions > 0 && (!b->d_out_partition || !b->d_out_member_rank)) return fail(ctx, LA_EINVAL, "null outputs");
+    const bool wire_out = (b->flags & LA_FLAG_WIRE_OUT) != 0;
+    if (b->n_partitions > 0 && !wire_out && (!b->d_out_partition || !b->d_out_member_rank)) return fail(ctx, LA_EINVAL, "null outputs");
+    if (wire_out) {
+        // the results in the all-gather's wire format straight from the kernels: the tile path's one-launch form only
+        if (!b->d_out_wire || (b->wire_elem_bytes != 2 && b->wire_elem_bytes != 4) ||
+            !la::wire_format_valid(b->wire_elem_bytes, b->wire_id_bits))
+            return fail(ctx, LA_EINVAL, "LA_FLAG_WIRE_OUT: d_out_wire and a 2- or 4-byte wire format are required");
+        if (b->algo != LA_ALGO_AUTO || (b->flags & LA_FLAG_RAGGED) ||
+            !la::wave_tile_fits(b->max_partitions_per_topic, b->max_consumers_per_topic) || b->n_partitions >= ((int64_t)1 << 29) ||
+            b->n_consumers >= ((int64_t)1 << 30) || (b->flags & LA_FLAG_INDEX64) || !(b->flags & LA_FLAG_BOUNDS) ||
+            !la::wave_tile_always_packs(b->max_partitions_per_topic, b->max_consumers_per_topic, b->max_lag_hint,
+                                        b->max_partition_id_hint))
+            return fail(ctx, LA_EINVAL, "LA_FLAG_WIRE_OUT needs a batch of tile-sized topics (shape hint within 1024 x 64, no LA_FLAG_RAGGED), "
+                                        "LA_FLAG_BOUNDS that prove every tile packs, and fewer than 2^29 partitions: run this batch "
+                                        "without the flag and pack the results with la_pack_results_on");
+    }
     if (b->n_partitions > 0 && (!b->d_partition_id || (!b->d_lag && (!b->d_end_off || !b->d_committed_off))))
         return fail(ctx, LA_EINVAL, "null per-partition input");
     if (b->n_consumers > 0 && !b->d_cons_rank) return fail(ctx, LA_EINVAL, "null cons_rank");
@@ -564,6 +579,12 @@ int enqueue_batch(la_ctx* ctx, Lane& ln, const la_device_batch* b, hipStream_t s
     a.reset_latest = (b->reset_mode == LA_RESET_LATEST) ? 1 : 0;
     a.n_total = b->n_partitions;
     a.flags = b->flags & (LA_FLAG_INDEX64 | LA_FLAG_DEFER_WIDE);
+    if (wire_out) {
+        a.flags |= la::kTileWireOut;
+        a.out_wire = b->d_out_wire;
+        a.wire_bytes = b->wire_elem_bytes;
+        a.wire_id_bits = b->wire_id_bits;
+    }
     a.topic_list = nullptr;
     a.k_total = b->n_consumers;
     if (int rc = reserve(ctx, ln.defer, la::wave_tile_defer_bytes(b->n_topics))) return rc;

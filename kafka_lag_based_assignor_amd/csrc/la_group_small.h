@@ -164,13 +164,13 @@ __device__ __forceinline__ void group_small_body(int n, int32_t n_members, int64
 // input is read ONCE, coalesced, all loads of a thread issued back to back: ranks and ids into LDS, and the topic of every
 // entry from ONE pass over part_off -- +1 at every topic's first position, an inclusive scan (topic of entry i = the number of
 // topic starts at or before i, minus one: the largest t with part_off[t] <= i, empty topics included).  The placement then
-// runs on LDS.  s_rank / s_part / s_topic: [cap] words each, n <= cap.
+// runs on LDS.  s_rank / s_part / s_topic / o_part / o_topic: [cap] words each, n <= cap.
 template <int NT, int M>
 __device__ __forceinline__ void group_small_body_staged(int n, int32_t n_members, int64_t n_topics, const int64_t* part_off,
                                                         const int32_t* out_partition, const int32_t* member_rank, int64_t* member_off,
                                                         int32_t* grouped_topic, int32_t* grouped_partition, int32_t* grouped_entry,
                                                         uint32_t* start, uint32_t* wsum, uint32_t* turn, int32_t* s_rank,
-                                                        int32_t* s_part, int32_t* s_topic) {
+                                                        int32_t* s_part, int32_t* s_topic, int32_t* o_part, int32_t* o_topic) {
     static_assert(M % NT == 0 && NT % kWave == 0, "M counters over NT threads");
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t G = (uint32_t)n_members + 1;
@@ -238,8 +238,16 @@ __device__ __forceinline__ void group_small_body_staged(int n, int32_t n_members
     __syncthreads();
     for (int k = tid; k <= n_members; k += NT) member_off[k] = (int64_t)start[k + 1];
     __syncthreads();                                                    // (the cursors move from here on)
-    group_small_place<1, NT>(n, G, n_topics, part_off, s_part, s_rank, grouped_topic, grouped_partition, grouped_entry, start, turn,
-                             lane, wave, s_topic);
+    // The lists are built in LDS (o_part / o_topic: [cap] words each) and leave in ONE coalesced pass: an entry's place is
+    // scattered, and a scattered 4-byte store into the host's memory (a zero-copy call's lists go straight there) is a PCIe
+    // write transaction of its own -- 2 x 2 000 of them were ~15 us of a 43 us rebalance.
+    group_small_place<1, NT>(n, G, n_topics, part_off, s_part, s_rank, grouped_topic ? o_topic : nullptr, o_part, grouped_entry, start,
+                             turn, lane, wave, s_topic);
+    __syncthreads();
+    for (int i = tid; i < n; i += NT) {
+        grouped_partition[i] = o_part[i];
+        if (grouped_topic) grouped_topic[i] = o_topic[i];
+    }
 }
 
 }  // namespace la

@@ -53,6 +53,7 @@ constexpr uint32_t kStatusBounds = 64u;    // LA_FLAG_BOUNDS: a lag or a partiti
 
 constexpr int32_t kTileNoDefer = 8;       // TileArgs::flags: the bounds prove that every tile packs -- no deferred list, no wide
                                           // launch; a tile that does not pack after all raises kStatusBounds
+constexpr int32_t kTileWireOut = 16;      // TileArgs::flags: out_wire instead of out_pid / out_rank (needs kTileNoDefer)
 constexpr int32_t kTileSkipOversize = 4;  // TileArgs::flags: topics beyond the tile belong to another path, no error
 
 constexpr int64_t kTileMaxPartitions = 1024;   // 64 lanes x 16 records
@@ -106,6 +107,10 @@ struct TileArgs {
     int32_t* defer_count_next;
     int32_t* defer_list;
     TileTail tail;              // honoured by the single-launch form only (wave_tile_launch says whether it was)
+    // LA_FLAG_WIRE_OUT: results as wire elements ((rank + 1) << wire_id_bits) | id of wire_bytes (2 or 4) each instead of the
+    // two int32 arrays; only with kTileNoDefer (one launch of the packed-record kernel, 32-bit indexing)
+    void* out_wire;
+    int32_t wire_bytes, wire_id_bits;
 };
 
 // bytes of defer_list a launch over n_topics topics may need (one tile holds >= 1 topic)

@@ -2711,10 +2711,10 @@ __global__ __launch_bounds__(1024) void group_small_kernel(int n, int32_t n_memb
     __shared__ uint32_t wsum[1024 / kWave];
     __shared__ uint32_t turn;
 #ifndef LA_GROUP_UNSTAGED
-    __shared__ int32_t s_in[3 * kSmallGroupN];        // ranks, ids, topics of the entries
+    __shared__ int32_t s_in[5 * kSmallGroupN];        // ranks, ids, topics of the entries; the lists
     group_small_body_staged<1024, kSmallGroupM>(n, n_members, n_topics, part_off, out_partition, member_rank, member_off,
                                                 grouped_topic, grouped_partition, grouped_entry, start, wsum, &turn, s_in,
-                                                s_in + kSmallGroupN, s_in + 2 * kSmallGroupN);
+                                                s_in + kSmallGroupN, s_in + 2 * kSmallGroupN, s_in + 3 * kSmallGroupN, s_in + 4 * kSmallGroupN);
 #elif defined(LA_GROUP_SUB)                                   // (lab builds: tools/group_probe.py compares the forms on one box)
     group_small_body<1024, kSmallGroupM, LA_GROUP_SUB>(n, n_members, n_topics, part_off, out_partition, member_rank, member_off,
                                                        grouped_topic, grouped_partition, grouped_entry, start, wsum, &turn);

@@ -390,7 +390,15 @@ __device__ __forceinline__ void greedy_rounds_tile(P64& bin, uint64_t* slice, in
 }
 
 // ---- 3..5: greedy rounds over the sorted slice, outputs ------------------------------------------------------
-template <int L, int E, bool FULL = false, typename IDX>
+// One wire element of the all-gather's narrow format (la_wire.hip): ((member rank + 1) << id_bits) | partition id.
+__device__ __forceinline__ uint32_t wire_element(int32_t id, int32_t rank, int id_bits, uint32_t limit, bool& bad) {
+    const uint32_t r1 = (uint32_t)rank + 1u;                                // -1 (no consumer) -> 0
+    const uint32_t w = (r1 << id_bits) | (uint32_t)id;
+    bad |= ((uint32_t)id >> id_bits) != 0 || r1 >= limit;
+    return w;
+}
+
+template <int L, int E, bool FULL = false, bool WIRE = false, typename IDX>
 __device__ __forceinline__ void assign_packed(const TileArgs& a, uint64_t* slice, int32_t* rank_tab, IDX p0,
                                               IDX c0, int P, int C, int gl, int sh, uint64_t lag_max,
                                               int32_t my_rank) {
@@ -416,6 +424,59 @@ __device__ __forceinline__ void assign_packed(const TileArgs& a, uint64_t* slice
 
     // ---- 5. outputs ------------------------------------------------------------------------------------
     if (a.out_total && gl < C) a.out_total[c0 + (bin.lo & 63u)] = (int64_t)(p64_value(bin) >> 6);
+    if constexpr (WIRE) {
+        // LA_FLAG_WIRE_OUT: the (partition, member) pairs leave as wire elements -- 2 (or 4) bytes per partition instead of 8
+        const int id_bits = a.wire_id_bits;
+        const bool two = a.wire_bytes == 2;                                  // (kernel-uniform)
+        const int rank_bits = (two ? 16 : 32) - id_bits;                      // bits of an element above the id: rank + 1 < 2^rank_bits
+        const uint32_t limit = rank_bits >= 32 ? 0xFFFFFFFFu : (1u << rank_bits);
+        bool bad = false;
+        if constexpr (E >= 4) {
+#pragma unroll
+            for (int k = 0; k < E / 4; ++k) {
+                const int s0 = k * 4 * L + 4 * gl;
+                uint32_t wv[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const uint64_t w = slice[slot_of(s0 + i)];
+                    wv[i] = wire_element((int32_t)((uint32_t)w & pid_mask), (C > 0) ? rank_tab[(uint32_t)(w >> 32) & 63u] : -1, id_bits, limit,
+                                         bad);
+                }
+                if (FULL || s0 + 3 < P) {
+                    if (two) {
+                        typedef uint32_t U32x2w __attribute__((ext_vector_type(2), aligned(2)));
+                        const U32x2w v = {wv[0] | (wv[1] << 16), wv[2] | (wv[3] << 16)};
+                        __builtin_nontemporal_store(v, reinterpret_cast<U32x2w*>(reinterpret_cast<uint16_t*>(a.out_wire) + p0 + s0));
+                    } else {
+                        typedef uint32_t U32x4w __attribute__((ext_vector_type(4), aligned(4)));
+                        const U32x4w v = {wv[0], wv[1], wv[2], wv[3]};
+                        __builtin_nontemporal_store(v, reinterpret_cast<U32x4w*>(reinterpret_cast<uint32_t*>(a.out_wire) + p0 + s0));
+                    }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        if (s0 + i < P) {
+                            if (two) reinterpret_cast<uint16_t*>(a.out_wire)[p0 + s0 + i] = (uint16_t)wv[i];
+                            else reinterpret_cast<uint32_t*>(a.out_wire)[p0 + s0 + i] = wv[i];
+                        }
+                }
+            }
+        } else {
+#pragma unroll
+            for (int v = 0; v < E; ++v) {
+                const int s = v * L + gl;
+                if (s < P) {
+                    const uint64_t w = slice[slot_of(s)];
+                    const uint32_t x = wire_element((int32_t)((uint32_t)w & pid_mask), (C > 0) ? rank_tab[(uint32_t)(w >> 32) & 63u] : -1, id_bits,
+                                                    limit, bad);
+                    if (two) reinterpret_cast<uint16_t*>(a.out_wire)[p0 + s] = (uint16_t)x;
+                    else reinterpret_cast<uint32_t*>(a.out_wire)[p0 + s] = x;
+                }
+            }
+        }
+        if (__builtin_amdgcn_ballot_w64(bad) != 0 && (threadIdx.x & (kWave - 1)) == 0) atomicOr(a.status, kStatusWire);
+        return;
+    }
     if constexpr (E >= 4) {
         // four consecutive positions per lane: 16-byte stores
 #pragma unroll
@@ -594,7 +655,7 @@ __device__ __forceinline__ TopicDescT<IDX> load_desc(const TileArgs& a, int64_t 
 }
 
 // One tile of kernel 1, from the descriptor on (see the kernel below).
-template <int L, int E, typename IDX, bool INLINE_WIDE, bool FULL>
+template <int L, int E, typename IDX, bool INLINE_WIDE, bool FULL, bool WIRE = false>
 __device__ __forceinline__ void packed_tile(const TileArgs& a, const TopicDescT<IDX>& cur, uint64_t* slice, int32_t* rank_tab,
                                             int64_t tile, int gl, int lane) {
     using Cfg = TileCfg<L, E>;
@@ -635,7 +696,7 @@ __device__ __forceinline__ void packed_tile(const TileArgs& a, const TopicDescT<
     }
     if (fits) {
         sort_into_slice<L, E, FULL>(slice, gl, rec, lbw, sh);
-        assign_packed<L, E, FULL>(a, slice, rank_tab, cur.p0, cur.c0, cur.P, cur.C, gl, sh, lag_max, my_rank);
+        assign_packed<L, E, FULL, WIRE>(a, slice, rank_tab, cur.p0, cur.c0, cur.P, cur.C, gl, sh, lag_max, my_rank);
     } else if constexpr (INLINE_WIDE) {
         assign_wide<L, E, false>(a, slice, (int64_t)cur.p0, (int64_t)cur.c0, cur.P, cur.C, gl, lag, pid);
     } else if (lane == 0) {
@@ -650,7 +711,7 @@ __device__ __forceinline__ void packed_tile(const TileArgs& a, const TopicDescT<
 // workgroups' results (one workgroup's job below kSmallGroupN entries) and stores `done | status` into the host's word.
 __device__ __forceinline__ void tile_tail(const TileTail& t, const uint32_t* status) {
     __shared__ uint32_t s_start[kTailGroupM];
-    __shared__ int32_t s_in[3 * kSmallGroupN];                // ranks, ids, topics of the entries (group_small_body_staged)
+    __shared__ int32_t s_in[5 * kSmallGroupN];                // ranks, ids, topics of the entries; the lists (group_small_body_staged)
     __shared__ uint32_t s_wsum[LA_WPB];
     __shared__ uint32_t s_turn, s_last;
     __threadfence_system();                                   // this thread's result stores (to HBM or into the host's arrays)
@@ -666,7 +727,8 @@ __device__ __forceinline__ void tile_tail(const TileTail& t, const uint32_t* sta
     if (t.member_off)
         group_small_body_staged<kWave * LA_WPB, kTailGroupM>(t.n, t.n_members, t.n_topics, t.part_off, t.out_pid, t.out_rank,
                                                              t.member_off, t.grouped_topic, t.grouped_partition, nullptr, s_start,
-                                                             s_wsum, &s_turn, s_in, s_in + kSmallGroupN, s_in + 2 * kSmallGroupN);
+                                                             s_wsum, &s_turn, s_in, s_in + kSmallGroupN, s_in + 2 * kSmallGroupN,
+                                                             s_in + 3 * kSmallGroupN, s_in + 4 * kSmallGroupN);
     __threadfence_system();
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -686,7 +748,7 @@ __device__ __forceinline__ void tile_tail(const TileTail& t, const uint32_t* sta
 #else
 #define LA_WPE_ATTR
 #endif
-template <int L, int E, typename IDX, bool INLINE_WIDE>
+template <int L, int E, typename IDX, bool INLINE_WIDE, bool WIRE = false>
 __global__ __launch_bounds__(256) LA_WPE_ATTR void wave_tile_packed_kernel(TileArgs a) {
     using Cfg = TileCfg<L, E>;
     __shared__ uint64_t lds[Cfg::kTopicsPerBlock * Cfg::kSlots];
@@ -724,11 +786,11 @@ __global__ __launch_bounds__(256) LA_WPE_ATTR void wave_tile_packed_kernel(TileA
     if constexpr (!INLINE_WIDE) {
         // (and lies inside the batch: the general form's clamps are also what keeps a bogus descriptor's loads in bounds)
         if (__builtin_amdgcn_ballot_w64(cur.P != Cfg::kCap || (int64_t)cur.p0 + Cfg::kCap > a.n_total) == 0) {
-            packed_tile<L, E, IDX, false, true>(a, cur, slice, rank_tab, tile, gl, lane);
+            packed_tile<L, E, IDX, false, true, WIRE>(a, cur, slice, rank_tab, tile, gl, lane);
             return;
         }
     }
-    packed_tile<L, E, IDX, INLINE_WIDE, false>(a, cur, slice, rank_tab, tile, gl, lane);
+    packed_tile<L, E, IDX, INLINE_WIDE, false, WIRE>(a, cur, slice, rank_tab, tile, gl, lane);
 }
 
 // ---- kernel 2: wide records (and the literal argmin form) ------------------------------------------------------
@@ -821,13 +883,20 @@ static hipError_t launch_one(const TileArgs& a_in, int mode, hipStream_t stream,
         if (!a.defer_count || !a.defer_count_next || !a.defer_list) return hipErrorInvalidValue;
         // 32-bit indexing when every byte offset (8-byte arrays) fits 32 bits
         const bool idx32 = a.n_total < ((int64_t)1 << 29) && a.k_total < ((int64_t)1 << 30) && !(a.flags & 1);
-        if (idx32 && blocks <= res_inline && !(a.flags & 2)) {
+        if (idx32 && blocks <= res_inline && !(a.flags & 2) && !(a.flags & kTileWireOut)) {
             // the whole batch is resident at once: one kernel with the wide code inline, no second launch
             if (want_tail && tail_done) {
                 a.tail.enabled = 1;
                 *tail_done = true;
             }
             LA_LAUNCH((wave_tile_packed_kernel<L, E, uint32_t, true>), dim3((unsigned)blocks), b, 0, stream, a);
+            return hipGetLastError();
+        }
+        if (a.flags & kTileWireOut) {
+            // results in the wire format: only the form whose bounds prove that every tile packs (no wide-record code has the
+            // wire stores) and whose indices fit 32 bits -- la_api.hip checks both before it sets the flag
+            if (!idx32 || !(a.flags & kTileNoDefer) || !a.out_wire) return hipErrorInvalidValue;
+            LA_LAUNCH((wave_tile_packed_kernel<L, E, uint32_t, false, true>), dim3((unsigned)blocks), b, 0, stream, a);
             return hipGetLastError();
         }
         if (idx32)

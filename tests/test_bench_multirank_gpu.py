@@ -46,10 +46,12 @@ def test_default_at_two_ranks_is_the_north_star_workload():
     assert d["parity"]["bit_exact"] is True and d["parity"]["checked_topics"] > 0
     assert len(d["roofline"]["per_rank_kernel_ms"]) == 2 and min(d["roofline"]["per_rank_kernel_ms"]) > 0
     assert d["cold_call_ms"] > 0                                 # rank 0's extras survive at N > 1
-    # the default wire format: 2 bytes per assigned partition (ids < 256, 32 members); the map stays packed on every rank and the
-    # expansion is timed beside the step
+    # the default wire format: 2 bytes per assigned partition (ids < 256, 32 members), written by the assignment kernels themselves
+    # (round 5: LA_FLAG_WIRE_OUT, no pack launch in the step); the map stays packed on every rank and the expansion is timed beside
+    # the step
     wire = d["config"]["wire"]
-    assert wire["format"] == "packed" and wire["elem_bytes"] == 2 and wire["id_bits"] == 8 and wire["unpacked_in_step"] is False
+    assert wire["format"] == "fused" and wire["pack_launch"] is False and wire["pack_ms"] < 0.02
+    assert wire["elem_bytes"] == 2 and wire["id_bits"] == 8 and wire["unpacked_in_step"] is False
     assert wire["unpack_ms"] > 0 and 0 < wire["value_if_unpacked_in_step"] < d["value"]
     assert wire["gather_bytes_per_rank"] == 2 * 12800000
 
@@ -81,6 +83,9 @@ def test_strong_scaling_three_ranks_other_wire_forms():
     d = _run(3, ["--workload", "cfg4", "--unpack"], GLOO)
     assert d["config"]["wire"]["unpacked_in_step"] is True and d["config"]["wire"]["elem_bytes"] == 2
     assert d["parity"]["bit_exact"] is True and d["parity"]["checked_topics"] == 100000
+    d = _run(3, ["--workload", "cfg4", "--wire", "packed"], GLOO)                 # round 4's form: a pack launch behind the kernels
+    assert d["config"]["wire"]["format"] == "packed" and d["config"]["wire"]["pack_launch"] is True and d["config"]["wire"]["pack_ms"] > 0
+    assert d["parity"]["bit_exact"] is True and d["parity"]["checked_topics"] == 100000
 
 
 @pytest.mark.timeout(1200)
@@ -99,4 +104,4 @@ def test_rccl_leg_one_rank_strong_cfg4():
     assert d["config"]["collectives_per_step"] == 1 and d["scaling"] == "strong"
     assert d["parity"]["bit_exact"] is True and d["parity"]["checked_topics"] == 100000
     assert d["roofline"]["per_rank_gather_ms"][0] > 0
-    assert d["config"]["wire"]["format"] == "packed" and d["config"]["wire"]["elem_bytes"] == 2     # bytes through RCCL (ncclUint8)
+    assert d["config"]["wire"]["format"] == "fused" and d["config"]["wire"]["elem_bytes"] == 2      # bytes through RCCL (ncclUint8)

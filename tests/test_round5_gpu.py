@@ -306,3 +306,94 @@ print("ok")
         out = subprocess.run([sys.executable, "-c", code % (ROOT, os.path.join(ROOT, "tests"))], env=env, capture_output=True,
                              text=True, timeout=600)
         assert out.returncode == 0 and "ok" in out.stdout, (mode, out.stdout[-1500:], out.stderr[-1500:])
+
+
+# ---- LA_FLAG_WIRE_OUT: the all-gather's wire elements straight from the assignment kernels ------------------
+def _wire_call(ctx, w, fmt, bounds, latest=False, flags=0, hint=None):
+    import torch
+    from kafka_lag_based_assignor_amd import sharding
+    dev = torch.device("cuda", 0)
+    d = {k: torch.from_numpy(np.ascontiguousarray(getattr(w, k))).to(dev) for k in
+         ("part_off", "partition_id", "begin", "end", "committed", "cons_off", "cons_rank")}
+    n = w.n_partitions
+    wire = torch.zeros(max(n, 1) * fmt.elem_bytes + 16, device=dev, dtype=torch.uint8)
+    out_total = torch.full((max(w.cons_rank.size, 1),), -7, device=dev, dtype=torch.int64)
+    b = N.DeviceBatch()
+    b.n_topics, b.reset_mode, b.algo = w.n_topics, (N.LA_RESET_LATEST if latest else N.LA_RESET_EARLIEST), N.LA_ALGO_AUTO
+    b.flags = N.LA_FLAG_WIRE_OUT | flags
+    b.n_partitions, b.n_consumers = n, w.cons_rank.size
+    mp, mc = hint or (w.max_partitions, w.max_consumers)
+    b.max_partitions_per_topic, b.max_consumers_per_topic = mp, mc
+    b.d_part_off, b.d_partition_id = d["part_off"].data_ptr(), d["partition_id"].data_ptr()
+    b.d_begin_off, b.d_end_off, b.d_committed_off = d["begin"].data_ptr(), d["end"].data_ptr(), d["committed"].data_ptr()
+    b.d_cons_off, b.d_cons_rank = d["cons_off"].data_ptr(), d["cons_rank"].data_ptr()
+    b.d_out_partition = b.d_out_member_rank = None
+    b.d_out_total_lag = out_total.data_ptr()
+    if bounds is not None:
+        b.flags |= N.LA_FLAG_BOUNDS
+        b.max_lag_hint, b.max_partition_id_hint = bounds
+    b.d_out_wire = wire.data_ptr() + 2                              # element-aligned only: 2 bytes off a 16-byte boundary
+    b.wire_elem_bytes, b.wire_id_bits = fmt.elem_bytes, fmt.id_bits
+    stream = torch.cuda.current_stream().cuda_stream
+    ctx.assign_batch_device(b, stream)
+    ctx.sync(stream)
+    raw = wire.cpu().numpy()[2:2 + n * fmt.elem_bytes].view(fmt.dtype)
+    return raw, out_total.cpu().numpy()[: w.cons_rank.size]
+
+
+@pytest.mark.parametrize("topics,p,c,dist", [(30000, 256, 32, "zipf"), (60000, 64, 8, "uniform40"), (20000, 1000, 64, "zipf"),
+                                             (50000, 37, 5, "zipf"), (300000, 7, 3, "uniform40"), (9000, 256, 32, "zipf")])
+def test_wire_out_equals_the_packed_results(ctx, topics, p, c, dist):
+    """The wire elements the tile kernels write themselves are what la_pack_results_on makes of the two int32 arrays (checked
+    against sharding.wire_pack_numpy of the ORACLE's arrays on a slice and of the plain device call's arrays in full); totals as
+    usual.  Topic starts that are odd multiples of the element size (37, 7 partitions per topic): the 8-byte stores are only
+    element-aligned.  A batch small enough to be resident at once (9 000 topics) still takes the one-launch wire form."""
+    from kafka_lag_based_assignor_amd import sharding
+    w = synth.make_uniform("wire", topics % 97, topics, p, c, dist)
+    bounds = N.offset_bounds(w.begin, w.end, w.committed, w.partition_id)
+    n_members = int(w.cons_rank.max()) + 1
+    fmt = N.wire_format_for(int(w.partition_id.max()), n_members)
+    assert fmt.elem_bytes in (2, 4)
+    raw, tot = _wire_call(ctx, w, fmt, bounds)
+    assert ctx.last_launches() == 1
+    ref_p, ref_m, ref_t = ctx.assign_batch(w.part_off, w.partition_id, w.begin, w.end, w.committed, N.LA_RESET_EARLIEST, w.cons_off,
+                                           w.cons_rank)
+    np.testing.assert_array_equal(raw, sharding.pack_results_numpy(ref_p, ref_m, fmt.elem_bytes, fmt.id_bits))
+    np.testing.assert_array_equal(tot, ref_t)
+    t = min(topics, 300)
+    p1, k1 = int(w.part_off[t]), int(w.cons_off[t])
+    lag = oracle.compute_lags(w.begin[:p1], w.end[:p1], w.committed[:p1], False)
+    e_pid, e_rank, _ = oracle.assign_flat(w.part_off[:t + 1], w.partition_id[:p1], lag, w.cons_off[:t + 1], w.cons_rank[:k1])
+    np.testing.assert_array_equal(raw[:p1], sharding.pack_results_numpy(e_pid, e_rank, fmt.elem_bytes, fmt.id_bits))
+
+
+def test_wire_out_topics_without_consumers_and_ragged_sizes(ctx):
+    import test_round4_gpu as t4
+    from kafka_lag_based_assignor_amd import sharding
+    rng = np.random.default_rng(4)
+    shapes = [(int(rng.integers(0, 257)), int(rng.integers(0, 33))) for _ in range(40000)]
+    w0 = t4._batch_of(shapes, 12, kinds=["u20", "zero", "ties"])
+    w = synth.Workload("ragged", w0.n_topics, w0.part_off, w0.partition_id, np.zeros_like(w0.lag), w0.lag.copy(), np.zeros_like(w0.lag),
+                       w0.lag, w0.cons_off, w0.cons_rank, 256, 32)
+    fmt = N.wire_format_for(255, int(w.cons_rank.max()) + 1)
+    raw, tot = _wire_call(ctx, w, fmt, (1 << 20, 255), hint=(256, 32))
+    e_pid, e_rank, e_tot = oracle.assign_flat(w.part_off, w.partition_id, w.lag, w.cons_off, w.cons_rank)
+    np.testing.assert_array_equal(raw, sharding.pack_results_numpy(e_pid, e_rank, fmt.elem_bytes, fmt.id_bits))   # rank -1 -> 0
+    np.testing.assert_array_equal(tot, e_tot)
+
+
+def test_wire_out_refuses_what_it_cannot_do(ctx):
+    w = synth.make_uniform("wire", 5, 20000, 256, 32, "zipf")
+    bounds = N.offset_bounds(w.begin, w.end, w.committed, w.partition_id)
+    fmt = N.wire_format_for(255, 32)
+    for kwargs in ({"bounds": None}, {"bounds": (1 << 60, 255)}, {"bounds": bounds, "flags": N.LA_FLAG_RAGGED},
+                   {"bounds": bounds, "hint": (2000, 32)}):
+        with pytest.raises(N.LagAssignError) as ei:
+            _wire_call(ctx, w, fmt, kwargs.get("bounds"), flags=kwargs.get("flags", 0), hint=kwargs.get("hint"))
+        assert ei.value.code == N.LA_EINVAL and "LA_FLAG_WIRE_OUT" in str(ei.value)
+    small = N.WireFormat(2, 12)                                    # 4 bits above the id: member ranks up to 14 only
+    with pytest.raises(N.LagAssignError) as ei:
+        _wire_call(ctx, w, small, bounds)
+    assert ei.value.code == N.LA_EINVAL and "wire format" in str(ei.value)
+    raw, _ = _wire_call(ctx, w, fmt, bounds)                       # and the context is fine afterwards
+    assert raw.size == w.n_partitions
