@@ -31,8 +31,20 @@ def test_library_exports_every_declared_symbol():
 
 
 def test_device_batch_struct_matches_header_layout():
-    # 4 x int32 + 4 x int64 + 13 pointers + 2 x int64 (the LA_FLAG_BOUNDS hints)
-    assert ctypes.sizeof(_native.DeviceBatch) == 16 + 32 + 13 * 8 + 16
+    # 4 x int32 + 4 x int64 + 13 pointers + 2 x int64 (the LA_FLAG_BOUNDS hints) + pointer + 2 x int32 (LA_FLAG_WIRE_OUT)
+    assert ctypes.sizeof(_native.DeviceBatch) == 16 + 32 + 13 * 8 + 16 + 8 + 8
+    # ... and it is the C compiler's layout of the header's struct (offsets of the fields added since ABI 0.3.0)
+    import subprocess
+    import tempfile
+    src = '#include <stdio.h>\n#include <stddef.h>\n#include "lagassign.h"\nint main(void){printf("%zu %zu %zu %zu %zu",sizeof(la_device_batch),' \
+          'offsetof(la_device_batch,max_lag_hint),offsetof(la_device_batch,d_out_wire),offsetof(la_device_batch,wire_id_bits),sizeof(la_call_hints));return 0;}'
+    with tempfile.TemporaryDirectory() as d:
+        c = os.path.join(d, "t.c")
+        open(c, "w").write(src)
+        subprocess.check_call(["gcc", "-std=c99", "-I" + os.path.join(ROOT, "include"), c, "-o", os.path.join(d, "t")])
+        got = [int(x) for x in subprocess.check_output([os.path.join(d, "t")]).split()]
+    B = _native.DeviceBatch
+    assert got == [ctypes.sizeof(B), B.max_lag_hint.offset, B.d_out_wire.offset, B.wire_id_bits.offset, ctypes.sizeof(_native.CallHints)]
 
 
 def test_binding_constants_match_the_header():
@@ -49,7 +61,7 @@ def test_binding_constants_match_the_header():
     assert checked >= 12
     # the device batch: field order and types as declared in the header
     body = header[header.index("typedef struct la_device_batch {"):header.index("} la_device_batch;")]
-    fields = re.findall(r"^\s*(?:const\s+)?(int32_t|int64_t)\s*(\*?)\s*(\w+);", body, re.M)
+    fields = re.findall(r"^\s*(?:const\s+)?(int32_t|int64_t|void)\s*(\*?)\s*(\w+);", body, re.M)
     declared = [(n, ("p" if star else t)) for t, star, n in fields]
     bound = [(n, ("p" if (isinstance(t, type) and issubclass(t, (ctypes._Pointer, ctypes.c_void_p))) else
                   {ctypes.c_int32: "int32_t", ctypes.c_int64: "int64_t"}[t])) for n, t in _native.DeviceBatch._fields_]
