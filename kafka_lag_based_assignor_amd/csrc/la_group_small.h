@@ -25,6 +25,22 @@
 
 namespace la {
 
+#ifdef LA_GROUP_CLOCKS   // lab build of la_large.hip: thread 0 accumulates the time of every phase of group_small_body_staged (100 MHz)
+__device__ unsigned long long g_group_clocks[12];
+#define LA_GCLK(i)                                                  \
+    do {                                                            \
+        if (threadIdx.x == 0) {                                     \
+            const unsigned long long now_ = wall_clock64();         \
+            g_group_clocks[i] += now_ - gclk_;                      \
+            gclk_ = now_;                                           \
+        }                                                           \
+    } while (0)
+#define LA_GCLK_START unsigned long long gclk_ = wall_clock64()
+#else
+#define LA_GCLK(i) do {} while (0)
+#define LA_GCLK_START do {} while (0)
+#endif
+
 constexpr int kSmallGroupN = 2560;       // entries.  Measured on one box, device-resident, back to back (tools/group_probe.py,
                                          // profiles/r04_group_probe.txt): this kernel 4.0 us at 100 entries, 9 at 1 000, 14.8 at 2 000, 26 at
                                          // 4 096 (its chunks' global loads and topic searches are dependent round trips, 16 chunks deep per
@@ -164,16 +180,18 @@ __device__ __forceinline__ void group_small_body(int n, int32_t n_members, int64
 // input is read ONCE, coalesced, all loads of a thread issued back to back: ranks and ids into LDS, and the topic of every
 // entry from ONE pass over part_off -- +1 at every topic's first position, an inclusive scan (topic of entry i = the number of
 // topic starts at or before i, minus one: the largest t with part_off[t] <= i, empty topics included).  The placement then
-// runs on LDS.  s_rank / s_part / s_topic / o_part / o_topic: [cap] words each, n <= cap.
+// runs on LDS.  s_rank / s_part / s_topic / o_part / o_topic / lead / first: [cap] words each, n <= cap.
 template <int NT, int M>
 __device__ __forceinline__ void group_small_body_staged(int n, int32_t n_members, int64_t n_topics, const int64_t* part_off,
                                                         const int32_t* out_partition, const int32_t* member_rank, int64_t* member_off,
                                                         int32_t* grouped_topic, int32_t* grouped_partition, int32_t* grouped_entry,
                                                         uint32_t* start, uint32_t* wsum, uint32_t* turn, int32_t* s_rank,
-                                                        int32_t* s_part, int32_t* s_topic, int32_t* o_part, int32_t* o_topic) {
+                                                        int32_t* s_part, int32_t* s_topic, int32_t* o_part, int32_t* o_topic,
+                                                        uint32_t* lead, uint32_t* first) {
     static_assert(M % NT == 0 && NT % kWave == 0, "M counters over NT threads");
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint32_t G = (uint32_t)n_members + 1;
+    LA_GCLK_START;
     for (int k = tid; k < M; k += NT) start[k] = 0;
     for (int i = tid; i < n; i += NT) s_topic[i] = 0;
     if (tid == 0) *turn = 0;
@@ -188,36 +206,66 @@ __device__ __forceinline__ void group_small_body_staged(int n, int32_t n_members
             if (at >= 0 && at < n) atomicAdd((uint32_t*)&s_topic[at], 1u);
         }
     __syncthreads();
-    for (int i = tid; i < n; i += NT) {
-        uint32_t gi = (uint32_t)(s_rank[i] + 1);
+    LA_GCLK(0);                                                            // zero + loads + topic heads
+    // A (all wavefronts, chunks of 64 consecutive entries in parallel): ranks and peer counts by ballots; the FIRST lane of every
+    // group present in a chunk leaves (group, count) in lead[chunk][lane] and adds the count to its group's counter -- one LDS
+    // atomic per (chunk, group) instead of one per entry: with a handful of members every entry of a rebalance lands on the same
+    // few counters, and 2 000 same-address atomics were 5 us of a 13 us grouping.
+    constexpr int W = NT / kWave;
+    const int nch = (n + kWave - 1) / kWave;
+    const uint64_t below = ((uint64_t)1 << lane) - 1;
+    for (int c = wave; c < nch; c += W) {
+        const int i = c * kWave + lane;
+        const bool valid = i < n;
+        uint32_t gi = valid ? (uint32_t)(s_rank[i] + 1) : 0u;
         gi = gi < G ? gi : G;
-        atomicAdd(&start[gi], 1u);
-    }
-    // inclusive scan of the topic starts over the n entries, in blocks of NT * PERT consecutive entries per pass
-    if (grouped_topic) {
-        uint32_t carry = 0;
-        for (int base = 0; base < n; base += NT) {
-            const int i = base + tid;
-            const uint32_t v = i < n ? (uint32_t)s_topic[i] : 0u;
-            uint32_t incl = v;
+        uint64_t peers = __ballot(valid);
 #pragma unroll
-            for (int o = 1; o < 64; o <<= 1) {
-                const uint32_t y = __shfl_up(incl, o);
-                if (lane >= o) incl += y;
-            }
-            if (lane == 63) wsum[wave] = incl;
-            __syncthreads();
-            uint32_t before = carry;
-            for (int w = 0; w < wave; ++w) before += wsum[w];
-            uint32_t all = 0;
-            for (int w = 0; w < NT / kWave; ++w) all += wsum[w];
-            if (i < n) s_topic[i] = (int32_t)(before + incl) - 1;
-            carry += all;
-            __syncthreads();
+        for (int bit = 0; bit < kSmallGroupBits + 1; ++bit) {               // (G itself may need one bit more than G - 1)
+            const bool one = (gi >> bit) & 1u;
+            const uint64_t bal = __ballot(one);
+            peers &= one ? bal : ~bal;
         }
-    } else {
-        __syncthreads();
+        const uint32_t rank = (uint32_t)__popcll(peers & below), cnt = (uint32_t)__popcll(peers);
+        const int leader = __ffsll((unsigned long long)peers) - 1;
+        if (valid) {
+            s_rank[i] = (int32_t)(((uint32_t)leader << 16) | rank);         // (the group id is not needed again)
+            lead[i] = lane == leader ? ((gi << 8) | cnt) : 0u;              // cnt in 1 .. 64: seven bits
+            if (lane == leader) atomicAdd(&start[gi], cnt);
+        }
     }
+    LA_GCLK(1);                                                            // A: ballots, leader counts
+    // inclusive scan of the topic starts over the n entries: PERT consecutive entries per thread, a wavefront scan of the
+    // threads' sums, the wavefronts' sums (the form of the counts' scan below; blocks of NT entries with two barriers and a
+    // serial walk over the wavefronts' sums each were 3.7 us of a 12 us grouping at 2 000 entries)
+    if (grouped_topic) {
+        constexpr int PERT = (kSmallGroupN + NT - 1) / NT;
+        uint32_t tv[PERT], trun = 0;
+#pragma unroll
+        for (int r = 0; r < PERT; ++r) {
+            const int i = PERT * tid + r;
+            tv[r] = i < n ? (uint32_t)s_topic[i] : 0u;
+            trun += tv[r];
+        }
+        uint32_t tincl = trun;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t y = __shfl_up(tincl, o);
+            if (lane >= o) tincl += y;
+        }
+        if (lane == 63) wsum[wave] = tincl;
+        __syncthreads();
+        uint32_t tbase = tincl - trun;
+        for (int w = 0; w < wave; ++w) tbase += wsum[w];
+#pragma unroll
+        for (int r = 0; r < PERT; ++r) {
+            const int i = PERT * tid + r;
+            tbase += tv[r];
+            if (i < n) s_topic[i] = (int32_t)tbase - 1;
+        }
+    }
+    __syncthreads();                                                    // (wsum is used again; the leaders' counts are in)
+    LA_GCLK(2);                                                            // topic scan
     // exclusive scan over the M counts: M / NT per thread, a wavefront scan, the wavefronts' sums
     constexpr int PER = M / NT;
     uint32_t c[PER], run = 0;
@@ -238,16 +286,63 @@ __device__ __forceinline__ void group_small_body_staged(int n, int32_t n_members
     __syncthreads();
     for (int k = tid; k <= n_members; k += NT) member_off[k] = (int64_t)start[k + 1];
     __syncthreads();                                                    // (the cursors move from here on)
-    // The lists are built in LDS (o_part / o_topic: [cap] words each) and leave in ONE coalesced pass: an entry's place is
-    // scattered, and a scattered 4-byte store into the host's memory (a zero-copy call's lists go straight there) is a PCIe
-    // write transaction of its own -- 2 x 2 000 of them were ~15 us of a 43 us rebalance.
-    group_small_place<1, NT>(n, G, n_topics, part_off, s_part, s_rank, grouped_topic ? o_topic : nullptr, o_part, grouped_entry, start,
-                             turn, lane, wave, s_topic);
+    // Places.  An entry's place is (its group's cursor when its chunk's turn comes) + (its rank among the chunk's entries of that
+    // group, found in A).  The form above passes the turn from chunk to chunk through a spin on an LDS word: ~0.4 us per chunk,
+    // one after another.  Here the serial part is cut down to what is serial:
+    //   B (every wavefront walks ALL chunks in order, for the groups g with g % wavefronts == its number): cursor read, cursor +
+    //     count in one returning LDS atomic, the old cursor left in first[chunk][lane] (NOT in lead: the other wavefronts, which
+    //     may be chunks behind or ahead, still read this chunk's (group, count) words).  Groups of different wavefronts are disjoint,
+    //     the groups inside a chunk distinct, and one wavefront's LDS operations execute in the order it issues them: no spinning;
+    //   C (chunks in parallel): place = first[chunk][first lane of my group] + my rank; the lists are built in LDS (o_part /
+    //     o_topic) and leave in ONE coalesced pass -- a scattered 4-byte store into the host's memory (a zero-copy call's lists
+    //     go straight there) is a PCIe write transaction of its own.
+    // lead, first: [cap] words each.  Stable by construction (chunk order, then lane order).
     __syncthreads();
+    LA_GCLK(3);                                                            // counts scan + member_off
+    {
+        // (returning atomics of ONE wavefront execute in the order they are issued, chunk by chunk; the groups of a chunk are
+        //  distinct and the groups of different wavefronts disjoint: the old value IS the cursor at the chunk's turn.  Four chunks
+        //  in flight: a read -> add -> write chain per chunk was 0.13 us x 32 chunks.)
+        constexpr int kAhead = 4;
+        for (int c0 = 0; c0 < nch; c0 += kAhead) {
+            uint32_t v[kAhead], f[kAhead];
+#pragma unroll
+            for (int u = 0; u < kAhead; ++u) {
+                const int i = (c0 + u) * kWave + lane;
+                v[u] = (c0 + u < nch && i < n) ? lead[i] : 0u;
+            }
+#pragma unroll
+            for (int u = 0; u < kAhead; ++u) {
+                const uint32_t cnt = v[u] & 0xFFu, g = v[u] >> 8;
+                f[u] = 0;
+                if (cnt != 0 && (g % W) == (uint32_t)wave) f[u] = atomicAdd(&start[g], cnt);
+            }
+#pragma unroll
+            for (int u = 0; u < kAhead; ++u) {
+                const uint32_t cnt = v[u] & 0xFFu, g = v[u] >> 8;
+                if (cnt != 0 && (g % W) == (uint32_t)wave) first[(c0 + u) * kWave + lane] = f[u];
+            }
+        }
+    }
+    __syncthreads();
+    LA_GCLK(4);                                                            // B: cursors
+    for (int c = wave; c < nch; c += W) {
+        const int i = c * kWave + lane;
+        if (i < n) {
+            const uint32_t pk = (uint32_t)s_rank[i];
+            const uint32_t pos = first[c * kWave + (int)(pk >> 16)] + (pk & 0xFFFFu);
+            o_part[pos] = s_part[i];
+            if (grouped_topic) o_topic[pos] = s_topic[i];
+            if (grouped_entry) grouped_entry[pos] = i;
+        }
+    }
+    __syncthreads();
+    LA_GCLK(5);                                                            // C: places
     for (int i = tid; i < n; i += NT) {
         grouped_partition[i] = o_part[i];
         if (grouped_topic) grouped_topic[i] = o_topic[i];
     }
+    LA_GCLK(6);                                                            // lists out
 }
 
 }  // namespace la

@@ -2711,10 +2711,12 @@ __global__ __launch_bounds__(1024) void group_small_kernel(int n, int32_t n_memb
     __shared__ uint32_t wsum[1024 / kWave];
     __shared__ uint32_t turn;
 #ifndef LA_GROUP_UNSTAGED
-    __shared__ int32_t s_in[5 * kSmallGroupN];        // ranks, ids, topics of the entries; the lists
+    __shared__ int32_t s_in[7 * kSmallGroupN];        // ranks, ids, topics of the entries; the lists; the chunks' group leaders
     group_small_body_staged<1024, kSmallGroupM>(n, n_members, n_topics, part_off, out_partition, member_rank, member_off,
                                                 grouped_topic, grouped_partition, grouped_entry, start, wsum, &turn, s_in,
-                                                s_in + kSmallGroupN, s_in + 2 * kSmallGroupN, s_in + 3 * kSmallGroupN, s_in + 4 * kSmallGroupN);
+                                                s_in + kSmallGroupN, s_in + 2 * kSmallGroupN, s_in + 3 * kSmallGroupN, s_in + 4 * kSmallGroupN,
+                                                reinterpret_cast<uint32_t*>(s_in + 5 * kSmallGroupN),
+                                                             reinterpret_cast<uint32_t*>(s_in + 6 * kSmallGroupN));
 #elif defined(LA_GROUP_SUB)                                   // (lab builds: tools/group_probe.py compares the forms on one box)
     group_small_body<1024, kSmallGroupM, LA_GROUP_SUB>(n, n_members, n_topics, part_off, out_partition, member_rank, member_off,
                                                        grouped_topic, grouped_partition, grouped_entry, start, wsum, &turn);
@@ -2762,6 +2764,17 @@ hipError_t group_by_member_launch(LargeScratch& scratch, int64_t n, int32_t n_me
                        out_partition, member_off, grouped_topic, grouped_partition, grouped_entry, status);
     return hipGetLastError();
 }
+
+#ifdef LA_GROUP_CLOCKS
+extern "C" __attribute__((visibility("default"))) int la_debug_group_clocks(unsigned long long* out, int reset) {
+    hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(g_group_clocks), sizeof(g_group_clocks));
+    if (e == hipSuccess && reset) {
+        unsigned long long zero[12] = {};
+        e = hipMemcpyToSymbol(HIP_SYMBOL(g_group_clocks), zero, sizeof zero);
+    }
+    return e == hipSuccess ? 0 : -3;
+}
+#endif
 
 #ifdef LA_SWEEP_CLOCKS
 extern "C" __attribute__((visibility("default"))) int la_debug_sweep_clocks(unsigned long long* out, int reset) {

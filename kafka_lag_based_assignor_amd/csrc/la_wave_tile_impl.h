@@ -439,8 +439,10 @@ __device__ __forceinline__ void assign_packed(const TileArgs& a, uint64_t* slice
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const uint64_t w = slice[slot_of(s0 + i)];
+                    bool b1 = false;
                     wv[i] = wire_element((int32_t)((uint32_t)w & pid_mask), (C > 0) ? rank_tab[(uint32_t)(w >> 32) & 63u] : -1, id_bits, limit,
-                                         bad);
+                                         b1);
+                    bad |= b1 && (FULL || s0 + i < P);                       // (slots past the topic hold no pair)
                 }
                 if (FULL || s0 + 3 < P) {
                     if (two) {
@@ -711,7 +713,7 @@ __device__ __forceinline__ void packed_tile(const TileArgs& a, const TopicDescT<
 // workgroups' results (one workgroup's job below kSmallGroupN entries) and stores `done | status` into the host's word.
 __device__ __forceinline__ void tile_tail(const TileTail& t, const uint32_t* status) {
     __shared__ uint32_t s_start[kTailGroupM];
-    __shared__ int32_t s_in[5 * kSmallGroupN];                // ranks, ids, topics of the entries; the lists (group_small_body_staged)
+    __shared__ int32_t s_in[7 * kSmallGroupN];                // ranks, ids, topics of the entries; the lists (group_small_body_staged)
     __shared__ uint32_t s_wsum[LA_WPB];
     __shared__ uint32_t s_turn, s_last;
     __threadfence_system();                                   // this thread's result stores (to HBM or into the host's arrays)
@@ -728,7 +730,9 @@ __device__ __forceinline__ void tile_tail(const TileTail& t, const uint32_t* sta
         group_small_body_staged<kWave * LA_WPB, kTailGroupM>(t.n, t.n_members, t.n_topics, t.part_off, t.out_pid, t.out_rank,
                                                              t.member_off, t.grouped_topic, t.grouped_partition, nullptr, s_start,
                                                              s_wsum, &s_turn, s_in, s_in + kSmallGroupN, s_in + 2 * kSmallGroupN,
-                                                             s_in + 3 * kSmallGroupN, s_in + 4 * kSmallGroupN);
+                                                             s_in + 3 * kSmallGroupN, s_in + 4 * kSmallGroupN,
+                                                             reinterpret_cast<uint32_t*>(s_in + 5 * kSmallGroupN),
+                                                             reinterpret_cast<uint32_t*>(s_in + 6 * kSmallGroupN));
     __threadfence_system();
     __syncthreads();
     if (threadIdx.x == 0) {

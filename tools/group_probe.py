@@ -36,6 +36,16 @@ def main():
             call()
         e1.record()
         ctx.sync(stream)
+        if hasattr(ctx._lib, "la_debug_group_clocks"):      # lab build (-DLA_GROUP_CLOCKS on la_large): phase times of the one-workgroup form
+            import ctypes
+            clk = (ctypes.c_ulonglong * 12)()
+            ctx._lib.la_debug_group_clocks(clk, 1)
+            for _ in range(50):
+                call()
+            ctx.sync(stream)
+            ctx._lib.la_debug_group_clocks(clk, 1)
+            names = ["zero+loads+heads", "A ballots", "topic scan", "counts scan", "B cursors", "C places", "lists out"]
+            print("   n=%d m=%d us per phase: " % (n, m) + ", ".join("%s %.2f" % (nm, clk[i] / 50 / 100.0) for i, nm in enumerate(names)))
         order = np.argsort(out_m.cpu().numpy(), kind="stable")
         ok = np.array_equal(g_p.cpu().numpy(), out_p.cpu().numpy()[order])
         row.append("%d x %d: %.1f us%s" % (n, m, e0.elapsed_time(e1) / 200 * 1e3, "" if ok else " WRONG"))
