@@ -72,9 +72,9 @@ class LagBasedPartitionAssignor:
         return {t: dict(v) for t, v in self._impl.last_topic_totals().items()}
 
     def last_order_exact(self) -> bool:
-        """False when the last assign() met a HashMap bucket a JVM would have turned into a tree bin: the C++ host's
-        container model has none, so the ORDER of topics inside the members' lists is then a guess (who gets what
-        is unaffected; the Java host uses the real HashMap).  Also reported through the warn hook."""
+        """False when the last assign() met a HashMap bucket a JVM turns into a tree bin: the ORDER of topics inside the
+        members' lists then follows the C++ host's restatement of HashMap's TreeNode handling (definite, equal to the oracle's
+        own restatement, unverified against a JVM); who gets what is unaffected.  Also reported through the warn hook."""
         return bool(self._impl.last_order_exact())
 
     @staticmethod

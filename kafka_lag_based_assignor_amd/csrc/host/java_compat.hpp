@@ -81,6 +81,14 @@ inline bool equals_ignore_case_latest(const std::string& mode) {
 
 // Iteration-order model of `new HashMap<String, V>()`.  Keys are identified by a caller
 // chosen int id (index into the caller's own storage); the map only tracks order.
+//
+// Tree bins (round 5).  A bucket of a >= 64-slot table that reaches 9 keys through put (8 through computeIfAbsent) becomes a
+// red-black tree of TreeNodes that KEEP their `next` links: iteration still walks `next`, but treeify / putTreeVal call
+// moveRootToFront (the tree's root is unlinked and put first) and putTreeVal links a new node right behind its tree PARENT
+// instead of at the tail -- the order depends on the tree's shape.  Restated here from OpenJDK 8's HashMap: treeifyBin,
+// TreeNode.treeify / putTreeVal / balanceInsertion / rotateLeft / rotateRight / moveRootToFront / split (with untreeify at
+// <= 6 nodes); inside a tree keys order by the spread hash as a signed int, then String.compareTo.  UNVERIFIED AGAINST A JVM
+// (none in the image): the oracle carries an independent restatement (oracle/java_collections.py) and the tests compare the two.
 class JavaHashMapOrder {
  public:
     JavaHashMapOrder() = default;                               // new HashMap<>()
@@ -91,40 +99,82 @@ class JavaHashMapOrder {
         while (cap < initial_capacity) cap <<= 1;
         threshold_ = cap;
     }
-    // HashMap.put of a NEW key (caller guarantees absence)
-    void put_new(int id, int32_t hash_code) {
+    // HashMap.put of a NEW key (caller guarantees absence): a plain bin appends at its tail
+    void put_new(int id, const std::string& key) {
         if (table_.empty()) resize();
-        const uint32_t h = spread(hash_code);
-        auto& chain = table_[(table_.size() - 1) & h];
-        chain.push_back({h, id});
-        if (chain.size() >= 9) treeify_bin();
+        const int n = new_node(id, key);
+        const size_t index = (table_.size() - 1) & nodes_[n].h;
+        Bin& bin = table_[index];
+        if (bin.tree) {
+            put_tree_val(bin, n);
+        } else {
+            bin.list.push_back(n);
+            if (bin.list.size() >= 9) treeify_bin(index);           // binCount >= TREEIFY_THRESHOLD - 1 when the 9th is appended
+        }
         if (++size_ > threshold_) resize();
     }
-    // HashMap.computeIfAbsent of a NEW key
-    void compute_if_absent_new(int id, int32_t hash_code) {
+    // HashMap.computeIfAbsent of a NEW key: resize BEFORE the insertion when size > threshold; a plain bin takes the new node
+    // at its HEAD
+    void compute_if_absent_new(int id, const std::string& key) {
         if (table_.empty() || size_ > threshold_) resize();
-        const uint32_t h = spread(hash_code);
-        auto& chain = table_[(table_.size() - 1) & h];
-        const size_t bin_count = chain.size();
-        chain.insert(chain.begin(), {h, id});
-        if (bin_count >= 7) treeify_bin();
+        const int n = new_node(id, key);
+        const size_t index = (table_.size() - 1) & nodes_[n].h;
+        Bin& bin = table_[index];
+        if (bin.tree) {
+            put_tree_val(bin, n);
+        } else {
+            const size_t bin_count = bin.list.size();
+            bin.list.insert(bin.list.begin(), n);
+            if (bin_count >= 7) treeify_bin(index);
+        }
         ++size_;
     }
     // ids in entrySet() iteration order
     std::vector<int> order() const {
         std::vector<int> out;
         out.reserve(size_);
-        for (const auto& chain : table_)
-            for (const auto& n : chain) out.push_back(n.second);
+        for (const Bin& bin : table_) {
+            if (bin.tree) {
+                for (int x = bin.first; x >= 0; x = nodes_[x].next) out.push_back(nodes_[x].id);
+            } else {
+                for (int x : bin.list) out.push_back(nodes_[x].id);
+            }
+        }
         return out;
     }
-    bool order_exact() const { return exact_; }
+    // false once some bucket became a tree bin: the order is then this file's restatement of TreeNode's list handling, which
+    // no JVM has confirmed here (who-gets-what never depends on it)
+    bool order_exact() const { return !treeified_; }
+    bool treeified() const { return treeified_; }
     size_t size() const { return size_; }
 
  private:
+    struct Node {
+        uint32_t h = 0;                    // spread hash (compared as a Java int inside a tree)
+        int id = 0;
+        std::u16string key;
+        int parent = -1, left = -1, right = -1, prev = -1, next = -1;
+        bool red = false;
+    };
+    struct Bin {
+        bool tree = false;
+        std::vector<int> list;             // plain bin: node indices in `next` order
+        int first = -1;                    // tree bin: table[index]
+    };
+
     static uint32_t spread(int32_t hc) {
         const uint32_t h = static_cast<uint32_t>(hc);
         return h ^ (h >> 16);
+    }
+    int new_node(int id, const std::string& key) {
+        Node n;
+        n.id = id;
+        n.key = utf8_to_utf16(key);
+        uint32_t hc = 0;
+        for (char16_t u : n.key) hc = 31u * hc + u;
+        n.h = spread(static_cast<int32_t>(hc));
+        nodes_.push_back(std::move(n));
+        return (int)nodes_.size() - 1;
     }
     // HashMap.resize(): oldCap > 0 -> double (threshold doubles only from 16 slots up, else 0.75 * newCap, truncated);
     // oldCap == 0 with a threshold set by the capacity constructor -> that many slots; else 16 / 12.
@@ -141,19 +191,188 @@ class JavaHashMapOrder {
             new_thr = 12;
         }
         if (new_thr == 0) new_thr = (size_t)((float)new_cap * 0.75f);
-        std::vector<std::vector<std::pair<uint32_t, int>>> fresh(new_cap);
-        for (size_t j = 0; j < old_cap; ++j)
-            for (const auto& n : table_[j]) fresh[(n.first & old_cap) ? j + old_cap : j].push_back(n);
+        std::vector<Bin> fresh(new_cap);
+        for (size_t j = 0; j < old_cap; ++j) {
+            Bin& bin = table_[j];
+            if (!bin.tree) {
+                for (int x : bin.list) fresh[(nodes_[x].h & old_cap) ? j + old_cap : j].list.push_back(x);
+                continue;
+            }
+            // TreeNode.split: lo / hi lists in `next` order.  A half of <= 6 nodes is untreeified (plain nodes, same order); a
+            // larger one is treeified AGAIN from its list -- unless the other half is empty: the tree then stays exactly as it is.
+            std::vector<int> lo, hi;
+            for (int x = bin.first; x >= 0; x = nodes_[x].next) ((nodes_[x].h & old_cap) ? hi : lo).push_back(x);
+            auto place = [&](const std::vector<int>& part, const std::vector<int>& other, size_t at) {
+                if (part.empty()) return;
+                if (part.size() <= 6) {
+                    fresh[at].list = part;
+                } else if (!other.empty()) {
+                    fresh[at].tree = true;
+                    link_and_treeify(fresh[at], part);
+                } else {
+                    fresh[at].tree = true;
+                    fresh[at].first = bin.first;
+                }
+            };
+            place(lo, hi, j);
+            place(hi, lo, j + old_cap);
+        }
         table_.swap(fresh);
         threshold_ = new_thr;
     }
-    void treeify_bin() {
-        if (table_.size() < 64) resize();
-        else exact_ = false;           // a real HashMap would build a tree bin and move its root to the front
+    void treeify_bin(size_t index) {
+        if (table_.size() < 64) { resize(); return; }              // MIN_TREEIFY_CAPACITY: grow instead
+        Bin& bin = table_[index];
+        const std::vector<int> nodes = bin.list;
+        bin.list.clear();
+        bin.tree = true;
+        link_and_treeify(bin, nodes);
+        treeified_ = true;
     }
-    std::vector<std::vector<std::pair<uint32_t, int>>> table_;
+    // treeifyBin's relinking (same order, prev / next) + TreeNode.treeify
+    void link_and_treeify(Bin& bin, const std::vector<int>& order) {
+        for (size_t k = 0; k < order.size(); ++k) {
+            Node& x = nodes_[order[k]];
+            x.prev = k ? order[k - 1] : -1;
+            x.next = k + 1 < order.size() ? order[k + 1] : -1;
+        }
+        bin.first = order.front();
+        int root = -1;
+        for (int x = bin.first, next; x >= 0; x = next) {
+            next = nodes_[x].next;
+            nodes_[x].left = nodes_[x].right = -1;
+            if (root < 0) {
+                nodes_[x].parent = -1;
+                nodes_[x].red = false;
+                root = x;
+                continue;
+            }
+            for (int p = root;;) {
+                const int dir = tree_dir(x, p);
+                const int xp = p;
+                p = dir <= 0 ? nodes_[p].left : nodes_[p].right;
+                if (p < 0) {
+                    nodes_[x].parent = xp;
+                    (dir <= 0 ? nodes_[xp].left : nodes_[xp].right) = x;
+                    root = balance_insertion(root, x);
+                    break;
+                }
+            }
+        }
+        move_root_to_front(bin, root);
+    }
+    // which way a key goes below p: the spread hashes as Java ints, then compareComparables (String.compareTo)
+    int tree_dir(int x, int p) const {
+        const int32_t ph = static_cast<int32_t>(nodes_[p].h), h = static_cast<int32_t>(nodes_[x].h);
+        if (ph > h) return -1;
+        if (ph < h) return 1;
+        return java_compare(nodes_[x].key, nodes_[p].key) < 0 ? -1 : 1;      // (equal keys never meet here)
+    }
+    // TreeNode.putTreeVal of a NEW key: a leaf below its tree parent xp, linked right BEHIND xp in the next list
+    void put_tree_val(Bin& bin, int x) {
+        int root = bin.first;
+        while (nodes_[root].parent >= 0) root = nodes_[root].parent;
+        for (int p = root;;) {
+            const int dir = tree_dir(x, p);
+            const int xp = p;
+            p = dir <= 0 ? nodes_[p].left : nodes_[p].right;
+            if (p < 0) {
+                const int xpn = nodes_[xp].next;
+                nodes_[x].next = xpn;
+                (dir <= 0 ? nodes_[xp].left : nodes_[xp].right) = x;
+                nodes_[xp].next = x;
+                nodes_[x].parent = nodes_[x].prev = xp;
+                if (xpn >= 0) nodes_[xpn].prev = x;
+                move_root_to_front(bin, balance_insertion(root, x));
+                return;
+            }
+        }
+    }
+    void move_root_to_front(Bin& bin, int root) {
+        if (root < 0 || root == bin.first) return;
+        const int first = bin.first, rn = nodes_[root].next, rp = nodes_[root].prev;
+        if (rn >= 0) nodes_[rn].prev = rp;
+        if (rp >= 0) nodes_[rp].next = rn;
+        if (first >= 0) nodes_[first].prev = root;
+        nodes_[root].next = first;
+        nodes_[root].prev = -1;
+        bin.first = root;
+    }
+    int rotate_left(int root, int p) {
+        const int r = p >= 0 ? nodes_[p].right : -1;
+        if (p >= 0 && r >= 0) {
+            const int rl = nodes_[p].right = nodes_[r].left;
+            if (rl >= 0) nodes_[rl].parent = p;
+            const int pp = nodes_[r].parent = nodes_[p].parent;
+            if (pp < 0) { root = r; nodes_[r].red = false; }
+            else if (nodes_[pp].left == p) nodes_[pp].left = r;
+            else nodes_[pp].right = r;
+            nodes_[r].left = p;
+            nodes_[p].parent = r;
+        }
+        return root;
+    }
+    int rotate_right(int root, int p) {
+        const int l = p >= 0 ? nodes_[p].left : -1;
+        if (p >= 0 && l >= 0) {
+            const int lr = nodes_[p].left = nodes_[l].right;
+            if (lr >= 0) nodes_[lr].parent = p;
+            const int pp = nodes_[l].parent = nodes_[p].parent;
+            if (pp < 0) { root = l; nodes_[l].red = false; }
+            else if (nodes_[pp].right == p) nodes_[pp].right = l;
+            else nodes_[pp].left = l;
+            nodes_[l].right = p;
+            nodes_[p].parent = l;
+        }
+        return root;
+    }
+    int balance_insertion(int root, int x) {
+        nodes_[x].red = true;
+        for (;;) {
+            int xp = nodes_[x].parent;
+            if (xp < 0) { nodes_[x].red = false; return x; }
+            if (!nodes_[xp].red || nodes_[xp].parent < 0) return root;
+            int xpp = nodes_[xp].parent;
+            const int xppl = nodes_[xpp].left;
+            if (xp == xppl) {
+                const int xppr = nodes_[xpp].right;
+                if (xppr >= 0 && nodes_[xppr].red) {
+                    nodes_[xppr].red = false; nodes_[xp].red = false; nodes_[xpp].red = true; x = xpp;
+                } else {
+                    if (x == nodes_[xp].right) {
+                        x = xp;
+                        root = rotate_left(root, x);
+                        xp = nodes_[x].parent;
+                        xpp = xp < 0 ? -1 : nodes_[xp].parent;
+                    }
+                    if (xp >= 0) {
+                        nodes_[xp].red = false;
+                        if (xpp >= 0) { nodes_[xpp].red = true; root = rotate_right(root, xpp); }
+                    }
+                }
+            } else {
+                if (xppl >= 0 && nodes_[xppl].red) {
+                    nodes_[xppl].red = false; nodes_[xp].red = false; nodes_[xpp].red = true; x = xpp;
+                } else {
+                    if (x == nodes_[xp].left) {
+                        x = xp;
+                        root = rotate_right(root, x);
+                        xp = nodes_[x].parent;
+                        xpp = xp < 0 ? -1 : nodes_[xp].parent;
+                    }
+                    if (xp >= 0) {
+                        nodes_[xp].red = false;
+                        if (xpp >= 0) { nodes_[xpp].red = true; root = rotate_left(root, xpp); }
+                    }
+                }
+            }
+        }
+    }
+
+    std::vector<Node> nodes_;
+    std::vector<Bin> table_;
     size_t threshold_ = 0, size_ = 0;
-    bool exact_ = true;
+    bool treeified_ = false;
 };
 
 }  // namespace kafka_lag

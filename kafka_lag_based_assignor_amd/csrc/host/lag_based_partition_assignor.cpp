@@ -32,7 +32,8 @@ la_ctx* shared_ctx_locked() {
 }
 
 // Whether the list order of the last static assign() on this thread is the modelled HashMap's exact order
-// (false: a bucket of consumersPerTopic reached tree-bin size, which java_compat.hpp does not model).
+// (false: a bucket of consumersPerTopic reached tree-bin size: the order is java_compat.hpp's restatement of TreeNode's list
+// handling, unverified against a JVM).
 thread_local bool t_last_order_exact = true;
 thread_local LagBasedPartitionAssignor::NativeCallStats t_last_native;
 
@@ -88,7 +89,7 @@ Plan make_plan(const GroupSubscription& subscriptions) {
                 names.push_back(topic);
                 ranks.emplace_back();
                 members_of.emplace_back();
-                order.compute_if_absent_new(ti, java_string_hash(topic));
+                order.compute_if_absent_new(ti, topic);
             } else {
                 ti = it->second;
             }
@@ -231,7 +232,7 @@ Assignment run_native(const Plan& plan, const std::vector<const TopicData*>& dat
             std::vector<int> uniq;
             for (int m : plan.topic_members[t])
                 if (std::find(uniq.begin(), uniq.end(), m) == uniq.end()) {
-                    order.put_new((int)uniq.size(), java_string_hash(plan.members[m]));
+                    order.put_new((int)uniq.size(), plan.members[m]);
                     uniq.push_back(m);
                 }
             std::string summary;
@@ -345,7 +346,7 @@ Assignment LagBasedPartitionAssignor::assign(const Cluster& metadata, const Grou
             auto it = seen.find(kv.first);
             if (it == seen.end()) {
                 seen.emplace(kv.first, (int)entries.size());
-                order.put_new((int)entries.size(), java_string_hash(kv.first));
+                order.put_new((int)entries.size(), kv.first);
                 entries.push_back(&kv);
             } else {
                 entries[it->second] = &kv;
@@ -357,9 +358,9 @@ Assignment LagBasedPartitionAssignor::assign(const Cluster& metadata, const Grou
     const Plan plan = make_plan(hashed);
     last_order_exact_ = last_order_exact_ && plan.order_exact;
     if (!last_order_exact_)
-        warn("list order may differ from the JVM's: a HashMap bucket reached tree-bin size (>= 9 colliding keys in a "
-             ">= 64-slot table), which the C++ host's container model does not reproduce; the partition -> member "
-             "map is unaffected");
+        warn("a HashMap bucket reached tree-bin size (>= 9 colliding keys in a >= 64-slot table): the list order follows the "
+             "C++ host's restatement of java.util.HashMap's tree bins, which no JVM has confirmed here; the partition -> "
+             "member map is unaffected");
 
     // readTopicPartitionLags, Main.java:317-365 -- batched: one request per kind for all topics
     std::vector<TopicPartition> all;

@@ -103,10 +103,11 @@ class LagBasedPartitionAssignor {
     const std::map<std::string, std::map<std::string, int64_t>>& lastTopicTotals() const { return last_totals_; }
 
     // List order (parity level P2, SURVEY 8a note 4) follows HashMap iteration order, which this C++ host reproduces
-    // with a model of OpenJDK's HashMap (java_compat.hpp) that has no tree bins.  false = the last assign met a bucket
-    // that a real HashMap would have treeified (>= 9 colliding keys in a >= 64-slot table): who-gets-what is still
-    // exact, the ORDER of topics inside the members' lists is then a guess.  The instance-level assign also says so
-    // through `warn`.  (The Java host uses the real HashMap and has no such caveat.)
+    // with a model of OpenJDK's HashMap (java_compat.hpp), tree bins included since round 5 (treeify / putTreeVal /
+    // moveRootToFront / split).  false = the last assign met a bucket that a real HashMap treeifies (>= 9 colliding keys in a
+    // >= 64-slot table): who-gets-what is exact as always, and the ORDER of topics inside the members' lists is the one the
+    // restated TreeNode code gives -- definite, equal to the oracle's independent restatement, but confirmed by no JVM (none
+    // in the image).  The instance-level assign also says so through `warn`.  (The Java host uses the real HashMap.)
     bool lastOrderExact() const { return last_order_exact_; }
     static bool lastStaticOrderExact();            // same, for the last static assign() on the calling thread
 

@@ -84,11 +84,18 @@ PYBIND11_MODULE(_host, m) {
     m.def("hashmap_put_order", [](const std::vector<std::string>& keys, py::object initial_capacity) {
         JavaHashMapOrder o = initial_capacity.is_none() ? JavaHashMapOrder()
                                                         : JavaHashMapOrder(initial_capacity.cast<size_t>());
-        for (size_t i = 0; i < keys.size(); ++i) o.put_new((int)i, java_string_hash(keys[i]));
+        for (size_t i = 0; i < keys.size(); ++i) o.put_new((int)i, keys[i]);
         std::vector<std::string> out;
         for (int i : o.order()) out.push_back(keys[i]);
         return py::make_tuple(out, o.order_exact());
     }, py::arg("keys"), py::arg("initial_capacity") = py::none());
+    m.def("hashmap_compute_if_absent_order", [](const std::vector<std::string>& keys) {
+        JavaHashMapOrder o;
+        for (size_t i = 0; i < keys.size(); ++i) o.compute_if_absent_new((int)i, keys[i]);
+        std::vector<std::string> out;
+        for (int i : o.order()) out.push_back(keys[i]);
+        return py::make_tuple(out, o.order_exact());
+    }, py::arg("keys"));
 
     py::class_<LagBasedPartitionAssignor>(m, "LagBasedPartitionAssignor")
         .def(py::init<>())

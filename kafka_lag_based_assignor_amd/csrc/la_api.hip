@@ -1146,9 +1146,19 @@ T* mapped_ptr(T* host) {
 }
 
 bool call_is_mapped(const HostCall& c) {
-    auto ok = [](const void* p) { return p == nullptr || mapped_ptr((const char*)p) != nullptr; };
-    return ok(c.part_off) && ok(c.cons_off) && ok(c.pid) && ok(c.end) && ok(c.committed) && ok(c.lag) && ok(c.begin) &&
-           ok(c.none_index) && ok(c.none_begin) && ok(c.cons_rank) && ok(c.out_pid) && ok(c.out_rank) && ok(c.out_total);
+    // first AND last byte of every array: an array registered only in part (hipHostRegister of a sub-range), or one
+    // that runs past its registration, must not be handed to kernels that read and write it in place -- its device view has to
+    // exist at both ends and advance with the host view in between; anything else takes a copying pipeline.
+    auto ok = [](const void* p, size_t bytes) {
+        if (p == nullptr || bytes == 0) return true;
+        const char* d0 = mapped_ptr((const char*)p);
+        const char* d1 = mapped_ptr((const char*)p + (bytes - 1));
+        return d0 != nullptr && d1 != nullptr && (size_t)(d1 - d0) == bytes - 1;
+    };
+    const size_t n = (size_t)c.shape.n, k = (size_t)c.shape.k, tb = ((size_t)c.T + 1) * 8, m = (size_t)c.n_none * 8;
+    return ok(c.part_off, tb) && ok(c.cons_off, tb) && ok(c.pid, n * 4) && ok(c.end, n * 8) && ok(c.committed, n * 8) &&
+           ok(c.lag, n * 8) && ok(c.begin, n * 8) && ok(c.none_index, m) && ok(c.none_begin, m) && ok(c.cons_rank, k * 4) &&
+           ok(c.out_pid, n * 4) && ok(c.out_rank, n * 4) && ok(c.out_total, k * 8);
 }
 
 int run_shard_mapped(la_ctx* ctx, const HostCall& c, Shard& sh, ShardPlan& sp) {

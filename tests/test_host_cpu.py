@@ -173,8 +173,9 @@ def _colliding_keys(n, slots=64):
 
 
 def test_order_exact_flag_trips_on_a_tree_bin():
-    """nine keys in one bucket of a >= 64-slot table is where a real HashMap builds a tree bin; the model
-    does not, and must say so instead of guessing silently."""
+    """nine keys in one bucket of a >= 64-slot table is where a real HashMap builds a tree bin.
+    Both container models now restate TreeNode's list handling (treeify / putTreeVal / moveRootToFront / split) and give ONE
+    definite order; the flag still says that the order came through a tree bin (unverified against a JVM: none here)."""
     h = _host()
     keys = _colliding_keys(9)
     def bucket0(k):
@@ -186,10 +187,59 @@ def test_order_exact_flag_trips_on_a_tree_bin():
     assert exact                                              # eight in a bucket: still a plain chain
     order, exact = h.hashmap_put_order(filler + keys)
     assert not exact
-    with pytest.raises(NotImplementedError):                  # the oracle's model refuses too
+    m = jc.JavaHashMap()
+    for k in filler + keys:
+        m.put(k, None)
+    assert m.treeified and list(m.keys()) == order            # the oracle's restatement walks the same order
+    # the root moved to the front: the bucket's keys no longer stand in insertion order
+    assert [k for k in order if k in keys] != keys and sorted(k for k in order if k in keys) == sorted(keys)
+
+
+def _keys_in_bucket(n, mask, want, start=0):
+    out, i = [], start
+    while len(out) < n:
+        k = "t%d" % i
+        x = jc.java_string_hash(k) & 0xFFFFFFFF
+        if ((x ^ (x >> 16)) & mask) == want:
+            out.append(k)
+        i += 1
+    return out
+
+
+@pytest.mark.parametrize("case", ["grow_in_place", "split_untreeify", "split_retreeify", "many", "compute_if_absent"])
+def test_tree_bin_orders_agree_between_the_two_container_models(case):
+    """The C++ host's JavaHashMapOrder and the oracle's JavaHashMap are independent restatements of OpenJDK 8's HashMap, tree
+    bins included; on keys chosen to collide they must walk the same order -- through treeification, later insertions into the
+    tree (putTreeVal: behind the tree parent, root to the front), table growth that keeps a tree whole ("already treeified"),
+    splits it into a tree and a plain chain (untreeify at <= 6) or into two trees (treeified again)."""
+    h = _host()
+    filler = [k for k in ("f%d" % i for i in range(400)) if (((jc.java_string_hash(k) & 0xFFFFFFFF) ^ ((jc.java_string_hash(k) & 0xFFFFFFFF) >> 16)) & 63) != 5]
+    if case == "grow_in_place":            # 14 keys that collide in every table up to 1024 slots; fillers grow the table around the tree
+        keys = filler[:60] + _keys_in_bucket(14, 1023, 5) + filler[60:300]
+    elif case == "split_untreeify":        # 9 + 3 keys in bucket 5 of a 64-slot table; at 128 slots three of them leave: 9 stay a tree? no: 12 -> 9 / 3
+        a = _keys_in_bucket(9, 127, 5)
+        b = _keys_in_bucket(3, 127, 5 + 64)
+        keys = filler[:40] + a[:5] + b + a[5:] + filler[40:200]
+    elif case == "split_retreeify":        # 10 + 9 keys: both halves stay trees after the split
+        a = _keys_in_bucket(10, 127, 5)
+        b = _keys_in_bucket(9, 127, 5 + 64)
+        keys = filler[:40] + [x for pair in zip(a, b) for x in pair] + a[9:] + filler[40:200]
+    elif case == "many":
+        keys = filler[:50] + _keys_in_bucket(40, 255, 5) + filler[50:120] + _keys_in_bucket(25, 511, 5 + 256, start=50000)
+    else:
+        keys = filler[:60] + _keys_in_bucket(20, 511, 5) + filler[60:250]
+    if case == "compute_if_absent":
+        order, exact = h.hashmap_compute_if_absent_order(keys)
         m = jc.JavaHashMap()
-        for k in filler + keys:
+        for k in keys:
+            m.compute_if_absent(k, lambda: None)
+    else:
+        order, exact = h.hashmap_put_order(keys)
+        m = jc.JavaHashMap()
+        for k in keys:
             m.put(k, None)
+    assert not exact and m.treeified
+    assert list(m.keys()) == order and sorted(order) == sorted(keys)
 
 
 def test_configure_requires_group_id():                   # Main.java:107-113
