@@ -748,7 +748,7 @@ void plan_ranges(const int64_t* po, int32_t t_begin, int32_t t_end, int parts, i
 constexpr int kMaxShards = 64;
 constexpr int64_t kMinShardPartitions = 1 << 16;   // below this a second device costs more than it saves
 constexpr int64_t kMinChunkPartitions = 1 << 19;   // a chunk's copies must be long enough to hide a kernel
-constexpr int64_t kMidChunkPartitions = 1 << 17;   // pageable arrays: from two such chunks on, a mid-size shard runs on two lanes
+constexpr int64_t kMidChunkPartitions = 100000;    // pageable arrays: from two such chunks on, a mid-size shard runs on two lanes
 constexpr int kMaxChunks = 64;
 
 // One host-buffer assign call (all pointers are the caller's host arrays).
