@@ -33,7 +33,7 @@ namespace la {
 namespace {
 
 #ifdef LA_BLOCK_CLOCKS   // development build: thread 0 of workgroup 0 accumulates the time of every stage (tools/block_probe.py --clocks)
-__device__ unsigned long long g_block_clocks[8];
+__device__ unsigned long long g_block_clocks[16];     // 0-5 stages, 6-7 key32 rounds, 8-12 phases of a digit pass
 #define LA_BCLK(i)                                                         \
     do {                                                                   \
         if (threadIdx.x == 0 && blockIdx.x == 0) {                         \
@@ -43,9 +43,20 @@ __device__ unsigned long long g_block_clocks[8];
         }                                                                  \
     } while (0)
 #define LA_BCLK_START unsigned long long bclk_ = wall_clock64()
+#define LA_RCLK(i)                                                         \
+    do {                                                                   \
+        if (threadIdx.x == 0 && blockIdx.x == 0) {                         \
+            const unsigned long long now_ = wall_clock64();                \
+            g_block_clocks[i] += now_ - rclk_;                             \
+            rclk_ = now_;                                                  \
+        }                                                                  \
+    } while (0)
+#define LA_RCLK_START unsigned long long rclk_ = wall_clock64()
 #else
 #define LA_BCLK(i) do {} while (0)
 #define LA_BCLK_START do {} while (0)
+#define LA_RCLK(i) do {} while (0)
+#define LA_RCLK_START do {} while (0)
 #endif
 
 constexpr int kSpan = 128;      // slots a wavefront owns: 64 pairs
@@ -238,6 +249,7 @@ __device__ __forceinline__ void block_sort_radix(P64 (&rec)[E], int live, int bi
         for (int k = 0; k < 4; ++k) mine[k * kWave + lane] = 0;
     }
     wave_lds_fence();
+    LA_RCLK_START;
     for (int shift = 0; shift < bits; shift += 8) {
         uint32_t old[E];
         if (act) {
@@ -263,6 +275,7 @@ __device__ __forceinline__ void block_sort_radix(P64 (&rec)[E], int live, int bi
             }
         }
         __syncthreads();
+        LA_RCLK(8);                                                      // counts (+ the barrier)
         for (int d = tid; d < 256; d += nt) {                            // digit d: first places of the wavefronts inside it
             uint32_t run = 0;
             for (int w = 0; w < nw; ++w) {
@@ -273,6 +286,7 @@ __device__ __forceinline__ void block_sort_radix(P64 (&rec)[E], int live, int bi
             total[d] = run;
         }
         __syncthreads();
+        LA_RCLK(9);                                                      // per-digit prefix over the wavefronts
         if (wave == 0) {                                                 // exclusive scan of the 256 totals, four per lane
             const uint4 t = reinterpret_cast<const uint4*>(total)[lane];
             const uint32_t s = t.x + t.y + t.z + t.w;
@@ -281,14 +295,25 @@ __device__ __forceinline__ void block_sort_radix(P64 (&rec)[E], int live, int bi
             reinterpret_cast<uint4*>(total)[lane] = make_uint4(excl, excl + t.x, excl + t.x + t.y, excl + t.x + t.y + t.z);
         }
         __syncthreads();
+        LA_RCLK(10);                                                     // scan of the totals
         if (act) {
+            // this wavefront's first place of every digit = the digit's first place + the wavefront's inside it: folded into the
+            // wavefront's own table once (four entries per lane), so that a record's place costs ONE table read, not two
+            {
+                const uint4 t = reinterpret_cast<const uint4*>(total)[lane];
+                uint4 m = reinterpret_cast<uint4*>(mine)[lane];
+                m.x += t.x; m.y += t.y; m.z += t.z; m.w += t.w;
+                reinterpret_cast<uint4*>(mine)[lane] = m;
+            }
+            wave_lds_fence();
 #pragma unroll
             for (int r = 0; r < E; ++r) {
                 const uint32_t d = (uint32_t)(p64_value(rec[r]) >> shift) & 255u;
-                buf[total[d] + mine[d] + old[r]] = p64_value(rec[r]);
+                buf[mine[d] + old[r]] = p64_value(rec[r]);
             }
         }
         __syncthreads();
+        LA_RCLK(11);                                                     // scatter
         if (act && shift + 8 < bits) {
 #pragma unroll
             for (int k = 0; k < 4; ++k) mine[k * kWave + lane] = 0;       // (read above, before the barrier)
@@ -296,6 +321,7 @@ __device__ __forceinline__ void block_sort_radix(P64 (&rec)[E], int live, int bi
             for (int r = 0; r < E; ++r) rec[r] = p64_from(buf[wave * kSpanSlots + r * kWave + lane]);
             // (the next scatter into buf comes three barriers later)
         }
+        LA_RCLK(12);                                                     // read back
     }
 }
 
@@ -822,6 +848,16 @@ __global__ __launch_bounds__(1024) void block_topic_kernel(BlockArgs a) {
             id_or |= (uint32_t)pid[r];
         }
     }
+    // the topic's member ranks, fetched with the records: their LDS copies are written after the sort, BEHIND the stores of the
+    // sorted partition ids -- a load issued there would have to wait for those stores (one in-order vmcnt), and so would the
+    // barrier in front of the greedy rounds
+    constexpr int kRankPre = E == 16 ? 1 : 4;                           // nc_cap / blockDim of the size classes (block_launch)
+    int32_t rank_pre[kRankPre];
+#pragma unroll
+    for (int k = 0; k < kRankPre; ++k) {
+        const int i = tid + k * nt;
+        rank_pre[k] = a.cons_rank[c0 + (i < C ? i : 0)];
+    }
     LA_BCLK(0);                                                         // record loads issued and consumed
     // do the topic's records fit one 64-bit word?  (workgroup-wide OR of the lags and the ids)
     uint32_t* s_or = reinterpret_cast<uint32_t*>(s_rank + a.nc_cap);   // [3] (4 allotted) workgroup-wide ORs
@@ -934,13 +970,17 @@ __global__ __launch_bounds__(1024) void block_topic_kernel(BlockArgs a) {
             }
         }
     }
-    for (int i = tid; i < C; i += nt) {
-        s_tot[i] = kTotalBias;                                          // total 0
-        s_idx[i] = (uint32_t)i;
-        s_rank[i] = a.cons_rank[c0 + i];
+#pragma unroll
+    for (int k = 0; k < kRankPre; ++k) {
+        const int i = tid + k * nt;
+        if (i < C) {
+            s_tot[i] = kTotalBias;                                      // total 0
+            s_idx[i] = (uint32_t)i;
+            s_rank[i] = rank_pre[k];
+        }
     }
     if (slots && tid == 0) s_key[P] = 0;                                // the slot idle lanes and rounds past P read
-    __syncthreads();
+    lds_barrier();                                                      // (LDS only: the stores of the sorted ids stay in flight)
     LA_BCLK(3);
     if (C == 0) return;
 
@@ -957,7 +997,7 @@ __global__ __launch_bounds__(1024) void block_topic_kernel(BlockArgs a) {
                 default: greedy_one_wave_slots<64>(a, s_key, c0, P, C, idx_bits, tid); break;
             }
         }
-        __syncthreads();
+        lds_barrier();
         LA_BCLK(4);
         // the winners (consumer positions, low word of each slot) -> member ranks, every wavefront, coalesced
         const uint32_t* won = reinterpret_cast<const uint32_t*>(s_key);
@@ -980,12 +1020,12 @@ __global__ __launch_bounds__(1024) void block_topic_kernel(BlockArgs a) {
         if (packed && n_c > kWave && a.key32_greedy && (n_c == 2 * kWave || a.key32_greedy >= 2)) {
             // 128 / 256 bins: ONE wavefront, the bins stay where they are (LDS), the order comes from 32-bit keys
             if (tid == 0) s_key[P] = kLagKeyFlip;                       // "lag 0" for idle slots and rounds past the topic (P + 1: scratch)
-            __syncthreads();
+            lds_barrier();
             if (tid < kWave) {
                 if (n_c == 2 * kWave) greedy_one_wave_key32<2>(a, s_key, s_tot, s_idx, c0, P, C, idx_bits, lag_bits, tid);
                 else greedy_one_wave_key32<4>(a, s_key, s_tot, s_idx, c0, P, C, idx_bits, lag_bits, tid);
             }
-            __syncthreads();
+            lds_barrier();
             LA_BCLK(4);
             // the winners (consumer positions, low word of each slot) -> member ranks, every wavefront, coalesced
             const uint32_t* won = reinterpret_cast<const uint32_t*>(s_key);
@@ -1080,7 +1120,7 @@ __global__ __launch_bounds__(1024) void block_topic_kernel(BlockArgs a) {
 extern "C" __attribute__((visibility("default"))) int la_debug_block_clocks(unsigned long long* out, int reset) {
     hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(g_block_clocks), sizeof(g_block_clocks));
     if (e == hipSuccess && reset) {
-        unsigned long long zero[8] = {};
+        unsigned long long zero[16] = {};
         e = hipMemcpyToSymbol(HIP_SYMBOL(g_block_clocks), zero, sizeof zero);
     }
     return e == hipSuccess ? 0 : -3;

@@ -48,12 +48,13 @@ def run(t, p, c, algo=N.LA_ALGO_AUTO, reps=5, lag_bits=34, offsets=False):
     return best
 
 if hasattr(ctx._lib, "la_debug_block_clocks"):          # development build (-DLA_BLOCK_CLOCKS): stage times of workgroup 0
-    names = ["loads", "decide", "sort", "slots + out_partition", "greedy rounds", "member ranks out", "key32: network", "key32: rest of the rounds"]
+    names = ["loads", "decide", "sort", "slots + out_partition", "greedy rounds", "member ranks out", "key32: network", "key32: rest of the rounds",
+             "radix: counts", "radix: prefix over wavefronts", "radix: scan", "radix: scatter", "radix: read back", "-", "-", "-"]
     shapes = [(200, 8000, 16), (200, 8000, 64), (200, 8000, 4), (1000, 2000, 16)]
     if len(sys.argv) > 1:                               # python tools/block_probe.py T,P,C [T,P,C ..]
         shapes = [tuple(int(x) for x in a.split(",")) for a in sys.argv[1:]]
     for (t, p, c) in shapes:
-        clk = (ctypes.c_ulonglong * 8)()
+        clk = (ctypes.c_ulonglong * 16)()
         run(t, p, c, reps=1)
         ctx._lib.la_debug_block_clocks(clk, 1)
         ms = run(t, p, c, reps=9) * 1e3                 # 1 warm-up + 9 timed calls
