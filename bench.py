@@ -1236,6 +1236,12 @@ def main():
                                    if (sh.bounds is not None and not os.environ.get("LA_BENCH_NO_BOUNDS")) else None),
                    "rotate": rot, "settle_ms": args.settle_ms, "settle_steps": settle_steps},
         "roofline": roofline,
+        "multi_gpu": {"ranks_in_this_run": world,
+                      "note": ("this line is a one-GPU measurement: no N > 1 throughput of this code has been measured anywhere yet (the "
+                               "boxes it was developed on have one GPU; the N > 1 path runs in the tests with 2-4 ranks sharing a GPU over "
+                               "gloo and with RCCL at one rank); roofline.wire_out is what one GPU can say about the N > 1 step's kernels"
+                               if world == 1 else
+                               "strong scaling: ONE batch split over the ranks by la_plan_shards, one all-gather per step inside the timed region")},
         "cold_call_ms": cold["ms"],
         "cold_call": cold,
         "sort_phase": sort_phase,

@@ -2,7 +2,7 @@
 import sys, time, ctypes
 import numpy as np
 import torch
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from kafka_lag_based_assignor_amd import _native as N
 
 dev = torch.device("cuda", 0)
