@@ -345,4 +345,206 @@ __device__ __forceinline__ void group_small_body_staged(int n, int32_t n_members
     LA_GCLK(6);                                                            // lists out
 }
 
+// ---- the same lists for a few thousand to 65 536 entries and FEW members: two launches -----------------------------------------
+// Between the one-workgroup form (<= kSmallGroupN entries) and the radix form (five dependent launches, 17-25 us whatever the
+// size) sits what a mid-size rebalance is: 3 000 - 65 000 partitions, a handful of members (10 000 entries: 85 -> 80 us per call).  With G = members + 2 <= kMidGroupM
+// groups a table of per-block counts is small, and the stable counting sort splits over workgroups:
+//   launch 1 (group_mid_count): block b = entries [b * kMidBlock, ...): the chunks' group leaders (ballots, as above) add their
+//            peer counts into LDS counters; the block's G counts go to cnt[b][*];
+//   launch 2 (group_mid_place): every block reads the whole table (blocks x G words), sums it per group (the groups' starts, an
+//            exclusive scan) and over the blocks before it (its own first places), then places its entries exactly like the
+//            one-workgroup form does -- ranks inside a chunk by ballots, cursors advanced chunk by chunk by in-order returning
+//            LDS atomics -- and stores them straight to their places.  The topic of every entry: the block's first topic by a
+//            256-ary search over part_off (two rounds up to 65 536 topics), the rest from the topic starts inside the block (+1
+//            at a topic's first position, an inclusive scan).
+// Stable by construction: blocks in order, chunks in order, lanes in order.
+constexpr int kMidBlock = 2048;          // entries per workgroup
+constexpr int kMidThreads = 256;
+constexpr int kMidGroupM = 512;          // groups (members + 2) the table form holds
+constexpr int kMidMaxBlocks = 32;        // 65 536 entries: every block sums the whole table (blocks x groups words); 125 blocks made it slower than the radix form
+
+#ifdef LA_GROUP_MID_KERNELS   // the two kernels are compiled by ONE translation unit (la_large.hip defines this before the include)
+__device__ __forceinline__ void group_mid_chunk_ranks(int nb, uint32_t G, const int32_t* s_rank_in, int32_t* s_pk, uint32_t* lead,
+                                                      uint32_t* counts, int lane, int wave) {
+    constexpr int W = kMidThreads / kWave;
+    const int nch = (nb + kWave - 1) / kWave;
+    const uint64_t below = ((uint64_t)1 << lane) - 1;
+    for (int c = wave; c < nch; c += W) {
+        const int i = c * kWave + lane;
+        const bool valid = i < nb;
+        uint32_t gi = valid ? (uint32_t)(s_rank_in[i] + 1) : 0u;
+        gi = gi < G ? gi : G;
+        uint64_t peers = __ballot(valid);
+#pragma unroll
+        for (int bit = 0; bit < 10; ++bit) {                                // G <= kMidGroupM - 1 < 2^9 (+ the clamp value G itself)
+            const bool one = (gi >> bit) & 1u;
+            const uint64_t bal = __ballot(one);
+            peers &= one ? bal : ~bal;
+        }
+        const uint32_t rank = (uint32_t)__popcll(peers & below), cnt = (uint32_t)__popcll(peers);
+        const int leader = __ffsll((unsigned long long)peers) - 1;
+        if (valid) {
+            if (s_pk) s_pk[i] = (int32_t)(((uint32_t)leader << 16) | rank);
+            if (lead) lead[i] = lane == leader ? ((gi << 8) | cnt) : 0u;
+            if (lane == leader) atomicAdd(&counts[gi], cnt);
+        }
+    }
+}
+
+__global__ __launch_bounds__(kMidThreads) void group_mid_count_kernel(int n, int32_t n_members, const int32_t* member_rank, uint32_t* cnt) {
+    __shared__ uint32_t counts[kMidGroupM];
+    __shared__ int32_t s_rank[kMidBlock];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int e0 = blockIdx.x * kMidBlock, nb = min(kMidBlock, n - e0);
+    const uint32_t G = (uint32_t)n_members + 1;
+    for (int k = tid; k < kMidGroupM; k += kMidThreads) counts[k] = 0;
+    for (int i = tid; i < nb; i += kMidThreads) s_rank[i] = member_rank[e0 + i];
+    __syncthreads();
+    group_mid_chunk_ranks(nb, G, s_rank, nullptr, nullptr, counts, lane, wave);
+    __syncthreads();
+    for (uint32_t g = tid; g <= G; g += kMidThreads) cnt[(size_t)blockIdx.x * kMidGroupM + g] = counts[g];
+}
+
+__global__ __launch_bounds__(kMidThreads) void group_mid_place_kernel(int n, int32_t n_members, int64_t n_topics, const int64_t* part_off,
+                                                                      const int32_t* out_partition, const int32_t* member_rank,
+                                                                      const uint32_t* cnt, int64_t* member_off, int32_t* grouped_topic,
+                                                                      int32_t* grouped_partition, int32_t* grouped_entry) {
+    __shared__ uint32_t cursor[kMidGroupM];           // this block's first place of every group, then its cursors
+    __shared__ uint32_t counts[kMidGroupM];           // (scratch of the chunk ranks: the block's own counts again)
+    __shared__ uint32_t wsum[kMidThreads / kWave];
+    __shared__ int32_t s_rank[kMidBlock], s_pk[kMidBlock], s_topic[kMidBlock];
+    __shared__ uint32_t lead[kMidBlock], first[kMidBlock];
+    __shared__ int s_t0;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int W = kMidThreads / kWave;
+    const int nblocks = gridDim.x;
+    const int e0 = blockIdx.x * kMidBlock, nb = min(kMidBlock, n - e0), e1 = e0 + nb;
+    const uint32_t G = (uint32_t)n_members + 1;
+    // inputs (independent loads first), the table's column sums
+    for (int i = tid; i < nb; i += kMidThreads) { s_rank[i] = member_rank[e0 + i]; s_topic[i] = 0; }
+    for (int k = tid; k < kMidGroupM; k += kMidThreads) counts[k] = 0;
+    uint32_t tot[kMidGroupM / kMidThreads], mine[kMidGroupM / kMidThreads];     // groups tid, tid + 256
+#pragma unroll
+    for (int r = 0; r < kMidGroupM / kMidThreads; ++r) {
+        const uint32_t g = (uint32_t)(tid + r * kMidThreads);
+        uint32_t all = 0, before = 0;
+        if (g <= G)
+            for (int b = 0; b < nblocks; ++b) {
+                const uint32_t c = cnt[(size_t)b * kMidGroupM + g];
+                all += c;
+                before += b < (int)blockIdx.x ? c : 0u;
+            }
+        tot[r] = all;
+        mine[r] = before;
+    }
+    // exclusive scan of the groups' totals over g (group g = tid + r * 256: scan the r = 0 half, then the r = 1 half behind it)
+    uint32_t base_of[kMidGroupM / kMidThreads];
+    uint32_t carry = 0;
+#pragma unroll
+    for (int r = 0; r < kMidGroupM / kMidThreads; ++r) {
+        uint32_t incl = tot[r];
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t y = __shfl_up(incl, o);
+            if (lane >= o) incl += y;
+        }
+        if (lane == 63) wsum[wave] = incl;
+        __syncthreads();
+        uint32_t before = carry, all = 0;
+        for (int w = 0; w < W; ++w) { before += w < wave ? wsum[w] : 0u; all += wsum[w]; }
+        base_of[r] = before + incl - tot[r];
+        carry += all;
+        __syncthreads();
+    }
+#pragma unroll
+    for (int r = 0; r < kMidGroupM / kMidThreads; ++r) {
+        const uint32_t g = (uint32_t)(tid + r * kMidThreads);
+        cursor[g] = base_of[r] + mine[r];
+        // member m's list starts where the groups 0 .. m end: member_off[m] = start of group m + 1
+        if (blockIdx.x == 0 && g >= 1 && g <= (uint32_t)n_members + 1) member_off[g - 1] = (int64_t)base_of[r];
+    }
+    // the block's first topic: the largest t with part_off[t] <= e0, by a 256-ary search
+    if (grouped_topic) {
+        int64_t lo = 0, hi = n_topics;                                       // invariant: part_off[lo] <= e0 (part_off[0] = 0), answer in [lo, hi)
+        while (hi - lo > 1) {
+            const int64_t step = (hi - lo + kMidThreads - 1) / kMidThreads;
+            if (tid == 0) s_t0 = 0;
+            __syncthreads();
+            const int64_t at = lo + (int64_t)tid * step;
+            if (at < hi && part_off[at] <= (int64_t)e0) atomicMax(&s_t0, tid);
+            __syncthreads();
+            const int64_t nlo = lo + (int64_t)s_t0 * step;
+            hi = nlo + step < hi ? nlo + step : hi;
+            lo = nlo;
+            __syncthreads();
+        }
+        const int64_t t0 = lo;
+        for (int64_t t = t0 + 1 + tid; t < n_topics; t += kMidThreads) {   // topic starts inside the block
+            const int64_t at = part_off[t];
+            if (at >= (int64_t)e1) break;
+            atomicAdd((uint32_t*)&s_topic[at - e0], 1u);
+        }
+        __syncthreads();
+        constexpr int PERT = kMidBlock / kMidThreads;
+        uint32_t tv[PERT], trun = 0;
+#pragma unroll
+        for (int r = 0; r < PERT; ++r) {
+            const int i = PERT * tid + r;
+            tv[r] = i < nb ? (uint32_t)s_topic[i] : 0u;
+            trun += tv[r];
+        }
+        uint32_t tincl = trun;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t y = __shfl_up(tincl, o);
+            if (lane >= o) tincl += y;
+        }
+        if (lane == 63) wsum[wave] = tincl;
+        __syncthreads();
+        uint32_t tbase = tincl - trun;
+        for (int w = 0; w < wave; ++w) tbase += wsum[w];
+#pragma unroll
+        for (int r = 0; r < PERT; ++r) {
+            const int i = PERT * tid + r;
+            tbase += tv[r];
+            if (i < nb) s_topic[i] = (int32_t)(t0 + tbase);
+        }
+    }
+    __syncthreads();
+    group_mid_chunk_ranks(nb, G, s_rank, s_pk, lead, counts, lane, wave);
+    __syncthreads();
+    {
+        const int nch = (nb + kWave - 1) / kWave;
+        constexpr int kAhead = 4;
+        for (int c0 = 0; c0 < nch; c0 += kAhead) {
+            uint32_t v[kAhead], f[kAhead];
+#pragma unroll
+            for (int u = 0; u < kAhead; ++u) {
+                const int i = (c0 + u) * kWave + lane;
+                v[u] = (c0 + u < nch && i < nb) ? lead[i] : 0u;
+            }
+#pragma unroll
+            for (int u = 0; u < kAhead; ++u) {
+                const uint32_t c = v[u] & 0xFFu, g = v[u] >> 8;
+                f[u] = 0;
+                if (c != 0 && (g % W) == (uint32_t)wave) f[u] = atomicAdd(&cursor[g], c);
+            }
+#pragma unroll
+            for (int u = 0; u < kAhead; ++u) {
+                const uint32_t c = v[u] & 0xFFu, g = v[u] >> 8;
+                if (c != 0 && (g % W) == (uint32_t)wave) first[(c0 + u) * kWave + lane] = f[u];
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < nb; i += kMidThreads) {
+        const uint32_t pk = (uint32_t)s_pk[i];
+        const uint32_t pos = first[(i & ~(kWave - 1)) + (int)(pk >> 16)] + (pk & 0xFFFFu);
+        grouped_partition[pos] = out_partition ? out_partition[e0 + i] : 0;
+        if (grouped_topic) grouped_topic[pos] = s_topic[i];
+        if (grouped_entry) grouped_entry[pos] = e0 + i;
+    }
+}
+#endif  // LA_GROUP_MID_KERNELS
+
 }  // namespace la

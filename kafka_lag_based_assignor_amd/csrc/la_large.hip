@@ -25,6 +25,7 @@
 #include "la_kernels.h"
 #include "la_device.h"
 #include "la_sort64.h"
+#define LA_GROUP_MID_KERNELS
 #include "la_group_small.h"
 
 #include <algorithm>
@@ -2747,6 +2748,17 @@ hipError_t group_by_member_launch(LargeScratch& scratch, int64_t n, int32_t n_me
                            member_rank, member_off, grouped_topic, grouped_partition, grouped_entry, (const uint32_t*)status,
                            fin_flag);
         if (fin_done) *fin_done = fin_flag != nullptr;
+        return hipGetLastError();
+    }
+    if (n <= (int64_t)kMidBlock * kMidMaxBlocks && (int64_t)n_members + 2 <= kMidGroupM && !getenv("LA_NO_MID_GROUP")) {
+        // a mid-size rebalance with few members: the stable counting sort over several workgroups, two launches
+        // (la_group_small.h) instead of the radix form's five
+        const int blocks = (int)((n + kMidBlock - 1) / kMidBlock);
+        if ((e = scratch_reserve(scratch, (size_t)blocks * kMidGroupM * sizeof(uint32_t), stream)) != hipSuccess) return e;
+        uint32_t* cnt = (uint32_t*)scratch.buf;
+        LA_LAUNCH(group_mid_count_kernel, dim3(blocks), dim3(kMidThreads), 0, stream, (int)n, n_members, member_rank, cnt);
+        LA_LAUNCH(group_mid_place_kernel, dim3(blocks), dim3(kMidThreads), 0, stream, (int)n, n_members, n_topics, part_off, out_partition,
+                  member_rank, (const uint32_t*)cnt, member_off, grouped_topic, grouped_partition, grouped_entry);
         return hipGetLastError();
     }
     SortBufs b{};

@@ -397,3 +397,30 @@ def test_wire_out_refuses_what_it_cannot_do(ctx):
     assert ei.value.code == N.LA_EINVAL and "wire format" in str(ei.value)
     raw, _ = _wire_call(ctx, w, fmt, bounds)                       # and the context is fine afterwards
     assert raw.size == w.n_partitions
+
+
+# ---- member lists of a mid-size rebalance: the two-launch counting sort (la_group_small.h, group_mid_*) ---------------------------
+@pytest.mark.parametrize("n_topics,max_p,members", [(300, 256, 32), (40, 3000, 5), (5000, 9, 3), (2, 70000, 510), (700, 700, 509),
+                                                   (1, 2561, 1), (9, 4096, 64), (60000, 4, 2), (3, 100000, 511)])
+def test_member_lists_of_a_mid_size_rebalance(ctx, n_topics, max_p, members):
+    """la_group_by_member between 2 560 and 65 536 entries with at most 510 members runs as two launches (per-block counts, then
+    placement); 511 members take the radix form.  Ragged topics, empty topics, topics without consumers (rank -1), blocks that end
+    in the middle of a topic: equal to a stable sort by member of the same arrays."""
+    rng = np.random.default_rng(n_topics + members)
+    sizes = rng.integers(0, max_p + 1, n_topics)
+    sizes[rng.integers(0, n_topics, max(1, n_topics // 7))] = 0                 # empty topics
+    part_off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    n = int(part_off[-1])
+    out_p = rng.integers(0, 1 << 20, n).astype(np.int32)
+    out_m = rng.integers(0, members, n).astype(np.int32)
+    for t in rng.integers(0, n_topics, max(1, n_topics // 9)):                  # topics without consumers
+        out_m[part_off[t]:part_off[t + 1]] = -1
+    off, g_t, g_p = ctx.group_by_member(part_off, out_p, out_m, members)
+    launches = ctx.last_launches()
+    order = np.argsort(out_m, kind="stable")
+    counts = np.bincount(out_m + 1, minlength=members + 1)
+    np.testing.assert_array_equal(off, np.cumsum(counts)[: members + 1])
+    np.testing.assert_array_equal(g_p, out_p[order])
+    np.testing.assert_array_equal(g_t, (np.searchsorted(part_off, order, side="right") - 1).astype(np.int32))
+    if 2560 < n <= 2048 * 32 and members <= 510:
+        assert launches == 2, launches
