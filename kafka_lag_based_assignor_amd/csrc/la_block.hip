@@ -776,9 +776,16 @@ __global__ __launch_bounds__(1024) void block_topic_kernel(BlockArgs a) {
     int32_t* s_rank = reinterpret_cast<int32_t*>(s_idx + a.nc_cap);   // [nc_cap] consumer position -> member rank
 
     const int tid = threadIdx.x, nt = blockDim.x;
-    const int64_t topic = a.list ? a.list[blockIdx.x] : a.inline_list[blockIdx.x & 7];
-    const int64_t p0 = a.part_off[topic], c0 = a.cons_off[topic];
-    const int64_t Pl = a.part_off[topic + 1] - p0, Cl = a.cons_off[topic + 1] - c0;
+    // the topic's segment bounds are the same in every lane: said so (v_readfirstlane -> SGPRs).  As four VGPR pairs they were
+    // the first thing a 128-register workgroup spilled, and the reload in front of every record's store (with the s_waitcnt
+    // vmcnt(0) that comes with it) made the sixteen stores of a thread wait for each other: 7 us of cfg2b's 100.
+    auto uniform64 = [](int64_t v) {
+        return (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)((uint64_t)v >> 32)) << 32) |
+                         (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uint64_t)v));
+    };
+    const int64_t topic = uniform64(a.list ? a.list[blockIdx.x] : a.inline_list[blockIdx.x & 7]);
+    const int64_t p0 = uniform64(a.part_off[topic]), c0 = uniform64(a.cons_off[topic]);
+    const int64_t Pl = uniform64(a.part_off[topic + 1]) - p0, Cl = uniform64(a.cons_off[topic + 1]) - c0;
     if (Pl < 0 || Cl < 0 || Pl > a.np_cap || Cl > a.nc_cap) {           // the host's lists disagree with the
         if (tid == 0) atomicOr(a.status, kStatusShape);                 // device's offsets: leave outputs alone
         return;
@@ -808,32 +815,34 @@ __global__ __launch_bounds__(1024) void block_topic_kernel(BlockArgs a) {
         // the critical path of a workgroup that has nothing else to run.  Now: one round trip for committed / end /
         // id (or the lags), one more for `begin` where there is no committed offset (lanes that do not need it all
         // read the topic's first word: one cache line per wavefront, Main.java:384-396).
-        int64_t g[E];
+        // (32-bit record offsets, the 64-bit address formed at each load: sixteen 64-bit addresses held across the whole
+        //  stage were sixteen registers more than the 128 a 1 024-thread workgroup gets, spilled and reloaded around every load)
+        int32_t g[E];
         bool valid[E];
 #pragma unroll
         for (int r = 0; r < E; ++r) {
             const int src = r * nt_ld + tid;
             valid[r] = tid < nt_ld && src < P;
-            g[r] = p0 + (valid[r] ? src : 0);
+            g[r] = valid[r] ? src : 0;
         }
         int32_t idv[E];
 #pragma unroll
-        for (int r = 0; r < E; ++r) idv[r] = a.pid[g[r]];
+        for (int r = 0; r < E; ++r) idv[r] = a.pid[p0 + g[r]];
         if (a.lag) {
             int64_t lv[E];
 #pragma unroll
-            for (int r = 0; r < E; ++r) lv[r] = a.lag[g[r]];
+            for (int r = 0; r < E; ++r) lv[r] = a.lag[p0 + g[r]];
 #pragma unroll
             for (int r = 0; r < E; ++r) lag[r] = valid[r] ? lv[r] : 0;
         } else {
             int64_t cm[E], en[E], bg[E];
 #pragma unroll
-            for (int r = 0; r < E; ++r) cm[r] = a.committed[g[r]];
+            for (int r = 0; r < E; ++r) cm[r] = a.committed[p0 + g[r]];
 #pragma unroll
-            for (int r = 0; r < E; ++r) en[r] = a.end[g[r]];
+            for (int r = 0; r < E; ++r) en[r] = a.end[p0 + g[r]];
             if (!latest && a.begin) {
 #pragma unroll
-                for (int r = 0; r < E; ++r) bg[r] = a.begin[(valid[r] && cm[r] < 0) ? g[r] : p0];
+                for (int r = 0; r < E; ++r) bg[r] = a.begin[p0 + ((valid[r] && cm[r] < 0) ? g[r] : 0)];
             } else {
 #pragma unroll
                 for (int r = 0; r < E; ++r) bg[r] = 0;
