@@ -236,7 +236,7 @@ __device__ __forceinline__ void block_sort_packed(P64 (&rec)[E], int n_eff, int 
 // until the sort is done), aux: [2][256].
 template <int E>
 __device__ __forceinline__ void block_sort_radix(P64 (&rec)[E], int live, int bits, int tid, int nt, uint64_t* buf,
-                                                 uint32_t* hist, uint32_t* aux) {
+                                                 uint32_t* hist, uint32_t* aux, int first_shift = 0) {
     constexpr int kSpanSlots = kWave * E;
     const int lane = tid & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -250,7 +250,7 @@ __device__ __forceinline__ void block_sort_radix(P64 (&rec)[E], int live, int bi
     }
     wave_lds_fence();
     LA_RCLK_START;
-    for (int shift = 0; shift < bits; shift += 8) {
+    for (int shift = first_shift; shift < bits; shift += 8) {
         uint32_t old[E];
         if (act) {
 #pragma unroll
@@ -908,7 +908,47 @@ __global__ __launch_bounds__(1024) void block_topic_kernel(BlockArgs a) {
         //  0.105 ms against 0.150, 5 000 x 512 x 100 and 4 000 x 700 x 100 even, 3 000 x 1 000 x 100 0.104 against 0.095)
         if (a.radix_sort && lbw + sh > 0 && (a.radix_sort >= 2 || P >= 768)) {
             uint32_t* aux = reinterpret_cast<uint32_t*>(s_rank + a.nc_cap) + 4;          // [512] behind the OR words
-            block_sort_radix<E>(rec, nt_ld * E, lbw + sh, tid, nt, x_key, reinterpret_cast<uint32_t*>(s_tot), aux);
+            // Partition ids of a Kafka topic are 0 .. P-1: a permutation.  Then "sorted by id" is ONE scatter -- record with id i to
+            // place i -- instead of the id's digit passes, and the stable passes over the lag's digits alone finish the order
+            // (lag desc, id asc): cfg2b (40-bit lags, 14-bit ids) runs 5 digits instead of 7.  Checked, not assumed: every id below
+            // P and a bit of an LDS bitmap per id set exactly once (returning atomic OR); anything else sorts all digits as before.
+            int first_shift = 0;
+            if (a.dense_ids && sh > 0 && (lbw + sh + 7) / 8 - (lbw + 7) / 8 >= 2) {
+                uint32_t* bitmap = reinterpret_cast<uint32_t*>(s_tot);                     // [(P + 31) / 32] words (the sort's counters: not in use yet)
+                for (int k = tid; k < (P + 31) / 32; k += nt) bitmap[k] = 0;
+                if (tid == 0) s_or[3] = 0;
+                __syncthreads();
+                bool bad = false;
+#pragma unroll
+                for (int r = 0; r < E; ++r) {
+                    const bool valid = tid < nt_ld && r * nt_ld + tid < P;
+                    const uint32_t id = rec[r].lo & id_mask;                               // (sh <= 31: the id sits in the low word)
+                    if (valid) {
+                        if (id >= (uint32_t)P) bad = true;
+                        else bad |= (atomicOr(&bitmap[id >> 5], 1u << (id & 31)) >> (id & 31)) & 1u;
+                    }
+                }
+                if (__builtin_amdgcn_ballot_w64(bad) != 0 && (tid & (kWave - 1)) == 0) atomicOr(&s_or[3], 1u);
+                __syncthreads();
+                if (s_or[3] == 0) {                                                        // workgroup-uniform
+#pragma unroll
+                    for (int r = 0; r < E; ++r) {
+                        const bool valid = tid < nt_ld && r * nt_ld + tid < P;
+                        if (valid) x_key[rec[r].lo & id_mask] = p64_value(rec[r]);
+                    }
+                    __syncthreads();
+                    // back into the registers in the order the passes rank in: blocked by wavefront, register-major
+                    const int w0 = (tid & ~(kWave - 1)) * E, ln = tid & (kWave - 1);
+#pragma unroll
+                    for (int r = 0; r < E; ++r) {
+                        const int pos = w0 + r * kWave + ln;
+                        rec[r] = p64_from(pos < P ? x_key[pos] : ~0ull);
+                    }
+                    __syncthreads();                                                       // (the first pass scatters into x_key again)
+                    first_shift = sh;
+                }
+            }
+            block_sort_radix<E>(rec, nt_ld * E, lbw + sh, tid, nt, x_key, reinterpret_cast<uint32_t*>(s_tot), aux, first_shift);
             LA_BCLK(2);
             // the sorted records lie in region A by position: record i becomes the key of position i, in place.  On the way
             // every record is compared with the one before it: the ranks of the sort rest on a property of the LDS atomics
@@ -1159,6 +1199,9 @@ hipError_t block_launch(BlockArgs a, int cls, hipStream_t stream) {
     // LA_BLOCK_KEY32=0: the 65 .. 256-bin greedy of rounds 3-4 (64-bit bins through the networks) instead of the 32-bit-key form (A/B, tests)
     static const int key32_mode = [] { const char* e = getenv("LA_BLOCK_KEY32"); return e ? atoi(e) : 1; }();
     a.key32_greedy = key32_mode;
+    // LA_BLOCK_DENSE_IDS=0: never the one-scatter placement by id in front of the digit passes (A/B, tests)
+    static const int dense_mode = [] { const char* e = getenv("LA_BLOCK_DENSE_IDS"); return e ? atoi(e) : 1; }();
+    a.dense_ids = dense_mode;
     static PerDeviceOnce lds_opt_in;
     hipError_t err = lds_opt_in.run([] {
         hipError_t e2 = hipFuncSetAttribute((const void*)block_topic_kernel<8>,

@@ -167,6 +167,7 @@ struct BlockArgs {
     uint32_t* status;
     int32_t reset_latest;
     int32_t np_cap, nc_cap;     // LDS capacity in records / bins, set by the launcher
+    int32_t dense_ids;          // set by the launcher: ids that are a permutation of 0 .. P-1 are placed by ONE scatter, not by digit passes
     int32_t key32_greedy;       // set by the launcher: 65 .. 256 consumers with packed totals take greedy_one_wave_key32
     int32_t radix_sort;         // set by the launcher: records that pack into one word are sorted by the workgroup's LSD radix
                                 // sort (block_sort_radix) -- needs ranks from returning LDS atomics (large_atomic_rank_supported)

@@ -301,8 +301,10 @@ for (P, C) in ((10000, 128), (3000, 200), (16000, 256), (1500, 66)):
         t4._same3(t4._device_call(ctx, w), exp, what=str((P, C)))
 print("ok")
 """
-    for mode in ("0", "2"):                                        # 2: the 32-bit-key form for 256 bins as well (default: 128 only)
+    for mode in ("0", "2", "dense0"):                              # 2: the 32-bit-key form for 256 bins as well (default: 128 only)
         env = dict(os.environ, LA_BLOCK_KEY32=mode)
+        if mode == "dense0":                                       # ... and without the one-scatter placement of dense ids in front of the digits
+            env = dict(os.environ, LA_BLOCK_DENSE_IDS="0")
         out = subprocess.run([sys.executable, "-c", code % (ROOT, os.path.join(ROOT, "tests"))], env=env, capture_output=True,
                              text=True, timeout=600)
         assert out.returncode == 0 and "ok" in out.stdout, (mode, out.stdout[-1500:], out.stderr[-1500:])

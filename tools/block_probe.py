@@ -9,7 +9,7 @@ dev = torch.device("cuda", 0)
 ctx = N.Context(0)
 rng = np.random.default_rng(1)
 
-def run(t, p, c, algo=N.LA_ALGO_AUTO, reps=5, lag_bits=34, offsets=False):
+def run(t, p, c, algo=N.LA_ALGO_AUTO, reps=5, lag_bits=int(__import__("os").environ.get("LAG_BITS", "34")), offsets=False):
     n, k = t * p, t * c
     part_off = np.arange(t + 1, dtype=np.int64) * p
     cons_off = np.arange(t + 1, dtype=np.int64) * c
