@@ -1265,6 +1265,8 @@ int run_workers(la_ctx* ctx, int n, F&& fn) {
 // for a three-partition batch.  Here the inputs are packed into one pinned staging buffer (a memcpy of kilobytes), go up
 // in ONE copy together with a zeroed status word, and status + results come back in ONE copy.
 constexpr size_t kSmallBytes = 2u << 20;
+constexpr size_t kMappedSmallBytes = 512u << 10;           // mapped caller arrays: layouts beyond this are read in place instead
+constexpr size_t kMappedSmallGroupedBytes = 1536u << 10;   // ... and beyond this when the call wants every member's list too
 constexpr size_t kSmallHostCheck = 16384;      // consumer entries up to which the small path validates the ranks on the host
 
 struct SmallLayout {
@@ -1629,7 +1631,16 @@ int assign_host(la_ctx* ctx, int32_t T, const int64_t* part_off, const int32_t* 
             c.g_members = -1;
             L = small_layout(c);
         }
-        if (L.total <= kSmallBytes) {
+        // Caller arrays that are themselves device-mapped (la_host_alloc: what the Java host's direct buffers are) and well
+        // beyond the zero-copy staging buffer: packing them into the staging buffer and copying that up is work the mapped
+        // pipeline below does not have -- its kernels read the caller's arrays in place.  Measured on pinned arrays, staged /
+        // in place (profiles/r05_m_latency_probe.txt): 16 000 partitions 69 / 65 us, 50 000: 118 / 85 us; with the lists
+        // aboard the staged form saves a round trip and wins up to ~1.5 MB (16 000: 93 / 121 us, 50 000: 182 / 157 us).
+        const size_t mapped_from = c.g_members >= 0 ? kMappedSmallGroupedBytes : kMappedSmallBytes;
+        const bool mapped_small = L.total > mapped_from && L.total > ctx->zero_copy_bytes && L.total <= kSmallBytes &&
+                                  !getenv("LA_NO_MAPPED_SMALL") && !getenv("LA_NO_MAPPED_PIPELINE") &&
+                                  !getenv("LA_NO_ASYNC_PIPELINE") && call_is_pinned(c) && call_is_mapped(c);
+        if (L.total <= kSmallBytes && !mapped_small) {
             Shard& sh = ctx->shards[0];
             sh.last_t0 = 0; sh.last_topics = T; sh.last_p0 = 0; sh.last_n = s.n;
             const bool zc = L.total <= ctx->zero_copy_bytes;

@@ -25,7 +25,10 @@ def med(f, reps):
 def main():
     ctx = N.Context(0)
     print("zero-copy threshold: LA_ZERO_COPY_BYTES=%s" % os.environ.get("LA_ZERO_COPY_BYTES", "default (128 KB)"))
-    for (t, p, c) in [(1, 3, 2), (10, 10, 3), (40, 50, 5), (100, 20, 4), (100, 100, 8), (1000, 16, 4), (1000, 50, 5), (1000, 256, 32), (10000, 64, 8)]:
+    rows = [(1, 3, 2), (10, 10, 3), (40, 50, 5), (100, 20, 4), (100, 100, 8), (1000, 16, 4), (1000, 50, 5), (1000, 256, 32), (10000, 64, 8)]
+    if os.environ.get("LAT_ROWS"):                     # e.g. LAT_ROWS=100x100x8,1000x50x5
+        rows = [tuple(int(v) for v in r.split("x")) for r in os.environ["LAT_ROWS"].split(",")]
+    for (t, p, c) in rows:
         w = synth.make_uniform("lat", 20, t, p, c, "uniform40")
         a = (w.part_off, w.partition_id, w.begin, w.end, w.committed, N.LA_RESET_EARLIEST, w.cons_off, w.cons_rank)
         out = ctx.assign_batch(*a)
@@ -64,17 +67,23 @@ def main():
             ctx.hint_next_call(hb)
             ctx.assign_batch(*pa, keep_on_device=True, want_totals=False)       # (totals would come back in a pageable array)
             return ctx.group_last_by_member(w.n_partitions, c, out=gout)
+        def pinned_grouped_call():                     # what the Java host calls: one grouped call on its direct buffers
+            ctx.hint_next_call(hb)
+            return ctx.assign_batch_grouped(*pa, c, want_totals=False)   # (totals would come back in a pageable array)
         for _ in range(5):
             pinned()
         t_pin, got_p = med(pinned, reps)
         pipe_p, launches_p = ctx.last_pipeline(), ctx.last_launches()
         t_pin_g, got_pg = med(pinned_grouped, reps // 3)
+        t_pin_gc, got_pgc = med(pinned_grouped_call, reps // 3)
+        pipe_gc = ctx.last_pipeline()
+        same = same and all(np.array_equal(x, y) for x, y in zip(got_pgc[:3], ref))
         same = same and all(np.array_equal(x, y) for x, y in zip(got_p, out)) and all(np.array_equal(x, y) for x, y in zip(got_pg, ref))
         print("%6d topics x %4d partitions x %3d consumers (%8d partitions) [%s]: assign %.1f us; assign + group_last %.1f us; "
               "assign_batch_grouped %.1f us (sparse begin %.1f us; same lists: %s); pinned arrays [%s, %d launches]: assign %.1f us, "
-              "assign + group_last %.1f us; C oracle + sort by member on one core %.1f us"
+              "assign + group_last %.1f us, assign_batch_grouped %.1f us [%s]; C oracle + sort by member on one core %.1f us"
               % (t, p, c, w.n_partitions, PIPE.get(pipe, pipe), t_assign, t_two, t_grouped, t_sparse, same, PIPE.get(pipe_p, pipe_p),
-                 launches_p, t_pin, t_pin_g, t_cpu))
+                 launches_p, t_pin, t_pin_g, t_pin_gc, PIPE.get(pipe_gc, pipe_gc), t_cpu))
     ctx.close()
 
 
