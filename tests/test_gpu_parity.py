@@ -680,9 +680,10 @@ def test_group_last_by_member_equals_group_by_member(ctx):
     # one output array without the other is refused
     import ctypes
     one = np.zeros(3, dtype=np.int32)
-    rc = ctx._lib.la_assign_batch_lags(ctx._h, 1, N._p64(np.array([0, 3], dtype=np.int64)), N._p32(np.arange(3, dtype=np.int32)),
-                                       N._p64(np.array([5, 6, 7], dtype=np.int64)), N._p64(np.array([0, 1], dtype=np.int64)),
-                                       N._p32(np.zeros(1, dtype=np.int32)), N._p32(one), None, None)
+    keep = (np.array([0, 3], dtype=np.int64), np.arange(3, dtype=np.int32), np.array([5, 6, 7], dtype=np.int64),
+            np.array([0, 1], dtype=np.int64), np.zeros(1, dtype=np.int32))        # (N._p64 is an address: the arrays must live)
+    rc = ctx._lib.la_assign_batch_lags(ctx._h, 1, N._p64(keep[0]), N._p32(keep[1]), N._p64(keep[2]), N._p64(keep[3]),
+                                       N._p32(keep[4]), N._p32(one), None, None)
     assert rc == N.LA_EINVAL
 
 
