@@ -213,6 +213,7 @@ struct la_ctx {
                                          // 1 = lanes (a host thread per stream; pageable arrays), 2 = three streams, no threads (pinned)
     std::vector<void*> comms;            // la_allgather_results: one ncclComm_t per shard, created on first use
     size_t zero_copy_bytes = 0;          // calls whose staging layout is at most this large run zero-copy (assign_small_zc)
+    size_t small_bytes = 0;              // ... and up to this large as ONE staging buffer at all (zero-copy or one copy)
     int last_shards = 0;                 // shards the last call used
     int32_t last_bounds[65] = {};        // their topic ranges
     la_call_hints hints{};               // la_hint_next_call: what the caller knows about its next host-buffer assign call
@@ -1264,9 +1265,11 @@ int run_workers(la_ctx* ctx, int n, F&& fn) {
 // at this size the call is API latency: 7 H2D copies of caller arrays, 3 D2H copies, the status word, ~8 us each -- 105 us
 // for a three-partition batch.  Here the inputs are packed into one pinned staging buffer (a memcpy of kilobytes), go up
 // in ONE copy together with a zeroed status word, and status + results come back in ONE copy.
-constexpr size_t kSmallBytes = 2u << 20;
-constexpr size_t kMappedSmallBytes = 512u << 10;           // mapped caller arrays: layouts beyond this are read in place instead
-constexpr size_t kMappedSmallGroupedBytes = 1536u << 10;   // ... and beyond this when the call wants every member's list too
+constexpr size_t kSmallBytes = 6u << 20;                    // (~170 000 partitions)
+constexpr size_t kGroupStageBytes = 2u << 20;               // la_group_last_by_member: CSRs up to this size cross in one copy
+constexpr size_t kMappedSmallBytes = 1280u << 10;          // mapped caller arrays: layouts beyond this are read in place instead
+constexpr size_t kMappedSmallGroupedBytes = 3u << 20;      // ... and beyond this when the call wants every member's list too
+constexpr size_t kPinnedSmallBytes = 2u << 20;             // pinned, not mapped: beyond this the three-stream pipeline
 constexpr size_t kSmallHostCheck = 16384;      // consumer entries up to which the small path validates the ranks on the host
 
 struct SmallLayout {
@@ -1303,8 +1306,13 @@ SmallLayout small_layout(const HostCall& c) {
 // loads of a tile go out back to back: a couple of ~1.5 us round trips), write what the caller wants back -- totals, results
 // or every member's list -- straight into it, and the call's last launch stores `done | status` where this thread is spinning.
 // The ungrouped result of a grouped call never leaves the device.  No hipMemcpy, no stream synchronize.
-constexpr size_t kZeroCopyBytes = 128u << 10;  // staging layouts up to this size (~2 500 partitions): beyond, PCIe reads at
-                                               // kernel rate lose to one DMA copy
+// Up to which staging layout: rounds 3-4 stopped at 128 KB, where the form's three dependent launches + PCIe reads at kernel
+// rate lost to one DMA copy each way.  With the call's end (and the small lists) fused into the tile kernel (round 5) it wins
+// at every size measured up to where packing the inputs on one thread loses to the lanes' overlapped copies
+// (profiles/r05_n_latency_probe.txt, r05_o_: 5 000 partitions 49 -> 35 us, 10 000: 56 -> 38, 30 000: 84 -> 65, 100 000:
+// 242 (lanes) -> 160; 256 000: 336 (lanes) vs 402) -- so every staged call is zero-copy now, and the one-copy form
+// (assign_small) is what LA_ZERO_COPY_BYTES=<smaller> still selects (A/B, tests).
+constexpr size_t kZeroCopyBytes = 6u << 20;
 
 int reserve_host_coherent(la_ctx* ctx, HostBuf& b, size_t bytes) {
     if (bytes <= b.cap) return LA_OK;
@@ -1627,20 +1635,28 @@ int assign_host(la_ctx* ctx, int32_t T, const int64_t* part_off, const int32_t* 
     ctx->last_shards = S;
     if (S == 1 && !ctx->split_always && s.n > 0) {
         SmallLayout L = small_layout(c);
-        if (L.total > kSmallBytes && c.g_members >= 0) {     // too large with the lists aboard: they take their own round trip
+        // How large a layout still travels through ONE staging buffer.  Pageable caller arrays: ctx->small_bytes (6 MB) -- beyond,
+        // packing the inputs on this one thread costs more than the lanes' overlapped copies.  Caller arrays that are pinned
+        // need no packing at all on the other side of the comparison: device-mapped ones (la_host_alloc: the Java host's direct
+        // buffers) are read in place by the kernels from 1.25 MB on (3 MB with the lists aboard, which the staged form brings
+        // back in the same round trip); pinned but not mapped ones keep round 4's 2 MB.  profiles/r05_o_latency_probe.txt.
+        const bool no_pinned_rule = getenv("LA_NO_MAPPED_SMALL") || getenv("LA_NO_ASYNC_PIPELINE");
+        auto staged_upto = [&](bool with_lists) {
+            size_t upto = ctx->small_bytes;
+            if (L.total > kMappedSmallBytes && !no_pinned_rule && call_is_pinned(c)) {
+                const bool mapped = !getenv("LA_NO_MAPPED_PIPELINE") && call_is_mapped(c);
+                const size_t lim = mapped ? (with_lists ? kMappedSmallGroupedBytes : kMappedSmallBytes) : kPinnedSmallBytes;
+                if (lim < upto) upto = lim;
+            }
+            return upto;
+        };
+        size_t upto = staged_upto(c.g_members >= 0);
+        if (L.total > upto && c.g_members >= 0) {            // too large with the lists aboard: they take their own round trip
             c.g_members = -1;
             L = small_layout(c);
+            upto = staged_upto(false);
         }
-        // Caller arrays that are themselves device-mapped (la_host_alloc: what the Java host's direct buffers are) and well
-        // beyond the zero-copy staging buffer: packing them into the staging buffer and copying that up is work the mapped
-        // pipeline below does not have -- its kernels read the caller's arrays in place.  Measured on pinned arrays, staged /
-        // in place (profiles/r05_m_latency_probe.txt): 16 000 partitions 69 / 65 us, 50 000: 118 / 85 us; with the lists
-        // aboard the staged form saves a round trip and wins up to ~1.5 MB (16 000: 93 / 121 us, 50 000: 182 / 157 us).
-        const size_t mapped_from = c.g_members >= 0 ? kMappedSmallGroupedBytes : kMappedSmallBytes;
-        const bool mapped_small = L.total > mapped_from && L.total > ctx->zero_copy_bytes && L.total <= kSmallBytes &&
-                                  !getenv("LA_NO_MAPPED_SMALL") && !getenv("LA_NO_MAPPED_PIPELINE") &&
-                                  !getenv("LA_NO_ASYNC_PIPELINE") && call_is_pinned(c) && call_is_mapped(c);
-        if (L.total <= kSmallBytes && !mapped_small) {
+        if (L.total <= upto) {
             Shard& sh = ctx->shards[0];
             sh.last_t0 = 0; sh.last_topics = T; sh.last_p0 = 0; sh.last_n = s.n;
             const bool zc = L.total <= ctx->zero_copy_bytes;
@@ -1864,6 +1880,8 @@ LA_API int la_create_multi(la_ctx** out, int n_devices, const int* device_ids, u
         if (const char* env = getenv("LA_CHUNK_PARTITIONS")) ctx->chunk_partitions = atoll(env);
         ctx->zero_copy_bytes = kZeroCopyBytes;
         if (const char* env = getenv("LA_ZERO_COPY_BYTES")) ctx->zero_copy_bytes = (size_t)atoll(env);
+        ctx->small_bytes = kSmallBytes;
+        if (const char* env = getenv("LA_SMALL_BYTES")) ctx->small_bytes = (size_t)atoll(env);      // (lab: where the forms hand over)
         ctx->shards.resize(ids.size());
         for (size_t i = 0; i < ids.size(); ++i) {
             Shard& sh = ctx->shards[i];
@@ -2261,7 +2279,7 @@ static int group_last_impl(la_ctx* ctx, int32_t n_members, int64_t* member_off, 
         const size_t nb4 = (size_t)n * 4;
         const size_t o_topic = (mb + 16 + 255) & ~(size_t)255, o_part = (o_topic + nb4 + 16 + 255) & ~(size_t)255;
         const size_t g_total = o_part + nb4 + 16;
-        if (g_total <= kSmallBytes) {
+        if (g_total <= kGroupStageBytes) {
             // small batch: the CSR is built in one staging buffer and crosses in one copy (see assign_small)
             int rc;
             if ((rc = reserve(ctx, sh.small_g, g_total)) || (rc = reserve_host(ctx, sh.small_gh, g_total))) return rc;

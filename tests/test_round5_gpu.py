@@ -428,35 +428,44 @@ def test_member_lists_of_a_mid_size_rebalance(ctx, n_topics, max_p, members):
         assert launches == 2, launches
 
 
-# ---- mapped caller arrays between the zero-copy and the one-copy staging sizes are read in place ------------------------------------
-@pytest.mark.parametrize("topics,p,c,grouped,pipeline", [(100, 100, 8, False, "ONE_COPY"), (1000, 30, 5, False, "MAPPED"),
-                                                        (1000, 30, 5, True, "ONE_COPY"), (1000, 50, 5, True, "MAPPED")])
-def test_mapped_arrays_of_a_mid_size_call_are_read_in_place(ctx, topics, p, c, grouped, pipeline):
-    """la_host_alloc arrays (what the Java host's direct buffers are): a layout beyond 512 KB (1.5 MB with the lists aboard) is not
-    packed into the staging buffer and copied up, the kernels read the caller's arrays; smaller ones keep the one-copy form.
-    Either way the result is the pageable call's."""
+# ---- which staged calls are zero-copy, and from where mapped caller arrays are read in place ---------------------------------------
+@pytest.mark.parametrize("topics,p,c,grouped,pipeline", [(100, 100, 8, False, "ZERO_COPY"), (1000, 30, 5, False, "ZERO_COPY"),
+                                                        (1000, 50, 5, False, "MAPPED"), (1000, 50, 5, True, "ZERO_COPY"),
+                                                        (1000, 100, 8, True, "MAPPED")])
+def test_mid_size_calls_staged_or_read_in_place(ctx, topics, p, c, grouped, pipeline):
+    """Pageable arrays: every layout up to 6 MB is packed into the mapped staging buffer and read there (zero-copy).
+    la_host_alloc arrays (what the Java host's direct buffers are): from 1.25 MB on (3 MB with the lists aboard) nothing is packed,
+    the kernels read the caller's arrays.  Either way the result is the oracle's."""
     w = synth.make_uniform("mid", topics + c, topics, p, c, "uniform40")
     a = (w.part_off, w.partition_id, w.begin, w.end, w.committed, N.LA_RESET_EARLIEST, w.cons_off, w.cons_rank)
     pa = _pinned_copy(ctx, a)
     want = getattr(N, "LA_PIPELINE_" + pipeline)
+    lag = oracle.compute_lags(w.begin, w.end, w.committed, False)
+    e = oracle.assign_flat(w.part_off, w.partition_id, lag, w.cons_off, w.cons_rank)
     if grouped:
         ref = ctx.assign_batch_grouped(*a, c, want_totals=False)
-        assert ctx.last_pipeline() == N.LA_PIPELINE_ONE_COPY
+        assert ctx.last_pipeline() == N.LA_PIPELINE_ZERO_COPY
         got = ctx.assign_batch_grouped(*pa, c, want_totals=False)
         assert ctx.last_pipeline() == want, ctx.last_pipeline()
         for x, y in zip(got[:3], ref[:3]):
             np.testing.assert_array_equal(x, y)
-        lag = oracle.compute_lags(w.begin, w.end, w.committed, False)
-        e = oracle.assign_flat(w.part_off, w.partition_id, lag, w.cons_off, w.cons_rank)
-        order = np.argsort(e[1], kind="stable")
-        np.testing.assert_array_equal(got[2], e[0][order])
+        np.testing.assert_array_equal(got[2], e[0][np.argsort(e[1], kind="stable")])
     else:
         pout = (ctx.host_alloc((w.n_partitions,), np.int32), ctx.host_alloc((w.n_partitions,), np.int32),
                 ctx.host_alloc((w.cons_rank.size,), np.int64))
         ref = ctx.assign_batch(*a)
-        assert ctx.last_pipeline() == N.LA_PIPELINE_ONE_COPY
+        assert ctx.last_pipeline() == N.LA_PIPELINE_ZERO_COPY
+        _same3(ref, e, "oracle, pageable")
         got = ctx.assign_batch(*pa, out=pout)
         assert ctx.last_pipeline() == want, ctx.last_pipeline()
-        _same3(got, ref, "mapped mid-size call")
+        _same3(got, e, "oracle, pinned")
+
+
+def test_a_staged_call_at_the_limit_and_just_beyond(ctx):
+    """165 000 / 180 000 partitions (5.8 / 6.3 MB of layout) on either side of the 6 MB limit: zero-copy, then the lanes."""
+    for topics, want in ((660, N.LA_PIPELINE_ZERO_COPY), (720, N.LA_PIPELINE_LANES)):
+        w = synth.make_uniform("edge", topics, topics, 250, 16, "zipf")
+        got = ctx.assign_batch(w.part_off, w.partition_id, w.begin, w.end, w.committed, N.LA_RESET_EARLIEST, w.cons_off, w.cons_rank)
+        assert ctx.last_pipeline() == want, (topics, ctx.last_pipeline())
         lag = oracle.compute_lags(w.begin, w.end, w.committed, False)
         _same3(got, oracle.assign_flat(w.part_off, w.partition_id, lag, w.cons_off, w.cons_rank), "oracle")
