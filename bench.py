@@ -506,9 +506,11 @@ def run_small_calls(N, ctx):
     cross = next((r["partitions"] for r in rows if r["gpu_call_us"] < r["cpu_oracle_us"]), None)
     return {"rows": rows, "gpu_faster_from_partitions": cross, "c_abi": _small_calls_c_abi(),
             "what": "median wall time of ONE la_assign_batch_grouped call (pageable host buffers in, every member's list out: "
-                    "one upload, the kernels, one download) against the C oracle + a stable sort by member for the same call on "
-                    "one host core (ctypes call overhead included on both sides).  Below the crossover a rebalance is cheaper "
-                    "on the CPU: the GPU path's floor is the ~30 us of two PCIe copies and two launches"}
+                    "inputs packed into mapped host memory, the kernels read and write it in place -- ONE launch up to ~2 500 "
+                    "partitions -- and the calling thread spins on a flag word) against the C oracle + a stable sort by member "
+                    "for the same call on one host core (ctypes call overhead included on both sides; c_abi = the same without "
+                    "an interpreter).  Below the crossover a rebalance is cheaper on the CPU: the GPU path's floor is ~20 us of "
+                    "launch, PCIe round trips and completion"}
 
 
 def run_sort_phase(torch, N, ctx, dev, n, reps, stream, form="single", live=False, ids=None):

@@ -482,7 +482,9 @@ def test_smallest_calls_run_zero_copy_and_agree_with_the_copying_forms():
             _same3(got, _expected(w, False), "sparse")
             _same3(c.assign_batch_lags(w.part_off, w.partition_id, w.lag, w.cons_off, w.cons_rank),
                    oracle.assign_flat(w.part_off, w.partition_id, w.lag, w.cons_off, w.cons_rank), "lags")
-        assert seen == {N.LA_PIPELINE_ZERO_COPY} and seen_ref == {N.LA_PIPELINE_ONE_COPY}, (seen, seen_ref)
+        # (the batches without partitions take no staged form at all)
+        assert N.LA_PIPELINE_ZERO_COPY in seen and N.LA_PIPELINE_ONE_COPY not in seen, seen
+        assert N.LA_PIPELINE_ONE_COPY in seen_ref and N.LA_PIPELINE_ZERO_COPY not in seen_ref, seen_ref
         # errors: unsorted ranks (validated on the host for a small call), then the context still works
         with pytest.raises(N.LagAssignError) as e:
             c.assign_batch_lags([0, 2], [0, 1], [5, 6], [0, 2], [3, 1])
