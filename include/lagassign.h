@@ -206,7 +206,7 @@ int la_last_shard_bounds(const la_ctx *ctx, int32_t *bounds, int32_t capacity);
 #define LA_PIPELINE_MAPPED    4   /* every array of the call is pinned AND device-mapped (la_host_alloc): no copies and no chunks --
                                    * the kernels read the caller's arrays in place over PCIe (each input byte is touched once,
                                    * `begin` only where there is no committed offset) and write the results straight into them */
-#define LA_PIPELINE_ZERO_COPY 3   /* calls whose arrays fit one staging buffer (up to 6 MB, ~170 000 partitions; for pinned
+#define LA_PIPELINE_ZERO_COPY 3   /* calls whose arrays fit one staging buffer (up to 12 MB, ~340 000 partitions; for pinned
                                    * caller arrays less, see LA_PIPELINE_MAPPED; environment LA_ZERO_COPY_BYTES overrides,
                                    * 0 = never): no copy at all -- the inputs are packed into coherent, device-mapped host
                                    * memory, the kernels read them there and write totals / results / member lists into it;
@@ -429,7 +429,7 @@ int la_group_last_by_member(la_ctx *ctx, int32_t n_members,
 
 /* Both steps in one call -- what the reference's assign(Cluster, GroupSubscription) does between reading the offsets
  * and wrapping the lists (Main.java:147-156): la_assign_batch with the ungrouped result left on the device, then
- * la_group_last_by_member.  For the call a real rebalance is (its arrays fit the library's staging buffer: 6 MB) the lists
+ * la_group_last_by_member.  For the call a real rebalance is (its arrays fit the library's staging buffer: 12 MB) the lists
  * are built behind the assignment kernels on the same stream -- up to 2 560 entries inside the assignment kernel itself -- and
  * land in that buffer with the status and the totals: no copy, one wait.  Larger batches run the two steps one after the other.  The results stay
  * on the device as after la_assign_batch (la_group_last_by_member may be called again).  grouped_topic and out_total_lag

@@ -1265,7 +1265,7 @@ int run_workers(la_ctx* ctx, int n, F&& fn) {
 // at this size the call is API latency: 7 H2D copies of caller arrays, 3 D2H copies, the status word, ~8 us each -- 105 us
 // for a three-partition batch.  Here the inputs are packed into one pinned staging buffer (a memcpy of kilobytes), go up
 // in ONE copy together with a zeroed status word, and status + results come back in ONE copy.
-constexpr size_t kSmallBytes = 6u << 20;                    // (~170 000 partitions)
+constexpr size_t kSmallBytes = 12u << 20;                   // (~340 000 partitions)
 constexpr size_t kGroupStageBytes = 2u << 20;               // la_group_last_by_member: CSRs up to this size cross in one copy
 constexpr size_t kMappedSmallBytes = 1280u << 10;          // mapped caller arrays: layouts beyond this are read in place instead
 constexpr size_t kMappedSmallGroupedBytes = 3u << 20;      // ... and beyond this when the call wants every member's list too
@@ -1308,11 +1308,12 @@ SmallLayout small_layout(const HostCall& c) {
 // The ungrouped result of a grouped call never leaves the device.  No hipMemcpy, no stream synchronize.
 // Up to which staging layout: rounds 3-4 stopped at 128 KB, where the form's three dependent launches + PCIe reads at kernel
 // rate lost to one DMA copy each way.  With the call's end (and the small lists) fused into the tile kernel (round 5) it wins
-// at every size measured up to where packing the inputs on one thread loses to the lanes' overlapped copies
-// (profiles/r05_n_latency_probe.txt, r05_o_: 5 000 partitions 49 -> 35 us, 10 000: 56 -> 38, 30 000: 84 -> 65, 100 000:
-// 242 (lanes) -> 160; 256 000: 336 (lanes) vs 402) -- so every staged call is zero-copy now, and the one-copy form
+// at every size measured up to where packing the inputs loses to the lanes' overlapped copies
+// (profiles/r05_n_latency_probe.txt, r05_o_, r05_q_: 5 000 partitions 49 -> 35 us, 10 000: 56 -> 38, 30 000: 84 -> 65, 100 000:
+// 242 (lanes) -> 160; 256 000: 335 (lanes) vs 402 packed by one thread, 267-310 with the parked threads' help (copy_pieces);
+// 512 000: 546 vs 552) -- so every staged call is zero-copy now, and the one-copy form
 // (assign_small) is what LA_ZERO_COPY_BYTES=<smaller> still selects (A/B, tests).
-constexpr size_t kZeroCopyBytes = 6u << 20;
+constexpr size_t kZeroCopyBytes = 12u << 20;
 
 int reserve_host_coherent(la_ctx* ctx, HostBuf& b, size_t bytes) {
     if (bytes <= b.cap) return LA_OK;
@@ -1324,6 +1325,39 @@ int reserve_host_coherent(la_ctx* ctx, HostBuf& b, size_t bytes) {
 }
 
 int small_fill_inputs(la_ctx* ctx, const HostCall& c, const SmallLayout& L, char* h);
+
+// The staged forms pack the caller's arrays into one buffer and unpack the results: plain memcpy.  From a few megabytes on that
+// is most of the call on ONE thread (~35 GB/s: 100 us for the inputs of 100 000 partitions), so the pieces are handed out to
+// the context's parked threads as well -- the calling thread starts on the first piece at once and simply does all of them
+// when nobody else turns up in time (a parked thread needs 30-50 us to be back).  Measured, serial / with help
+// (profiles/r05_q_latency_probe.txt): 100 000 partitions 161 / 139-166 us, 256 000: 402 / 267-310 us (lanes: 335).
+struct CopyPiece { void* dst; const void* src; size_t bytes; };
+constexpr size_t kParallelCopyBytes = 3u << 20, kCopyPieceBytes = 256u << 10;
+
+void copy_pieces(la_ctx* ctx, const CopyPiece* cp, int n) {
+    size_t total = 0;
+    for (int i = 0; i < n; ++i) total += cp[i].bytes;
+    static const bool serial = getenv("LA_NO_PARALLEL_COPY") != nullptr;                // (A/B hook)
+    if (total < kParallelCopyBytes || serial) {
+        for (int i = 0; i < n; ++i)
+            if (cp[i].bytes) memcpy(cp[i].dst, cp[i].src, cp[i].bytes);
+        return;
+    }
+    std::vector<CopyPiece> pieces;
+    pieces.reserve(total / kCopyPieceBytes + (size_t)n);
+    for (int i = 0; i < n; ++i)
+        for (size_t o = 0; o < cp[i].bytes; o += kCopyPieceBytes)
+            pieces.push_back({(char*)cp[i].dst + o, (const char*)cp[i].src + o,
+                              cp[i].bytes - o < kCopyPieceBytes ? cp[i].bytes - o : kCopyPieceBytes});
+    std::atomic<size_t> next{0};
+    ctx->pool.run(total >= (4u << 20) ? 4 : 3, [&](int) {
+        for (;;) {
+            const size_t i = next.fetch_add(1, std::memory_order_relaxed);
+            if (i >= pieces.size()) break;
+            memcpy(pieces[i].dst, pieces[i].src, pieces[i].bytes);
+        }
+    });
+}
 
 int assign_small_zc(la_ctx* ctx, const HostCall& c, Shard& sh, const SmallLayout& L) {
     LA_HIP(ctx, hipSetDevice(sh.device));
@@ -1445,15 +1479,15 @@ int assign_small_zc(la_ctx* ctx, const HostCall& c, Shard& sh, const SmallLayout
             LA_HIP(ctx, hipMemcpyAsync(c.out_rank, d + L.orank, n * 4, hipMemcpyDeviceToHost, st));
             LA_HIP(ctx, hipStreamSynchronize(st));
         } else {
-            memcpy(c.out_pid, h + L.op, n * 4);
-            memcpy(c.out_rank, h + L.orank, n * 4);
+            const CopyPiece out[2] = {{c.out_pid, h + L.op, n * 4}, {c.out_rank, h + L.orank, n * 4}};
+            copy_pieces(ctx, out, 2);
         }
     }
     if (grouped) {
         memcpy(c.g_off, h + L.goff, ((size_t)c.g_members + 1) * 8);
         if (n) {
-            memcpy(c.g_part, h + L.gp, n * 4);
-            if (c.g_topic) memcpy(c.g_topic, h + L.gt, n * 4);
+            const CopyPiece out[2] = {{c.g_part, h + L.gp, n * 4}, {c.g_topic, h + L.gt, c.g_topic ? n * 4 : 0}};
+            copy_pieces(ctx, out, 2);
         }
         if (c.grouped_done) *c.grouped_done = true;
     }
@@ -1470,10 +1504,11 @@ int small_fill_inputs(la_ctx* ctx, const HostCall& c, const SmallLayout& L, char
     memcpy(h + L.po, c.part_off, (T + 1) * 8);
     memcpy(h + L.co, c.cons_off, (T + 1) * 8);
     if (n) {
-        memcpy(h + L.pid, c.pid, n * 4);
-        memcpy(h + L.end, c.lag ? c.lag : c.end, n * 8);
-        if (!c.lag) memcpy(h + L.com, c.committed, n * 8);
-        if (c.use_begin && !c.sparse) memcpy(h + L.beg, c.begin, n * 8);
+        const CopyPiece in[4] = {{h + L.pid, c.pid, n * 4},
+                                 {h + L.end, c.lag ? c.lag : c.end, n * 8},
+                                 {h + L.com, c.committed, c.lag ? 0 : n * 8},
+                                 {h + L.beg, c.begin, (c.use_begin && !c.sparse) ? n * 8 : 0}};
+        copy_pieces(ctx, in, 4);
         if (c.sparse) {
             // a small call rebuilds the dense array right here in the staging buffer: unlisted partitions have begin 0
             int64_t* hb = (int64_t*)(h + L.beg);
@@ -1635,8 +1670,8 @@ int assign_host(la_ctx* ctx, int32_t T, const int64_t* part_off, const int32_t* 
     ctx->last_shards = S;
     if (S == 1 && !ctx->split_always && s.n > 0) {
         SmallLayout L = small_layout(c);
-        // How large a layout still travels through ONE staging buffer.  Pageable caller arrays: ctx->small_bytes (6 MB) -- beyond,
-        // packing the inputs on this one thread costs more than the lanes' overlapped copies.  Caller arrays that are pinned
+        // How large a layout still travels through ONE staging buffer.  Pageable caller arrays: ctx->small_bytes (12 MB) -- beyond,
+        // packing the inputs costs as much as the lanes' overlapped copies.  Caller arrays that are pinned
         // need no packing at all on the other side of the comparison: device-mapped ones (la_host_alloc: the Java host's direct
         // buffers) are read in place by the kernels from 1.25 MB on (3 MB with the lists aboard, which the staged form brings
         // back in the same round trip); pinned but not mapped ones keep round 4's 2 MB.  profiles/r05_o_latency_probe.txt.

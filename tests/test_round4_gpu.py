@@ -444,7 +444,7 @@ def test_huge_consumer_topic_inside_a_batch(ctx):
 
 # ---- zero-copy small calls ------------------------------------------------------------------------------------
 def test_smallest_calls_run_zero_copy_and_agree_with_the_copying_forms():
-    """Staged calls (layouts up to 6 MB; 128 KB until round 5): the kernels read the inputs from coherent host memory in place
+    """Staged calls (layouts up to 12 MB; 128 KB until round 5): the kernels read the inputs from coherent host memory in place
     and write results / totals / lists into it; no hipMemcpy, no stream wait.  Same results as the one-copy form
     (LA_ZERO_COPY_BYTES=0) on every entry point, across the old threshold, alternating on one context; errors surface and
     leave the context usable."""

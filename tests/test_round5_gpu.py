@@ -433,7 +433,7 @@ def test_member_lists_of_a_mid_size_rebalance(ctx, n_topics, max_p, members):
                                                         (1000, 50, 5, False, "MAPPED"), (1000, 50, 5, True, "ZERO_COPY"),
                                                         (1000, 100, 8, True, "MAPPED")])
 def test_mid_size_calls_staged_or_read_in_place(ctx, topics, p, c, grouped, pipeline):
-    """Pageable arrays: every layout up to 6 MB is packed into the mapped staging buffer and read there (zero-copy).
+    """Pageable arrays: every layout up to 12 MB is packed into the mapped staging buffer and read there (zero-copy).
     la_host_alloc arrays (what the Java host's direct buffers are): from 1.25 MB on (3 MB with the lists aboard) nothing is packed,
     the kernels read the caller's arrays.  Either way the result is the oracle's."""
     w = synth.make_uniform("mid", topics + c, topics, p, c, "uniform40")
@@ -462,8 +462,9 @@ def test_mid_size_calls_staged_or_read_in_place(ctx, topics, p, c, grouped, pipe
 
 
 def test_a_staged_call_at_the_limit_and_just_beyond(ctx):
-    """165 000 / 180 000 partitions (5.8 / 6.3 MB of layout) on either side of the 6 MB limit: zero-copy, then the lanes."""
-    for topics, want in ((660, N.LA_PIPELINE_ZERO_COPY), (720, N.LA_PIPELINE_LANES)):
+    """335 000 / 365 000 partitions (11.8 / 12.8 MB of layout) on either side of the 12 MB limit: zero-copy (packed and unpacked
+    with the parked threads' help), then the lanes."""
+    for topics, want in ((1340, N.LA_PIPELINE_ZERO_COPY), (1460, N.LA_PIPELINE_LANES)):
         w = synth.make_uniform("edge", topics, topics, 250, 16, "zipf")
         got = ctx.assign_batch(w.part_off, w.partition_id, w.begin, w.end, w.committed, N.LA_RESET_EARLIEST, w.cons_off, w.cons_rank)
         assert ctx.last_pipeline() == want, (topics, ctx.last_pipeline())
