@@ -403,12 +403,14 @@ __global__ __launch_bounds__(kMidThreads) void group_mid_count_kernel(int n, int
     group_mid_chunk_ranks(nb, G, s_rank, nullptr, nullptr, counts, lane, wave);
     __syncthreads();
     for (uint32_t g = tid; g <= G; g += kMidThreads) cnt[(size_t)blockIdx.x * kMidGroupM + g] = counts[g];
+    if (blockIdx.x == 0 && tid == 0) cnt[(size_t)gridDim.x * kMidGroupM] = 0;      // the place kernel's "blocks done" counter
 }
 
 __global__ __launch_bounds__(kMidThreads) void group_mid_place_kernel(int n, int32_t n_members, int64_t n_topics, const int64_t* part_off,
                                                                       const int32_t* out_partition, const int32_t* member_rank,
-                                                                      const uint32_t* cnt, int64_t* member_off, int32_t* grouped_topic,
-                                                                      int32_t* grouped_partition, int32_t* grouped_entry) {
+                                                                      uint32_t* cnt, int64_t* member_off, int32_t* grouped_topic,
+                                                                      int32_t* grouped_partition, int32_t* grouped_entry,
+                                                                      const uint32_t* status, uint32_t* fin_flag) {
     __shared__ uint32_t cursor[kMidGroupM];           // this block's first place of every group, then its cursors
     __shared__ uint32_t counts[kMidGroupM];           // (scratch of the chunk ranks: the block's own counts again)
     __shared__ uint32_t wsum[kMidThreads / kWave];
@@ -543,6 +545,20 @@ __global__ __launch_bounds__(kMidThreads) void group_mid_place_kernel(int n, int
         grouped_partition[pos] = out_partition ? out_partition[e0 + i] : 0;
         if (grouped_topic) grouped_topic[pos] = s_topic[i];
         if (grouped_entry) grouped_entry[pos] = e0 + i;
+    }
+    if (fin_flag) {
+        // a zero-copy call ends here (as in tile_tail): every block releases what it wrote -- the lists sit in host memory -- and
+        // counts itself done; the last one stores `done | status` where the calling thread spins
+        __threadfence_system();
+        __syncthreads();
+        if (tid == 0) {
+            uint32_t* done = cnt + (size_t)gridDim.x * kMidGroupM;
+            if (__hip_atomic_fetch_add(done, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1) {
+                const uint32_t st = __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __threadfence_system();
+                __hip_atomic_store(fin_flag, 0x80000000u | st, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
     }
 }
 #endif  // LA_GROUP_MID_KERNELS

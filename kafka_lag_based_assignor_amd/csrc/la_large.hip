@@ -2754,11 +2754,12 @@ hipError_t group_by_member_launch(LargeScratch& scratch, int64_t n, int32_t n_me
         // a mid-size rebalance with few members: the stable counting sort over several workgroups, two launches
         // (la_group_small.h) instead of the radix form's five
         const int blocks = (int)((n + kMidBlock - 1) / kMidBlock);
-        if ((e = scratch_reserve(scratch, (size_t)blocks * kMidGroupM * sizeof(uint32_t), stream)) != hipSuccess) return e;
+        if ((e = scratch_reserve(scratch, ((size_t)blocks * kMidGroupM + 1) * sizeof(uint32_t), stream)) != hipSuccess) return e;
         uint32_t* cnt = (uint32_t*)scratch.buf;
         LA_LAUNCH(group_mid_count_kernel, dim3(blocks), dim3(kMidThreads), 0, stream, (int)n, n_members, member_rank, cnt);
         LA_LAUNCH(group_mid_place_kernel, dim3(blocks), dim3(kMidThreads), 0, stream, (int)n, n_members, n_topics, part_off, out_partition,
-                  member_rank, (const uint32_t*)cnt, member_off, grouped_topic, grouped_partition, grouped_entry);
+                  member_rank, cnt, member_off, grouped_topic, grouped_partition, grouped_entry, (const uint32_t*)status, fin_flag);
+        if (fin_done) *fin_done = fin_flag != nullptr;
         return hipGetLastError();
     }
     SortBufs b{};

@@ -24,7 +24,7 @@ def med(f, reps):
 
 def main():
     ctx = N.Context(0)
-    print("zero-copy threshold: LA_ZERO_COPY_BYTES=%s" % os.environ.get("LA_ZERO_COPY_BYTES", "default (128 KB)"))
+    print("zero-copy threshold: LA_ZERO_COPY_BYTES=%s" % os.environ.get("LA_ZERO_COPY_BYTES", "default (12 MB)"))
     rows = [(1, 3, 2), (10, 10, 3), (40, 50, 5), (100, 20, 4), (100, 100, 8), (1000, 16, 4), (1000, 50, 5), (1000, 256, 32), (10000, 64, 8)]
     if os.environ.get("LAT_ROWS"):                     # e.g. LAT_ROWS=100x100x8,1000x50x5
         rows = [tuple(int(v) for v in r.split("x")) for r in os.environ["LAT_ROWS"].split(",")]
