@@ -471,3 +471,26 @@ def test_a_staged_call_at_the_limit_and_just_beyond(ctx):
         assert ctx.last_pipeline() == want, (topics, ctx.last_pipeline())
         lag = oracle.compute_lags(w.begin, w.end, w.committed, False)
         _same3(got, oracle.assign_flat(w.part_off, w.partition_id, lag, w.cons_off, w.cons_rank), "oracle")
+
+
+# ---- under-filled tile launches run a wider shape; the narrow shapes at small sizes keep their tests -------------------------------
+def test_tile_tests_with_the_narrow_shapes_in_a_fresh_process():
+    """wave_tile_widen (la_wave_tile.hip) gives every topic of a small batch twice / four times the lanes: the whole suite's small tile
+    batches now run the wide shapes.  The narrowest shape of every (partitions, consumers) -- what large batches run, and everything
+    ran until round 5 -- is kept under test by running the tile tests once more with LA_NO_TILE_WIDEN=1."""
+    env = dict(os.environ, LA_NO_TILE_WIDEN="1")
+    out = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_parity.py"), "-q", "-m", "gpu", "-x",
+                          "-k", "tile or target_shape or ragged or grouped", "-p", "no:cacheprovider"],
+                         env=env, capture_output=True, text=True, timeout=1200, cwd=ROOT)
+    assert out.returncode == 0, (out.stdout[-2000:], out.stderr[-1000:])
+
+
+def test_widened_and_narrow_tile_shapes_agree(ctx):
+    """The same small batches through the default (widened) pick and the oracle; shapes chosen so that the pick widens by 2x and 4x and
+    not at all (64 consumers; one record per lane)."""
+    import test_round4_gpu as t4
+    for (t, p, c) in [(1000, 256, 32), (300, 64, 8), (50, 1000, 9), (2000, 100, 5), (7, 1024, 64), (400, 8, 8), (3000, 30, 3)]:
+        w = synth.make_uniform("widen", t + p, t, p, c, "zipf")
+        lag = oracle.compute_lags(w.begin, w.end, w.committed, False)
+        exp = oracle.assign_flat(w.part_off, w.partition_id, lag, w.cons_off, w.cons_rank)
+        _same3(t4._device_call(ctx, w), exp, "%d x %d x %d" % (t, p, c))
