@@ -31,29 +31,27 @@ void wave_tile_pick(int64_t max_p, int64_t max_c, int* L, int* E) {
 }
 
 // A launch that leaves most of the chip idle is a matter of one wavefront's latency, not of throughput: the chain a wavefront
-// runs is E x steps(L x E) slots of the partitions' sort network plus rounds x steps(L) of the bins' (steps(n) = the bitonic
-// network's log2 n (log2 n + 1) / 2), so with wavefronts to spare a topic gets twice the lanes and half the records per lane
-// as long as that chain gets shorter and the launch stays within two wavefronts per SIMD (2 048 on this chip).  BASELINE config
-// 3 (1 000 x 256 x 32) runs as 64 lanes x 4 records instead of 32 x 8: 0.0139 -> 0.0111 ms; 4 000 x 100 x 5: 0.0164 -> 0.0097 ms;
-// a 2 000-partition rebalance at the C ABI 40 -> 36 us.  Limit 1 024 / 2 048 / 4 096 / 8 192 wavefronts: 2 048 takes most of
-// the gain, 8 192 loses on 8 000 x 256 x 32 and 12 000 x 64 x 8 (profiles/r05_w_tile_widen.txt).  Same results for any valid
-// shape (the tests run them all; the narrow shapes at small sizes in a process with LA_NO_TILE_WIDEN=1, which keeps round 4's pick).
+// runs is E x steps(L x E) slots of the partitions' sort network (steps(n) = the bitonic network's log2 n (log2 n + 1) / 2)
+// plus the greedy rounds, whose network is as wide as the consumers need whatever L is (greedy_rounds_tile<L, LB>).  So with
+// wavefronts to spare a topic gets twice the lanes and half the records per lane, again and again, as long as the launch stays
+// within two wavefronts per SIMD (2 048 on this chip).  BASELINE config 3 (1 000 x 256 x 32) runs as 64 lanes x 4 records
+// instead of 32 x 8: 0.0139 -> 0.0111 ms; 4 000 x 100 x 5: 0.0164 -> 0.0097 ms; 2 000 x 128 x 4: 0.0136 -> 0.0096 ms; a
+// 2 000-partition rebalance at the C ABI 40 -> 36 us.  Limit 1 024 / 2 048 / 4 096 / 8 192 wavefronts: 2 048 takes most of the
+// gain, 8 192 loses on 8 000 x 256 x 32 and 12 000 x 64 x 8; a cost model that charged the rounds steps(L) stopped too early
+// (2 000 x 128 x 4: 0.0111 ms).  profiles/r05_w_tile_widen.txt.  Same results for any valid shape (the tests run them all; the
+// narrow shapes at small sizes in a process with LA_NO_TILE_WIDEN=1, which keeps round 4's pick).  L x E does not change, so
+// wave_tile_always_packs (the packed format's capacity term) holds for the widened shape as well.
 constexpr int64_t kLatencyWaves = 2048;
 
-static void wave_tile_widen(int64_t n_topics, int64_t max_p, int64_t max_c, int* L, int* E) {
+static void wave_tile_widen(int64_t n_topics, int64_t max_p, int* L, int* E) {
     static const bool off = getenv("LA_NO_TILE_WIDEN") != nullptr;
     if (off) return;
     static const int64_t max_waves = [] { const char* e = getenv("LA_TILE_WIDEN_WAVES"); return e ? (int64_t)atoll(e) : kLatencyWaves; }();  // (lab)
-    auto steps = [](int n) { int k = 0; while ((1 << k) < n) ++k; return k * (k + 1) / 2; };
-    const int64_t c = max_c > 1 ? max_c : 1;
-    const double rounds = (double)((max_p + c - 1) / c);
-    auto cost = [&](int l, int e) { return (double)e * steps(l * e) + rounds * steps(l); };
-    for (;;) {
+    while (*L < 64 && *E >= 2) {
         const int l2 = *L * 2;
-        if (l2 > 64 || *E < 2) break;
+        const int64_t per_wave = 64 / l2;
+        if ((n_topics + per_wave - 1) / per_wave > max_waves) break;
         const int e2 = pow2ceil((max_p + l2 - 1) / l2);
-        const int64_t per_wave = 64 / l2, waves2 = (n_topics + per_wave - 1) / per_wave;
-        if (waves2 > max_waves || cost(l2, e2) >= cost(*L, *E)) break;
         *L = l2;
         *E = e2 < 1 ? 1 : e2;
     }
@@ -81,7 +79,7 @@ hipError_t wave_tile_launch(TileArgs a, int64_t max_p, int64_t max_c, int mode, 
     if (a.n_total <= 0) return hipSuccess;
     if (max_p > a.n_total) max_p = a.n_total;      // no topic holds more than the batch (E >= 2 needs 2 elements)
     wave_tile_pick(max_p, max_c, &L, &E);
-    wave_tile_widen(a.n_topics, max_p, max_c, &L, &E);
+    wave_tile_widen(a.n_topics, max_p, &L, &E);
     switch (L) {
         case 8: return wave_tile_launch_l8(E, a, mode, stream, tail_done);
         case 16: return wave_tile_launch_l16(E, a, mode, stream, tail_done);
