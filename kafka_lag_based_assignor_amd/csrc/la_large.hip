@@ -145,6 +145,21 @@ __device__ __forceinline__ uint32_t digit_of(int pass, uint64_t key, uint32_t va
     return pass < 4 ? (val >> (8 * pass)) & 0xFFu : (uint32_t)(key >> (8 * (pass - 4))) & 0xFFu;
 }
 
+// grid of build_keys_kernel.  Every block ends by adding its non-zero digit counters (up to 12 x 256) to the global histograms with
+// atomics, so beyond 512 blocks a block takes 2 048 partitions instead of 256 (grid stride), up to 1 024 blocks (2 048 from 16 M
+// partitions on, where the flush is noise and the loads want every CU several times over).  1 M partitions (cfg5): 0.057 ->
+// 0.040 ms; 4 M: 0.079 -> 0.074 ms (profiles/r05_aa_keys_grid.txt).
+static int keys_grid(int64_t n) {
+    static const int forced = [] { const char* e = getenv("LA_KEYS_GRID"); return e ? atoi(e) : 0; }();   // (lab)
+    const int64_t fine = (n + 255) / 256;
+    if (forced > 0) return (int)(fine > forced ? forced : fine);
+    if (fine <= 512) return (int)fine;
+    const int64_t cap = n >= ((int64_t)16 << 20) ? 2048 : 1024;
+    const int64_t coarse = (n + 2047) / 2048;
+    const int64_t g = coarse > cap ? cap : coarse;
+    return (int)(g < 512 ? 512 : g);
+}
+
 // ---- kernel 1: keys + all digit histograms ---------------------------------------------------
 __global__ __launch_bounds__(256) void build_keys_kernel(LargeArgs a0, SortBufs b0, const LargeItem* items, char* scratch) {
     LA_PICK_ITEM(a, b, a0, b0, items, scratch, blockIdx.y)
@@ -2438,7 +2453,7 @@ hipError_t large_topic_launch(LargeScratch& scratch, const LargeArgs& a, bool ar
         LargeProfile& pf; bool on; hipStream_t st;
         ~Done() { if (on) (void)hipEventRecord(pf.ev[3], st); }
     } done{pf, profile, stream};
-    LA_LAUNCH(build_keys_kernel, dim3(grid), dim3(256), 0, stream, a, b, (const LargeItem*)nullptr, (char*)nullptr);
+    LA_LAUNCH(build_keys_kernel, dim3(keys_grid(n)), dim3(256), 0, stream, a, b, (const LargeItem*)nullptr, (char*)nullptr);
     if (b.samp) LA_LAUNCH(sample_scan_kernel, dim3(256), dim3(256), 0, stream, b, (const LargeItem*)nullptr, (char*)nullptr);
     sort_run_passes(b, stream, a.status, profile ? pf.ev[1] : nullptr);
     if (b.samp) {
@@ -2568,8 +2583,7 @@ hipError_t large_topics_launch(LargeScratch& scratch, const LargeArgs* args, int
         pf.recorded = true;
         (void)hipEventRecord(pf.ev[0], stream);
     }
-    int gx = (int)((max_n + 255) / 256);
-    if (gx > 2048) gx = 2048;
+    const int gx = keys_grid(max_n);
     // a0: the batch's arrays and flags, shared by every item (an item overrides the four segment fields); b0: what is common
     // to a launch's items besides their buffers
     LargeArgs a0 = args[0];
@@ -2678,8 +2692,7 @@ hipError_t huge_topic_launch(LargeScratch& scratch, const LargeArgs& a, hipStrea
     SortBufs bins[2] = {sort_bind(lc, base + lp.zero_bytes, base + zero + lp.data_bytes),
                         sort_bind(lc, base + lp.zero_bytes + lc.zero_bytes, base + zero + lp.data_bytes + lc.data_bytes)};
     if ((e = hipMemsetAsync(base, 0, lp.zero_bytes, stream)) != hipSuccess) return e;
-    int grid = (int)((P + 255) / 256);
-    if (grid > 2048) grid = 2048;
+    const int grid = keys_grid(P);
     LA_LAUNCH(build_keys_kernel, dim3(grid), dim3(256), 0, stream, a, bp, (const LargeItem*)nullptr, (char*)nullptr);
     if (bp.samp) LA_LAUNCH(sample_scan_kernel, dim3(256), dim3(256), 0, stream, bp, (const LargeItem*)nullptr, (char*)nullptr);
     sort_run_passes(bp, stream, a.status);
