@@ -256,7 +256,7 @@ public class GpuLagBasedPartitionAssignor implements ConsumerPartitionAssignor, 
             lists = engine.memberLists(plan, n);
         } else {
             // normally the ungrouped result never leaves the device, and assignment + every member's list are ONE native
-            // call: for a rebalance of ordinary size one upload, one download, one wait (la_assign_batch_grouped_sparse)
+            // call: for a rebalance of ordinary size no copy at all and ONE kernel launch (la_assign_batch_grouped_sparse)
             final int nMembers = plan.byRank.length;
             engine.memberOff.ensure(engine, 8L * (nMembers + 1));
             engine.check(LagAssignNative.assignBatchGroupedSparse(engine.ctx, nTopics, engine.partOff.bytes,
