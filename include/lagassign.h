@@ -430,7 +430,7 @@ int la_group_last_by_member(la_ctx *ctx, int32_t n_members,
 /* Both steps in one call -- what the reference's assign(Cluster, GroupSubscription) does between reading the offsets
  * and wrapping the lists (Main.java:147-156): la_assign_batch with the ungrouped result left on the device, then
  * la_group_last_by_member.  For the call a real rebalance is (its arrays fit the library's staging buffer: 12 MB) the lists
- * are built behind the assignment kernels on the same stream -- up to 2 560 entries inside the assignment kernel itself -- and
+ * are built behind the assignment kernels on the same stream -- up to 1 024 entries inside the assignment kernel itself -- and
  * land in that buffer with the status and the totals: no copy, one wait.  Larger batches run the two steps one after the other.  The results stay
  * on the device as after la_assign_batch (la_group_last_by_member may be called again).  grouped_topic and out_total_lag
  * may be NULL. */

@@ -1403,10 +1403,19 @@ int assign_small_zc(la_ctx* ctx, const HostCall& c, Shard& sh, const SmallLayout
     b.d_out_total_lag = c.out_total ? (int64_t*)(m + L.ot) : nullptr;
     b.h_part_off = c.part_off;
     b.h_cons_off = c.cons_off;
-    // ONE launch for the whole rebalance where the batch is one resident tile launch: its last workgroup builds the lists (up
-    // to kSmallGroupN entries) and stores the completion word -- otherwise the grouping / finishing launches below
-    const bool one_wg_lists = !grouped || (c.shape.n <= la::kSmallGroupN && (int64_t)c.g_members + 2 <= la::kTailGroupM);
-    static const bool no_tail = getenv("LA_NO_FUSED_TAIL") != nullptr;                 // (A/B hook)
+    // ONE launch for the whole rebalance where the batch is one resident tile launch: its last workgroup builds the lists and
+    // stores the completion word -- otherwise the grouping / finishing launches below.  Where that pays was measured at the C
+    // ABI (profiles/r05_ae_fused_tail.txt): with lists, 100 / 500 partitions 22-24 / 25 us fused against 25 / 26.5 us with the
+    // one-workgroup grouping as its own launch, but 2 000 partitions 37-38 against 34 -- the tail is 256 threads of the tile
+    // kernel, the grouping kernel 1 024, and every workgroup of a fused launch pays a system-scope fence -- so the lists are fused
+    // up to kTailMaxEntries entries; a call WITHOUT lists is faster with the plain finishing launch at every size (100
+    // partitions 16.6 against 18.6 us, 10 000: 31 against 38) and never takes the tail.  LA_FUSED_TAIL=all restores round
+    // 5's first form (every staged call that can), LA_NO_FUSED_TAIL=1 never fuses.
+    static const bool no_tail = getenv("LA_NO_FUSED_TAIL") != nullptr;                 // (A/B hooks)
+    static const bool tail_all = [] { const char* e = getenv("LA_FUSED_TAIL"); return e && !strcmp(e, "all"); }();
+    const bool one_wg_lists = grouped ? (c.shape.n <= (tail_all ? la::kSmallGroupN : la::kTailMaxEntries) &&
+                                         (int64_t)c.g_members + 2 <= la::kTailGroupM)
+                                      : tail_all;
     ln.tail_done = false;
     ln.tail_wanted = one_wg_lists && !no_tail && k <= kSmallHostCheck;
     if (ln.tail_wanted) {

@@ -48,6 +48,7 @@ constexpr int kSmallGroupN = 2560;       // entries.  Measured on one box, devic
                                          // the five launches win
 constexpr int kSmallGroupM = 8192;       // groups (members + 2) of the 1 024-thread kernel
 constexpr int kSmallGroupBits = 13;      // bits of a group id
+constexpr int kTailMaxEntries = 1024;    // entries up to which a zero-copy call fuses its lists into the tile kernel (la_api.hip, assign_small_zc)
 constexpr int kTailGroupM = 2048;        // groups (members + 2) the tile kernel's tail holds (8 KB of LDS beside the tiles' slices)
 
 // A TURN is kSub consecutive chunks of one wavefront: their ranks are found first, side by side; inside the turn the wavefront's
