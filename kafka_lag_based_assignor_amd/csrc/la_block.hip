@@ -835,20 +835,46 @@ __global__ __launch_bounds__(1024) void block_topic_kernel(BlockArgs a) {
 #pragma unroll
             for (int r = 0; r < E; ++r) lag[r] = valid[r] ? lv[r] : 0;
         } else {
-            int64_t cm[E], en[E], bg[E];
+            // computePartitionLag (Main.java:376-404; la_device.h partition_lag) in two stages, so that the committed and end
+            // offsets are dead before the begin offsets arrive: sixteen records x three 64-bit arrays held at once were 96
+            // registers of the 128 a 1 024-thread workgroup gets (E = 16: 30 spilled registers -> 12; cfg2b 0.0885 -> 0.0879 ms.
+            // The offsets form still runs ~6 us behind the lags form, profiles/r05_ag_block_kernel_durations.txt: three arrays'
+            // loads and a dependent second stage against one array's).
+            //   committed >= 0:            lag = max(end - committed, 0)          (done after stage 1)
+            //   none, reset latest:        lag = max(end - end, 0) = 0            (done after stage 1)
+            //   none, reset earliest:      lag = max(end - begin, 0)              (lag[r] holds `end` until stage 2)
+            uint32_t need = 0;                                          // bit r: record r waits for its begin offset
+            {
+                int64_t cm[E], en[E];
 #pragma unroll
-            for (int r = 0; r < E; ++r) cm[r] = a.committed[p0 + g[r]];
+                for (int r = 0; r < E; ++r) cm[r] = a.committed[p0 + g[r]];
 #pragma unroll
-            for (int r = 0; r < E; ++r) en[r] = a.end[p0 + g[r]];
-            if (!latest && a.begin) {
+                for (int r = 0; r < E; ++r) en[r] = a.end[p0 + g[r]];
 #pragma unroll
-                for (int r = 0; r < E; ++r) bg[r] = a.begin[p0 + ((valid[r] && cm[r] < 0) ? g[r] : 0)];
-            } else {
+                for (int r = 0; r < E; ++r) {
+                    const bool none = cm[r] < 0;
+                    const int64_t d = (int64_t)((uint64_t)en[r] - (uint64_t)cm[r]);
+                    lag[r] = none ? (latest ? 0 : en[r]) : (d > 0 ? d : 0);
+                    if (none && !latest && valid[r]) need |= 1u << r;
+                }
+            }
+            if (!latest) {
+                int64_t bg[E];
+                if (a.begin) {
 #pragma unroll
-                for (int r = 0; r < E; ++r) bg[r] = 0;
+                    for (int r = 0; r < E; ++r) bg[r] = a.begin[p0 + (((need >> r) & 1u) ? g[r] : 0)];
+                } else {
+#pragma unroll
+                    for (int r = 0; r < E; ++r) bg[r] = 0;
+                }
+#pragma unroll
+                for (int r = 0; r < E; ++r) {
+                    const int64_t d = (int64_t)((uint64_t)lag[r] - (uint64_t)bg[r]);      // (lag[r] is `end` here)
+                    if ((need >> r) & 1u) lag[r] = d > 0 ? d : 0;
+                }
             }
 #pragma unroll
-            for (int r = 0; r < E; ++r) lag[r] = valid[r] ? partition_lag(bg[r], en[r], cm[r], latest) : 0;
+            for (int r = 0; r < E; ++r) lag[r] = valid[r] ? lag[r] : 0;
         }
 #pragma unroll
         for (int r = 0; r < E; ++r) {
