@@ -510,3 +510,15 @@ def test_offset_bounds_is_what_a_marshaller_may_promise():
     assert N.offset_bounds(None, end, end, np.array([0, -1, 1], np.int32)) is None                                   # a negative id
     assert N.offset_bounds(None, None, None, np.array([3, 1], np.int32), lag=np.array([9, 4], np.int64)) == (9, 3)
     assert N.offset_bounds(None, None, None, np.array([3, 1], np.int32), lag=np.array([9, -4], np.int64)) is None
+
+
+def test_tools_and_bench_scripts_compile():
+    """The probes, sessions' helpers and bench.py only ever run on the GPU box: a syntax error in one of them would surface there,
+    minutes into a session.  Byte-compile them all here."""
+    import glob
+    import py_compile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    files = sorted(glob.glob(os.path.join(root, "tools", "*.py"))) + [os.path.join(root, "bench.py"), os.path.join(root, "__graft_entry__.py")]
+    assert len(files) > 10
+    for f in files:
+        py_compile.compile(f, doraise=True, cfile=os.devnull)
