@@ -241,6 +241,18 @@ _p64 = _addr       # (dtype and contiguity are the business of _a64 / _a32 befor
 _p32 = _addr
 
 
+def _check_out3(out, n: int, k: int):
+    """Caller-owned result buffers (out_partition int32[N], out_member_rank int32[N], totals int64[K] or None): the library writes
+    N / K contiguous elements at each address, so anything else -- a strided view above all -- is refused here."""
+    out_p, out_m, out_t = out
+    ok = (isinstance(out_p, np.ndarray) and isinstance(out_m, np.ndarray) and out_p.dtype == np.int32 and out_m.dtype == np.int32 and
+          out_p.size == n and out_m.size == n and out_p.flags.c_contiguous and out_m.flags.c_contiguous and
+          (out_t is None or (isinstance(out_t, np.ndarray) and out_t.dtype == np.int64 and out_t.size == k and out_t.flags.c_contiguous)))
+    if not ok:
+        raise ValueError("out buffers must be contiguous int32[N], int32[N], int64[K]")
+    return out_p, out_m, out_t
+
+
 def plan_shards(part_off, n_shards: int) -> np.ndarray:
     """la_plan_shards: the library's own planner (pure host code, no device needed).  Returns int32
     bounds[n_shards + 1]: shard r owns topics [bounds[r], bounds[r+1])."""
@@ -410,12 +422,7 @@ class Context:
             out_p = out_m = None
             out_t = np.zeros(cons_rank.size, dtype=np.int64) if want_totals else None
         elif out is not None:
-            out_p, out_m, out_t = out
-            if (out_p.dtype != np.int32 or out_m.dtype != np.int32 or out_p.size != partition_id.size or
-                    out_m.size != partition_id.size or not out_p.flags.c_contiguous or not out_m.flags.c_contiguous or
-                    (out_t is not None and (out_t.dtype != np.int64 or out_t.size != cons_rank.size or
-                                            not out_t.flags.c_contiguous))):
-                raise ValueError("out buffers must be contiguous int32[N], int32[N], int64[K]")
+            out_p, out_m, out_t = _check_out3(out, partition_id.size, cons_rank.size)
         else:
             out_p = np.empty(partition_id.size, dtype=np.int32)
             out_m = np.empty(partition_id.size, dtype=np.int32)
@@ -439,7 +446,7 @@ class Context:
             out_p = out_m = None
             out_t = np.zeros(cons_rank.size, dtype=np.int64) if want_totals else None
         elif out is not None:
-            out_p, out_m, out_t = out
+            out_p, out_m, out_t = _check_out3(out, partition_id.size, cons_rank.size)
         else:
             out_p = np.empty(partition_id.size, dtype=np.int32)
             out_m = np.empty(partition_id.size, dtype=np.int32)
@@ -478,10 +485,7 @@ class Context:
         part_off, cons_off = _a64(part_off), _a64(cons_off)
         partition_id, cons_rank, lag = _a32(partition_id), _a32(cons_rank), _a64(lag)
         if out is not None and not keep_on_device:
-            out_p, out_m, out_t = out
-            if out_p.size != partition_id.size or out_m.size != partition_id.size or out_p.dtype != np.int32 or \
-                    out_m.dtype != np.int32 or (out_t is not None and (out_t.size != cons_rank.size or out_t.dtype != np.int64)):
-                raise ValueError("out buffers must be int32[N], int32[N], int64[K]")
+            out_p, out_m, out_t = _check_out3(out, partition_id.size, cons_rank.size)
         else:
             out_p = None if keep_on_device else np.empty(partition_id.size, dtype=np.int32)
             out_m = None if keep_on_device else np.empty(partition_id.size, dtype=np.int32)

@@ -522,3 +522,24 @@ def test_tools_and_bench_scripts_compile():
     for f in files:
         with open(f, "rb") as src:
             compile(src.read(), f, "exec")                         # (raises SyntaxError; nothing is written)
+
+
+def test_binding_refuses_result_buffers_the_library_cannot_fill():
+    """_native._check_out3: caller-owned result buffers must be contiguous arrays of the right type and size (the library writes N / K
+    elements at one address each); arrays over foreign memory, as host_alloc builds them, are fine."""
+    import numpy as np
+    n, k = 12, 5
+    p, m, t = np.empty(n, np.int32), np.empty(n, np.int32), np.empty(k, np.int64)
+    assert _native._check_out3((p, m, t), n, k) == (p, m, t)
+    assert _native._check_out3((p, m, None), n, k)[2] is None
+    buf = (ctypes.c_char * (4 * n)).from_address(ctypes.addressof(ctypes.create_string_buffer(4 * n)))
+    foreign = np.frombuffer(buf, dtype=np.int32, count=n)
+    assert _native._check_out3((foreign, m, t), n, k)[0] is foreign
+    assert _native._addr(foreign) == foreign.ctypes.data and _native._addr(p) == p.ctypes.data
+    ro = np.zeros(3, np.int64)
+    ro.flags.writeable = False
+    assert _native._addr(ro) == ro.ctypes.data and _native._addr(np.empty(0, np.int32)) is not None and _native._addr(None) is None
+    for bad in ((np.empty(2 * n, np.int32)[::2], m, t), (p.astype(np.int64), m, t), (p, m[:-1], t), (p, m, t.astype(np.int32)),
+                (p, m, np.empty(k + 1, np.int64)), (list(p), m, t)):
+        with pytest.raises(ValueError):
+            _native._check_out3(bad, n, k)
