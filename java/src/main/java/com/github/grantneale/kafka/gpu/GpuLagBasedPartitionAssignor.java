@@ -682,6 +682,9 @@ public class GpuLagBasedPartitionAssignor implements ConsumerPartitionAssignor, 
     private ConsumerPartitionAssignor fallback() {
         if (fallback == null) {
             String cls = groupProps == null ? null : groupProps.getProperty(FALLBACK_CLASS_CONFIG);
+            if (cls != null && cls.trim().equalsIgnoreCase("none")) {
+                return null;            // explicit opt-out: a native failure propagates out of assign() (ADVICE r5)
+            }
             if (cls == null || cls.trim().isEmpty()) {
                 // A drop-in must not break a rebalance on a GPU fault (SURVEY 8b, "errors"): with no class configured, the
                 // reference itself takes over when it is on the class path -- found by name, nothing of it is linked here.

@@ -10,7 +10,12 @@
 // 0.75), hash spread h ^ (h >>> 16), order-preserving lo/hi split on resize, put() appends at
 // a bin's tail and resizes after insertion, computeIfAbsent() resizes before insertion and
 // links the new node at the bin's HEAD.  Tree bins (>= 9 keys in one bucket of a >= 64 slot
-// table) are not modelled: order_exact() turns false and callers may report it.
+// table) ARE modelled since round 5 -- treeifyBin / putTreeVal / moveRootToFront / split with
+// untreeify and re-treeify, restated from the published OpenJDK 8 algorithm -- and agree with the
+// independent restatement in oracle/java_collections.py, but no JVM has confirmed either (there is
+// none in the image): order_exact() now means "no tree bin occurred"; it turns false the moment a
+// bucket treeifies, i.e. "the order below is this model's, unverified against a JVM", and callers
+// may report that.
 #pragma once
 #include <cstdint>
 #include <string>

@@ -118,6 +118,18 @@ struct Shard {
     std::vector<hipEvent_t> chunk_ev;    // two per chunk: inputs landed, results ready
 };
 
+// one polite spin step of a host thread: the x86 pause where there is one, the architecture's yield elsewhere (the host side
+// of the library builds on aarch64 / ppc64 hosts too)
+static inline void cpu_relax() {
+#if defined(__x86_64__) || defined(__i386__)
+    __builtin_ia32_pause();
+#elif defined(__aarch64__) || defined(__arm__)
+    __asm__ __volatile__("yield" ::: "memory");
+#else
+    std::this_thread::yield();
+#endif
+}
+
 // The host threads of the host-buffer calls, PARKED between calls.  The copies of a pageable caller array block the thread that
 // issues them, which is why a shard's lanes are threads; spawning and joining them on every call cost ~50 us per thread
 // (VERDICT r4 weak #5).  The pool belongs to the context (created with its first multi-lane call, joined by la_destroy); a call
@@ -139,7 +151,7 @@ struct WorkerPool {
         uint64_t seen = 0;
         for (;;) {
             // a short spin first: jobs of one call follow each other within microseconds
-            for (int spin = 0; spin < 2000 && gen.load(std::memory_order_acquire) == seen; ++spin) __builtin_ia32_pause();
+            for (int spin = 0; spin < 2000 && gen.load(std::memory_order_acquire) == seen; ++spin) cpu_relax();
             const std::function<void(int)>* my_job = nullptr;
             int my_n = 0;
             {
@@ -1626,6 +1638,18 @@ int assign_small(la_ctx* ctx, const HostCall& c, Shard& sh, const SmallLayout& L
     return LA_OK;
 }
 
+// la_hint_next_call is one-shot: "forgotten when the next host-buffer assign call returns, whatever it returns".  assign_host
+// takes the hints when it starts; every host-buffer entry point also holds one of these, so that a call that returns BEFORE
+// it gets there (a NULL result array, n_topics <= 0, a NULL lag array) spends them too and a stale bound cannot fail the
+// next, unrelated call.
+struct HintSpender {
+    la_ctx* ctx;
+    explicit HintSpender(la_ctx* c) : ctx(c) {}
+    ~HintSpender() { if (ctx) ctx->hints_set = false; }
+    HintSpender(const HintSpender&) = delete;
+    HintSpender& operator=(const HintSpender&) = delete;
+};
+
 int assign_host(la_ctx* ctx, int32_t T, const int64_t* part_off, const int32_t* pid, const int64_t* begin,
                 const int64_t* end, const int64_t* committed, const int64_t* lag, int32_t reset_mode,
                 const int64_t* cons_off, const int32_t* cons_rank, int32_t* out_pid, int32_t* out_rank,
@@ -2220,6 +2244,7 @@ LA_API int la_assign_batch(la_ctx* ctx, int32_t n_topics, const int64_t* part_of
                            int32_t* out_partition, int32_t* out_member_rank, int64_t* out_total_lag) {
     DeviceGuard restore_device;
     LaunchSpan span(ctx);
+    HintSpender spend_hints(ctx);
     try {
         return assign_host(ctx, n_topics, part_off, partition_id, begin_off, end_off, committed_off, nullptr,
                            reset_mode, cons_off, cons_rank, out_partition, out_member_rank, out_total_lag);
@@ -2233,6 +2258,7 @@ LA_API int la_assign_batch_lags(la_ctx* ctx, int32_t n_topics, const int64_t* pa
                                 int32_t* out_partition, int32_t* out_member_rank, int64_t* out_total_lag) {
     DeviceGuard restore_device;
     LaunchSpan span(ctx);
+    HintSpender spend_hints(ctx);
     try {
         if (ctx && !lag && n_topics > 0 && part_off && part_off[n_topics] > 0)
             return fail(ctx, LA_EINVAL, "lag is NULL");
@@ -2551,6 +2577,7 @@ LA_API int la_assign_batch_grouped(la_ctx* ctx, int32_t n_topics, const int64_t*
                                    int64_t* out_total_lag) {
     DeviceGuard restore_device;
     LaunchSpan span(ctx);
+    HintSpender spend_hints(ctx);
     if (!ctx) return LA_EINVAL;
     try {
         return assign_grouped(ctx, n_topics, part_off, partition_id, begin_off, end_off, committed_off, reset_mode, cons_off,
@@ -2567,6 +2594,7 @@ LA_API int la_assign_batch_sparse(la_ctx* ctx, int32_t n_topics, const int64_t* 
                                   int64_t* out_total_lag) {
     DeviceGuard restore_device;
     LaunchSpan span(ctx);
+    HintSpender spend_hints(ctx);
     try {
         HostCall sp;
         sp.n_none = n_none; sp.none_index = none_index; sp.none_begin = none_begin;
@@ -2585,6 +2613,7 @@ LA_API int la_assign_batch_grouped_sparse(la_ctx* ctx, int32_t n_topics, const i
                                           int64_t* out_total_lag) {
     DeviceGuard restore_device;
     LaunchSpan span(ctx);
+    HintSpender spend_hints(ctx);
     if (!ctx) return LA_EINVAL;
     try {
         HostCall sp;

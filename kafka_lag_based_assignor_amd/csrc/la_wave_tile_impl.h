@@ -194,12 +194,17 @@ __device__ __forceinline__ void issue_begin_loads(const TileArgs& a, const D& d,
         // cache line per wavefront instead of a second pass over their own lines through L2) and keep their value
         using G = decltype(g);
         const bool nx = raw.cm[k].x < 0;
-        const int64_t vx = a.begin[nx ? g : (G)0];
-        raw.cm[k].x = nx ? vx : raw.cm[k].x;
         if constexpr (E >= 2) {
+            // the pair's two begin offsets in ONE 16-byte load (the form of stage 1) when either is needed: a group
+            // that has no committed offsets at all -- a new consumer group, Main.java:393-396 -- then streams `begin`
+            // exactly as it streams `end` and `committed` (two 8-byte loads per pair until round 6)
             const bool ny = raw.cm[k].y < 0;
-            const int64_t vy = a.begin[ny ? (G)(g + 1) : (G)0];
-            raw.cm[k].y = ny ? vy : raw.cm[k].y;
+            const I64x2 bv = load_at<I64x2>(a.begin, (nx | ny) ? g : (G)0);
+            raw.cm[k].x = nx ? bv.x : raw.cm[k].x;
+            raw.cm[k].y = ny ? bv.y : raw.cm[k].y;
+        } else {
+            const int64_t vx = a.begin[nx ? g : (G)0];
+            raw.cm[k].x = nx ? vx : raw.cm[k].x;
         }
     }
 }

@@ -74,8 +74,12 @@ def _draw_lags(dist: str, seed: int, t: int, p: int) -> np.ndarray:
 
 
 def make_uniform(name: str, config_id: int, n_topics: int, partitions: int, consumers: int, dist: str,
-                 offsets: bool = True) -> Workload:
-    """T topics, each with `partitions` partitions and `consumers` consumers."""
+                 offsets: bool = True, none_frac: Optional[float] = None) -> Workload:
+    """T topics, each with `partitions` partitions and `consumers` consumers.  `none_frac`: the share of partitions
+    without a committed offset (default: the fixed ~1 % of SURVEY 8d; 1.0 = a brand-new consumer group, where
+    computePartitionLag falls back for EVERY partition, Main.java:393-396).  With a fall-back to `earliest` such a
+    partition's lag is end - begin, so `begin` is drawn too (uniform on [0, 2^20), end = begin + lag): the whole
+    36 B/partition of SURVEY 8d then really moves and the lags stay the drawn ones."""
     seed = 0x9E3779B97F4A7C15 ^ config_id
     t, p, c = n_topics, partitions, consumers
     n = t * p
@@ -85,9 +89,14 @@ def make_uniform(name: str, config_id: int, n_topics: int, partitions: int, cons
         r = splitmix64(seed, n, 3)
         com = (r >> np.uint64(44)).astype(np.int64)                    # [0, 2^20)
         end = com + lag                                                # wraps only for uniform63
-        none = (r & np.uint64(0xFFFF)) < np.uint64(655)                # ~1 %
+        if none_frac is None:
+            none = (r & np.uint64(0xFFFF)) < np.uint64(655)            # ~1 %
+            begin = np.zeros(n, dtype=np.int64)
+        else:
+            none = (r & np.uint64(0xFFFF)) < np.uint64(int(round(min(max(none_frac, 0.0), 1.0) * 65536)))
+            # where there is no committed offset the drawn lag is end - begin: begin = what committed would have been
+            begin = np.where(none, com, np.int64(0))
         com = np.where(none, np.int64(-1), com)
-        begin = np.zeros(n, dtype=np.int64)
     else:
         com = np.zeros(n, dtype=np.int64)
         end = lag.copy()
@@ -103,9 +112,13 @@ def make_uniform(name: str, config_id: int, n_topics: int, partitions: int, cons
 
 # The BASELINE.json configs.  `scale` shrinks the topic count
 # (or, for single-topic configs, the partition count) for CPU-sized parity runs.
-def config(name: str, scale: float = 1.0) -> Workload:
+def config(name: str, scale: float = 1.0, none_frac: Optional[float] = None) -> Workload:
     def s(x: int) -> int:
         return max(1, int(round(x * scale)))
+    if none_frac is not None:
+        shape = {"cfg3": (3, 1000, 256, 32, "zipf"), "cfg4": (4, 100000, 64, 8, "uniform40"),
+                 "target": (6, 100000, 256, 32, "zipf")}[name]
+        return make_uniform(name, shape[0], s(shape[1]), shape[2], shape[3], shape[4], none_frac=none_frac)
     if name == "cfg1":      # README example, README.md:42-52
         w = make_uniform("cfg1", 1, 1, 3, 2, "zero", offsets=False)
         w.partition_id = np.array([0, 1, 2], dtype=np.int32)

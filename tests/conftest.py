@@ -43,3 +43,18 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if "gpu" in item.keywords:
             item.add_marker(skip)
+
+
+# ---- shared by the per-component GPU test files (a module that defines its own `ctx` keeps its own) ----------------
+@pytest.fixture(scope="module")
+def ctx():
+    from kafka_lag_based_assignor_amd import _native as N
+    c = N.Context(0)
+    yield c
+    c.close()
+
+
+@pytest.fixture(scope="module")
+def torch_dev():
+    import torch
+    return torch, torch.device("cuda", 0)

@@ -1,4 +1,4 @@
-"""Round-5 additions, through the C ABI, bit-exact against the oracle."""
+"""Host-buffer entry points (la_assign_batch*, la_hint_next_call, la_group_*: pipelines, hints, sparse begin, the one-launch small rebalance) through the C ABI, bit-exact against the oracle."""
 import os
 import subprocess
 import sys
@@ -9,70 +9,186 @@ import pytest
 from kafka_lag_based_assignor_amd import _native as N
 from kafka_lag_based_assignor_amd import synth
 from oracle import oracle
+from gpu_helpers import *  # noqa: F401,F403
 
 pytestmark = pytest.mark.gpu
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.fixture(scope="module")
-def ctx():
-    c = N.Context(0)
-    yield c
-    c.close()
+@pytest.mark.parametrize("frac_none", [0.0, 0.01, 0.3, 1.0])
+@pytest.mark.parametrize("kind", ["one_copy", "lanes", "streams", "mapped", "shards", "mapped_shards"])
+def test_sparse_begin_equals_the_dense_call(frac_none, kind):
+    big = kind != "one_copy"
+    w = _workload(int(frac_none * 100) + len(kind), frac_none, topics=400 if big else 60, big=big)
+    idx, val = N.sparse_begin(w.begin, w.committed)
+    assert idx.size == int((w.committed < 0).sum())
+    flags = {"one_copy": 0, "lanes": N.LA_CREATE_SPLIT_ALWAYS | 3, "streams": 0, "mapped": 0, "shards": N.LA_CREATE_SPLIT_ALWAYS,
+             "mapped_shards": N.LA_CREATE_SPLIT_ALWAYS}[kind]
+    dev = [0, 0, 0] if kind in ("shards", "mapped_shards") else 0
+    if kind == "one_copy":
+        os.environ["LA_ZERO_COPY_BYTES"] = "0"                  # (read at la_create; every staged call is zero-copy by default)
+    try:
+        c_made = N.Context(dev, flags=flags)
+    finally:
+        os.environ.pop("LA_ZERO_COPY_BYTES", None)
+    with c_made as c:
+        if kind == "streams":
+            os.environ["LA_CHUNK_PARTITIONS"] = "20000"
+            os.environ["LA_NO_MAPPED_PIPELINE"] = "1"
+        try:
+            exp = _expected(w, False)
+            args = (w.part_off, w.partition_id, w.end, w.committed, N.LA_RESET_EARLIEST)
+            if kind in ("streams", "mapped", "mapped_shards"):
+                # every array pinned: the thread-less three-stream pipeline, or -- the default -- the kernels on the arrays in place
+                with N.Context(dev, flags=flags) as cp:                           # (a context created under the chunk override)
+                    pin = lambda a: _pinned(cp, a)                                # noqa: E731
+                    out = (cp.host_alloc((w.n_partitions,), np.int32), cp.host_alloc((w.n_partitions,), np.int32),
+                           cp.host_alloc((w.cons_rank.size,), np.int64))
+                    got = cp.assign_batch_sparse(pin(w.part_off), pin(w.partition_id), pin(w.end), pin(w.committed),
+                                                 N.LA_RESET_EARLIEST, pin(idx), pin(val), pin(w.cons_off), pin(w.cons_rank), out=out)
+                    assert cp.last_pipeline() == (N.LA_PIPELINE_STREAMS if kind == "streams" else N.LA_PIPELINE_MAPPED)
+                    # the dense call on the same pinned arrays, and the results left on the device + grouped
+                    dense = cp.assign_batch(pin(w.part_off), pin(w.partition_id), pin(w.begin), pin(w.end), pin(w.committed),
+                                            N.LA_RESET_EARLIEST, pin(w.cons_off), pin(w.cons_rank), out=out)
+                    for g, e in zip(dense, exp):
+                        np.testing.assert_array_equal(g, e)
+                    n_members = int(w.cons_rank.max()) + 1 if w.cons_rank.size else 0
+                    cp.assign_batch_sparse(pin(w.part_off), pin(w.partition_id), pin(w.end), pin(w.committed), N.LA_RESET_EARLIEST,
+                                           pin(idx), pin(val), pin(w.cons_off), pin(w.cons_rank), keep_on_device=True)
+                    g_off, g_t, g_p = cp.group_last_by_member(w.n_partitions, n_members)
+                    order = np.argsort(exp[1], kind="stable")
+                    np.testing.assert_array_equal(g_p, exp[0][order])
+            else:
+                got = c.assign_batch_sparse(*args, idx, val, w.cons_off, w.cons_rank)
+                assert c.last_pipeline() == (N.LA_PIPELINE_ONE_COPY if kind == "one_copy" else N.LA_PIPELINE_LANES)
+            for g, e, what in zip(got, exp, ("order", "member", "totals")):
+                np.testing.assert_array_equal(g, e, err_msg=what)
+            # and the dense call on the same context agrees (same bits either way)
+            dense = c.assign_batch(w.part_off, w.partition_id, w.begin, w.end, w.committed, N.LA_RESET_EARLIEST, w.cons_off, w.cons_rank)
+            for g, e in zip(dense, exp):
+                np.testing.assert_array_equal(g, e)
+        finally:
+            os.environ.pop("LA_CHUNK_PARTITIONS", None)
+            os.environ.pop("LA_NO_MAPPED_PIPELINE", None)
 
 
-def _same3(got, exp, what=""):
-    for g, e, name in zip(got, exp, ("partition order", "member", "totals")):
-        np.testing.assert_array_equal(g, e, err_msg="%s %s" % (name, what))
+def test_sparse_begin_semantics(ctx):
+    w = _workload(5, 0.2, topics=50)
+    idx, val = N.sparse_begin(w.begin, w.committed)
+    a = (w.part_off, w.partition_id, w.end, w.committed)
+    # `latest` never reads begin: the list is ignored, may be absent
+    exp = _expected(w, True)
+    for lst in ((idx, val), (None, None)):
+        got = ctx.assign_batch_sparse(*a, N.LA_RESET_LATEST, lst[0], lst[1], w.cons_off, w.cons_rank)
+        np.testing.assert_array_equal(got[1], exp[1])
+    # an unlisted partition without a committed offset has begin 0 (getOrDefault(tp, 0L), Main.java:350-351)
+    keep = np.arange(idx.size) % 2 == 0
+    begin0 = np.zeros_like(w.begin)
+    begin0[idx[keep]] = val[keep]
+    exp = _expected(w, False, begin0)
+    got = ctx.assign_batch_sparse(*a, N.LA_RESET_EARLIEST, idx[keep], val[keep], w.cons_off, w.cons_rank)
+    for g, e in zip(got, exp):
+        np.testing.assert_array_equal(g, e)
+    # entries for partitions that HAVE a committed offset are harmless
+    extra_idx = np.arange(w.n_partitions, dtype=np.int64)
+    got = ctx.assign_batch_sparse(*a, N.LA_RESET_EARLIEST, extra_idx, w.begin, w.cons_off, w.cons_rank)
+    for g, e in zip(got, _expected(w, False)):
+        np.testing.assert_array_equal(g, e)
+    # the grouped form: the same lists as the dense grouped call
+    n_members = int(w.cons_rank.max()) + 1
+    g_dense = ctx.assign_batch_grouped(w.part_off, w.partition_id, w.begin, w.end, w.committed, N.LA_RESET_EARLIEST, w.cons_off,
+                                       w.cons_rank, n_members)
+    g_sparse = ctx.assign_batch_grouped_sparse(*a, N.LA_RESET_EARLIEST, idx, val, w.cons_off, w.cons_rank, n_members)
+    for x, y in zip(g_dense, g_sparse):
+        np.testing.assert_array_equal(x, y)
 
 
-# ---- block_sort_radix, a padding sentinel against the record whose examined bits are all ones ------------
-def test_block_radix_sentinel_against_all_ones_record_in_fresh_process():
-    """The workgroup's digit sort pads with all-ones sentinels and looks at ceil((lbw + sh) / 8) digits.  When lbw + sh is a
-    multiple of 8, the record (lag 0, id 2^sh - 1) has the sentinel's digits; a sentinel of an earlier wavefront may then sort
-    before it.  P is not a multiple of 64 x 8, the special record sits in the second wavefront, lbw + sh in {8, 16, 24}; every
-    topic through the digits (LA_BLOCK_RADIX=3, read once per process), against the oracle."""
-    code = r"""
-import numpy as np, sys
-sys.path.insert(0, %r); sys.path.insert(0, %r)
-from kafka_lag_based_assignor_amd import _native as N, synth
-from oracle import oracle
-import test_round4_gpu as t
-ctx = N.Context(0)
-rng = np.random.default_rng(5)
-for P, C, sh, lbw in ((924, 65, 10, 6), (924, 70, 10, 14), (924, 65, 4, 4), (1500, 3, 11, 5), (3000, 100, 12, 12), (9000, 8, 14, 10),
-                      (924, 65, 10, 7)):
-    for at in (64, 100, 127, P - 1):
-        ids = rng.permutation((1 << sh) - 1)[:P] if (1 << sh) - 1 >= P else rng.integers(0, (1 << sh) - 1, P)
-        ids = ids.astype(np.int32)
-        lag = rng.integers(0, 1 << lbw, P).astype(np.int64)
-        lag[0] = (1 << lbw) - 1                       # the OR of the lags has lbw bits
-        ids[at] = (1 << sh) - 1                       # the record whose lbw + sh bits are all ones ...
-        lag[at] = 0                                   # ... : lag_max - 0 = all ones, id all ones
-        part_off = np.array([0, P], np.int64); cons_off = np.array([0, C], np.int64)
-        ranks = np.arange(C, dtype=np.int32) * 2
-        w = synth.Workload("s", 1, part_off, ids, np.zeros(P, np.int64), lag.copy(), np.zeros(P, np.int64), lag, cons_off, ranks, P, C)
-        exp = oracle.assign_flat(part_off, ids, lag, cons_off, ranks)
-        t._same3(t._device_call(ctx, w), exp, what=str((P, C, sh, lbw, at)))
-print("ok")
-"""
-    env = dict(os.environ, LA_BLOCK_RADIX="3")
-    out = subprocess.run([sys.executable, "-c", code % (ROOT, os.path.join(ROOT, "tests"))], env=env, capture_output=True,
-                         text=True, timeout=900)
-    assert out.returncode == 0 and "ok" in out.stdout, (out.stdout[-1500:], out.stderr[-1500:])
+@pytest.mark.parametrize("flags", [0, N.LA_CREATE_SPLIT_ALWAYS | 3])
+def test_sparse_begin_bad_lists_are_errors(flags):
+    w = _workload(9, 0.1, topics=200, big=flags != 0)
+    idx, val = N.sparse_begin(w.begin, w.committed)
+    a = (w.part_off, w.partition_id, w.end, w.committed, N.LA_RESET_EARLIEST)
+    with N.Context(0, flags=flags) as c:
+        swapped = idx.copy()
+        swapped[[0, -1]] = swapped[[-1, 0]]                                        # not ascending (across chunks)
+        beyond = idx.copy()
+        beyond[-1] = w.n_partitions                                                # outside the batch
+        negative = idx.copy()
+        negative[0] = -1
+        for bad in (swapped, beyond, negative):
+            with pytest.raises(N.LagAssignError) as e:
+                c.assign_batch_sparse(*a, bad, val, w.cons_off, w.cons_rank)
+            assert e.value.code == N.LA_EINVAL and "none_index" in str(e.value)
+        good = c.assign_batch_sparse(*a, idx, val, w.cons_off, w.cons_rank)        # the context is usable afterwards
+        np.testing.assert_array_equal(good[1], _expected(w, False)[1])
+        with pytest.raises(N.LagAssignError):
+            c.assign_batch_sparse(*a, idx, None, w.cons_off, w.cons_rank)          # a null array with n_none > 0
 
 
-# ---- la_hint_next_call: the caller's bounds reach the host-buffer entry points (VERDICT r4 next #1) -------------------------
-def _pinned_copy(ctx, arrays):
-    out = []
-    for a in arrays:
-        if a is None or isinstance(a, int):
-            out.append(a)
-        else:
-            p = ctx.host_alloc(a.shape, a.dtype)
-            p[...] = a
-            out.append(p)
-    return out
+def test_version_follows_the_header():
+    header = open(os.path.join(ROOT, "include", "lagassign.h")).read()
+    v = int(re.search(r"#define\s+LA_VERSION\s+(\d+)", header).group(1))
+    assert N.load().la_version() == v >= 300
+
+
+def test_calls_leave_the_current_device_alone(ctx, torch_dev):
+    torch, dev = torch_dev
+    before = torch.cuda.current_device()                                              # torch owns the HIP runtime: ask torch
+    w = synth.config("cfg3", 0.01)
+    ctx.assign_batch(w.part_off, w.partition_id, w.begin, w.end, w.committed, N.LA_RESET_EARLIEST, w.cons_off, w.cons_rank)
+    ctx.device_features(0)
+    assert torch.cuda.current_device() == before
+
+
+# ---- zero-copy small calls ------------------------------------------------------------------------------------
+def test_smallest_calls_run_zero_copy_and_agree_with_the_copying_forms():
+    """Staged calls (layouts up to 12 MB; 128 KB until round 5): the kernels read the inputs from coherent host memory in place
+    and write results / totals / lists into it; no hipMemcpy, no stream wait.  Same results as the one-copy form
+    (LA_ZERO_COPY_BYTES=0) on every entry point, across the old threshold, alternating on one context; errors surface and
+    leave the context usable."""
+    os.environ["LA_ZERO_COPY_BYTES"] = "0"
+    try:
+        ref_ctx = N.Context(0)
+    finally:
+        os.environ.pop("LA_ZERO_COPY_BYTES", None)
+    with N.Context(0) as c, ref_ctx:
+        seen, seen_ref = set(), set()
+        for seed, (t, p, cc) in enumerate([(1, 3, 2), (10, 10, 3), (40, 50, 5), (3, 700, 90), (1, 2500, 3), (1, 1800, 300),
+                                           (60, 64, 8), (300, 100, 7), (1, 20, 0), (5, 0, 3)]):
+            w = synth.ragged(100 + seed, t, p, cc)
+            n_members = int(w.cons_rank.max()) + 1 if w.cons_rank.size else 0
+            for mode in (N.LA_RESET_EARLIEST, N.LA_RESET_LATEST):
+                a = (w.part_off, w.partition_id, None if mode == N.LA_RESET_LATEST else w.begin, w.end, w.committed, mode,
+                     w.cons_off, w.cons_rank)
+                exp = _expected(w, mode == N.LA_RESET_LATEST)
+                got = c.assign_batch(*a)
+                seen.add(c.last_pipeline())
+                _same3(got, exp, "zero copy? %d" % c.last_pipeline())
+                _same3(ref_ctx.assign_batch(*a), exp, "one copy")
+                seen_ref.add(ref_ctx.last_pipeline())
+                g = c.assign_batch_grouped(*a, n_members)
+                g_ref = ref_ctx.assign_batch_grouped(*a, n_members)
+                for x, y in zip(g, g_ref):
+                    np.testing.assert_array_equal(x, y)
+                # results kept on the device, grouped by a second call
+                c.assign_batch(*a, keep_on_device=True)
+                g2 = c.group_last_by_member(w.n_partitions, n_members)
+                for x, y in zip(g2, (g[0], g[1], g[2])):
+                    np.testing.assert_array_equal(x, y)
+            idx, val = N.sparse_begin(w.begin, w.committed)
+            got = c.assign_batch_sparse(w.part_off, w.partition_id, w.end, w.committed, N.LA_RESET_EARLIEST, idx, val, w.cons_off, w.cons_rank)
+            _same3(got, _expected(w, False), "sparse")
+            _same3(c.assign_batch_lags(w.part_off, w.partition_id, w.lag, w.cons_off, w.cons_rank),
+                   oracle.assign_flat(w.part_off, w.partition_id, w.lag, w.cons_off, w.cons_rank), "lags")
+        # (the batches without partitions take no staged form at all)
+        assert N.LA_PIPELINE_ZERO_COPY in seen and N.LA_PIPELINE_ONE_COPY not in seen, seen
+        assert N.LA_PIPELINE_ONE_COPY in seen_ref and N.LA_PIPELINE_ZERO_COPY not in seen_ref, seen_ref
+        # errors: unsorted ranks (validated on the host for a small call), then the context still works
+        with pytest.raises(N.LagAssignError) as e:
+            c.assign_batch_lags([0, 2], [0, 1], [5, 6], [0, 2], [3, 1])
+        assert e.value.code == N.LA_EINVAL
+        p, m, t = c.assign_batch_lags([0, 3], [0, 1, 2], [100000, 50000, 60000], [0, 2], [0, 1])      # README.md:42-57
+        assert c.last_pipeline() == N.LA_PIPELINE_ZERO_COPY
+        assert p.tolist() == [0, 2, 1] and m.tolist() == [0, 1, 1] and t.tolist() == [100000, 110000]
 
 
 def test_hinted_host_call_is_one_tile_launch_per_chunk(ctx):
@@ -167,16 +283,6 @@ def test_grouped_and_sparse_calls_take_the_hint(ctx):
     _same3(r, e, "lags entry with a hint")
 
 
-# ---- one launch for a small rebalance -------------------------------------------------------------------
-def _grouped_expect(w, n_members):
-    lag = oracle.compute_lags(w.begin, w.end, w.committed, False)
-    e_pid, e_rank, e_tot = oracle.assign_flat(w.part_off, w.partition_id, lag, w.cons_off, w.cons_rank)
-    order = np.argsort(e_rank, kind="stable")                     # member by member, inside a member in the reference's order
-    first = np.searchsorted(e_rank[order], np.arange(n_members + 1))
-    topic = (np.searchsorted(w.part_off, order, side="right") - 1).astype(np.int32)
-    return first.astype(np.int64), topic, e_pid[order], e_tot, (e_pid, e_rank)
-
-
 @pytest.mark.parametrize("t,p,c", [(1, 3, 2), (10, 10, 3), (40, 25, 5), (3, 300, 33), (1, 1000, 64), (25, 40, 8), (1, 1, 1),
                                    (40, 50, 5), (7, 300, 33), (2, 1000, 64), (60, 40, 8)])
 def test_small_rebalance_is_one_launch(ctx, t, p, c):
@@ -216,7 +322,7 @@ def test_small_rebalance_falls_back_to_separate_launches_when_it_must(ctx):
         np.testing.assert_array_equal(g_p, part)
         np.testing.assert_array_equal(g_t, topic)
     # a block-path topic (1 100 partitions) beside tile topics: the tile launch is not the batch's last
-    import test_round4_gpu as t4
+    import gpu_helpers as t4
     w = t4._batch_of([(20, 4), (1100, 5), (30, 3)], 9, kinds=["u40"])
     lag = w.lag
     n_members = int(w.cons_rank.max()) + 1
@@ -235,7 +341,7 @@ def test_fused_tail_off_gives_the_same_lists_in_a_fresh_process():
 import numpy as np, sys
 sys.path.insert(0, %r); sys.path.insert(0, %r)
 from kafka_lag_based_assignor_amd import _native as N, synth
-import test_round5_gpu as t
+import gpu_helpers as t
 ctx = N.Context(0)
 for (tt, p, c) in ((10, 10, 3), (40, 50, 5), (2, 1000, 64)):
     w = synth.make_uniform("small", 40 + tt, tt, p, c, "uniform40")
@@ -257,159 +363,6 @@ print("ok")
         out = subprocess.run([sys.executable, "-c", code.replace("WANT", str(want)) % (ROOT, os.path.join(ROOT, "tests"))], env=env,
                              capture_output=True, text=True, timeout=600)
         assert out.returncode == 0 and "ok" in out.stdout, (env_add, out.stdout[-1500:], out.stderr[-1500:])
-
-
-# ---- block path: 65 .. 256 consumers, the greedy's bins ordered through 32-bit keys -------------------------
-def _one_topic(P, C, lag, seed):
-    rng = np.random.default_rng(seed)
-    pid = rng.permutation(P).astype(np.int32)
-    ranks = np.sort(rng.choice(3 * C + 5, C, replace=False)).astype(np.int32)
-    lag = np.asarray(lag, np.int64)
-    return synth.Workload("k32", 1, np.array([0, P], np.int64), pid, np.zeros(P, np.int64), lag.copy(), np.zeros(P, np.int64), lag,
-                          np.array([0, C], np.int64), ranks, P, C)
-
-
-@pytest.mark.parametrize("P,C", [(10000, 128), (1100, 65), (2049, 100), (4097, 129), (8193, 200), (16384, 256), (300, 70), (5000, 255)])
-@pytest.mark.parametrize("kind", ["u40", "bigties", "zero", "pareto", "u20", "nearties"])
-def test_block_greedy_through_32_bit_keys(ctx, P, C, kind):
-    """greedy_one_wave_key32 against the literal oracle: uniform 40-bit lags (bits dropped from the key, shared truncated totals
-    rare), many EQUAL large lags (every round meets tied totals with bits dropped: the exact re-ordering runs), lags that differ
-    only below the dropped bits, all-zero and small lags (drop == 0: the key is exact, memberId breaks the ties), a Pareto tail."""
-    import test_round4_gpu as t4
-    rng = np.random.default_rng(P + C)
-    if kind == "u40":
-        lag = rng.integers(0, 1 << 40, P)
-    elif kind == "bigties":
-        lag = (1 << 39) + rng.integers(0, 3, P) * (1 << 20)
-    elif kind == "nearties":
-        lag = (1 << 41) + rng.integers(0, 64, P)
-    elif kind == "zero":
-        lag = np.zeros(P, np.int64)
-    elif kind == "u20":
-        lag = rng.integers(0, 1 << 20, P)
-    else:
-        lag = np.floor(np.minimum(float(1 << 40), 1000.0 * (1.0 - rng.random(P)) ** (-1.0 / 1.5))).astype(np.int64)
-    w = _one_topic(P, C, lag, P * 7 + C)
-    exp = oracle.assign_flat(w.part_off, w.partition_id, w.lag, w.cons_off, w.cons_rank)
-    _same3(t4._device_call(ctx, w), exp, "%s %d x %d" % (kind, P, C))
-
-
-def test_block_greedy_forms_agree_in_a_fresh_process():
-    """LA_BLOCK_KEY32=0 (the 64-bit bins through the networks, rounds 3-4) and =2 (32-bit keys for 256 bins too) give what the
-    default gives: the oracle's assignment.  With bigties / nearties lags the exact re-ordering of tied rounds runs in mode 2."""
-    code = r"""
-import numpy as np, sys
-sys.path.insert(0, %r); sys.path.insert(0, %r)
-from kafka_lag_based_assignor_amd import _native as N
-from oracle import oracle
-import test_round4_gpu as t4, test_round5_gpu as t5
-ctx = N.Context(0)
-rng = np.random.default_rng(3)
-for (P, C) in ((10000, 128), (3000, 200), (16000, 256), (1500, 66)):
-    for lag in (rng.integers(0, 1 << 40, P), (1 << 39) + rng.integers(0, 3, P) * (1 << 20), (1 << 41) + rng.integers(0, 64, P)):
-        w = t5._one_topic(P, C, lag, P + C)
-        exp = oracle.assign_flat(w.part_off, w.partition_id, w.lag, w.cons_off, w.cons_rank)
-        t4._same3(t4._device_call(ctx, w), exp, what=str((P, C)))
-print("ok")
-"""
-    for mode in ("0", "2", "dense0"):                              # 2: the 32-bit-key form for 256 bins as well (default: 128 only)
-        env = dict(os.environ, LA_BLOCK_KEY32=mode)
-        if mode == "dense0":                                       # ... and without the one-scatter placement of dense ids in front of the digits
-            env = dict(os.environ, LA_BLOCK_DENSE_IDS="0")
-        out = subprocess.run([sys.executable, "-c", code % (ROOT, os.path.join(ROOT, "tests"))], env=env, capture_output=True,
-                             text=True, timeout=600)
-        assert out.returncode == 0 and "ok" in out.stdout, (mode, out.stdout[-1500:], out.stderr[-1500:])
-
-
-# ---- LA_FLAG_WIRE_OUT: the all-gather's wire elements straight from the assignment kernels (VERDICT r4 next #7) ------------------
-def _wire_call(ctx, w, fmt, bounds, latest=False, flags=0, hint=None):
-    import torch
-    from kafka_lag_based_assignor_amd import sharding
-    dev = torch.device("cuda", 0)
-    d = {k: torch.from_numpy(np.ascontiguousarray(getattr(w, k))).to(dev) for k in
-         ("part_off", "partition_id", "begin", "end", "committed", "cons_off", "cons_rank")}
-    n = w.n_partitions
-    wire = torch.zeros(max(n, 1) * fmt.elem_bytes + 16, device=dev, dtype=torch.uint8)
-    out_total = torch.full((max(w.cons_rank.size, 1),), -7, device=dev, dtype=torch.int64)
-    b = N.DeviceBatch()
-    b.n_topics, b.reset_mode, b.algo = w.n_topics, (N.LA_RESET_LATEST if latest else N.LA_RESET_EARLIEST), N.LA_ALGO_AUTO
-    b.flags = N.LA_FLAG_WIRE_OUT | flags
-    b.n_partitions, b.n_consumers = n, w.cons_rank.size
-    mp, mc = hint or (w.max_partitions, w.max_consumers)
-    b.max_partitions_per_topic, b.max_consumers_per_topic = mp, mc
-    b.d_part_off, b.d_partition_id = d["part_off"].data_ptr(), d["partition_id"].data_ptr()
-    b.d_begin_off, b.d_end_off, b.d_committed_off = d["begin"].data_ptr(), d["end"].data_ptr(), d["committed"].data_ptr()
-    b.d_cons_off, b.d_cons_rank = d["cons_off"].data_ptr(), d["cons_rank"].data_ptr()
-    b.d_out_partition = b.d_out_member_rank = None
-    b.d_out_total_lag = out_total.data_ptr()
-    if bounds is not None:
-        b.flags |= N.LA_FLAG_BOUNDS
-        b.max_lag_hint, b.max_partition_id_hint = bounds
-    b.d_out_wire = wire.data_ptr() + 2                              # element-aligned only: 2 bytes off a 16-byte boundary
-    b.wire_elem_bytes, b.wire_id_bits = fmt.elem_bytes, fmt.id_bits
-    stream = torch.cuda.current_stream().cuda_stream
-    ctx.assign_batch_device(b, stream)
-    ctx.sync(stream)
-    raw = wire.cpu().numpy()[2:2 + n * fmt.elem_bytes].view(fmt.dtype)
-    return raw, out_total.cpu().numpy()[: w.cons_rank.size]
-
-
-@pytest.mark.parametrize("topics,p,c,dist", [(30000, 256, 32, "zipf"), (60000, 64, 8, "uniform40"), (20000, 1000, 64, "zipf"),
-                                             (50000, 37, 5, "zipf"), (300000, 7, 3, "uniform40"), (9000, 256, 32, "zipf")])
-def test_wire_out_equals_the_packed_results(ctx, topics, p, c, dist):
-    """The wire elements the tile kernels write themselves are what la_pack_results_on makes of the two int32 arrays (checked
-    against sharding.wire_pack_numpy of the ORACLE's arrays on a slice and of the plain device call's arrays in full); totals as
-    usual.  Topic starts that are odd multiples of the element size (37, 7 partitions per topic): the 8-byte stores are only
-    element-aligned.  A batch small enough to be resident at once (9 000 topics) still takes the one-launch wire form."""
-    from kafka_lag_based_assignor_amd import sharding
-    w = synth.make_uniform("wire", topics % 97, topics, p, c, dist)
-    bounds = N.offset_bounds(w.begin, w.end, w.committed, w.partition_id)
-    n_members = int(w.cons_rank.max()) + 1
-    fmt = N.wire_format_for(int(w.partition_id.max()), n_members)
-    assert fmt.elem_bytes in (2, 4)
-    raw, tot = _wire_call(ctx, w, fmt, bounds)
-    assert ctx.last_launches() == 1
-    ref_p, ref_m, ref_t = ctx.assign_batch(w.part_off, w.partition_id, w.begin, w.end, w.committed, N.LA_RESET_EARLIEST, w.cons_off,
-                                           w.cons_rank)
-    np.testing.assert_array_equal(raw, sharding.pack_results_numpy(ref_p, ref_m, fmt.elem_bytes, fmt.id_bits))
-    np.testing.assert_array_equal(tot, ref_t)
-    t = min(topics, 300)
-    p1, k1 = int(w.part_off[t]), int(w.cons_off[t])
-    lag = oracle.compute_lags(w.begin[:p1], w.end[:p1], w.committed[:p1], False)
-    e_pid, e_rank, _ = oracle.assign_flat(w.part_off[:t + 1], w.partition_id[:p1], lag, w.cons_off[:t + 1], w.cons_rank[:k1])
-    np.testing.assert_array_equal(raw[:p1], sharding.pack_results_numpy(e_pid, e_rank, fmt.elem_bytes, fmt.id_bits))
-
-
-def test_wire_out_topics_without_consumers_and_ragged_sizes(ctx):
-    import test_round4_gpu as t4
-    from kafka_lag_based_assignor_amd import sharding
-    rng = np.random.default_rng(4)
-    shapes = [(int(rng.integers(0, 257)), int(rng.integers(0, 33))) for _ in range(40000)]
-    w0 = t4._batch_of(shapes, 12, kinds=["u20", "zero", "ties"])
-    w = synth.Workload("ragged", w0.n_topics, w0.part_off, w0.partition_id, np.zeros_like(w0.lag), w0.lag.copy(), np.zeros_like(w0.lag),
-                       w0.lag, w0.cons_off, w0.cons_rank, 256, 32)
-    fmt = N.wire_format_for(255, int(w.cons_rank.max()) + 1)
-    raw, tot = _wire_call(ctx, w, fmt, (1 << 20, 255), hint=(256, 32))
-    e_pid, e_rank, e_tot = oracle.assign_flat(w.part_off, w.partition_id, w.lag, w.cons_off, w.cons_rank)
-    np.testing.assert_array_equal(raw, sharding.pack_results_numpy(e_pid, e_rank, fmt.elem_bytes, fmt.id_bits))   # rank -1 -> 0
-    np.testing.assert_array_equal(tot, e_tot)
-
-
-def test_wire_out_refuses_what_it_cannot_do(ctx):
-    w = synth.make_uniform("wire", 5, 20000, 256, 32, "zipf")
-    bounds = N.offset_bounds(w.begin, w.end, w.committed, w.partition_id)
-    fmt = N.wire_format_for(255, 32)
-    for kwargs in ({"bounds": None}, {"bounds": (1 << 60, 255)}, {"bounds": bounds, "flags": N.LA_FLAG_RAGGED},
-                   {"bounds": bounds, "hint": (2000, 32)}):
-        with pytest.raises(N.LagAssignError) as ei:
-            _wire_call(ctx, w, fmt, kwargs.get("bounds"), flags=kwargs.get("flags", 0), hint=kwargs.get("hint"))
-        assert ei.value.code == N.LA_EINVAL and "LA_FLAG_WIRE_OUT" in str(ei.value)
-    small = N.WireFormat(2, 12)                                    # 4 bits above the id: member ranks up to 14 only
-    with pytest.raises(N.LagAssignError) as ei:
-        _wire_call(ctx, w, small, bounds)
-    assert ei.value.code == N.LA_EINVAL and "wire format" in str(ei.value)
-    raw, _ = _wire_call(ctx, w, fmt, bounds)                       # and the context is fine afterwards
-    assert raw.size == w.n_partitions
 
 
 # ---- member lists of a mid-size rebalance: the two-launch counting sort (la_group_small.h, group_mid_*) ---------------------------
@@ -483,23 +436,42 @@ def test_a_staged_call_at_the_limit_and_just_beyond(ctx):
         _same3(got, oracle.assign_flat(w.part_off, w.partition_id, lag, w.cons_off, w.cons_rank), "oracle")
 
 
-# ---- under-filled tile launches run a wider shape; the narrow shapes at small sizes keep their tests -------------------------------
-def test_tile_tests_with_the_narrow_shapes_in_a_fresh_process():
-    """wave_tile_widen (la_wave_tile.hip) gives every topic of a small batch twice / four times the lanes: the whole suite's small tile
-    batches now run the wide shapes.  The narrowest shape of every (partitions, consumers) -- what large batches run, and everything
-    ran until round 5 -- is kept under test by running the tile tests once more with LA_NO_TILE_WIDEN=1."""
-    env = dict(os.environ, LA_NO_TILE_WIDEN="1")
-    out = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_parity.py"), "-q", "-m", "gpu", "-x",
-                          "-k", "tile or target_shape or ragged or grouped", "-p", "no:cacheprovider"],
-                         env=env, capture_output=True, text=True, timeout=1200, cwd=ROOT)
-    assert out.returncode == 0, (out.stdout[-2000:], out.stderr[-1000:])
+def test_a_call_that_fails_before_it_starts_spends_the_hint(ctx):
+    """la_hint_next_call is one-shot: the hint is forgotten when the next host-buffer assign call returns, WHATEVER it returns --
+    also when that call returns before it looks at the hint (a NULL lag array, a negative member count, n_topics
+    = 0 used to leave it pending, and the stale bound then failed the next, unrelated call with LA_EINVAL)."""
+    import ctypes
+    w = synth.make_uniform("spend", 41, 3000, 256, 32, "zipf")
+    big = w.end.copy()
+    big[1234] = 1 << 56                                            # breaks a bound of 2^31 (its tile needs wide records)
+    exp = oracle.assign_flat(w.part_off, w.partition_id, oracle.compute_lags(w.begin, big, w.committed, False),
+                             w.cons_off, w.cons_rank)
+    lib, h = ctx._lib, ctx._h
+    n_members = int(w.cons_rank.max()) + 1
+    p64 = lambda a: a.ctypes.data_as(ctypes.POINTER(ctypes.c_int64))     # noqa: E731
+    p32 = lambda a: a.ctypes.data_as(ctypes.POINTER(ctypes.c_int32))     # noqa: E731
+    po, co = np.ascontiguousarray(w.part_off), np.ascontiguousarray(w.cons_off)
+    pid, cr = np.ascontiguousarray(w.partition_id), np.ascontiguousarray(w.cons_rank)
+    out_p, out_m = np.empty(pid.size, np.int32), np.empty(pid.size, np.int32)
+    out_t = np.zeros(cr.size, np.int64)
 
-
-def test_widened_and_narrow_tile_shapes_agree(ctx):
-    """The same small batches through the default (widened) pick and the oracle; shapes chosen so that the pick widens by 2x and 4x and
-    not at all (64 consumers; one record per lane)."""
-    import test_round4_gpu as t4
-    for (t, p, c) in [(1000, 256, 32), (300, 64, 8), (50, 1000, 9), (2000, 100, 5), (7, 1024, 64), (400, 8, 8), (3000, 30, 3)]:
-        w = synth.make_uniform("widen", t + p, t, p, c, "zipf")
-        exp = oracle.assign_flat(w.part_off, w.partition_id, w.lag, w.cons_off, w.cons_rank)     # (_device_call hands over w.lag)
-        _same3(t4._device_call(ctx, w), exp, "%d x %d x %d" % (t, p, c))
+    def early_failures():
+        # (1) the lags entry with lag = NULL  (2) a grouped call with a negative member count  (3) grouped, n_topics = 0
+        yield lambda: lib.la_assign_batch_lags(h, w.n_topics, p64(po), p32(pid), None, p64(co), p32(cr), p32(out_p), p32(out_m),
+                                               p64(out_t)), N.LA_EINVAL
+        moff = np.zeros(n_members + 1, np.int64)
+        yield lambda: lib.la_assign_batch_grouped(h, w.n_topics, p64(po), p32(pid), p64(w.begin), p64(big), p64(w.committed),
+                                                  N.LA_RESET_EARLIEST, p64(co), p32(cr), -1, p64(moff), None, p32(out_p),
+                                                  p64(out_t)), N.LA_EINVAL
+        yield lambda: lib.la_assign_batch_grouped(h, 0, p64(po), p32(pid), p64(w.begin), p64(big), p64(w.committed),
+                                                  N.LA_RESET_EARLIEST, p64(co), p32(cr), n_members, p64(moff), None, p32(out_p),
+                                                  p64(out_t)), N.LA_OK
+    for call, want in early_failures():
+        ctx.hint_next_call(((1 << 31), 255))                       # a promise the NEXT-but-one call's data would break
+        assert int(call()) == want
+        got = ctx.assign_batch(w.part_off, w.partition_id, w.begin, big, w.committed, N.LA_RESET_EARLIEST, w.cons_off, w.cons_rank)
+        _same3(got, exp, "unhinted call after an early return")
+    # and the control: the same hint, pending, does fail that call
+    ctx.hint_next_call(((1 << 31), 255))
+    with pytest.raises(N.LagAssignError):
+        ctx.assign_batch(w.part_off, w.partition_id, w.begin, big, w.committed, N.LA_RESET_EARLIEST, w.cons_off, w.cons_rank)

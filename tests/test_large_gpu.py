@@ -1,0 +1,112 @@
+"""Large path (csrc/la_large.hip: device radix sort + one-workgroup greedy rounds; the multi-pass form beyond 8 192 consumers) through the C ABI, bit-exact against the oracle."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from kafka_lag_based_assignor_amd import _native as N
+from kafka_lag_based_assignor_amd import synth
+from oracle import oracle
+from gpu_helpers import *  # noqa: F401,F403
+
+pytestmark = pytest.mark.gpu
+
+
+def test_large_topics_side_by_side_mixed_batch(ctx):
+    """Large topics of every tile class and rounds class, with and without consumers, between tile- and block-sized topics and
+    topics without partitions: the shared launches give what the serial form gives, which is what the oracle gives."""
+    shapes = [(100, 5), (20000, 50), (0, 3), (70000, 300), (3000, 200), (18000, 3000), (17000, 0), (150000, 8192),
+              (40000, 1), (0, 0), (16385, 64), (300000, 700), (20000, 2049), (64, 8), (3300000, 5)]
+    w = _batch_of(shapes, 11)
+    exp = round_form(w.part_off, w.partition_id, w.lag, w.cons_off, w.cons_rank)
+    got = _device_call(ctx, w)
+    _same3(got, exp, "side by side")
+    serial = _device_call(ctx, w, flags=N.LA_FLAG_SERIAL_LARGE)
+    _same3(serial, exp, "serial hook")
+    host = ctx.assign_batch_lags(w.part_off, w.partition_id, w.lag, w.cons_off, w.cons_rank)       # the host entry, chunks and all
+    _same3(host, exp, "host entry")
+    # and twice in a row on the same context (the staging slots alternate; scratch is reused)
+    _same3(_device_call(ctx, w), exp, "second call")
+    # test hooks of the sort / the greedy still apply to every topic of the launch
+    for fl in (N.LA_FLAG_NO_SAMPLE_SORT, N.LA_FLAG_SAMPLE_TIGHT, N.LA_FLAG_NO_RUN_MERGE, N.LA_FLAG_SORT_MULTIKERNEL):
+        _same3(_device_call(ctx, w, flags=fl), exp, "flag %d" % fl)
+
+
+def test_many_equal_large_topics_literal_oracle(ctx):
+    """24 topics x 20 000 partitions x 2 100 consumers with wide, negative and tied lags, against the LITERAL oracle."""
+    w = _batch_of([(20000, 2100)] * 24, 5, kinds=["full", "u40", "ties"], negative=True)
+    exp = oracle.assign_flat(w.part_off, w.partition_id, w.lag, w.cons_off, w.cons_rank)
+    _same3(_device_call(ctx, w), exp)
+
+
+@pytest.mark.parametrize("p,c,kind", [
+    (200000, 20000, "pareto"), (8193 * 3, 8193, "u40"), (5000, 9000, "u40"), (18000, 9000, "ties"), (30000, 10000, "zero"),
+    (27000, 9000, "full"), (100000, 70000, "u20")])
+def test_more_consumers_than_one_workgroup_holds(ctx, p, c, kind):
+    """> 8 192 consumers: bins in HBM, a device sort per round.  P < C (one partial round), P = k * C exactly,
+    ties, zero lags, negative lags with wrapping totals."""
+    w = _batch_of([(p, c)], p + c, kinds=[kind], negative=True)
+    exp = round_form(w.part_off, w.partition_id, w.lag, w.cons_off, w.cons_rank)
+    _same3(_device_call(ctx, w), exp, "%d x %d %s" % (p, c, kind))
+    if p * c <= 200_000_000:                                             # the literal per-step min where it is affordable
+        _same3(exp, oracle.assign_flat(w.part_off, w.partition_id, w.lag, w.cons_off, w.cons_rank), "round form vs literal")
+    got = _device_call(ctx, w, want_totals=False)
+    np.testing.assert_array_equal(got[1], exp[1])
+
+
+def test_huge_consumer_topic_inside_a_batch(ctx):
+    w = _batch_of([(256, 32), (30000, 8300), (20000, 100), (0, 9000), (60000, 20000), (5000, 300)], 21)
+    exp = round_form(w.part_off, w.partition_id, w.lag, w.cons_off, w.cons_rank)
+    _same3(_device_call(ctx, w), exp)
+    _same3(ctx.assign_batch_lags(w.part_off, w.partition_id, w.lag, w.cons_off, w.cons_rank), exp, "host entry")
+
+
+@pytest.mark.parametrize("n,kind,shuffled,dup,expect_first,expect_redo", [
+    (70000, "wide", True, False, 1, 0), (200000, "runs", True, False, 1, 0), (150000, "run4096", True, False, 1, 0),
+    (150000, "run9000", True, False, 1, 1), (300000, "run20000_top", True, False, 1, 1), (50000, "equal", True, False, 0, 0),
+    (90000, "full", True, False, 1, 1), (120000, "runs", True, True, 1, 0), (80000, "runs", False, False, 0, 0),
+    (20000, "runs", True, False, 1, 0), (16385, "wide", True, False, 1, 0), (40000, "pairs", True, False, 1, 0)])
+def test_keys_first_sort_forced_on_small_topics(n, kind, shuffled, dup, expect_first, expect_redo):
+    """LA_SORT_KEYS_FIRST=2 (test hook): every large-path sort with shuffled ids skips its id passes and repairs the runs of
+    equal lags afterwards, whatever the sample says.  Same order as the comparator's (lag desc, id asc): no ties, thousands of
+    short runs, a run that just fits a workgroup, runs that do not (the redo slots), negative lags, duplicate ids; ids already
+    ascending and all-equal lags never go keys first."""
+    os.environ["LA_SORT_KEYS_FIRST"] = "2"
+    try:
+        with N.Context(0) as c:
+            w = _sort_topic(n, kind, n + len(kind), shuffled, dup)
+            got = _device_call(c, w, flags=N.LA_FLAG_PROFILE)
+            t = c.last_phase_times()
+            assert (t.keys_first, t.redone) == (expect_first, expect_redo), (t.keys_first, t.redone)
+            order = np.lexsort((w.partition_id, ~w.lag))
+            np.testing.assert_array_equal(got[0], w.partition_id[order])
+            assert (got[1] == -1).all()
+            # with consumers: the greedy reads the repaired order
+            w2 = _batch_of([(n, 37)], n, kinds=["ties"])
+            _same3(_device_call(c, w2), round_form(w2.part_off, w2.partition_id, w2.lag, w2.cons_off, w2.cons_rank), "with consumers")
+            # several topics side by side, each with its own decision
+            w3 = _batch_of([(30000, 5), (50000, 0), (20000, 100), (65536, 3)], n + 1, kinds=["ties", "u40", "zero", "pareto"])
+            _same3(_device_call(c, w3), round_form(w3.part_off, w3.partition_id, w3.lag, w3.cons_off, w3.cons_rank), "side by side")
+    finally:
+        os.environ.pop("LA_SORT_KEYS_FIRST", None)
+
+
+@pytest.mark.parametrize("kind,expect_first", [("wide", 1), ("runs", 0), ("run20000_top", 0), ("equal", 0)])
+def test_keys_first_sort_by_the_sample_at_five_million(ctx, kind, expect_first):
+    """The default rule: from 4 M partitions on, with shuffled ids, keys first unless the sample of the lags shows a frequent one."""
+    n = 5_000_000
+    w = _sort_topic(n, kind, 77)
+    got = _device_call(ctx, w, flags=N.LA_FLAG_PROFILE)
+    t = ctx.last_phase_times()
+    assert t.keys_first == expect_first and t.redone == 0, (t.keys_first, t.redone, t.id_passes, t.key_passes)
+    order = np.lexsort((w.partition_id, ~w.lag))
+    np.testing.assert_array_equal(got[0], w.partition_id[order])
+    os.environ["LA_SORT_KEYS_FIRST"] = "0"                  # never: the round-3 order of passes, same answer
+    try:
+        got0 = _device_call(ctx, w, flags=N.LA_FLAG_PROFILE)
+        assert ctx.last_phase_times().keys_first == 0
+        np.testing.assert_array_equal(got0[0], got[0])
+    finally:
+        os.environ.pop("LA_SORT_KEYS_FIRST", None)

@@ -37,6 +37,8 @@ def main():
     ap.add_argument("--large-partitions", type=int, default=0,
                     help="also run ONE large topic of this many partitions (radix-sort path)")
     ap.add_argument("--large-consumers", type=int, default=1024)
+    ap.add_argument("--none-frac", type=float, default=None,
+                    help="share of partitions without a committed offset (synth.config none_frac; default: the fixed 1 %%)")
     args = ap.parse_args()
 
     import torch
@@ -59,7 +61,8 @@ def main():
     T, P, C = args.topics, args.partitions, args.consumers
     if T > 0:
         # the bench's own vectors when the shape is the target's (synth.config), the same generator otherwise
-        w = synth.config("target") if (T, P, C) == (100000, 256, 32) else synth.make_uniform("custom", 11, T, P, C, "zipf")
+        w = (synth.config("target", none_frac=args.none_frac) if (T, P, C) == (100000, 256, 32) else
+             synth.make_uniform("custom", 11, T, P, C, "zipf", none_frac=args.none_frac))
         sh = bench.DeviceShard(torch, N, dev, w, 0, T, args.reset_mode == "latest", args.algo)
         b = sh.batch
         stream = torch.cuda.current_stream().cuda_stream

@@ -57,7 +57,7 @@ def main():
                           name, summ["calibration"]["fetch_bytes_per_count"],
                           summ["calibration"]["write_bytes_per_count"]),
         })
-    # keep what other sessions put there (the sort-phase entry of tools/gpu_session_large.sh)
+    # keep what other sessions put there (the sort-phase entry of tools/gpu_session.sh ... sort)
     try:
         old = json.load(open(os.path.join(dst, "traffic.json"))).get("entries", [])
     except (OSError, ValueError):
