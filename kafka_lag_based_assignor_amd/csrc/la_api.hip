@@ -477,6 +477,16 @@ int launch_block_topics(la_ctx* ctx, Lane& ln, const la_device_batch* b, const B
     return LA_OK;
 }
 
+// Greedy rounds of the large path with at most this many ascending runs place the bins that move by search (la_large.hip,
+// search_sort_bins).  LA_SEARCH_MAX_RUNS is a lab knob, read at every call so that one process can sweep it (1 .. 64; 0 = off).
+int search_max_runs_default() {
+    if (const char* e = getenv("LA_SEARCH_MAX_RUNS")) {
+        const int v = atoi(e);
+        return v < 0 ? 0 : (v > 64 ? 64 : v);
+    }
+    return 16;
+}
+
 int launch_large_topics(la_ctx* ctx, Lane& ln, const la_device_batch* b, const BatchPlan& plan, bool argmin, hipStream_t stream) {
     // The per-topic loop of assign(Map,Map) (Main.java:177-184) is independent across topics: all large topics of the batch
     // run SIDE BY SIDE (la::large_topics_launch: every phase one launch over all of them, one greedy workgroup per topic),
@@ -520,6 +530,7 @@ int launch_large_topics(la_ctx* ctx, Lane& ln, const la_device_batch* b, const B
         g.sort_multi_kernel = (b->flags & LA_FLAG_SORT_MULTIKERNEL) ? 1 : 0;
         g.no_run_merge = (b->flags & LA_FLAG_NO_RUN_MERGE) ? 1 : 0;
         g.no_moved_sort = (b->flags & LA_FLAG_NO_MOVED_SORT) ? 1 : 0;
+        g.search_max_runs = (b->flags & LA_FLAG_NO_SEARCH_SORT) ? 0 : search_max_runs_default();
         g.status = ln.status();
         hipError_t e = hipSuccess;
         if (c > la::kLargeMaxConsumers) {
@@ -863,7 +874,7 @@ int prepare_shard(la_ctx* ctx, const HostCall& c, Shard& sh, ShardPlan& sp) {
         int64_t target = ctx->chunk_partitions > 0 ? ctx->chunk_partitions : sp.n / 16;
         if (ctx->chunk_partitions <= 0 && target < kMinChunkPartitions) target = kMinChunkPartitions;
         // three-stream form: chunks of ~1 M partitions (28 MB of input) measured best on the 25.6 M-partition batch -- 13.6 ms
-        // against 18-20 ms at 512 K, 14.4 at 2 M, 14.5 with few chunks that are small at both ends (profiles/r03_host_probe.txt)
+        // against 18-20 ms at 512 K, 14.4 at 2 M, 14.5 with few chunks that are small at both ends (profiles/archive/r03_host_probe.txt)
         // (by bytes: 1 M partitions of the dense offsets form = 28 MB of input; the sparse-begin and the lags forms move fewer
         //  bytes per partition and take proportionally more partitions per chunk -- a chunk's copies cost ~20 us each before their
         //  first byte moves, whatever they carry)
@@ -1045,7 +1056,7 @@ bool call_is_pinned(const HostCall& c) {
 //   lane 0   : wait "in"; check_consumers; the kernels over its topics     -> event "out"
 //   copy_out : wait "out"; D2H of the chunk's results straight into the caller's arrays
 // so the link carries input bytes back to back from the first chunk to the last (the H2D leg IS the floor of the call:
-// 717 MB at the 57 GB/s this link sustains = 12.5 ms for the 25.6 M-partition batch, profiles/r03_pcie_probe.txt) while
+// 717 MB at the 57 GB/s this link sustains = 12.5 ms for the 25.6 M-partition batch, profiles/archive/r03_pcie_probe.txt) while
 // kernels and result copies of earlier chunks run beside it.  Returns after enqueueing; finish_shard_async waits.
 int run_shard_async(la_ctx* ctx, const HostCall& c, Shard& sh, ShardPlan& sp) {
     LA_HIP(ctx, hipSetDevice(sh.device));

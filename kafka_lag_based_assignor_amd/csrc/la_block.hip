@@ -1218,7 +1218,7 @@ hipError_t block_launch(BlockArgs a, int cls, hipStream_t stream) {
     // classes, 2 every class: the default; topics of fewer than 768 partitions keep the network; needs the atomic ranks).
     // Same box, ms per call, network / digits: 1 x 10 000 x 128 0.164 / 0.126, 1 x 16 000 x 200 0.226 / 0.177, 200 x 8 000 x 16
     // 0.147 / 0.124, 64 x 8 192 x 2 048 0.098 / 0.075, 1 000 x 2 000 x 100 0.089 / 0.072, 1 000 x 4 000 x 100 0.190 / 0.153
-    // (profiles/r04_block_radix.txt)
+    // (profiles/archive/r04_block_radix.txt)
     // (3: every topic whatever its size -- the test hook that drives small topics through the digits)
     static const int radix_mode = [] { const char* e = getenv("LA_BLOCK_RADIX"); return e ? atoi(e) : 2; }();
     a.radix_sort = (large_atomic_rank_supported() && (radix_mode >= 2 || (radix_mode == 1 && cls >= 2))) ? (radix_mode >= 3 ? 2 : 1) : 0;

@@ -42,7 +42,7 @@ __device__ unsigned long long g_group_clocks[12];
 #endif
 
 constexpr int kSmallGroupN = 2560;       // entries.  Measured on one box, device-resident, back to back (tools/group_probe.py,
-                                         // profiles/r04_group_probe.txt): this kernel 4.0 us at 100 entries, 9 at 1 000, 14.8 at 2 000, 26 at
+                                         // profiles/archive/r04_group_probe.txt): this kernel 4.0 us at 100 entries, 9 at 1 000, 14.8 at 2 000, 26 at
                                          // 4 096 (its chunks' global loads and topic searches are dependent round trips, 16 chunks deep per
                                          // wavefront at 16 384: 90-100 us), the radix form 17-23 us whatever the size: beyond ~2 500 entries
                                          // the five launches win

@@ -1,6 +1,7 @@
 """Helpers shared by the per-component GPU test files (test_tile_gpu / test_block_gpu / test_large_gpu / test_host_calls_gpu):
 workload builders, the device-entry call, comparisons.  Not a test module; the fresh-process tests import it by name."""
 import os
+import re
 import subprocess
 import sys
 
@@ -8,8 +9,9 @@ import numpy as np
 import pytest
 
 from kafka_lag_based_assignor_amd import _native as N
-from kafka_lag_based_assignor_amd import synth
+from kafka_lag_based_assignor_amd import sharding, synth
 from oracle import oracle
+from oracle.round_form import round_form
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 

@@ -1,5 +1,6 @@
 """Block path (csrc/la_block.hip: one workgroup per topic, up to 8 192 x 2 048 / 16 384 x 1 024) through the C ABI, bit-exact against the oracle."""
 import os
+import re
 import subprocess
 import sys
 
@@ -7,8 +8,9 @@ import numpy as np
 import pytest
 
 from kafka_lag_based_assignor_amd import _native as N
-from kafka_lag_based_assignor_amd import synth
+from kafka_lag_based_assignor_amd import sharding, synth
 from oracle import oracle
+from oracle.round_form import round_form
 from gpu_helpers import *  # noqa: F401,F403
 
 pytestmark = pytest.mark.gpu

@@ -1,5 +1,6 @@
 """Host-buffer entry points (la_assign_batch*, la_hint_next_call, la_group_*: pipelines, hints, sparse begin, the one-launch small rebalance) through the C ABI, bit-exact against the oracle."""
 import os
+import re
 import subprocess
 import sys
 
@@ -7,8 +8,9 @@ import numpy as np
 import pytest
 
 from kafka_lag_based_assignor_amd import _native as N
-from kafka_lag_based_assignor_amd import synth
+from kafka_lag_based_assignor_amd import sharding, synth
 from oracle import oracle
+from oracle.round_form import round_form
 from gpu_helpers import *  # noqa: F401,F403
 
 pytestmark = pytest.mark.gpu

@@ -2,7 +2,7 @@
 """What a greedy round of cfg5 (1 topic x 1 048 576 partitions x 8 192 consumers, Pareto lags) looks like, on the CPU: per round
 the number of ascending runs of the bins after the add, how many bins change places when the round is sorted, the largest
 distance a bin travels and where the first descents are.  The numbers behind moved_sort_bins / merge_runs_bins (la_large.hip).
-    python tools/cfg5_rounds.py [--config cfg5] > profiles/r04_cfg5_rounds.txt
+    python tools/cfg5_rounds.py [--config cfg5] > profiles/archive/r04_cfg5_rounds.txt
 """
 import argparse, os, sys
 import numpy as np
