@@ -123,9 +123,6 @@ extern "C" {
 #define LA_FLAG_NO_MOVED_SORT 2048 /* large path: greedy rounds in which few bins change places sort all of them like any other    *
                                   * round instead of only the bins that move (test hook / A-B)                            */
 
-#define LA_FLAG_NO_SEARCH_SORT 8192 /* large path: greedy rounds whose bins are a few ascending runs never place the bins that move by     *
-                                  * search (round 6's form of such a round) but sort them as rounds 4-5 did (test hook / A-B)          */
-
 #define LA_FLAG_BOUNDS      1024 /* max_lag_hint and max_partition_id_hint below are valid: the caller guarantees 0 <= lag <=          *
                                  * max_lag_hint for every lag the batch produces (the largest end offset will do: a lag never exceeds    *
                                  * it) and 0 <= partition id <= max_partition_id_hint.  When the bounds PROVE that every tile's records  *

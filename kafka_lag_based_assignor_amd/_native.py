@@ -23,7 +23,6 @@ LA_FLAG_PROFILE, LA_FLAG_NO_SAMPLE_SORT, LA_FLAG_SAMPLE_TIGHT = 16, 32, 64
 LA_FLAG_SORT_MULTIKERNEL = 128
 LA_FLAG_NO_RUN_MERGE = 256
 LA_FLAG_NO_MOVED_SORT = 2048
-LA_FLAG_NO_SEARCH_SORT = 8192
 LA_FLAG_SERIAL_LARGE = 512
 LA_FLAG_BOUNDS = 1024
 LA_FLAG_WIRE_OUT = 4096

@@ -477,16 +477,6 @@ int launch_block_topics(la_ctx* ctx, Lane& ln, const la_device_batch* b, const B
     return LA_OK;
 }
 
-// Greedy rounds of the large path with at most this many ascending runs place the bins that move by search (la_large.hip,
-// search_sort_bins).  LA_SEARCH_MAX_RUNS is a lab knob, read at every call so that one process can sweep it (1 .. 64; 0 = off).
-int search_max_runs_default() {
-    if (const char* e = getenv("LA_SEARCH_MAX_RUNS")) {
-        const int v = atoi(e);
-        return v < 0 ? 0 : (v > 64 ? 64 : v);
-    }
-    return 16;
-}
-
 int launch_large_topics(la_ctx* ctx, Lane& ln, const la_device_batch* b, const BatchPlan& plan, bool argmin, hipStream_t stream) {
     // The per-topic loop of assign(Map,Map) (Main.java:177-184) is independent across topics: all large topics of the batch
     // run SIDE BY SIDE (la::large_topics_launch: every phase one launch over all of them, one greedy workgroup per topic),
@@ -530,7 +520,6 @@ int launch_large_topics(la_ctx* ctx, Lane& ln, const la_device_batch* b, const B
         g.sort_multi_kernel = (b->flags & LA_FLAG_SORT_MULTIKERNEL) ? 1 : 0;
         g.no_run_merge = (b->flags & LA_FLAG_NO_RUN_MERGE) ? 1 : 0;
         g.no_moved_sort = (b->flags & LA_FLAG_NO_MOVED_SORT) ? 1 : 0;
-        g.search_max_runs = (b->flags & LA_FLAG_NO_SEARCH_SORT) ? 0 : search_max_runs_default();
         g.status = ln.status();
         hipError_t e = hipSuccess;
         if (c > la::kLargeMaxConsumers) {

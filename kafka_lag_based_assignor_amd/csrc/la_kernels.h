@@ -229,8 +229,6 @@ struct LargeArgs {
     int32_t no_run_merge;       // LA_FLAG_NO_RUN_MERGE: greedy rounds never merge ascending runs (they sort as if there were none)
     int32_t sort_multi_kernel;  // LA_FLAG_SORT_MULTIKERNEL: four kernels per radix pass (count, scans, scatter) instead of one
     int32_t no_moved_sort;      // LA_FLAG_NO_MOVED_SORT: greedy rounds never sort only the bins that move
-    int32_t search_max_runs;    // greedy rounds with at most this many ascending runs place the bins that move by search
-                                // (search_sort_bins, round 6); 0 = never (LA_FLAG_NO_SEARCH_SORT)
 };
 
 // Once per device at context creation (synchronous): checks the hardware property the radix sort's atomic ranking relies on.

@@ -978,7 +978,7 @@ __device__ __forceinline__ void cross_wave_step(P64 (&rec)[EC], ExchangeBufs& xb
 }
 
 #ifdef LA_ROUND_CLOCKS   // development build: thread 0 accumulates the cycles of every phase of a round (tools/cfg5_probe.py)
-__device__ unsigned long long g_round_clocks[24];
+__device__ unsigned long long g_round_clocks[16];
 #define LA_CLK(i)                                                          \
     do {                                                                   \
         if (threadIdx.x == 0) {                                            \
@@ -1630,230 +1630,6 @@ __device__ __forceinline__ bool moved_sort_bins(P64 (&rec)[EC], const SampleLds&
     return true;
 }
 
-// ---- a round whose bins are a few ascending runs: every bin that moves finds its place by SEARCH (round 6) -----------------------
-// The round's new values are (ascending totals) + (descending lags): ascending RUNS, one per stretch of equal lags -- on a
-// power-law topic 30 runs by round 32 and 3 - 8 from round 48 on, with the ~850 bins that move standing in the few runs of the
-// dense bulk.  A bin's place is the number of bins below it = the sum over the runs of a lower bound in each -- and almost every
-// run is entirely below or entirely above a given bin: with PL[s] = the largest bin of runs 0 .. s and SF[s] = the smallest bin of
-// runs s .. R - 1 (both ascending in s), the runs a bin x of run s has to LOOK INTO are the neighbours s - 1, s - 2 .. while
-// PL > x and s + 1, s + 2 .. while SF < x: one or two in the late rounds.  So a round is
-//   1. the new values to LDS in position order (array A); who stays (prefix maximum / suffix minimum, as in moved_sort_bins);
-//      where the descents are: one byte of descent bits and one of mover bits per thread                         (barriers 1, 2)
-//   2. every wavefront that has work builds the table of runs for itself from the 128 words of descent bits (start, first, last,
-//      PL, SF: one run per lane; all wavefronts write the same values to the same words), then takes the words of mover bits
-//      c = wave, wave + 16 .. -- the dense bulk is positions ~60 .. 1 100, i.e. ONE word per wavefront: the search is spread over the
-//      whole workgroup although three wavefronts own the bulk -- and ranks one mover per lane: both neighbours' binary searches
-//      run interleaved (two LDS reads in flight per step); the mover goes to B[rank]                              (barrier 3)
-//   3. the owners of the places that moved read them back from B.
-// No compaction, no atomics, no staging, no way back: three barriers where moved_sort_bins has six, and nothing in it depends on
-// how many bins move.  Returns false -- rec untouched -- when the round has more than `max_runs` runs (the caller sorts as
-// before and looks again later); *runs_out = the number of runs.
-// Position p lives at word p ^ ((p >> 5) & 7) of A / B: a thread's 8 consecutive positions (stride of 8 words between lanes)
-// and 64 consecutive positions both touch every bank once.
-__device__ __forceinline__ int search_swz(int p) { return p ^ ((p >> 5) & 7); }
-
-template <int EC>
-__device__ __forceinline__ bool search_sort_bins(P64 (&rec)[EC], const SampleLds& L, int tid, int max_runs, int* runs_out) {
-    static_assert(EC == 8, "one byte of flag bits per thread, 128 words of 64 positions");
-    constexpr int NT = kSampleThreads, N = EC * NT, NW = N / 64;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    uint64_t* A = reinterpret_cast<uint64_t*>(L.stage);          // [N] the round's values in position order
-    uint64_t* B = A + N;                                         // [N] the bins that move, at their new places
-    uint64_t* dbits = L.spl;                                     // [NW] bit p % 64 of word p / 64: position p starts a run
-    uint64_t* mbits = dbits + NW;                                // [NW] position p moves
-    uint64_t* t_first = mbits + NW;                              // [64] a run's first (smallest) bin
-    uint64_t* t_last = t_first + 64;                             // [64] its last (largest) bin
-    uint64_t* t_pl = t_last + 64;                                // [64] the largest bin of runs 0 .. s
-    uint64_t* t_sf = t_pl + 64;                                  // [64] the smallest bin of runs s .. R - 1
-    uint32_t* t_start = reinterpret_cast<uint32_t*>(t_sf + 64);  // [R + 1] a run's first position; [R] = N
-    uint64_t* wmax = reinterpret_cast<uint64_t*>(L.moved);       // [16] a wavefront's largest bin
-    uint64_t* wmin = wmax + 16;                                  // [16] its smallest
-    LA_CLK_START;
-    // 1. values to A; descents inside the thread and against the lane before; the wavefront's extremes
-    uint64_t v[EC];
-#pragma unroll
-    for (int r = 0; r < EC; ++r) {
-        v[r] = p64_value(rec[r]);
-        A[search_swz(tid * EC + r)] = v[r];
-    }
-    uint32_t dm = 0;
-#pragma unroll
-    for (int r = 1; r < EC; ++r) dm |= (v[r - 1] > v[r]) ? (1u << r) : 0u;
-    const bool asc = dm == 0;
-    const uint64_t prev_last = wave_shr1_u64(v[EC - 1]);
-    dm |= ((lane != 0) & (prev_last > v[0])) ? 1u : 0u;
-    const bool wave_asc = __builtin_amdgcn_ballot_w64(dm != 0) == 0;             // wavefront-uniform
-    uint64_t pm_in = 0, sm_in = ~0ull;
-    uint64_t w_hi, w_lo;
-    if (wave_asc) {
-        w_hi = readlane_u64(v[EC - 1], 63);
-        w_lo = readlane_u64(v[0], 0);
-    } else {
-        uint64_t tmax = v[0], tmin = v[0];
-#pragma unroll
-        for (int r = 1; r < EC; ++r) { tmax = v[r] > tmax ? v[r] : tmax; tmin = v[r] < tmin ? v[r] : tmin; }
-        const uint64_t incl = wave_incl_max_u64(tmax);
-        pm_in = wave_shr1_u64(incl);
-        w_hi = readlane_u64(incl, 63);
-        const uint64_t incl_m = wave_incl_max_u64(wave_mirror_u64(~tmin));
-        sm_in = ~wave_mirror_u64(wave_shr1_u64(incl_m));
-        w_lo = ~readlane_u64(incl_m, 63);
-    }
-    if (lane == 0) { wmax[wave] = w_hi; wmin[wave] = w_lo; }
-    lds_barrier();                                               // (1)
-    LA_CLK(16);
-    // 2. who stays; the descent between this wavefront and the one before; the flag bytes
-    uint64_t pm_w, sm_w;
-    {
-        uint64_t a = lane < wave ? wmax[lane & 15] : 0;
-        uint64_t b = (lane > wave && lane < NT / 64) ? wmin[lane & 15] : ~0ull;
-#define LA_RED_STEP(J)                                                        \
-        {                                                                     \
-            const uint64_t oa_ = shfl_xor_u64<J>(a), ob_ = shfl_xor_u64<J>(b); \
-            a = oa_ > a ? oa_ : a;                                            \
-            b = ob_ < b ? ob_ : b;                                            \
-        }
-        LA_RED_STEP(1) LA_RED_STEP(2) LA_RED_STEP(4) LA_RED_STEP(8)
-#undef LA_RED_STEP
-        pm_w = readlane_u64(a, 0);
-        sm_w = readlane_u64(b, 0);
-    }
-    if (lane == 0) {
-        // position 0 starts a run; a later wavefront's first position does when the bin before it is larger
-        const uint64_t before0 = wave > 0 ? A[search_swz(wave * 64 * EC - 1)] : ~0ull;
-        dm |= (before0 > v[0]) ? 1u : 0u;
-    }
-    const uint64_t before = pm_in > pm_w ? pm_in : pm_w, behind = sm_in < sm_w ? sm_in : sm_w;
-    const bool moves = !(asc & (before < v[0]) & (v[EC - 1] < behind));
-    uint32_t mask = 0;
-    if (__builtin_amdgcn_ballot_w64(moves) != 0) {               // (wavefront-uniform)
-        uint64_t sm[EC];
-        {
-            uint64_t x = behind;
-#pragma unroll
-            for (int r = EC - 1; r >= 0; --r) { sm[r] = x; x = v[r] < x ? v[r] : x; }
-        }
-        uint64_t run = before;
-#pragma unroll
-        for (int r = 0; r < EC; ++r) {
-            mask |= ((run < v[r]) & (v[r] < sm[r])) ? 0u : (1u << r);
-            run = v[r] > run ? v[r] : run;
-        }
-    }
-    reinterpret_cast<uint8_t*>(dbits)[tid] = (uint8_t)dm;
-    reinterpret_cast<uint8_t*>(mbits)[tid] = (uint8_t)mask;
-    lds_barrier();                                               // (2)
-    LA_CLK(17);
-    // 3. the runs: counted by every wavefront (the decision is the workgroup's)
-    const uint64_t w0 = dbits[lane], w1 = dbits[64 + lane];
-    const uint32_t c0 = (uint32_t)__builtin_popcountll(w0), c1 = (uint32_t)__builtin_popcountll(w1);
-    const uint32_t incl = wave_incl_scan_u32(c0 | (c1 << 16));
-    const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-    const uint32_t tot0 = tot & 0xFFFFu;
-    const int R = (int)(tot0 + (tot >> 16));
-    *runs_out = R;
-    if (R > max_runs) return false;                              // (workgroup-uniform: every wavefront read the same words)
-    const uint32_t e0 = (incl & 0xFFFFu) - c0, e1 = tot0 + (incl >> 16) - c1;     // runs that start before word lane / 64 + lane
-    // which of my words hold bins that move?  (word u * 16 + wave: lane u asks)
-    const uint64_t my_m = lane < NW / 16 ? mbits[lane * 16 + wave] : 0;
-    const uint32_t work = (uint32_t)__builtin_amdgcn_ballot_w64(my_m != 0);
-    if (work != 0) {
-        // the table, by this wavefront for itself (the same values from every wavefront that builds it)
-        {
-            uint64_t w = w0;
-            uint32_t at = e0;
-            while (__builtin_amdgcn_ballot_w64(w != 0) != 0) {
-                if (w != 0) {
-                    t_start[at++] = (uint32_t)(64 * lane + __builtin_ctzll(w));
-                    w &= w - 1;
-                }
-            }
-            w = w1;
-            at = e1;
-            while (__builtin_amdgcn_ballot_w64(w != 0) != 0) {
-                if (w != 0) {
-                    t_start[at++] = (uint32_t)(64 * (64 + lane) + __builtin_ctzll(w));
-                    w &= w - 1;
-                }
-            }
-            if (lane == 0) t_start[R] = (uint32_t)N;
-        }
-        wave_lds_fence();
-        {
-            const bool have = lane < R;
-            const uint32_t st = have ? t_start[lane] : 0u, en = have ? t_start[lane + 1] : 1u;
-            const uint64_t f = A[search_swz((int)st)], l = A[search_swz((int)en - 1)];
-            const uint64_t fv = have ? f : ~0ull, lv = have ? l : 0ull;
-            const uint64_t pl = wave_incl_max_u64(lv);
-            const uint64_t sf = ~wave_mirror_u64(wave_incl_max_u64(wave_mirror_u64(~fv)));
-            t_first[lane] = fv;
-            t_last[lane] = lv;
-            t_pl[lane] = pl;
-            t_sf[lane] = sf;
-        }
-        wave_lds_fence();
-        LA_CLK(18);
-        for (uint32_t todo = work; todo != 0; todo &= todo - 1) {
-            const int c = __builtin_ctz(todo) * 16 + wave;       // the word of 64 positions (wavefront-uniform)
-            const uint64_t mw = readlane_u64(my_m, __builtin_ctz(todo));
-            const uint64_t dw = dbits[c];
-            const uint32_t cp = c < 64 ? (uint32_t)__builtin_amdgcn_readlane((int)e0, c & 63)
-                                       : (uint32_t)__builtin_amdgcn_readlane((int)e1, c & 63);
-            const bool active = ((mw >> lane) & 1) != 0;
-            const int k = 64 * c + lane;
-            const uint64_t x = A[search_swz(k)];
-            const int s = (int)cp + __builtin_popcountll(dw & ((2ull << lane) - 1ull)) - 1;      // my run
-            uint32_t rank = (uint32_t)k - t_start[s];            // the bins of my own run below me
-            int sl = s - 1, sr = s + 1;
-            bool left_on = active & (sl >= 0), right_on = active & (sr < R);
-            while (__builtin_amdgcn_ballot_w64(left_on | right_on) != 0) {
-                uint32_t llo = 0, lhi = 0, lbase = 0, rlo = 0, rhi = 0, rbase = 0;
-                if (left_on) {
-                    if (t_pl[sl] > x) {                          // something in runs 0 .. sl is above me: look into run sl
-                        const uint32_t st = t_start[sl], en = t_start[sl + 1];
-                        if (t_last[sl] > x) { llo = lbase = st; lhi = en; }
-                        else rank += en - st;
-                        --sl;
-                        left_on = sl >= 0;
-                    } else {                                     // runs 0 .. sl are all below me
-                        rank += t_start[sl + 1];
-                        left_on = false;
-                    }
-                }
-                if (right_on) {
-                    if (t_sf[sr] < x) {                          // something in runs sr .. is below me
-                        if (t_first[sr] < x) { rlo = rbase = t_start[sr]; rhi = t_start[sr + 1]; }
-                        ++sr;
-                        right_on = sr < R;
-                    } else {
-                        right_on = false;
-                    }
-                }
-                // both lower bounds, step by step side by side
-                while (__builtin_amdgcn_ballot_w64((llo < lhi) | (rlo < rhi)) != 0) {
-                    const uint32_t lm = (llo + lhi) >> 1, rm = (rlo + rhi) >> 1;
-                    const uint64_t lv = A[search_swz((int)lm)], rv = A[search_swz((int)rm)];
-                    if (llo < lhi) { if (lv < x) llo = lm + 1; else lhi = lm; }
-                    if (rlo < rhi) { if (rv < x) rlo = rm + 1; else rhi = rm; }
-                }
-                rank += (llo - lbase) + (rlo - rbase);
-            }
-            if (active) B[search_swz((int)rank)] = x;
-        }
-    }
-    lds_barrier();                                               // (3)
-    LA_CLK(19);
-    // 4. the places that moved take what arrived there
-    if (mask != 0) {
-#pragma unroll
-        for (int r = 0; r < EC; ++r)
-            if (mask & (1u << r)) rec[r] = p64_from(B[search_swz(tid * EC + r)]);
-    }
-    LA_CLK(20);
-    return true;
-}
-
 template <int EC>
 __device__ void greedy_rounds_packed(const LargeArgs& a, const uint64_t* key, int64_t P, int C, int64_t rounds,
                                      int idx_bits, void* smem) {
@@ -1882,7 +1658,6 @@ __device__ void greedy_rounds_packed(const LargeArgs& a, const uint64_t* key, in
     [[maybe_unused]] int64_t next_moved = 2;             // the next round that looks whether few of its bins move (round 1 sorts
                                                          // what round 0 made of equal bins: every bin moves)
     [[maybe_unused]] int moved_wait = 0;
-    [[maybe_unused]] int64_t next_search = 2;            // the next round that looks whether its bins are few enough runs to search
     const int tid_fixed = tid;
     for (int64_t q = 0; q < rounds; ++q) {
         // The thread index, opaque once per round: everything a round derives from it (lane predicates, LDS addresses, masks)
@@ -1896,19 +1671,7 @@ __device__ void greedy_rounds_packed(const LargeArgs& a, const uint64_t* key, in
                 // few bins move?  A topic that has the property has it round after round (the bulk of a power-law topic);
                 // one that does not (lags spread like the totals) has every bin move in every round: after a look that
                 // found more than twice what fits, the next one waits 1, 2, 4 .. 32 rounds.
-                // a few ascending runs?  Every bin that moves finds its place by search (search_sort_bins); the number of runs
-                // falls from round to round on the topics that have the property: look again after as many rounds as the count
-                // missed by in factors of two, every round once it has held.
-                if constexpr (EC == 8) {
-                    if (use_sample && a.search_max_runs > 0 && q >= next_search) {
-                        int runs = 0;
-                        sorted = search_sort_bins<EC>(rec, L, tid, a.search_max_runs, &runs);
-                        int wait = 0;
-                        for (int x = runs; x > 2 * a.search_max_runs && wait < 16; x >>= 1) ++wait;
-                        next_search = q + 1 + wait;
-                    }
-                }
-                if (!sorted && use_sample && a.no_moved_sort == 0 && q >= next_moved) {
+                if (use_sample && a.no_moved_sort == 0 && q >= next_moved) {
                     int moved = 0;
                     sorted = moved_sort_bins<EC>(rec, L, tid, a.no_sample_sort == 2 ? 20u : kMovedBucket, &moved);
                     if (sorted || moved <= 512 * EC) moved_wait = 0;
@@ -3065,7 +2828,7 @@ extern "C" __attribute__((visibility("default"))) int la_debug_lookback_stats(un
 extern "C" __attribute__((visibility("default"))) int la_debug_round_clocks(unsigned long long* out, int reset) {
     hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(g_round_clocks), sizeof(g_round_clocks));
     if (e == hipSuccess && reset) {
-        unsigned long long zero[24] = {};
+        unsigned long long zero[16] = {};
         e = hipMemcpyToSymbol(HIP_SYMBOL(g_round_clocks), zero, sizeof zero);
     }
     return e == hipSuccess ? 0 : -3;

@@ -484,7 +484,6 @@ def test_cfg5_full_size_other_forms(ctx):
     lag = oracle.compute_lags(w.begin, w.end, w.committed, False)
     exp = _round_form(w.part_off, w.partition_id, lag, w.cons_off, w.cons_rank)
     for flags, what in ((0, "default"), (N.LA_FLAG_NO_RUN_MERGE, "runs sorted, not merged"),
-                        (N.LA_FLAG_NO_SEARCH_SORT, "round 5's rounds (no search rounds)"),
                         (N.LA_FLAG_SORT_MULTIKERNEL, "four-kernel radix passes"),
                         (N.LA_FLAG_NO_RUN_MERGE | N.LA_FLAG_SORT_MULTIKERNEL | N.LA_FLAG_SAMPLE_TIGHT, "all three hooks"),
                         (N.LA_FLAG_NO_SAMPLE_SORT | N.LA_FLAG_NO_RUN_MERGE, "full network every round")):
@@ -897,8 +896,7 @@ def test_large_rounds_merge_ascending_runs(ctx, p, c, kind):
                            lag.copy(), np.zeros(p, np.int64), lag, np.array([0, c], np.int64),
                            np.sort(rng.choice(3 * c + 1, c, replace=False)).astype(np.int32), p, c)
     exp = oracle.assign_flat(w.part_off, w.partition_id, w.lag, w.cons_off, w.cons_rank)
-    for flags, what in ((N.LA_FLAG_NO_SEARCH_SORT, "runs merged"), (N.LA_FLAG_NO_SEARCH_SORT | N.LA_FLAG_NO_RUN_MERGE, "runs sorted"),
-                        (0, "default: movers placed by search where the runs are few")):
+    for flags, what in ((0, "runs merged"), (N.LA_FLAG_NO_RUN_MERGE, "runs sorted")):
         got = _run_device(ctx, w, N.LA_ALGO_AUTO, use_lag=True, flags=flags)
         for g, e, name in zip(got, exp, ("partition order", "member", "totals")):
             np.testing.assert_array_equal(g, e, err_msg="%s, %s" % (name, what))
@@ -936,11 +934,9 @@ def test_large_rounds_sort_only_the_bins_that_move(ctx, p, c, kind):
                            lag.copy(), np.zeros(p, np.int64), lag, np.array([0, c], np.int64),
                            np.sort(rng.choice(3 * c + 1, c, replace=False)).astype(np.int32), p, c)
     exp = oracle.assign_flat(w.part_off, w.partition_id, w.lag, w.cons_off, w.cons_rank)
-    S = N.LA_FLAG_NO_SEARCH_SORT                                 # (round 6's search rounds off: the forms of rounds 3-5)
-    for flags, what in ((0, "default"), (S, "moved sort"), (S | N.LA_FLAG_NO_MOVED_SORT, "moved sort off"),
-                        (S | N.LA_FLAG_NO_MOVED_SORT | N.LA_FLAG_NO_RUN_MERGE, "sample sort only"),
-                        (S | N.LA_FLAG_SAMPLE_TIGHT, "tight limits"), (S | N.LA_FLAG_NO_RUN_MERGE, "moved sort, no run merge"),
-                        (N.LA_FLAG_NO_MOVED_SORT | N.LA_FLAG_NO_RUN_MERGE, "search rounds, else sample sort")):
+    for flags, what in ((0, "default"), (N.LA_FLAG_NO_MOVED_SORT, "moved sort off"),
+                        (N.LA_FLAG_NO_MOVED_SORT | N.LA_FLAG_NO_RUN_MERGE, "sample sort only"),
+                        (N.LA_FLAG_SAMPLE_TIGHT, "tight limits"), (N.LA_FLAG_NO_RUN_MERGE, "moved sort, no run merge")):
         got = _run_device(ctx, w, N.LA_ALGO_AUTO, use_lag=True, flags=flags)
         for g, e, name in zip(got, exp, ("partition order", "member", "totals")):
             np.testing.assert_array_equal(g, e, err_msg="%s, %s" % (name, what))

@@ -281,110 +281,3 @@ def test_generated_sort_networks_sort_in_the_lane_level_simulator_and_are_curren
             if not text.startswith("s_nop"):
                 for r in (ops[:2] if text.startswith("v_permlane") else ops[:1]):
                     last[r] = i
-
-
-# ---- round 6: search_sort_bins (la_large.hip) -- a bin's place from lower bounds in the neighbouring runs -------------------------
-def _search_round_model(v, max_runs=64):
-    """The device algorithm step for step on one array of distinct values: runs from the descent bits, the table (start, first,
-    last, PL = largest bin of runs 0..s, SF = smallest bin of runs s..), who stays, and for every bin that moves the walk over the
-    neighbouring runs while PL > x (left) / SF < x (right) with a lower bound in each run it has to look into.  Returns (sorted
-    array or None when there are more runs than max_runs, runs, movers, most runs any mover looked into)."""
-    v = np.asarray(v, dtype=np.uint64)
-    n = v.size
-    start_flag = np.ones(n, dtype=bool)
-    start_flag[1:] = v[:-1] > v[1:]
-    starts = np.nonzero(start_flag)[0]
-    R = starts.size
-    if R > max_runs:
-        return None, R, 0, 0
-    t_start = np.concatenate((starts, [n]))
-    first, last = v[t_start[:-1]], v[t_start[1:] - 1]
-    PL = np.maximum.accumulate(last)
-    SF = np.minimum.accumulate(first[::-1])[::-1]
-    pm = np.maximum.accumulate(np.concatenate(([np.uint64(0)], v[:-1])))
-    sm = np.minimum.accumulate(np.concatenate((v[1:], [np.uint64(2**64 - 1)]))[::-1])[::-1]
-    moves = ~(((np.arange(n) == 0) | (pm < v)) & ((np.arange(n) == n - 1) | (v < sm)))
-    run_of = np.cumsum(start_flag) - 1
-    out = v.copy()
-    taken = np.zeros(n, dtype=bool)
-    looked_max = 0
-    for k in np.nonzero(moves)[0]:
-        x, s = v[k], run_of[k]
-        rank = k - t_start[s]
-        looked = 0
-        sl = s - 1
-        while sl >= 0:
-            if PL[sl] > x:
-                if last[sl] > x:
-                    rank += np.searchsorted(v[t_start[sl]:t_start[sl + 1]], x, side="left")
-                    looked += 1
-                else:
-                    rank += t_start[sl + 1] - t_start[sl]
-                sl -= 1
-            else:
-                rank += t_start[sl + 1]
-                break
-        sr = s + 1
-        while sr < R and SF[sr] < x:
-            if first[sr] < x:
-                rank += np.searchsorted(v[t_start[sr]:t_start[sr + 1]], x, side="left")
-                looked += 1
-            sr += 1
-        assert moves[rank] and not taken[rank]              # movers permute among the places of movers
-        taken[rank] = True
-        out[rank] = x
-        looked_max = max(looked_max, looked)
-    return out, R, int(moves.sum()), looked_max
-
-
-@pytest.mark.parametrize("kind", ["ones", "steps", "bulk", "pairs", "sorted", "tworuns", "pareto_round"])
-def test_search_round_model_sorts(kind):
-    rng = np.random.default_rng(3 + len(kind))
-    n = 8192
-    idx_bits = 13
-    for rep in range(6):
-        totals = np.sort(rng.integers(0, 1 << 24, n)).astype(np.int64)
-        if kind == "ones":                                  # lags that differ by one: whole stretches pass each other
-            totals = np.sort(rng.integers(0, 2000, n)).astype(np.int64)
-            lags = np.sort(1000 + rng.integers(0, 4, n))[::-1]
-        elif kind == "steps":
-            lags = np.sort(rng.integers(0, 12, n) * 5000)[::-1]
-        elif kind == "bulk":                                # a dense bulk at the low end, far-apart bins above it
-            totals = np.sort(np.concatenate((rng.integers(0, 300, n // 8), (1 << 30) * (1 + np.arange(n - n // 8))))).astype(np.int64)
-            lags = np.sort(1500 + rng.integers(0, 6, n))[::-1]
-        elif kind == "pairs":
-            totals = np.arange(n, dtype=np.int64) * 1000
-            lags = np.sort(rng.integers(0, 3, n) * 1500)[::-1]
-        elif kind == "sorted":
-            lags = np.full(n, 7)
-        elif kind == "tworuns":
-            lags = np.where(np.arange(n) < n // 3, 10**6, 0)
-        else:                                               # a late round of a power-law topic: few distinct lags, dense low end
-            totals = np.sort(np.floor(30000 + 2000 * rng.pareto(1.5, n))).astype(np.int64)
-            lags = np.sort(np.floor(1580 + 12 * rng.random(n)))[::-1].astype(np.int64)
-        ids = rng.permutation(n).astype(np.int64)
-        order = np.lexsort((ids, totals))                   # bins ascending by (total, index): the state a round starts from
-        t_sorted, id_sorted = totals[order], ids[order]
-        v = ((t_sorted + lags.astype(np.int64)) << idx_bits) | id_sorted
-        got, runs, movers, looked = _search_round_model(v.astype(np.uint64))
-        if got is None:
-            assert runs > 64
-            continue
-        assert np.array_equal(got, np.sort(v.astype(np.uint64))), (kind, rep, runs, movers)
-        if kind == "sorted":
-            assert runs == 1 and movers == 0
-
-
-def test_search_round_position_swizzle_is_conflict_free():
-    """Position p lives at word p ^ ((p >> 5) & 7): a bijection on [0, n) under which a thread's 8 consecutive positions
-    (half a wavefront: 32 lanes at a stride of 8 words) and 32 consecutive positions both touch 32 different banks of 8 bytes."""
-    n = 8192
-    p = np.arange(n)
-    a = p ^ ((p >> 5) & 7)
-    assert np.array_equal(np.sort(a), p)
-    for r in range(8):
-        for t0 in range(0, 1024, 32):
-            banks = a[(np.arange(t0, t0 + 32) * 8 + r)] % 32
-            assert np.unique(banks).size == 32
-    for p0 in range(0, n, 32):
-        assert np.unique(a[p0:p0 + 32] % 32).size == 32

@@ -114,61 +114,3 @@ def test_keys_first_sort_by_the_sample_at_five_million(ctx, kind, expect_first):
         os.environ.pop("LA_SORT_KEYS_FIRST", None)
 
 
-# ---- round 6: greedy rounds whose bins are a few ascending runs place the bins that move by search (search_sort_bins) ----------
-def _search_topic(kind, p, c, seed):
-    rng = np.random.default_rng(seed)
-    if kind == "pareto":
-        from test_gpu_parity import _pareto_topic
-        return _pareto_topic(seed, p, c)
-    first = None
-    if kind == "ties":
-        lag = rng.integers(0, 5, p) * 1000
-    elif kind == "zero":
-        lag = np.zeros(p, dtype=np.int64)
-    elif kind == "few":
-        lag = rng.choice(np.array([7, 7, 7, 8, 1_000_000]), p)
-    elif kind == "steps":
-        lag = (np.arange(p) // 997)[::-1] + rng.integers(0, 2, p)
-    elif kind == "ones":                                          # lags differ by one: whole stretches pass each other
-        lag = 1000 + rng.integers(0, 3, p)
-    elif kind == "bulk":                                          # a dense bulk of a quarter of the consumers, the rest far apart
-        first = np.empty(c, dtype=np.int64)
-        far = c - c // 4
-        first[:far] = 10**13 - np.arange(far, dtype=np.int64) * 10**9
-        first[far:] = 10**6 + rng.integers(0, 50, c - far)
-        lag = np.concatenate([first, 2000 + rng.integers(0, 4, p - c)])
-        lag = rng.permutation(lag)
-    elif kind == "twobulks":                                      # two dense groups far from each other, sparse bins between
-        first = np.empty(c, dtype=np.int64)
-        a, b = c // 3, 2 * c // 3
-        first[:a] = 10**6 + rng.integers(0, 30, a)
-        first[a:b] = 10**9 * (1 + np.arange(b - a, dtype=np.int64))
-        first[b:] = 10**13 + rng.integers(0, 30, c - b)
-        lag = rng.permutation(np.concatenate([first, 500 + rng.integers(0, 6, p - c)]))
-    else:
-        raise ValueError(kind)
-    lag = np.ascontiguousarray(lag, dtype=np.int64)
-    return synth.Workload(kind, 1, np.array([0, p], np.int64), rng.permutation(p).astype(np.int32), np.zeros(p, np.int64),
-                          lag.copy(), np.zeros(p, np.int64), lag, np.array([0, c], np.int64),
-                          np.sort(rng.choice(3 * c + 1, c, replace=False)).astype(np.int32), p, c)
-
-
-@pytest.mark.parametrize("p,c,kind", [
-    (400_000, 8192, "pareto"), (300_000, 5000, "pareto"), (200_000, 8192, "ties"), (150_000, 5000, "zero"),
-    (100_000, 4100, "few"), (250_000, 8000, "steps"), (300_000, 8192, "ones"), (200_000, 8192, "bulk"),
-    (160_000, 6000, "twobulks"), (90_000, 4097, "ones"), (70_000, 8192, "bulk"),
-])
-def test_large_rounds_place_the_bins_that_move_by_search(ctx, p, c, kind):
-    """search_sort_bins (la_large.hip): in a round with at most LA_SEARCH_MAX_RUNS ascending runs every bin that moves finds its
-    place by lower bounds in the neighbouring runs.  The same result with the limit at 1 (only rounds that are in order already),
-    2, 5, 16 (default) and 64 runs, as with LA_FLAG_NO_SEARCH_SORT -- the oracle's."""
-    w = _search_topic(kind, p, c, 11 * p + c)
-    exp = oracle.assign_flat(w.part_off, w.partition_id, w.lag, w.cons_off, w.cons_rank)
-    try:
-        for limit in ("1", "2", "5", "16", "64"):
-            os.environ["LA_SEARCH_MAX_RUNS"] = limit
-            for flags in (0, N.LA_FLAG_NO_MOVED_SORT | N.LA_FLAG_NO_RUN_MERGE):
-                _same3(_device_call(ctx, w, flags=flags), exp, "%s, at most %s runs, flags %d" % (kind, limit, flags))
-    finally:
-        os.environ.pop("LA_SEARCH_MAX_RUNS", None)
-    _same3(_device_call(ctx, w, flags=N.LA_FLAG_NO_SEARCH_SORT), exp, "%s, no search rounds" % kind)

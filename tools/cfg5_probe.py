@@ -15,8 +15,7 @@ def main():
     ap.add_argument("--partitions", type=int, default=1048576)
     ap.add_argument("--consumers", type=int, default=8192)
     ap.add_argument("--reps", type=int, default=5)
-    ap.add_argument("--sweep", type=int, nargs="*", default=None, help="also run with LA_SEARCH_MAX_RUNS = each of these")
-    ap.add_argument("--quick", action="store_true", help="only the default form, round 5's form and the sweep")
+    ap.add_argument("--quick", action="store_true", help="only the default form")
     ap.add_argument("--dist", default="pareto")
     args = ap.parse_args()
     import torch
@@ -43,18 +42,10 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream
     lag = np.maximum(w.end - np.where(w.committed >= 0, w.committed, w.begin), 0)
     exp = round_form(w.part_off, w.partition_id, lag, w.cons_off, w.cons_rank)
-    S = N.LA_FLAG_NO_SEARCH_SORT
-    forms = [(0, "default", None), (S, "no search", None)]
-    forms += [(0, "search<=%d" % r, str(r)) for r in (args.sweep or [])]
-    if not args.quick:
-        forms += [(S | N.LA_FLAG_NO_MOVED_SORT, "run merge", None),
-                  (S | N.LA_FLAG_NO_MOVED_SORT | N.LA_FLAG_NO_RUN_MERGE, "sample sort", None), (N.LA_FLAG_NO_SAMPLE_SORT, "full network", None),
-                  (S | N.LA_FLAG_SAMPLE_TIGHT | N.LA_FLAG_NO_RUN_MERGE, "tight", None)]
-    for flags, what, limit in forms:
-        if limit is None:
-            os.environ.pop("LA_SEARCH_MAX_RUNS", None)
-        else:
-            os.environ["LA_SEARCH_MAX_RUNS"] = limit
+    forms = ((0, "default"), (N.LA_FLAG_NO_MOVED_SORT, "run merge"),
+             (N.LA_FLAG_NO_MOVED_SORT | N.LA_FLAG_NO_RUN_MERGE, "sample sort"), (N.LA_FLAG_NO_SAMPLE_SORT, "full network"),
+             (N.LA_FLAG_SAMPLE_TIGHT | N.LA_FLAG_NO_RUN_MERGE, "tight"))
+    for flags, what in (forms[:1] if args.quick else forms):
         b.flags = flags | N.LA_FLAG_PROFILE
         ctx.assign_batch_device(b, stream); ctx.sync(stream)
         ts = []
@@ -68,13 +59,12 @@ def main():
         ok = all(np.array_equal(a, e) for a, e in zip((out_pid.cpu().numpy(), out_rank.cpu().numpy(), out_total.cpu().numpy()), exp))
         k, s, g = np.mean(ts, axis=0)
         if hasattr(ctx._lib, "la_debug_round_clocks"):      # development build (-DLA_ROUND_CLOCKS)
-            clk = (ctypes.c_ulonglong * 24)()
+            clk = (ctypes.c_ulonglong * 16)()
             ctx._lib.la_debug_round_clocks(clk, 1)
             names = ("sample sort", "bucket search", "slots+scan", "stage", "rank walk", "final order", "add+stores",
                      "moved: who stays", "moved: across waves", "moved: hand in", "moved: samples", "moved: buckets",
-                     "moved: scan", "moved: stage", "moved: walk", "moved: back",
-                     "search: values+extremes", "search: who stays", "search: table", "search: ranks", "search: back")
-            tot = float(sum(clk[:21])) or 1.0
+                     "moved: scan", "moved: stage", "moved: walk", "moved: back")
+            tot = float(sum(clk[:16])) or 1.0
             print("   cycles per phase (thread 0, %d calls): " % (args.reps + 1) +
                   ", ".join("%s %.1f%%" % (n, 100.0 * clk[i] / tot) for i, n in enumerate(names) if clk[i]) +
                   "; total %.3g = %.0f per round" % (tot, tot / (args.reps + 1) / 127.0))
