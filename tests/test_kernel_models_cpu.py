@@ -281,3 +281,4 @@ def test_generated_sort_networks_sort_in_the_lane_level_simulator_and_are_curren
             if not text.startswith("s_nop"):
                 for r in (ops[:2] if text.startswith("v_permlane") else ops[:1]):
                     last[r] = i
+

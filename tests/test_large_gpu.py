@@ -114,3 +114,4 @@ def test_keys_first_sort_by_the_sample_at_five_million(ctx, kind, expect_first):
         os.environ.pop("LA_SORT_KEYS_FIRST", None)
 
 
+

@@ -238,3 +238,46 @@ def test_order_exact_is_surfaced_when_a_bucket_would_treeify():
     zeros = {(t, p): 0 for t in topics for p in (0, 1)}
     a.assign(metadata, subs, FakeOffsets(zeros, {k: 7 for k in zeros}, {}))
     assert a.last_order_exact() is False and any("tree-bin" in w for w in warnings)
+
+
+# ---- round 6: the GPU path against the SECOND reading of the reference (oracle/literal_py.py), on what the reference's own
+# tests leave unpinned: memberIds whose string order is not their numeric order (and UTF-16 order), shuffled partition ids with
+# tied lags, negative lags, totals that wrap a long, a topic listed twice, topics without a lag list -------------
+@pytest.mark.parametrize("kind", ["numbered", "utf16", "prefixes"])
+@pytest.mark.parametrize("lags", ["ties", "negative", "wrapping", "uniform"])
+def test_static_assign_against_the_second_reading(kind, lags):
+    from oracle import literal_py as lit
+    rng = random.Random(hash((kind, lags)) % 100000)
+    pools = {"numbered": lambda i: "consumer-%d" % i,
+             "utf16": lambda i: "%s-%d" % (["z", "é", "￮", "\U0001f600", "퟿", "", "Z", "中"][i % 8], i // 8),
+             "prefixes": lambda i: ["a", "ab", "abc", "b", "B", "aB", "a0", "a-", "", "a-1", "a-10", "a-2"][i % 12] + ("" if i < 12 else str(i))}
+    for trial in range(10):
+        members = [pools[kind](i) for i in rng.sample(range(40), rng.randint(1, 14))]
+        topics = ["topic-%d" % i for i in range(rng.randint(1, 6))]
+        subs = {}
+        for m in members:
+            mine = [t for t in topics if rng.random() < 0.7]
+            if mine and rng.random() < 0.3:
+                mine.append(mine[0])
+            subs[m] = mine
+        pl = {}
+        for t in topics:
+            if rng.random() < 0.15:
+                continue
+            p = rng.randint(0, 60)
+            ids = rng.sample(range(3 * p + 1), p)
+            if lags == "ties":
+                ls = [rng.choice([0, 1000, 2000]) for _ in range(p)]
+            elif lags == "negative":
+                ls = [rng.randint(-(1 << 40), 1 << 40) for _ in range(p)]
+            elif lags == "wrapping":
+                ls = [rng.randint(1 << 62, (1 << 63) - 1) for _ in range(p)]
+            else:
+                ls = [rng.randint(0, 1 << 40) for _ in range(p)]
+            pl[t] = [TopicPartitionLag(t, i, l) for i, l in zip(ids, ls)]
+        got = LagBasedPartitionAssignor.assign_lags(pl, subs)
+        exp = lit.assign({t: [tuple(e) for e in v] for t, v in pl.items()}, subs)
+        assert set(got) == set(exp) == set(subs)
+        for m in subs:                                       # list order inside every topic; across topics it is the HashMap's
+            for t in topics:
+                assert [tuple(tp) for tp in got[m] if tp[0] == t] == [tp for tp in exp[m] if tp[0] == t], (trial, m, t)
