@@ -35,6 +35,25 @@ def main():
             lines = [l for l in open(p) if l.startswith("{")]
             if lines:
                 open(os.path.join(dst, "%s_%s.json" % (name, b)), "w").write(lines[-1])
+    # the other steps of tools/gpu_session.sh: kernel stats of the cfg5 / block / sort probes, text records
+    for sub, label in (("stats_cfg5", "cfg5"), ("stats_block", "block"), ("stats_sort", "sort")):
+        for f in glob.glob(os.path.join(src, sub, "*", "*kernel_stats.csv")):
+            rows = list(csv.reader(open(f)))
+            with open(os.path.join(dst, "%s_%s_kernel_stats.csv" % (name, label)), "w", newline="") as fh:
+                w = csv.writer(fh, quoting=csv.QUOTE_ALL)
+                for r in rows:
+                    r[0] = r[0][:160]
+                    w.writerow(r)
+    for txt, out in (("cfg5_probe.txt", "cfg5_probe.txt"), ("block_probe.txt", "block_probe.txt"), ("stress.txt", "stress.txt"),
+                     ("latency.txt", "latency_probe.txt"), ("latency_c.txt", "latency_c.txt"), ("sort_timeline.txt", "sort_timeline.txt"),
+                     ("bench_digest.txt", "bench_digest.txt"), ("pmc_block_summary.json", "block_pmc_summary.json")):
+        if os.path.exists(os.path.join(src, txt)):
+            shutil.copyfile(os.path.join(src, txt), os.path.join(dst, "%s_%s" % (name, out)))
+    if os.path.exists(os.path.join(src, "pytest.log")):
+        tail = [l for l in open(os.path.join(src, "pytest.log")) if any(k in l for k in ("passed", "failed", "FAILED", "rror", "pytest exit"))]
+        open(os.path.join(dst, name + "_gpu_tests.txt"), "w").write("".join(tail[-20:]))
+    if not os.path.exists(os.path.join(src, "pmc_summary.json")):
+        return
     summ = json.load(open(os.path.join(src, "pmc_summary.json")))
     ours = {k: v for k, v in summ["kernels"].items() if "la::" in k}
     json.dump({"calibration": summ["calibration"], "kernels": ours},

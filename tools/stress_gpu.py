@@ -115,7 +115,8 @@ def main():
     # by side; topics beyond 8 192 consumers; the sparse-begin entry, dense and sparse, pageable and pinned (in place / three streams)
     n4 = int(sys.argv[6]) if len(sys.argv) > 6 else 40
     from oracle.round_form import round_form
-    spec4 = importlib.util.spec_from_file_location("tr4", os.path.join(ROOT, "tests", "test_round4_gpu.py"))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    spec4 = importlib.util.spec_from_file_location("tr4", os.path.join(ROOT, "tests", "gpu_helpers.py"))     # (the tests' helpers)
     tr4 = importlib.util.module_from_spec(spec4); spec4.loader.exec_module(tr4)
     os.environ["LA_SORT_KEYS_FIRST"] = "2"
     try:
@@ -145,8 +146,7 @@ def main():
     # calls of every size up to the lanes through la_assign_batch_grouped on pageable and on pinned arrays, hinted or not:
     # zero-copy staging with the fused end, the two-launch grouping, mapped arrays read in place -- against the oracle + a stable sort
     n5 = int(sys.argv[7]) if len(sys.argv) > 7 else 40
-    spec5 = importlib.util.spec_from_file_location("tr5", os.path.join(ROOT, "tests", "test_round5_gpu.py"))
-    tr5 = importlib.util.module_from_spec(spec5); spec5.loader.exec_module(tr5)
+    tr5 = tr4
     for seed in range(S0, S0 + n5):
         rng = np.random.default_rng(seed)
         C = int(rng.integers(65, 257))
