@@ -31,6 +31,7 @@
  *                           (Main.java:344-356) knows for free -- the largest end offset and partition id it walked past
  *   la_last_phase_times     nothing: measurement hook (radix-sort phase against the HBM roofline)
  *   la_device_features, la_last_pipeline, la_last_launches   nothing: diagnostics (what the library found / did)
+ *   la_wake                       nothing in the reference: the head start its RPC phase (Main.java:147) gives the device
  *
  * Data model (SoA; TopicPartitionLag, Main.java:431-455, flattened):
  *   topic t owns partitions [part_off[t], part_off[t+1]) of the per-partition arrays and
@@ -228,8 +229,9 @@ const char *la_last_error(const la_ctx *ctx);
  *                format of the all-gather), la_assign_batch_sparse / la_assign_batch_grouped_sparse (begin offsets only
  *                where there is no committed offset); every entry point restores the caller's current HIP device
  *   0.4.0 (400)  round 5: la_hint_next_call (the caller's bounds on lags and ids reach the host-buffer calls: one tile launch
- *                instead of two), la_last_launches, la_last_phase_times_sized */
-#define LA_VERSION 400
+ *                instead of two), la_last_launches, la_last_phase_times_sized
+ *   0.5.0 (500)  round 6: la_wake (the device's queues woken while the host still fetches offsets); LA_FLAG values unchanged */
+#define LA_VERSION 500
 int la_version(void);
 
 /* computePartitionLag over n partitions (host buffers).  begin_off may be NULL when
@@ -260,6 +262,16 @@ typedef struct la_call_hints {
     int64_t max_partition_id;    /* LA_HINT_BOUNDS */
 } la_call_hints;
 int la_hint_next_call(la_ctx *ctx, const la_call_hints *hints);
+
+/* Wake the device's queues for the assign call that is about to come (since ABI 0.5.0).  Asynchronous, returns at once: one empty
+ * kernel on every stream the context's host-buffer calls use.  What it is for: Kafka calls assign() on the group leader once per
+ * rebalance -- minutes apart -- and the reference's assign() spends its first milliseconds on broker round trips
+ * (readTopicPartitionLags, Main.java:147, :317-365) before it has a single offset to hand over.  The first submission to a queue
+ * that has been idle for more than a few milliseconds costs ~100 us before its first instruction runs (tools/cold_probe.py on
+ * MI355X: a 100-partition la_assign_batch_grouped takes 28 us back to back, 150-180 us after 50 ms of idle, 70-85 us when
+ * la_wake preceded it by 0.3-5 ms); a host that calls la_wake when it ENTERS assign() moves that cost under its own RPCs.
+ * Optional, never needed for correctness; calling it when no assign call follows costs one empty launch. */
+int la_wake(la_ctx *ctx);
 
 /* Kernel launches the last host-buffer call (or the last la_assign_batch_device[_on] call) on this context enqueued -- every
  * kernel of the library counts, copies and memsets do not.  Diagnostics / tests: a batch of tile-sized topics whose hints prove

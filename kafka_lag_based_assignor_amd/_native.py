@@ -41,7 +41,7 @@ EXPORTED_SYMBOLS = (
     "la_allgather_results", "la_assign_batch_grouped",
     "la_wire_format_for", "la_pack_results_on", "la_unpack_results_on", "la_allgather_packed",
     "la_assign_batch_sparse", "la_assign_batch_grouped_sparse",
-    "la_hint_next_call", "la_last_launches", "la_last_phase_times_sized",
+    "la_hint_next_call", "la_last_launches", "la_last_phase_times_sized", "la_wake",
 )
 
 _i64p = ctypes.POINTER(ctypes.c_int64)
@@ -210,6 +210,8 @@ def load() -> ctypes.CDLL:
     L.la_hint_next_call.argtypes = [ctypes.c_void_p, ctypes.POINTER(CallHints)]
     L.la_last_launches.restype = ctypes.c_int64
     L.la_last_launches.argtypes = [ctypes.c_void_p]
+    L.la_wake.restype = ctypes.c_int
+    L.la_wake.argtypes = [ctypes.c_void_p]
     L.la_last_phase_times_sized.restype = ctypes.c_int
     L.la_last_phase_times_sized.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]
     _lib = L
@@ -397,6 +399,11 @@ class Context:
     def last_launches(self) -> int:
         """Kernel launches the last call on this context enqueued (la_last_launches)."""
         return int(self._lib.la_last_launches(self._h))
+
+    def wake(self) -> None:
+        """la_wake: one empty kernel on every stream of the context, asynchronously -- for the moment a host ENTERS assign(),
+        milliseconds before it has offsets to hand over."""
+        self._check(self._lib.la_wake(self._h))
 
     # -- host-buffer entry points ------------------------------------------------
     def compute_lag(self, begin, end, committed, reset_mode: int) -> np.ndarray:

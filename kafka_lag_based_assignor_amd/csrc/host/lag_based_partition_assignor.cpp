@@ -335,6 +335,14 @@ Assignment LagBasedPartitionAssignor::assign(const OrderedMap<std::vector<TopicP
 
 Assignment LagBasedPartitionAssignor::assign(const Cluster& metadata, const GroupSubscription& subscriptions,
                                              OffsetSource& offsets) {
+    // The device's queues are idle when a rebalance comes (Kafka calls the leader's assign() minutes apart) and the first
+    // submission to an idle queue costs ~100 us: wake them NOW, asynchronously -- the three broker round trips below
+    // (Main.java:147 -> :317-365) take milliseconds before there is an offset to hand over.  Best effort: a failure here is
+    // the assign call's to report.
+    {
+        std::lock_guard<std::mutex> lock(g_ctx_mutex);
+        try { (void)la_wake(shared_ctx_locked()); } catch (const std::exception&) {}
+    }
     // topicSubscriptions is a HashMap<memberId, topics> filled with put (Main.java:141-146);
     // the static assign then walks it in HashMap order.
     GroupSubscription hashed;

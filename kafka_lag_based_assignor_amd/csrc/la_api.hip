@@ -2157,6 +2157,19 @@ LA_API int la_last_pipeline(const la_ctx* ctx) { return ctx ? ctx->last_pipeline
 
 LA_API int64_t la_last_launches(const la_ctx* ctx) { return ctx ? ctx->last_launches : (int64_t)LA_EINVAL; }
 
+// Asynchronous: one empty kernel on every stream a host-buffer call of this context may use.  Nothing waits for them; the next
+// call's work queues behind them on the same streams.
+LA_API int la_wake(la_ctx* ctx) {
+    if (!ctx) return LA_EINVAL;
+    DeviceGuard restore_device;
+    for (Shard& sh : ctx->shards) {
+        LA_HIP(ctx, hipSetDevice(sh.device));
+        for (Lane& ln : sh.lanes)
+            if (ln.stream) LA_HIP(ctx, la::wake_launch(ln.stream));
+    }
+    return LA_OK;
+}
+
 LA_API int la_hint_next_call(la_ctx* ctx, const la_call_hints* hints) {
     if (!ctx) return LA_EINVAL;
     ctx->hints_set = false;

@@ -477,3 +477,42 @@ def test_a_call_that_fails_before_it_starts_spends_the_hint(ctx):
     ctx.hint_next_call(((1 << 31), 255))
     with pytest.raises(N.LagAssignError):
         ctx.assign_batch(w.part_off, w.partition_id, w.begin, big, w.committed, N.LA_RESET_EARLIEST, w.cons_off, w.cons_rank)
+
+
+def test_la_wake_is_harmless_and_asynchronous(ctx):
+    """la_wake (ABI 0.5.0): one empty launch per stream, for the moment a host enters assign().  Before a call, twice, between a
+    hint and its call, with no call behind it, on a multi-shard context, on a context that has not run anything yet: the
+    results are the oracle's and the pending hint survives it (the wake is not an assign call)."""
+    import time
+    assert N.load().la_version() >= 500
+    w = synth.make_uniform("wake", 51, 300, 100, 8, "uniform40")
+    a = (w.part_off, w.partition_id, w.begin, w.end, w.committed, N.LA_RESET_EARLIEST, w.cons_off, w.cons_rank)
+    exp = oracle.assign_flat(w.part_off, w.partition_id, oracle.compute_lags(w.begin, w.end, w.committed, False), w.cons_off, w.cons_rank)
+    fresh = N.Context(0)
+    try:
+        fresh.wake()                                               # the very first thing a context is asked to do
+        _same3(fresh.assign_batch(*a), exp, "fresh context")
+    finally:
+        fresh.close()
+    ctx.wake()
+    ctx.wake()
+    _same3(ctx.assign_batch(*a), exp, "after two wakes")
+    ctx.hint_next_call(N.offset_bounds(w.begin, w.end, w.committed, w.partition_id))
+    ctx.wake()
+    _same3(ctx.assign_batch(*a), exp, "hint, wake, call")
+    plain = ctx.last_launches()
+    _same3(ctx.assign_batch(*a), exp, "no hint")
+    assert ctx.last_launches() >= plain                            # (the hinted call was the one-launch form: the wake did not eat the hint)
+    t0 = time.perf_counter()
+    for _ in range(200):
+        ctx.wake()
+    per = (time.perf_counter() - t0) / 200
+    assert per < 200e-6, per                                       # asynchronous: a launch, not a wait
+    _same3(ctx.assign_batch(*a), exp, "behind 200 wakes")
+    multi = N.Context([0, 0], flags=N.LA_CREATE_SPLIT_ALWAYS | 2)
+    try:
+        multi.wake()
+        _same3(multi.assign_batch(*a), exp, "two shards")
+    finally:
+        multi.close()
+    assert N.load().la_wake(None) == N.LA_EINVAL

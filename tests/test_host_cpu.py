@@ -487,13 +487,13 @@ def test_java_host_hints_bounds_and_falls_back_to_the_reference_by_default():
     assert "import com.github.grantneale.kafka.LagBasedPartitionAssignor" not in host
 
 
-def test_library_exports_the_round5_symbols_and_version():
+def test_library_exports_the_round5_and_round6_symbols_and_version():
     from kafka_lag_based_assignor_amd import _native as N
     lib = N.load()
-    assert lib.la_version() == 400
+    assert lib.la_version() == 500
     header = open(os.path.join(ROOT, "include", "lagassign.h")).read()
-    assert "#define LA_VERSION 400" in header
-    for sym in ("la_hint_next_call", "la_last_launches", "la_last_phase_times_sized"):
+    assert "#define LA_VERSION 500" in header
+    for sym in ("la_hint_next_call", "la_last_launches", "la_last_phase_times_sized", "la_wake"):
         assert sym in header and getattr(lib, sym)
     # la_call_hints of the ctypes binding is the header's struct: 4 + 4 + 8 + 8 bytes
     import ctypes

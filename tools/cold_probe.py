@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """What a REAL rebalance pays: one host-buffer call after the GPU idled (a group leader rebalances once in a while, not back
 to back).  For each batch: the warm median (back-to-back calls), the call after `idle` seconds of nothing, and the same cold
-call when something woke the device `lead` milliseconds earlier (a 1-element la_compute_lag: what a host could issue at the top
-of assign(), before the broker round trips that fetch the offsets).
+call when la_wake went out `lead` milliseconds earlier (what a host issues at the top of assign(), before the broker round
+trips that fetch the offsets); controls: the host core kept busy with the device idle, a spin kernel on another stream.
     python tools/cold_probe.py [--idle 0.2 1.0] [--lead 0.5 2 10]
 """
 import argparse, os, sys, time
@@ -17,6 +17,7 @@ def main():
     ap.add_argument("--idle", type=float, nargs="*", default=[0.05, 0.3, 1.0])
     ap.add_argument("--lead", type=float, nargs="*", default=[0.2, 1.0, 5.0])
     ap.add_argument("--reps", type=int, default=7)
+    ap.add_argument("--wake", choices=["wake", "lag"], default="wake")
     ap.add_argument("--spin", type=float, nargs="*", default=[100, 1000, 4000], help="device spin kernels of this many us as the wake-up")
     args = ap.parse_args()
     ctx = N.Context(0)
@@ -71,7 +72,10 @@ def main():
             woke = []
             for _ in range(args.reps):
                 time.sleep(idle)
-                ctx.compute_lag(None, one, one, N.LA_RESET_LATEST)          # the wake-up: one tiny kernel + its copies
+                if args.wake == "lag":
+                    ctx.compute_lag(None, one, one, N.LA_RESET_LATEST)      # (round 6's first probe: one tiny kernel + its copies + a wait)
+                else:
+                    ctx.wake()                                              # la_wake: one empty launch per stream, asynchronous
                 t_w = time.perf_counter()
                 while (time.perf_counter() - t_w) * 1e3 < lead:
                     pass
