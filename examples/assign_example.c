@@ -28,8 +28,8 @@ int main(void) {
     const int64_t cons_off[2] = {0, 2};
     const int32_t cons_rank[2] = {0, 1};                        /* "C0" < "C1" under String.compareTo */
 
-    /* a real host calls this when it ENTERS assign(), before it fetches the offsets: the device's idle queues wake up meanwhile
-     * (ABI 0.5.0; optional, asynchronous) */
+    /* a real host calls this when it ENTERS assign(), before it fetches the offsets: a one-partition rebalance through the real
+     * path, so that the call that matters runs warm (ABI 0.5.0; optional) */
     if (la_version() >= 500) (void)la_wake(ctx);
     /* what the marshalling loop knows for free (ABI 0.4.0): no lag exceeds the largest end offset (no offset here is negative)
      * and no partition id exceeds 2.  One-shot: it applies to the next assign call.  Optional -- a call without it is the same

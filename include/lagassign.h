@@ -263,14 +263,19 @@ typedef struct la_call_hints {
 } la_call_hints;
 int la_hint_next_call(la_ctx *ctx, const la_call_hints *hints);
 
-/* Wake the device's queues for the assign call that is about to come (since ABI 0.5.0).  Asynchronous, returns at once: one empty
- * kernel on every stream the context's host-buffer calls use.  What it is for: Kafka calls assign() on the group leader once per
- * rebalance -- minutes apart -- and the reference's assign() spends its first milliseconds on broker round trips
- * (readTopicPartitionLags, Main.java:147, :317-365) before it has a single offset to hand over.  The first submission to a queue
- * that has been idle for more than a few milliseconds costs ~100 us before its first instruction runs (tools/cold_probe.py on
- * MI355X: a 100-partition la_assign_batch_grouped takes 28 us back to back, 150-180 us after 50 ms of idle, 70-85 us when
- * la_wake preceded it by 0.3-5 ms); a host that calls la_wake when it ENTERS assign() moves that cost under its own RPCs.
- * Optional, never needed for correctness; calling it when no assign call follows costs one empty launch. */
+/* Warm the path of the assign call that is about to come (since ABI 0.5.0).  What it is for: Kafka calls assign() on the group
+ * leader once per rebalance -- minutes apart -- and the reference's assign() spends its first milliseconds on broker round trips
+ * (readTopicPartitionLags, Main.java:147, :317-365) before it has a single offset to hand over.  After a second of idle a small
+ * call costs several times what it costs back to back (tools/cold_c.c at the C ABI on MI355X, profiles/r06_p_cold_c.txt: a
+ * 100-partition la_assign_batch_grouped 23 us back to back, 36 us after 50 ms of idle, 85 us after 1 s; 2 000 partitions 32 / 46 /
+ * 101 us): the device's queue, the link, the mapped pages, the runtime's code in the host's caches are all cold.  la_wake runs
+ * ONE one-partition rebalance through the real small-call path and waits for it (it pays the cold call itself: ~95 us), and
+ * launches one empty kernel on every other stream of the context; the assign call that follows within ~20 ms then takes 34 us
+ * (100 partitions) / 48 us (2 000) / 73 us (10 000: 127 cold); 200 ms later most of the effect is gone, and calls of hundreds of
+ * thousands of partitions gain nothing.  A host calls it when it ENTERS assign(), before its RPCs.  Optional, never needed for
+ * correctness.  A pending
+ * la_hint_next_call and the diagnostics of the last real call (la_last_pipeline, la_last_launches) survive it; results kept on
+ * the device for la_group_last_by_member do not (LA_EINVAL until the next assign call, as after la_compute_lag). */
 int la_wake(la_ctx *ctx);
 
 /* Kernel launches the last host-buffer call (or the last la_assign_batch_device[_on] call) on this context enqueued -- every

@@ -401,8 +401,8 @@ class Context:
         return int(self._lib.la_last_launches(self._h))
 
     def wake(self) -> None:
-        """la_wake: one empty kernel on every stream of the context, asynchronously -- for the moment a host ENTERS assign(),
-        milliseconds before it has offsets to hand over."""
+        """la_wake: one one-partition rebalance through the real small-call path (waited for) + an empty kernel on every other
+        stream -- for the moment a host ENTERS assign(), milliseconds before it has offsets to hand over."""
         self._check(self._lib.la_wake(self._h))
 
     # -- host-buffer entry points ------------------------------------------------

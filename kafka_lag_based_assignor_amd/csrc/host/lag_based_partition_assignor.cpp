@@ -335,10 +335,10 @@ Assignment LagBasedPartitionAssignor::assign(const OrderedMap<std::vector<TopicP
 
 Assignment LagBasedPartitionAssignor::assign(const Cluster& metadata, const GroupSubscription& subscriptions,
                                              OffsetSource& offsets) {
-    // The device's queues are idle when a rebalance comes (Kafka calls the leader's assign() minutes apart) and the first
-    // submission to an idle queue costs ~100 us: wake them NOW, asynchronously -- the three broker round trips below
-    // (Main.java:147 -> :317-365) take milliseconds before there is an offset to hand over.  Best effort: a failure here is
-    // the assign call's to report.
+    // Everything is cold when a rebalance comes (Kafka calls the leader's assign() minutes apart): la_wake runs a one-partition
+    // rebalance through the real path NOW (~95 us, cold) -- the three broker round trips below (Main.java:147 -> :317-365)
+    // take milliseconds before there is an offset to hand over, and the call that matters then runs warm (at the C ABI a
+    // 100-partition call 34 us instead of 85, profiles/r06_p_cold_c.txt).  Best effort: a failure here is the assign call's to report.
     {
         std::lock_guard<std::mutex> lock(g_ctx_mutex);
         try { (void)la_wake(shared_ctx_locked()); } catch (const std::exception&) {}

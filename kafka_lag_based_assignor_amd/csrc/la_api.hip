@@ -1842,7 +1842,12 @@ int create_lane(Lane& ln) {
     hipError_t e;
     if ((e = hipStreamCreateWithFlags(&ln.stream, hipStreamNonBlocking)) != hipSuccess ||
         (e = hipMalloc((void**)&ln.d_status, 256)) != hipSuccess ||
-        (e = hipMemset(ln.d_status, 0, 256)) != hipSuccess ||
+        // zeroed ON the lane's stream and waited for: the stream is non-blocking, so a null-stream hipMemset is not ordered
+        // before the first kernel launched on it -- a context whose very first call came right behind la_create could find
+        // the status word or the fused tail's workgroup counter stale (a small grouped call then came back with empty lists;
+        // found by la_wake's test in round 6: hipMalloc hands back memory a destroyed context had used)
+        (e = hipMemsetAsync(ln.d_status, 0, 256, ln.stream)) != hipSuccess ||
+        (e = hipStreamSynchronize(ln.stream)) != hipSuccess ||
         (e = hipHostMalloc((void**)&ln.h_status, 64, hipHostMallocDefault)) != hipSuccess)
         return fail(nullptr, e == hipErrorOutOfMemory ? LA_ENOMEM : LA_EHIP, "context setup: %s", hipGetErrorString(e));
     *ln.h_status = 0;
@@ -2156,19 +2161,6 @@ LA_API int la_unpack_results_on(la_ctx* ctx, int shard, int64_t n, const void* d
 LA_API int la_last_pipeline(const la_ctx* ctx) { return ctx ? ctx->last_pipeline : LA_EINVAL; }
 
 LA_API int64_t la_last_launches(const la_ctx* ctx) { return ctx ? ctx->last_launches : (int64_t)LA_EINVAL; }
-
-// Asynchronous: one empty kernel on every stream a host-buffer call of this context may use.  Nothing waits for them; the next
-// call's work queues behind them on the same streams.
-LA_API int la_wake(la_ctx* ctx) {
-    if (!ctx) return LA_EINVAL;
-    DeviceGuard restore_device;
-    for (Shard& sh : ctx->shards) {
-        LA_HIP(ctx, hipSetDevice(sh.device));
-        for (Lane& ln : sh.lanes)
-            if (ln.stream) LA_HIP(ctx, la::wake_launch(ln.stream));
-    }
-    return LA_OK;
-}
 
 LA_API int la_hint_next_call(la_ctx* ctx, const la_call_hints* hints) {
     if (!ctx) return LA_EINVAL;
@@ -2581,6 +2573,53 @@ static int assign_grouped(la_ctx* ctx, int32_t n_topics, const int64_t* part_off
         return LA_OK;
     }
     return group_last_impl(ctx, n_members, member_off, grouped_topic, grouped_partition);
+}
+
+// la_wake: ONE-PARTITION REBALANCE through the path a real small call takes (zero-copy staging, the tile kernel with its fused
+// end, the spin on the completion word), waited for, and one empty kernel on every other stream of the context.  Why a whole
+// call and why synchronous (tools/cold_probe.py through ctypes, profiles/r06_j_cold_probe.txt, one box, a 100-partition grouped
+// call: 30 us back to back, 135-175 us after 1 s of idle): an empty asynchronous launch leaves it at 107-124 us, a 1-element
+// la_compute_lag (copies, a kernel, a stream wait) at 69-74, a dummy rebalance through the real path at 43-45.  At the C ABI
+// (tools/cold_c.c, profiles/r06_p_cold_c.txt): 23 us back to back, 85 us after 1 s of idle, 34 us with la_wake 1-20 ms before
+// it.  What is cold after an idle second is not one thing (the queue, the link, the mapped pages' translations, the runtime's
+// and this library's own code and data in the host's caches): the cheapest way to warm all of it is to do the thing once.  It
+// costs the caller the cold call it spares the rebalance (~95 us) -- at the top of assign(), where milliseconds of broker round
+// trips follow anyway.  The pending hint and the diagnostics of the last real call survive; results kept on the device do not.
+LA_API int la_wake(la_ctx* ctx) {
+    if (!ctx) return LA_EINVAL;
+    DeviceGuard restore_device;
+    const la_call_hints saved_hints = ctx->hints;
+    const bool saved_set = ctx->hints_set;
+    const int saved_pipeline = ctx->last_pipeline;
+    const int64_t saved_launches = ctx->last_launches;
+    ctx->hints_set = false;
+    int rc = LA_OK;
+    try {
+        static const int64_t off[2] = {0, 1}, begin[1] = {0}, end[1] = {1}, committed[1] = {0};
+        static const int32_t pid[1] = {0}, rank[1] = {0};
+        int64_t member_off[2] = {0, 0};
+        int32_t grouped_partition[1] = {0};
+        rc = assign_grouped(ctx, 1, off, pid, begin, end, committed, LA_RESET_EARLIEST, off, rank, 1, member_off, nullptr,
+                            grouped_partition, nullptr, nullptr);
+        if (rc == LA_OK && !(member_off[1] == 1 && grouped_partition[0] == 0))
+            rc = fail(ctx, LA_EHIP, "la_wake: the one-partition rebalance came back wrong (member_off %lld %lld, partition %d)",
+                      (long long)member_off[0], (long long)member_off[1], (int)grouped_partition[0]);
+    } catch (...) {
+        rc = fail(ctx, LA_ENOMEM, "exception in la_wake");
+    }
+    ctx->hints = saved_hints;
+    ctx->hints_set = saved_set;
+    ctx->last_pipeline = saved_pipeline;
+    ctx->last_launches = saved_launches;
+    ctx->last_valid = false;                                  // (the staging buffers of the last real call were reused)
+    if (rc != LA_OK) return rc;
+    for (size_t s = 0; s < ctx->shards.size(); ++s) {
+        Shard& sh = ctx->shards[s];
+        LA_HIP(ctx, hipSetDevice(sh.device));
+        for (size_t i = (s == 0 ? 1 : 0); i < sh.lanes.size(); ++i)          // (shard 0's first lane just ran the call)
+            if (sh.lanes[i].stream) LA_HIP(ctx, la::wake_launch(sh.lanes[i].stream));
+    }
+    return LA_OK;
 }
 
 LA_API int la_assign_batch_grouped(la_ctx* ctx, int32_t n_topics, const int64_t* part_off, const int32_t* partition_id,

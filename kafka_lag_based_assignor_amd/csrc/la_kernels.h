@@ -137,7 +137,7 @@ hipError_t sparse_begin_launch(int64_t m, const int64_t* idx, const int64_t* val
 
 // The last launch of a zero-copy small call: *h_flag = 0x80000000 | *d_status (h_flag in coherent host memory).
 hipError_t finish_status_launch(const uint32_t* d_status, uint32_t* h_flag, hipStream_t stream);
-hipError_t wake_launch(hipStream_t stream);                  // one empty kernel (la_wake)
+hipError_t wake_launch(hipStream_t stream);                  // one empty kernel (la_wake, for the streams its dummy call does not use)
 
 // Checks that every topic's cons_rank segment is strictly ascending; sets kStatusUnsorted.
 hipError_t check_consumers_launch(int64_t n_topics, const int64_t* cons_off, const int32_t* cons_rank,

@@ -106,12 +106,7 @@ hipError_t finish_status_launch(const uint32_t* d_status, uint32_t* h_flag, hipS
     return hipGetLastError();
 }
 
-// ---- la_wake: one empty launch per stream -------------------------------------------------------------------------------------
-// A group leader rebalances once in a while: its assign call finds the device's queues idle, and the first submission to an idle
-// queue costs ~100 us before its first instruction runs (tools/cold_probe.py: a 100-partition call 28 us back to back, 150-180 us
-// after 50 ms of nothing; 70-85 us when the queue took ANY launch a moment earlier -- a busy host core or a kernel on another
-// stream do not help, it is the queue).  The hosts enter assign() milliseconds before they have offsets to hand over
-// (Main.java:147: the broker round trips of readTopicPartitionLags): that is where this goes.
+// ---- la_wake's empty launch (the streams its one-partition rebalance does not run on; la_api.hip) ------------------------------
 __global__ void wake_kernel() {}
 
 hipError_t wake_launch(hipStream_t stream) {

@@ -17,11 +17,13 @@ def main():
     ap.add_argument("--idle", type=float, nargs="*", default=[0.05, 0.3, 1.0])
     ap.add_argument("--lead", type=float, nargs="*", default=[0.2, 1.0, 5.0])
     ap.add_argument("--reps", type=int, default=7)
-    ap.add_argument("--wake", choices=["wake", "lag"], default="wake")
+    ap.add_argument("--wake", choices=["wake", "lag", "call"], default="wake")
     ap.add_argument("--spin", type=float, nargs="*", default=[100, 1000, 4000], help="device spin kernels of this many us as the wake-up")
     args = ap.parse_args()
     ctx = N.Context(0)
     one = np.array([5], np.int64)
+    dummy = (np.array([0, 1], np.int64), np.array([0], np.int32), np.array([0], np.int64), one, np.array([1], np.int64), N.LA_RESET_EARLIEST,
+             np.array([0, 1], np.int64), np.array([0], np.int32))
     if args.spin:
         import torch
         torch.zeros(1, device="cuda")
@@ -72,10 +74,12 @@ def main():
             woke = []
             for _ in range(args.reps):
                 time.sleep(idle)
-                if args.wake == "lag":
+                if args.wake == "call":
+                    ctx.assign_batch_grouped(*dummy, 1)                     # a one-partition rebalance through the real path, waited for
+                elif args.wake == "lag":
                     ctx.compute_lag(None, one, one, N.LA_RESET_LATEST)      # (round 6's first probe: one tiny kernel + its copies + a wait)
                 else:
-                    ctx.wake()                                              # la_wake: one empty launch per stream, asynchronous
+                    ctx.wake()                                              # la_wake
                 t_w = time.perf_counter()
                 while (time.perf_counter() - t_w) * 1e3 < lead:
                     pass
