@@ -498,8 +498,21 @@ def _small_calls_c_abi():
             rows = json.loads(out.stdout)
         except Exception as exc:  # noqa: BLE001 -- a reported extra
             return {"error": str(exc)}
+        # ... and what a REAL rebalance pays (tools/cold_c.c): the same call after the process and the device idled for a second,
+        # without and with la_wake 5 ms before it (what a host issues when it enters assign(), before its broker round trips)
+        cold = None
+        try:
+            exe2 = os.path.join(d, "cold_c")
+            subprocess.check_call([cc, "-O2", "-std=c99", "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "tools", "cold_c.c"),
+                                   "-L" + pkg, "-llagassign", "-ldl", "-Wl,-rpath," + pkg, "-o", exe2], timeout=120)
+            out2 = subprocess.run([exe2, "--json", "100", "20", "4"], capture_output=True, text=True, timeout=120)
+            cold = json.loads(out2.stdout)
+            cold["what"] = ("tools/cold_c.c at the C ABI: la_assign_batch_grouped back to back, after 1 s of idle (a rebalance is "
+                            "never back to back), and after 1 s of idle with la_wake 5 ms before the call; medians of 5")
+        except Exception as exc:  # noqa: BLE001 -- a reported extra
+            cold = {"error": str(exc)}
     cross = next((r["partitions"] for r in rows if r["cpu_oracle_us"] > 0 and r["grouped_us"] < r["cpu_oracle_us"]), None)
-    return {"rows": rows, "gpu_faster_from_partitions": cross,
+    return {"rows": rows, "gpu_faster_from_partitions": cross, "cold": cold,
             "what": "tools/latency_c.c: median wall time of ONE la_assign_batch_grouped call (pageable buffers in, every member's list "
                     "out) at the C ABI, and of the C oracle + a stable counting sort by member for the same call on one host core"}
 

@@ -24,6 +24,9 @@ def main(path):
     if "rows" in sc:
         print("  small_call", [(x["partitions"], x["gpu_call_us"], x["cpu_oracle_us"]) for x in sc["rows"]],
               [(x["partitions"], x["grouped_us"], x["cpu_oracle_us"]) for x in (sc.get("c_abi") or {}).get("rows", [])])
+        cold = (sc.get("c_abi") or {}).get("cold")
+        if cold:
+            print("  cold small call (C ABI)", {k: v for k, v in cold.items() if k != "what"})
     sp = d.get("sort_phase") or {}
     print("  sort_phase", sp.get("kernel_ms"), sp.get("frac"), sp.get("frac_moved"), sp.get("error"),
           "| parity", d.get("parity"), "| cpu", (d.get("cpu_baseline") or {}).get("value"))

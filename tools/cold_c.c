@@ -2,6 +2,7 @@
  * and without la_wake before it, no interpreter anywhere.
  *   gcc -O2 -std=c99 -Iinclude tools/cold_c.c -Lkafka_lag_based_assignor_amd -llagassign -Wl,-rpath,$PWD/kafka_lag_based_assignor_amd -o /tmp/cold_c
  *   cold_c [idle_ms ...]        (default 50 1000)
+ *   cold_c --json T P C         one shape, 1 s of idle, 5 tries, la_wake 5 ms before: one JSON object (bench.py's small_call.cold)
  * Per batch shape: the back-to-back median; then per idle time, medians over 7 tries of (a) the call right after the idle
  * (nanosleep), (b) la_wake after the idle, LEAD ms of "broker round trips" (nanosleep: the host really is away), the call. */
 #define _POSIX_C_SOURCE 199309L
@@ -29,9 +30,12 @@ static int cmp_double(const void *a, const void *b) {
 }
 static double median(double *v, int n) { qsort(v, n, sizeof(double), cmp_double); return v[n / 2]; }
 
+static int json_mode(int T, int P, int C);
+
 int main(int argc, char **argv) {
     double idles[8];
     int n_idle = 0;
+    if (argc == 5 && !strcmp(argv[1], "--json")) return json_mode(atoi(argv[2]), atoi(argv[3]), atoi(argv[4]));
     for (int i = 1; i < argc && n_idle < 8; ++i) idles[n_idle++] = atof(argv[i]);
     if (!n_idle) { idles[0] = 50; idles[1] = 1000; n_idle = 2; }
     static const double leads[] = {1.0, 20.0, 200.0};
@@ -87,6 +91,44 @@ int main(int argc, char **argv) {
         printf("\n");
         fflush(stdout);
     }
+    la_destroy(ctx);
+    return 0;
+}
+
+static int json_mode(int T, int P, int C) {
+    la_ctx *ctx = NULL;
+    if (la_create(&ctx, 0, 0) != LA_OK) { fprintf(stderr, "la_create: %s\n", la_last_error(NULL)); return 1; }
+    const int64_t n = (int64_t)T * P, k = (int64_t)T * C;
+    int64_t *part_off = malloc((T + 1) * 8), *cons_off = malloc((T + 1) * 8);
+    int32_t *pid = malloc(n * 4), *cons_rank = malloc(k * 4);
+    int64_t *begin = calloc(n, 8), *end = malloc(n * 8), *committed = malloc(n * 8);
+    int64_t *member_off = malloc((C + 1) * 8), *total = malloc(k * 8);
+    int32_t *g_topic = malloc(n * 4), *g_part = malloc(n * 4);
+    uint64_t x = 88172645463325252ull;
+    for (int t = 0; t <= T; ++t) { part_off[t] = (int64_t)t * P; cons_off[t] = (int64_t)t * C; }
+    for (int64_t i = 0; i < n; ++i) {
+        x ^= x << 13; x ^= x >> 7; x ^= x << 17;
+        pid[i] = (int32_t)(i % P);
+        committed[i] = (x & 127) == 0 ? LA_NO_COMMITTED : (int64_t)(x >> 44);
+        end[i] = (int64_t)(x >> 44) + (int64_t)((x >> 8) & 0xFFFFFFFFFFull);
+    }
+    for (int64_t i = 0; i < k; ++i) cons_rank[i] = (int32_t)(i % C);
+    double w[200], c[5], v[5], wk[5];
+    for (int r = -30; r < 200; ++r) { const double t0 = now_us(); CALL(); if (r >= 0) w[r] = now_us() - t0; }
+    for (int r = 0; r < 5; ++r) { sleep_ms(1000); const double t0 = now_us(); CALL(); c[r] = now_us() - t0; }
+    for (int r = 0; r < 5; ++r) {
+        sleep_ms(1000);
+        double t0 = now_us();
+        if (la_wake(ctx) != LA_OK) { fprintf(stderr, "la_wake: %s\n", la_last_error(ctx)); return 1; }
+        wk[r] = now_us() - t0;
+        sleep_ms(5);
+        t0 = now_us();
+        CALL();
+        v[r] = now_us() - t0;
+    }
+    printf("{\"topics\": %d, \"partitions_per_topic\": %d, \"consumers\": %d, \"partitions\": %lld, \"back_to_back_us\": %.1f, "
+           "\"after_1s_idle_us\": %.1f, \"la_wake_us\": %.1f, \"after_1s_idle_and_la_wake_5ms_before_us\": %.1f}\n",
+           T, P, C, (long long)n, median(w, 200), median(c, 5), median(wk, 5), median(v, 5));
     la_destroy(ctx);
     return 0;
 }
