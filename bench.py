@@ -1048,7 +1048,20 @@ def main():
                 done_total += e - done
                 done = e
             spent += local
-        parity = {"checked_topics": done_total, "bit_exact": ok,
+        frozen_ok = None
+        if world == 1 and wname == "target" and not latest and g_tot is not None:
+            # ... and the WHOLE result against the committed digest of the literal oracle on this batch (tests/golden/oracle_frozen_full.json)
+            try:
+                import hashlib
+                with open(FROZEN_FULL) as fh:
+                    fz = json.load(fh).get("target@1/earliest", {}).get("sha256")
+                h = hashlib.sha256()
+                for a_ in (g_pid.astype("<i4"), g_rank.astype("<i4"), g_tot.astype("<i8")):
+                    h.update(np.ascontiguousarray(a_).tobytes())
+                frozen_ok = (h.hexdigest() == fz) if fz else None
+            except (OSError, ValueError):
+                frozen_ok = None
+        parity = {"checked_topics": done_total, "bit_exact": ok, "sha256_matches_frozen_literal_oracle": frozen_ok,
                   "against": "oracle/lag_oracle.c (literal per-step min)%s" % (
                       "; the all-gathered global arrays, a slice of every rank's shard" if strong else "")}
         if world == 1:
@@ -1208,6 +1221,7 @@ def main():
                              "ms_per_call": round(kern_ms, 5), "value": round(n_part / (kern_ms * 1e-3), 1),
                              "frac": roofline["frac"], "kernel": roofline["kernel"],
                              "bit_exact": parity["bit_exact"] if parity else None,
+                             "sha256_matches_frozen_literal_oracle": parity.get("sha256_matches_frozen_literal_oracle") if parity else None,
                              "against": "oracle/lag_oracle.c on the first %d topics (the cpu_baseline leg's budget)" % parity["checked_topics"] if parity else None}
 
     # ---- the workload in which the whole 36 B/partition really moves: NO committed offset anywhere (a brand-new consumer
@@ -1234,15 +1248,27 @@ def main():
             n_lag = oracle.compute_lags(wn.begin, wn.end, wn.committed, False)
             e_p, e_m, e_t = oracle.assign_flat(wn.part_off, wn.partition_id, n_lag, wn.cons_off, wn.cons_rank)
             an_cpu_s = time.perf_counter() - c0
-            same = bool(np.array_equal(n_lag, wn.lag) and np.array_equal(sh.out_pid[:n_part].cpu().numpy(), e_p) and
-                        np.array_equal(sh.out_rank[:n_part].cpu().numpy(), e_m) and
-                        np.array_equal(sh.out_total[: sh.k].cpu().numpy(), e_t))
-            del e_p, e_m, e_t, n_lag
+            a_pid, a_rank, a_tot = sh.out_pid[:n_part].cpu().numpy(), sh.out_rank[:n_part].cpu().numpy(), sh.out_total[: sh.k].cpu().numpy()
+            same = bool(np.array_equal(n_lag, wn.lag) and np.array_equal(a_pid, e_p) and np.array_equal(a_rank, e_m) and
+                        np.array_equal(a_tot, e_t))
+            an_frozen = None
+            try:
+                import hashlib
+                with open(FROZEN_FULL) as fh:
+                    fz = json.load(fh).get("target@1/earliest/none=1", {}).get("sha256")
+                h = hashlib.sha256()
+                for a_ in (a_pid.astype("<i4"), a_rank.astype("<i4"), a_tot.astype("<i8")):
+                    h.update(np.ascontiguousarray(a_).tobytes())
+                an_frozen = (h.hexdigest() == fz) if fz else None
+            except (OSError, ValueError):
+                pass
+            del e_p, e_m, e_t, n_lag, a_pid, a_rank, a_tot
             an = {"kernel_ms": round(ams, 4), "calls_timed": acalls, "rotation_sets": len(sets), "none_frac": 1.0,
                   "algorithmic_bytes_per_partition": 36,
                   "frac": round(36.0 * n_part / (ams * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                   "value": round(n_part / (ams * 1e-3), 1),
                   "bit_exact": same, "against": "oracle/lag_oracle.c on all %d partitions of the all-none batch (%.1f s)" % (n_part, an_cpu_s),
+                  "sha256_matches_frozen_literal_oracle": an_frozen,
                   "what": "the target shape with NO committed offset at all (100 % fall back to `begin`, earliest; begin = what "
                           "committed would have been, so every lag is the drawn one): every byte of the 36 B contract is read or written"}
             if not args.no_live_traffic:

@@ -31,7 +31,9 @@ CASES = [  # (config name, scale, reset mode)
 # Full-size BASELINE configurations whose literal oracle run is too long for the per-round CPU suite (cfg5: 8.6e9 comparator
 # steps, ~15 s): `make_golden.py --full` freezes them into oracle_frozen_full.json once; bench.py's `configs` block and the
 # GPU tests check the HIP path against these digests (the GPU tests ALSO re-run the oracle).
-FULL_CASES = [("cfg2b", 1.0, "earliest"), ("cfg3", 1.0, "earliest"), ("cfg4", 1.0, "earliest"), ("cfg5", 1.0, "earliest")]
+FULL_CASES = [("cfg2b", 1.0, "earliest"), ("cfg3", 1.0, "earliest"), ("cfg4", 1.0, "earliest"), ("cfg5", 1.0, "earliest"),
+              # round 6: the headline batch itself and its form without any committed offset (synth.config(..., none_frac=1.0))
+              ("target", 1.0, "earliest"), ("target", 1.0, "earliest/none=1")]
 
 
 def digest(*arrays):
@@ -59,8 +61,9 @@ def main():
     out = {}
     full = "--full" in sys.argv
     for name, scale, mode in (FULL_CASES if full else CASES):
-        w = synth.config(name, scale)
-        p, m, t = run_oracle(w, mode)
+        none_frac = float(mode.split("none=")[1]) if "none=" in mode else None
+        w = synth.config(name, scale, none_frac=none_frac) if none_frac is not None else synth.config(name, scale)
+        p, m, t = run_oracle(w, mode.split("/")[0])
         ratio = synth.lag_ratio(t, w.cons_off)
         out[case_key(name, scale, mode)] = {
             "n_topics": int(w.n_topics), "n_partitions": int(w.n_partitions), "n_consumers": int(w.cons_rank.size),

@@ -1191,6 +1191,27 @@ def test_hip_path_matches_frozen_digests(ctx):
         assert got == frozen[mg.case_key(name, scale, mode)]["sha256"], "%s %s" % (name, mode)
 
 
+def test_hip_path_matches_the_full_size_frozen_digests(ctx):
+    """tests/golden/oracle_frozen_full.json (make_golden.py --full): every BASELINE config at FULL size, the headline batch
+    and its form without any committed offset -- committed fixtures of the literal oracle; the HIP path must reproduce the
+    digests through the host entry point (and the inputs are the generator's: their digest is in the fixture too)."""
+    import importlib.util
+    import json
+    import os
+    gdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    spec = importlib.util.spec_from_file_location("make_golden", os.path.join(gdir, "make_golden.py"))
+    mg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mg)
+    frozen = json.load(open(os.path.join(gdir, "oracle_frozen_full.json")))
+    for name, scale, mode in mg.FULL_CASES:
+        none_frac = float(mode.split("none=")[1]) if "none=" in mode else None
+        w = synth.config(name, scale, none_frac=none_frac) if none_frac is not None else synth.config(name, scale)
+        fz = frozen[mg.case_key(name, scale, mode)]
+        assert mg.digest(w.part_off, w.partition_id, w.begin, w.end, w.committed, w.cons_off, w.cons_rank) == fz["inputs_sha256"]
+        p, m, t = ctx.assign_batch(w.part_off, w.partition_id, w.begin, w.end, w.committed, N.LA_RESET_EARLIEST, w.cons_off, w.cons_rank)
+        assert mg.digest(p.astype(np.int32), m.astype(np.int32), t.astype(np.int64)) == fz["sha256"], "%s %s" % (name, mode)
+
+
 def test_deferred_wide_tiles_in_a_batch_larger_than_the_resident_grid(ctx):
     # Small batches run one kernel with the wide-record code inline; beyond one round of resident workgroups
     # the packed kernel defers tiles it cannot pack to a list that the wide kernel walks.  100 000 tiny topics

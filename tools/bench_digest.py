@@ -18,7 +18,7 @@ def main(path):
         if isinstance(v, dict):
             print(" ", k, {a: b for a, b in v.items() if not isinstance(b, str) or a == "error"})
     cfgs = d.get("configs") or {}
-    print("  configs", {k: (v.get("ms_per_call"), v.get("frac"), v.get("bit_exact"), v.get("sha256_matches_frozen_literal_oracle"),
+    print("  configs (ms, frac, bit_exact, sha256 == frozen, copies)", {k: (v.get("ms_per_call"), v.get("frac"), v.get("bit_exact"), v.get("sha256_matches_frozen_literal_oracle"),
                             (v.get("rotation") or {}).get("sets")) for k, v in cfgs.items() if isinstance(v, dict)})
     sc = d.get("small_call") or {}
     if "rows" in sc:
