@@ -520,6 +520,9 @@ int launch_large_topics(la_ctx* ctx, Lane& ln, const la_device_batch* b, const B
         g.sort_multi_kernel = (b->flags & LA_FLAG_SORT_MULTIKERNEL) ? 1 : 0;
         g.no_run_merge = (b->flags & LA_FLAG_NO_RUN_MERGE) ? 1 : 0;
         g.no_moved_sort = (b->flags & LA_FLAG_NO_MOVED_SORT) ? 1 : 0;
+        const bool bounded_large = (b->flags & LA_FLAG_BOUNDS) && b->max_lag_hint >= 0 && b->max_partition_id_hint >= 0;
+        g.max_lag_hint = bounded_large ? b->max_lag_hint : -1;
+        g.max_id_hint = bounded_large ? b->max_partition_id_hint : -1;
         g.status = ln.status();
         hipError_t e = hipSuccess;
         if (c > la::kLargeMaxConsumers) {

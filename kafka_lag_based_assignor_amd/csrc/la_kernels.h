@@ -230,6 +230,8 @@ struct LargeArgs {
     int32_t no_run_merge;       // LA_FLAG_NO_RUN_MERGE: greedy rounds never merge ascending runs (they sort as if there were none)
     int32_t sort_multi_kernel;  // LA_FLAG_SORT_MULTIKERNEL: four kernels per radix pass (count, scans, scatter) instead of one
     int32_t no_moved_sort;      // LA_FLAG_NO_MOVED_SORT: greedy rounds never sort only the bins that move
+    int64_t max_lag_hint;       // LA_FLAG_BOUNDS: 0 <= lag <= max_lag_hint and 0 <= id <= max_id_hint for every partition (the caller's
+    int64_t max_id_hint;        // guarantee), or -1: radix passes over digits the bounds rule out are not even launched (round 6)
 };
 
 // Once per device at context creation (synchronous): checks the hardware property the radix sort's atomic ranking relies on.

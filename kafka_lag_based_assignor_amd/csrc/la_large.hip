@@ -171,6 +171,7 @@ __global__ __launch_bounds__(256) void build_keys_kernel(LargeArgs a0, SortBufs 
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     uint64_t last_sample = 0;                                          // (lane 0 of a sampling wavefront)
     bool have_sample = false, sampling = true;
+    bool out_of_bounds = false;
     for (int64_t base = (int64_t)blockIdx.x * blockDim.x; base < b.n; base += stride) {
         const int64_t i = base + threadIdx.x;
         const bool valid = i < b.n;
@@ -186,6 +187,10 @@ __global__ __launch_bounds__(256) void build_keys_kernel(LargeArgs a0, SortBufs 
             val = (uint32_t)id ^ kPidBias;
             b.key[0][i] = key;
             b.val[0][i] = val;
+            // the caller's bounds decided which passes were launched at all (bounds_pass_mask): a partition outside them is an
+            // error of the call (LA_EINVAL), never a differently sorted topic
+            if (a.max_lag_hint >= 0 && ((uint64_t)lag > (uint64_t)a.max_lag_hint || (uint64_t)(int64_t)id > (uint64_t)a.max_id_hint))
+                out_of_bounds = true;
             if (i + 1 < b.n && a.pid[g + 1] < id) b.ctl->unsorted_ids = 1;
         }
         const uint64_t vmask = __ballot(valid);
@@ -230,6 +235,7 @@ __global__ __launch_bounds__(256) void build_keys_kernel(LargeArgs a0, SortBufs 
     __syncthreads();
     for (int i = threadIdx.x; i < kDigits * kRadix; i += blockDim.x)
         if (h[i]) atomicAdd(&b.hist[i], h[i]);
+    if (__any(out_of_bounds) && (threadIdx.x & (kWave - 1)) == 0) atomicOr(a.status, kStatusBounds);
 }
 
 // ---- the sample of the lags: did any counter reach kSampleHeavy? ----------------------------------------------------------
@@ -2364,6 +2370,22 @@ static hipError_t sort_prepare(LargeScratch& scratch, int64_t n, hipStream_t str
     return hipMemsetAsync(base, 0, L.zero_bytes, stream);
 }
 
+// The passes a caller's bounds (LA_FLAG_BOUNDS: 0 <= lag <= max_lag, 0 <= id <= max_id) leave possible: a key digit above the
+// lag's bits holds the same value in every record (key = lag ^ 0x7FFF..., so the bits above are all ones), an id digit above the
+// id's bits likewise (val = id ^ 0x80000000) -- the device-side plan would find them constant and skip them, but each skipped
+// pass is still a launch (3-4.5 us apiece: cfg5 launches 6 such, a 33.5 M-partition keys-first sort 3 + 3 redo slots).
+// build_keys_kernel raises kStatusBounds on a partition outside the bounds.
+static uint32_t bounds_pass_mask(const LargeArgs& a) {
+    uint32_t mask = (1u << kDigits) - 1;
+    if (a.max_lag_hint < 0 || a.max_id_hint < 0) return mask;
+    const int lag_bits = a.max_lag_hint > 0 ? 64 - __builtin_clzll((unsigned long long)a.max_lag_hint) : 0;
+    const int id_bits = a.max_id_hint > 0 ? 64 - __builtin_clzll((unsigned long long)a.max_id_hint) : 0;
+    mask = 0;
+    for (int d = 0; d < 4; ++d) if (8 * d < id_bits) mask |= 1u << d;
+    for (int d = 0; d < 8; ++d) if (8 * d < lag_bits) mask |= 1u << (4 + d);
+    return mask;
+}
+
 // plan + the 12 (mostly skipped) passes; keys/vals/hist/unsorted flag must already be in buffer 0
 // `pass_mask`: passes the HOST knows can matter (bit p = digit p); the kernels of the others are not even launched.  The
 // device-side plan still decides among the launched ones (a launched pass whose digit turns out constant returns at
@@ -2455,10 +2477,11 @@ hipError_t large_topic_launch(LargeScratch& scratch, const LargeArgs& a, bool ar
     } done{pf, profile, stream};
     LA_LAUNCH(build_keys_kernel, dim3(keys_grid(n)), dim3(256), 0, stream, a, b, (const LargeItem*)nullptr, (char*)nullptr);
     if (b.samp) LA_LAUNCH(sample_scan_kernel, dim3(256), dim3(256), 0, stream, b, (const LargeItem*)nullptr, (char*)nullptr);
-    sort_run_passes(b, stream, a.status, profile ? pf.ev[1] : nullptr);
+    const uint32_t pass_mask = bounds_pass_mask(a);
+    sort_run_passes(b, stream, a.status, profile ? pf.ev[1] : nullptr, pass_mask);
     if (b.samp) {
         if ((e = sort_repair_launch(b, stream, nullptr, 1, nullptr, n)) != hipSuccess) return e;
-        sort_run_passes(b, stream, a.status, nullptr, (1u << kDigits) - 1, nullptr, 1, 0, nullptr, kDigits);
+        sort_run_passes(b, stream, a.status, nullptr, pass_mask, nullptr, 1, 0, nullptr, kDigits);
     }
     if (profile) (void)hipEventRecord(pf.ev[2], stream);
     LA_LAUNCH(emit_ids_kernel, dim3(grid), dim3(256), 0, stream, a, b, (const LargeItem*)nullptr, (char*)nullptr);
@@ -2605,7 +2628,7 @@ hipError_t large_topics_launch(LargeScratch& scratch, const LargeArgs* args, int
         SortBufs bc = b0;
         bc.sweep_threads = sweep;
         bc.tile_state = (unsigned long long*)base;                 // (non-null: the single-kernel passes; items carry the real one)
-        sort_run_passes(bc, stream, status, nullptr, (1u << kDigits) - 1, d_items + first, n, max_tiles, base);
+        sort_run_passes(bc, stream, status, nullptr, bounds_pass_mask(a0), d_items + first, n, max_tiles, base);
         first += n;
     }
     if (any_keys_first) {
@@ -2620,7 +2643,7 @@ hipError_t large_topics_launch(LargeScratch& scratch, const LargeArgs* args, int
             SortBufs bc = b0;
             bc.sweep_threads = sweep;
             bc.tile_state = (unsigned long long*)base;
-            sort_run_passes(bc, stream, status, nullptr, (1u << kDigits) - 1, d_items + first, n, max_tiles, base, kDigits);
+            sort_run_passes(bc, stream, status, nullptr, bounds_pass_mask(a0), d_items + first, n, max_tiles, base, kDigits);
             first += n;
         }
     }

@@ -115,3 +115,58 @@ def test_keys_first_sort_by_the_sample_at_five_million(ctx, kind, expect_first):
 
 
 
+
+
+# ---- round 6: the caller's bounds rule radix passes out before they are launched ---------------------------------------------------
+def _bounded_call(ctx, w, max_lag, max_id, flags=0):
+    import ctypes
+    import torch
+    dev = torch.device("cuda", 0)
+    d = {k: torch.from_numpy(np.ascontiguousarray(getattr(w, k))).to(dev) for k in ("part_off", "partition_id", "lag", "cons_off", "cons_rank")}
+    out_pid = torch.full((w.n_partitions,), -7, device=dev, dtype=torch.int32)
+    out_rank = torch.full((w.n_partitions,), -7, device=dev, dtype=torch.int32)
+    out_total = torch.full((max(w.cons_rank.size, 1),), -7, device=dev, dtype=torch.int64)
+    b = N.DeviceBatch()
+    b.n_topics, b.reset_mode, b.algo, b.flags = w.n_topics, N.LA_RESET_LATEST, N.LA_ALGO_AUTO, flags
+    b.n_partitions, b.n_consumers = w.n_partitions, w.cons_rank.size
+    b.max_partitions_per_topic, b.max_consumers_per_topic = w.max_partitions, w.max_consumers
+    b.d_part_off, b.d_partition_id, b.d_lag = d["part_off"].data_ptr(), d["partition_id"].data_ptr(), d["lag"].data_ptr()
+    b.d_cons_off, b.d_cons_rank = d["cons_off"].data_ptr(), d["cons_rank"].data_ptr()
+    b.d_out_partition, b.d_out_member_rank, b.d_out_total_lag = out_pid.data_ptr(), out_rank.data_ptr(), out_total.data_ptr()
+    po, co = np.ascontiguousarray(w.part_off, np.int64), np.ascontiguousarray(w.cons_off, np.int64)
+    b.h_part_off = po.ctypes.data_as(ctypes.POINTER(ctypes.c_int64))
+    b.h_cons_off = co.ctypes.data_as(ctypes.POINTER(ctypes.c_int64))
+    if max_lag is not None:
+        b.flags |= N.LA_FLAG_BOUNDS
+        b.max_lag_hint, b.max_partition_id_hint = int(max_lag), int(max_id)
+    stream = torch.cuda.current_stream().cuda_stream
+    ctx.assign_batch_device(b, stream)
+    ctx.sync(stream)
+    return (out_pid.cpu().numpy(), out_rank.cpu().numpy(), out_total.cpu().numpy()[: w.cons_rank.size]), ctx.last_launches()
+
+
+@pytest.mark.parametrize("p,c,lag_bits,dense", [(300_000, 3000, 24, True), (200_000, 0, 40, True), (150_000, 1500, 17, False),
+                                                (5_000_000, 0, 33, True), (120_000, 8192, 8, True)])
+def test_bounds_rule_radix_passes_out_and_a_broken_bound_is_an_error(ctx, p, c, lag_bits, dense):
+    """LA_FLAG_BOUNDS on the large path (round 6): key digits above the largest lag's bits and id digits above the largest id's
+    bits hold one value in every record -- the device-side plan skips such passes anyway, the host now does not even launch
+    them (fewer launches, the same result: the oracle's); a partition outside the bounds is LA_EINVAL, never another order."""
+    rng = np.random.default_rng(p + lag_bits)
+    lag = rng.integers(0, 1 << lag_bits, p).astype(np.int64)
+    ids = rng.permutation(p).astype(np.int32) if dense else (rng.permutation(p).astype(np.int64) * 5 + 3).astype(np.int32)
+    w = synth.Workload("bounds", 1, np.array([0, p], np.int64), ids, np.zeros(p, np.int64), lag.copy(), np.zeros(p, np.int64), lag,
+                       np.array([0, c], np.int64), np.arange(c, dtype=np.int32), p, c)
+    exp = round_form(w.part_off, w.partition_id, w.lag, w.cons_off, w.cons_rank)
+    plain, n_plain = _bounded_call(ctx, w, None, None)
+    _same3(plain, exp, "no bounds")
+    tight, n_tight = _bounded_call(ctx, w, int(lag.max()), int(ids.max()))
+    _same3(tight, exp, "tight bounds")
+    loose, n_loose = _bounded_call(ctx, w, (1 << 62) - 1, (1 << 31) - 1)
+    _same3(loose, exp, "bounds that rule nothing out")
+    assert n_tight < n_plain and n_loose == n_plain, (n_tight, n_loose, n_plain)
+    # a bound the data breaks: the largest lag (or id) minus one
+    for ml, mi in ((int(lag.max()) - 1, int(ids.max())), (int(lag.max()), int(ids.max()) - 1)):
+        with pytest.raises(N.LagAssignError) as e:
+            _bounded_call(ctx, w, ml, mi)
+        assert e.value.code == N.LA_EINVAL
+    _same3(_bounded_call(ctx, w, int(lag.max()), int(ids.max()))[0], exp, "after the errors")
