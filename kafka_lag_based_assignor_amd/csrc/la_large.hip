@@ -60,7 +60,8 @@ struct SortCtl {
     uint32_t tie_heavy;                // build_keys: a key came up often in the sample (or filled a whole wavefront): many equal lags
     uint32_t keys_first;               // plan: the id passes are skipped, ties are put in id order by tie_repair_kernel
     uint32_t redo;                     // tie_repair: a run of equal keys did not fit its workgroup -> the redo slots sort in full
-    uint32_t pad[11];
+    uint32_t redo_arrived;             // onesweep_redo_kernel's grid barrier: workgroups that finished a redo pass (zeroed with ctl)
+    uint32_t pad[10];
 };
 
 struct SortBufs {
@@ -703,30 +704,22 @@ constexpr uint32_t kStateAggregate = 1u, kStateInclusive = 2u;
 constexpr int kLookWindow = LA_LOOK_WINDOW;           // predecessors a walk polls at once
 constexpr uint32_t kLookbackSpinLimit = 1u << 22;     // polls of one granule (~1 us each with the sleep) before giving up
 
+// One tile of one pass: the body of onesweep_pass_kernel (one tile per workgroup, taken by arrival) and of onesweep_redo_kernel
+// (round 6: workgroups that loop over tickets and passes).  s_ticket: the tile's number, written by thread 0 of the caller BEFORE
+// the call and read here after the first barrier.
 template <bool ATOMIC_RANK, int THREADS>
-__global__ __launch_bounds__(THREADS, 4) void onesweep_pass_kernel(SortBufs b0, int pass, uint32_t* status, const LargeItem* items,
-                                                                   char* scratch) {
-    LargeArgs unused{};
-    SortBufs b = b0;
-    if (items) bind_item(unused, b, items[blockIdx.y], scratch);
-    // several topics per launch: the grid is as wide as the launch's largest topic, and only workgroups that have a tile to
-    // sort may draw a ticket (tiles are taken by arrival, so exactly n_tiles workgroups of a topic must arrive)
-    if ((int)blockIdx.x >= b.n_tiles) return;
-    const int slot = pass;                            // control-block slot (skip / cur / ticket / tag of the granules) ...
-    if (b.ctl->skip[slot]) return;
-    pass = slot >= kDigits ? slot - kDigits : slot;   // ... and the digit it sorts by (the redo slots repeat the digits)
+__device__ __forceinline__ void onesweep_tile(const SortBufs& b, const int slot, uint32_t* status, const uint32_t* s_ticket) {
+    const int pass = slot >= kDigits ? slot - kDigits : slot;   // the digit the slot sorts by (the redo slots repeat the digits)
     static_assert(THREADS >= kRadix && THREADS % kWave == 0, "one thread per digit in the look-back");
     constexpr int WAVES = THREADS / kWave, TILE = THREADS * kItems;
     __shared__ uint32_t cnt[WAVES][kRadix];
     __shared__ uint32_t bin_start[kRadix];            // tile-local position of the digit's first element
     __shared__ uint32_t bin_base[kRadix];             // global position of it, minus bin_start
     __shared__ uint32_t wsum[kRadix / kWave];
-    __shared__ uint32_t s_ticket;
     __shared__ uint64_t s_stage[TILE];                // the tile reordered by digit: one array at a time
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const bool digit_thread = threadIdx.x < kRadix;   // (whole wavefronts: 0 .. 3)
     LA_SCLK_START;
-    if (threadIdx.x == 0) s_ticket = atomicAdd(&b.ticket[slot], 1u);
     for (int i = threadIdx.x; i < WAVES * kRadix; i += THREADS) (&cnt[0][0])[i] = 0;
     __syncthreads();
     const uint32_t cur = b.ctl->cur[slot];
@@ -734,7 +727,7 @@ __global__ __launch_bounds__(THREADS, 4) void onesweep_pass_kernel(SortBufs b0, 
     const uint32_t* vin = val_buf(b, cur);
     uint64_t* kout = key_buf(b, cur ^ 1u);
     uint32_t* vout = val_buf(b, cur ^ 1u);
-    const int tile = (int)s_ticket;
+    const int tile = (int)*s_ticket;
     const int64_t t0 = (int64_t)tile * TILE;
     const int64_t w0 = t0 + (int64_t)wave * kItems * kWave;
     const int n_here = (int)((b.n - t0) < TILE ? (b.n - t0) : TILE);
@@ -910,6 +903,64 @@ __global__ __launch_bounds__(THREADS, 4) void onesweep_pass_kernel(SortBufs b0, 
         }
     }
     LA_SCLK(6);                                       // both scatters issued (stores still in flight)
+}
+
+template <bool ATOMIC_RANK, int THREADS>
+__global__ __launch_bounds__(THREADS, 4) void onesweep_pass_kernel(SortBufs b0, int pass, uint32_t* status, const LargeItem* items,
+                                                                   char* scratch) {
+    LargeArgs unused{};
+    SortBufs b = b0;
+    if (items) bind_item(unused, b, items[blockIdx.y], scratch);
+    // several topics per launch: the grid is as wide as the launch's largest topic, and only workgroups that have a tile to
+    // sort may draw a ticket (tiles are taken by arrival, so exactly n_tiles workgroups of a topic must arrive)
+    if ((int)blockIdx.x >= b.n_tiles) return;
+    const int slot = pass;                            // control-block slot (skip / cur / ticket / tag of the granules)
+    if (b.ctl->skip[slot]) return;
+    __shared__ uint32_t s_ticket;
+    if (threadIdx.x == 0) s_ticket = atomicAdd(&b.ticket[slot], 1u);
+    onesweep_tile<ATOMIC_RANK, THREADS>(b, slot, status, &s_ticket);
+}
+
+// ---- the redo slots of a keys-first sort as ONE launch (round 6) ---------------------------------------------------------------
+// A keys-first sort whose tie repair met a run of equal lags longer than a workgroup holds (ctl->redo: the sample said there
+// was none, or a test forced keys first) is sorted again in full, ids first.  Rounds 4-5 kept a second set of pass launches
+// for that -- up to twelve kernels that return at once in every ordinary sort, 4.4 us apiece: 50 us of a 1.15 ms sort of 33.5 M
+// partitions, a fifth of the sort of a 5 M-partition topic.  Now: ONE kernel whose workgroups return at once unless ctl->redo
+// is set, and otherwise run all the redo passes themselves -- tiles by ticket as in the pass kernel (a workgroup that holds
+// ticket t walks back over tiles that running workgroups hold: the look-back cannot wait for a workgroup that has not
+// started), an agent-scope barrier over the launch's workgroups between passes.  The grid is small enough to be resident at
+// once (a workgroup keeps its CU until the last pass is done).
+template <bool ATOMIC_RANK, int THREADS>
+__global__ __launch_bounds__(THREADS, 4) void onesweep_redo_kernel(SortBufs b0, uint32_t pass_mask, uint32_t* status, const LargeItem* items,
+                                                                   char* scratch) {
+    LargeArgs unused{};
+    SortBufs b = b0;
+    if (items) bind_item(unused, b, items[blockIdx.y], scratch);
+    if (!b.ctl->keys_first || !b.ctl->redo) return;   // (every workgroup of the topic reads the same words: replan_kernel ran before)
+    __shared__ uint32_t s_ticket;
+    uint32_t passes_done = 0;
+    for (int d = 0; d < kDigits; ++d) {
+        const int slot = kDigits + d;
+        if (!((pass_mask >> d) & 1u) || b.ctl->skip[slot]) continue;          // (uniform over the topic's workgroups)
+        for (;;) {
+            if (threadIdx.x == 0) s_ticket = atomicAdd(&b.ticket[slot], 1u);
+            __syncthreads();
+            const bool more = (int)s_ticket < b.n_tiles;
+            if (!more) break;                          // (uniform: one shared word; nobody writes it before the barrier below)
+            onesweep_tile<ATOMIC_RANK, THREADS>(b, slot, status, &s_ticket);
+            __syncthreads();                           // the tile's last reads of the staging buffer and of s_ticket
+        }
+        // every workgroup's stores of this pass, visible to every other before the next pass reads them
+        ++passes_done;
+        __threadfence();
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __hip_atomic_fetch_add(&b.ctl->redo_arrived, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            const uint32_t want = passes_done * gridDim.x;
+            while (__hip_atomic_load(&b.ctl->redo_arrived, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < want) __builtin_amdgcn_s_sleep(2);
+        }
+        __syncthreads();
+    }
 }
 
 // ---- outputs that do not depend on the greedy ----------------------------------------------------
@@ -2401,6 +2452,25 @@ static void sort_run_passes(const SortBufs& b, hipStream_t stream, uint32_t* sta
     if (!items && slot0 == 0)
         LA_LAUNCH(plan_kernel, dim3(kDigits), dim3(kRadix), 0, stream, b, (const LargeItem*)nullptr, (char*)nullptr);
     if (planned) (void)hipEventRecord(planned, stream);
+    if (slot0 == kDigits && b.tile_state) {
+        // the redo slots of a keys-first sort: one launch (onesweep_redo_kernel), a grid that is resident at once -- at most 128
+        // workgroups over all the launch's topics (a workgroup of 1 024 threads keeps 130 KB of LDS: one per CU)
+        int gx = items ? max_tiles : b.n_tiles;
+        const int per_topic = 128 / (items ? (count < 128 ? count : 128) : 1);
+        if (gx > per_topic) gx = per_topic < 1 ? 1 : per_topic;
+        const dim3 grid(gx, items ? count : 1);
+        if (b.sweep_threads == 1024) {
+            if (b.atomic_rank) LA_LAUNCH((onesweep_redo_kernel<true, 1024>), grid, dim3(1024), 0, stream, b, pass_mask, status, items, scratch);
+            else LA_LAUNCH((onesweep_redo_kernel<false, 1024>), grid, dim3(1024), 0, stream, b, pass_mask, status, items, scratch);
+        } else if (b.sweep_threads == 512) {
+            if (b.atomic_rank) LA_LAUNCH((onesweep_redo_kernel<true, 512>), grid, dim3(512), 0, stream, b, pass_mask, status, items, scratch);
+            else LA_LAUNCH((onesweep_redo_kernel<false, 512>), grid, dim3(512), 0, stream, b, pass_mask, status, items, scratch);
+        } else {
+            if (b.atomic_rank) LA_LAUNCH((onesweep_redo_kernel<true, 256>), grid, dim3(256), 0, stream, b, pass_mask, status, items, scratch);
+            else LA_LAUNCH((onesweep_redo_kernel<false, 256>), grid, dim3(256), 0, stream, b, pass_mask, status, items, scratch);
+        }
+        return;
+    }
     for (int d = 0; d < kDigits; ++d) {
         if (!((pass_mask >> d) & 1u)) continue;
         const int p = slot0 + d;
