@@ -338,17 +338,17 @@ def live_sort_traffic(n, form):
         os.environ.pop("LA_SORT_MULTIKERNEL", None)
     if not d:
         return None
-    # launches of a sort per kernel: 12 pass slots + 12 redo slots (no-ops unless a keys-first sort has to be redone) and the
-    # tie repair in the single-kernel form; 12 of each in the four-kernel form
-    capable = n >= (1 << 22) and os.environ.get("LA_SORT_KEYS_FIRST") != "0"      # (la_large.hip, keys_first_mode)
-    names = ({"onesweep_pass_kernel": 24 if capable else 12, "tie_scan_kernel": 1, "tie_repair_kernel": 1} if form == "single" else
-             {"tile_count_kernel": 12, "scan_group_sums_kernel": 12, "scan_offsets_kernel": 12, "tile_scatter_kernel": 12})
+    # every launch of the sort phase's kernels in the probe (how many pass slots a sort launches depends on the caller's bounds
+    # and on the plan since round 6), over the probe's two sorts: mean bytes per launch x launches / 2
+    sorts_in_probe = 2                                           # (tools/pmc_probe.py runs the large topic twice)
+    names = (("onesweep_pass_kernel", "onesweep_redo_kernel", "tie_scan_kernel", "tie_repair_kernel") if form == "single" else
+             ("tile_count_kernel", "scan_group_sums_kernel", "scan_offsets_kernel", "tile_scatter_kernel", "tie_scan_kernel", "tie_repair_kernel"))
     rd = wr = 0.0
     for k, e in d["kernels"].items():
-        for x, launches in names.items():
-            if x in k:
-                rd += launches * e.get("fetch_bytes_calibrated", 0.0)
-                wr += launches * e.get("write_bytes_calibrated", 0.0)
+        if any(x in k for x in names):
+            launches = float(e.get("dispatches", 0)) / sorts_in_probe
+            rd += launches * e.get("fetch_bytes_calibrated", 0.0)
+            wr += launches * e.get("write_bytes_calibrated", 0.0)
     if rd <= 0 or wr <= 0:
         return None
     return {"hbm_bytes_per_launch": round(rd + wr), "read_bytes": round(rd), "written_bytes": round(wr), "source": d["how"]}
