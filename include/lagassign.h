@@ -128,8 +128,10 @@ extern "C" {
                                  * max_lag_hint for every lag the batch produces (the largest end offset will do: a lag never exceeds    *
                                  * it) and 0 <= partition id <= max_partition_id_hint.  When the bounds PROVE that every tile's records  *
                                  * pack into 64 bits, the tile path drops its second launch (the wide-record kernel over the list of     *
-                                 * deferred tiles, empty in that case): one launch per batch instead of two.  A partition that violates  *
-                                 * the bounds is reported by la_sync as LA_EINVAL -- never a silently different result.                  */
+                                 * deferred tiles, empty in that case): one launch per batch instead of two.  On the large path (since   *
+                                 * round 6) the radix passes over digits the bounds rule out -- key digits above the largest lag's bits, *
+                                 * id digits above the largest id's -- are not launched.  A partition that violates the bounds is        *
+                                 * reported by la_sync as LA_EINVAL -- never a silently different result.                                */
 #define LA_FLAG_WIRE_OUT    4096 /* d_out_wire / wire_elem_bytes / wire_id_bits below are valid (since ABI 0.4.0): the results leave the kernels     *
                                  * in the narrow wire format of the multi-GPU all-gather (la_wire_format_for, below) -- one element of 2 or 4 bytes  *
                                  * per assigned partition, ((member rank + 1) << id_bits) | partition id, in assignment order -- INSTEAD of the two   *
