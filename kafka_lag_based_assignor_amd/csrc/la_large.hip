@@ -2453,10 +2453,13 @@ static void sort_run_passes(const SortBufs& b, hipStream_t stream, uint32_t* sta
         LA_LAUNCH(plan_kernel, dim3(kDigits), dim3(kRadix), 0, stream, b, (const LargeItem*)nullptr, (char*)nullptr);
     if (planned) (void)hipEventRecord(planned, stream);
     if (slot0 == kDigits && b.tile_state) {
-        // the redo slots of a keys-first sort: one launch (onesweep_redo_kernel), a grid that is resident at once -- at most 128
-        // workgroups over all the launch's topics (a workgroup of 1 024 threads keeps 130 KB of LDS: one per CU)
+        // the redo slots of a keys-first sort: one launch (onesweep_redo_kernel), a grid that is resident at once -- at most 64
+        // workgroups over all the launch's topics (a workgroup of 1 024 threads keeps 130 KB of LDS: one per CU; the lanes of a
+        // host-buffer call may run up to four such launches side by side on their streams: 4 x 64 = the chip's 256 CUs, so
+        // every launch's workgroups become resident whatever the others do -- a workgroup waiting for a CU behind spinning
+        // ones of ANOTHER launch would otherwise be a deadlock in the making)
         int gx = items ? max_tiles : b.n_tiles;
-        const int per_topic = 128 / (items ? (count < 128 ? count : 128) : 1);
+        const int per_topic = 64 / (items ? (count < 64 ? count : 64) : 1);
         if (gx > per_topic) gx = per_topic < 1 ? 1 : per_topic;
         const dim3 grid(gx, items ? count : 1);
         if (b.sweep_threads == 1024) {
