@@ -595,6 +595,7 @@ int enqueue_batch(la_ctx* ctx, Lane& ln, const la_device_batch* b, hipStream_t s
     a.reset_latest = (b->reset_mode == LA_RESET_LATEST) ? 1 : 0;
     a.n_total = b->n_partitions;
     a.flags = b->flags & (LA_FLAG_INDEX64 | LA_FLAG_DEFER_WIDE);
+    if (getenv("LA_TILE_ALWAYS_STAGE2")) a.flags |= la::kTileAlwaysStage2;       // (A/B hook, read at every call)
     if (wire_out) {
         a.flags |= la::kTileWireOut;
         a.out_wire = b->d_out_wire;

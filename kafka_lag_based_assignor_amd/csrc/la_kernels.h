@@ -55,6 +55,7 @@ constexpr int32_t kTileNoDefer = 8;       // TileArgs::flags: the bounds prove t
                                           // launch; a tile that does not pack after all raises kStatusBounds
 constexpr int32_t kTileWireOut = 16;      // TileArgs::flags: out_wire instead of out_pid / out_rank (needs kTileNoDefer)
 constexpr int32_t kTileSkipOversize = 4;  // TileArgs::flags: topics beyond the tile belong to another path, no error
+constexpr int32_t kTileAlwaysStage2 = 32; // TileArgs::flags: (lab hook, LA_TILE_ALWAYS_STAGE2) never skip the second-stage `begin` loads
 
 constexpr int64_t kTileMaxPartitions = 1024;   // 64 lanes x 16 records
 constexpr int64_t kTileMaxConsumers = 64;      // one consumer bin per lane
