@@ -121,12 +121,38 @@ using TopicDesc = TopicDescT<int64_t>;
 
 // element `idx` of `base`, read as V (a 1- or 2-element vector of T).  With 32-bit indexing the byte offset is
 // formed in 32 bits, which lets the load use the SGPR-base + VGPR-offset form (no 64-bit VALU address math).
+// The tile's inputs are read ONCE: non-temporal loads (round 6) keep them from displacing anything in the caches on their way
+// through -- same-box A/B on the 25.6 M-partition target, three alternations: 0.1440 / 0.1434 / 0.1442 ms per step with plain
+// loads, 0.1387 / 0.1387 / 0.1385 with these (frac 0.79 -> 0.82; profiles/r06_ab_nt_loads.txt).  -DLA_NT_LOADS=0: plain loads.
+#ifndef LA_NT_LOADS
+#define LA_NT_LOADS 1
+#endif
 template <typename V, typename T, typename IDX>
 __device__ __forceinline__ V load_at(const T* base, IDX idx) {
+    const V* p;
     if constexpr (sizeof(IDX) == 4)
-        return *reinterpret_cast<const V*>(reinterpret_cast<const char*>(base) + (uint32_t)(idx * (uint32_t)sizeof(T)));
+        p = reinterpret_cast<const V*>(reinterpret_cast<const char*>(base) + (uint32_t)(idx * (uint32_t)sizeof(T)));
     else
-        return *reinterpret_cast<const V*>(base + idx);
+        p = reinterpret_cast<const V*>(base + idx);
+#if LA_NT_LOADS
+    if constexpr (sizeof(V) == 16) {
+        typedef long long LL2 __attribute__((ext_vector_type(2), aligned(8)));
+        const LL2 v = __builtin_nontemporal_load(reinterpret_cast<const LL2*>(p));
+        V out;
+        __builtin_memcpy(&out, &v, 16);
+        return out;
+    } else if constexpr (sizeof(V) == 8) {
+        typedef int I2 __attribute__((ext_vector_type(2), aligned(4)));
+        const I2 v = __builtin_nontemporal_load(reinterpret_cast<const I2*>(p));
+        V out;
+        __builtin_memcpy(&out, &v, 8);
+        return out;
+    } else {
+        return *p;
+    }
+#else
+    return *p;
+#endif
 }
 
 // element index of a lane's v-th pair, clamped so that a 2-element load stays inside [0, n_total).
