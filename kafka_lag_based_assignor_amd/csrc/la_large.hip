@@ -36,6 +36,20 @@ namespace la {
 
 namespace {
 
+// Arrays that a kernel reads ONCE (the caller's inputs in build_keys_kernel, a pass's source buffers) as non-temporal loads
+// (round 6, after the tile kernel's A/B: profiles/r06_ab_nt_loads.txt).  -DLA_LARGE_NT_LOADS=0: plain loads.
+#ifndef LA_LARGE_NT_LOADS
+#define LA_LARGE_NT_LOADS 1
+#endif
+template <typename T>
+__device__ __forceinline__ T stream_load(const T* p) {
+#if LA_LARGE_NT_LOADS
+    return __builtin_nontemporal_load(p);
+#else
+    return *p;
+#endif
+}
+
 constexpr int kDigits = 12;            // 4 id digits + 8 key digits
 constexpr int kRadix = 256;
 constexpr int kSortThreads = 256;
@@ -181,8 +195,8 @@ __global__ __launch_bounds__(256) void build_keys_kernel(LargeArgs a0, SortBufs 
         if (valid) {
             const int64_t g = a.p0 + i;
             int64_t lag;
-            if (a.lag) lag = a.lag[g];
-            else lag = partition_lag(a.begin ? a.begin[g] : 0, a.end[g], a.committed[g], latest);
+            if (a.lag) lag = stream_load(a.lag + g);
+            else lag = partition_lag(a.begin ? stream_load(a.begin + g) : 0, stream_load(a.end + g), stream_load(a.committed + g), latest);
             key = (uint64_t)lag ^ kLagKeyFlip;
             const int32_t id = a.pid[g];
             val = (uint32_t)id ^ kPidBias;
@@ -574,8 +588,8 @@ __global__ __launch_bounds__(kSortThreads) void tile_scatter_kernel(SortBufs b, 
     for (int it = 0; it < kItems; ++it) {
         const int64_t i = w0 + it * kWave + lane;
         const bool valid = i < b.n;
-        key[it] = valid ? kin[i] : 0;
-        val[it] = valid ? vin[i] : 0;
+        key[it] = valid ? stream_load(kin + i) : 0;
+        val[it] = valid ? stream_load(vin + i) : 0;
     }
     rank_in_wave<ATOMIC_RANK>(key, val, loc, cnt[wave], pass, w0, b.n, lane);
     __syncthreads();
@@ -741,8 +755,8 @@ __device__ __forceinline__ void onesweep_tile(const SortBufs& b, const int slot,
     for (int it = 0; it < kItems; ++it) {
         const int64_t i = w0 + it * kWave + lane;
         const bool valid = i < b.n;
-        key[it] = valid ? kin[i] : 0;
-        val[it] = valid ? vin[i] : 0;
+        key[it] = valid ? stream_load(kin + i) : 0;
+        val[it] = valid ? stream_load(vin + i) : 0;
     }
     LA_SCLK(0);                                       // ticket, counters, loads issued
     rank_in_wave<ATOMIC_RANK>(key, val, loc, cnt[wave], pass, w0, b.n, lane);
