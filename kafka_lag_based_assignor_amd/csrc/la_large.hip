@@ -50,6 +50,19 @@ __device__ __forceinline__ T stream_load(const T* p) {
 #endif
 }
 
+// Round 1 of the greedy turns the bins around instead of sorting them from scratch (greedy_rounds_packed).  -DLA_ROUND1_REVERSE=0: round 5's form.
+#ifndef LA_ROUND1_REVERSE
+#define LA_ROUND1_REVERSE 1
+#endif
+// The moved-bins sort takes up to twice its narrow capacity in a wide form (moved_sort_bins).  -DLA_WIDE_MOVED=0: narrow only.
+// LA_WIDE_MOVED_LIMIT x (bins per thread of the round) = the most bins the wide form is tried on (512 = all that fit).
+#ifndef LA_WIDE_MOVED
+#define LA_WIDE_MOVED 1
+#endif
+#ifndef LA_WIDE_MOVED_LIMIT
+#define LA_WIDE_MOVED_LIMIT 512
+#endif
+
 constexpr int kDigits = 12;            // 4 id digits + 8 key digits
 constexpr int kRadix = 256;
 constexpr int kSortThreads = 256;
@@ -1050,6 +1063,14 @@ __device__ __forceinline__ void cross_wave_step(P64 (&rec)[EC], ExchangeBufs& xb
 
 #ifdef LA_ROUND_CLOCKS   // development build: thread 0 accumulates the cycles of every phase of a round (tools/cfg5_probe.py)
 __device__ unsigned long long g_round_clocks[16];
+__device__ unsigned long long g_round_stamp[520];        // [q] clock at the start of round q; [260 + q] path << 32 | bins that moved
+#define LA_STAMP(q, path, m)                                                                           \
+    do {                                                                                               \
+        if (threadIdx.x == 0 && (q) < 259) {                                                           \
+            g_round_stamp[q] = clock64();                                                              \
+            g_round_stamp[260 + (q)] = ((unsigned long long)(path) << 32) | (unsigned)(m);             \
+        }                                                                                              \
+    } while (0)
 #define LA_CLK(i)                                                          \
     do {                                                                   \
         if (threadIdx.x == 0) {                                            \
@@ -1059,9 +1080,14 @@ __device__ unsigned long long g_round_clocks[16];
         }                                                                  \
     } while (0)
 #define LA_CLK_START unsigned long long clk_ = clock64()
+#define LA_CLK_PARAM , unsigned long long& clk_          // a helper that times its phases on the caller's clock
+#define LA_CLK_ARG , clk_
 #else
+#define LA_CLK_PARAM
+#define LA_CLK_ARG
 #define LA_CLK(i) do {} while (0)
 #define LA_CLK_START do {} while (0)
+#define LA_STAMP(q, path, m) do {} while (0)
 #endif
 
 constexpr int kSampleThreads = 1024;
@@ -1084,7 +1110,7 @@ struct SampleLds {
     uint32_t* misc;       // [32] per-wavefront sums and maxima; [32 .. 32 + 66) second-level bucket counts, flag
     uint32_t* moved;      // [kMovedWords] the moved-bins sort's own words (moved_sort_bins): nothing else touches them
 };
-constexpr int kMovedWords = 160;
+constexpr int kMovedWords = 256;
 
 __host__ __device__ constexpr size_t sample_lds_bytes(int ec) {
     return ((size_t)ec * kSampleThreads + kWalkPad) * 16 + (size_t)kSamplesPerThread * kSampleThreads * (16 + 4) + 64 + (32 + 128) * 4 +
@@ -1472,23 +1498,160 @@ __device__ __forceinline__ uint64_t readlane_u64(uint64_t v, int lane) {   // (l
            (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, lane);
 }
 
+// The small sort of moved_sort_bins: the m bins that move stand side by side in comp[0 .. m); on return they stand there in
+// order.  NS samples (64 or 128) cut them into NS + 1 buckets; a bin's place is its bucket's first place plus the number of
+// bins of its bucket below it.  CPT = bins per thread (m <= CPT * 1 024).  false: a bucket grew beyond `bucket_limit` (the
+// caller sorts the round another way; comp is spent either way).
+template <int CPT, int NS>
+__device__ __forceinline__ bool moved_small_sort(uint64_t* comp, ulonglong2* stage2, uint64_t* sup, uint64_t* sup1, uint32_t* cnt2,
+                                                 const int m, const int tid, const uint32_t bucket_limit LA_CLK_PARAM) {
+    constexpr int NT = kSampleThreads;
+    constexpr int NSUP = NS / 8;                                 // every eighth sample
+    static_assert(NS == 64 || NS == 128, "one or two samples per lane");
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    {
+        // NS evenly spaced samples (distinct places: m > NS), every wavefront ranks NS / 16 of them: the number of samples
+        // below one is its place among them
+        if constexpr (NS == 64) {
+            const uint64_t smp = comp[((uint32_t)lane * (uint32_t)m + (uint32_t)m / 2u) >> 6];
+#pragma unroll
+            for (int k = 0; k < 64 / (NT / 64); ++k) {
+                const uint64_t s = readlane_u64(smp, wave * (64 / (NT / 64)) + k);
+                const int rank = __builtin_popcountll(__builtin_amdgcn_ballot_w64(smp < s));
+                if (lane == 0) {
+                    sup[rank] = s;
+                    if ((rank & 7) == 7) sup1[rank >> 3] = s;
+                }
+            }
+        } else {
+            const uint64_t smp0 = comp[((uint32_t)lane * (uint32_t)m + (uint32_t)m / 2u) >> 7];
+            const uint64_t smp1 = comp[((uint32_t)(64 + lane) * (uint32_t)m + (uint32_t)m / 2u) >> 7];
+            const uint64_t mine = wave < 8 ? smp0 : smp1;        // wavefronts 0 .. 7 rank samples 0 .. 63, the others 64 .. 127
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const uint64_t s = readlane_u64(mine, (wave & 7) * 8 + k);
+                const int rank = __builtin_popcountll(__builtin_amdgcn_ballot_w64(smp0 < s)) +
+                                 __builtin_popcountll(__builtin_amdgcn_ballot_w64(smp1 < s));
+                if (lane == 0) {
+                    sup[rank] = s;
+                    if ((rank & 7) == 7) sup1[rank >> 3] = s;
+                }
+            }
+        }
+        if (tid < kMovedPad) stage2[m + tid] = make_ulonglong2(~0ull, 0);     // sentinels behind the staged bins
+    }
+    lds_barrier();                                               // (3)
+    LA_CLK(10);
+    uint64_t x[CPT];
+    uint32_t b2[CPT], slot[CPT];
+#pragma unroll
+    for (int u = 0; u < CPT; ++u) {
+        const int c = tid + u * NT;
+        x[u] = ~0ull; b2[u] = 0; slot[u] = 0;
+        if (u * NT + wave * 64 < m) {                            // (wavefront-uniform: a wavefront without a bin skips the phase)
+            const bool valid = c < m;
+            x[u] = comp[valid ? c : 0];
+            // bucket = the number of samples below the bin, in two steps (two dependent trips to LDS where a binary search
+            // makes seven): which eighth (sixteenth) of the samples, then where inside it
+            uint32_t c1 = 0, c2 = 0;
+#pragma unroll
+            for (int i = 0; i < NSUP; ++i) c1 += (sup1[i] < x[u]) ? 1u : 0u;
+            const uint32_t r1 = c1 < (uint32_t)(NSUP - 1) ? c1 : (uint32_t)(NSUP - 1);
+            const uint64_t* row = sup + 8u * r1;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) c2 += (row[i] < x[u]) ? 1u : 0u;           // (c1 < NSUP: row[7] is not below)
+            const uint32_t b = 8u * r1 + c2;
+            b2[u] = b;
+            if (valid) slot[u] = atomicAdd(&cnt2[b], 1u);
+        }
+    }
+    lds_barrier();                                               // (4)
+    LA_CLK(11);
+    // first places of the NS + 1 buckets, the largest bucket: every wavefront for itself (a scan over its lanes), no barrier
+    uint32_t first[CPT], size[CPT];
+    if constexpr (NS == 64) {
+        const uint32_t c = cnt2[lane];
+        const uint32_t incl = wave_incl_scan_u32(c);
+        const uint32_t last = cnt2[64];
+        if (wave_max_u32(max(c, last)) > bucket_limit) return false;             // (workgroup-uniform: same counts everywhere)
+        const uint32_t all = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+#pragma unroll
+        for (int u = 0; u < CPT; ++u) {
+            const uint32_t bl = b2[u] & 63u;
+            const uint32_t f = (uint32_t)__shfl((int)(incl - c), (int)bl), z = (uint32_t)__shfl((int)c, (int)bl);
+            first[u] = b2[u] < 64u ? f : all;
+            size[u] = b2[u] < 64u ? z : last;
+        }
+    } else {
+        const uint32_t c0 = cnt2[lane], c1 = cnt2[64 + lane];
+        const uint32_t last = cnt2[128];
+        if (wave_max_u32(max(max(c0, c1), last)) > bucket_limit) return false;   // (workgroup-uniform)
+        const uint32_t incl0 = wave_incl_scan_u32(c0);
+        const uint32_t all0 = (uint32_t)__builtin_amdgcn_readlane((int)incl0, 63);
+        const uint32_t incl1 = wave_incl_scan_u32(c1) + all0;
+        const uint32_t all = (uint32_t)__builtin_amdgcn_readlane((int)incl1, 63);
+#pragma unroll
+        for (int u = 0; u < CPT; ++u) {
+            const uint32_t bl = b2[u] & 63u;
+            const uint32_t f0 = (uint32_t)__shfl((int)(incl0 - c0), (int)bl), z0 = (uint32_t)__shfl((int)c0, (int)bl);
+            const uint32_t f1 = (uint32_t)__shfl((int)(incl1 - c1), (int)bl), z1 = (uint32_t)__shfl((int)c1, (int)bl);
+            first[u] = b2[u] < 64u ? f0 : (b2[u] < 128u ? f1 : all);
+            size[u] = b2[u] < 64u ? z0 : (b2[u] < 128u ? z1 : last);
+        }
+    }
+    LA_CLK(12);
+#pragma unroll
+    for (int u = 0; u < CPT; ++u) {
+        const int c = tid + u * NT;
+        if (c < m) stage2[first[u] + slot[u]] = make_ulonglong2(x[u], (uint64_t)((size[u] << 16) | slot[u]));
+    }
+    lds_barrier();                                               // (5)
+    LA_CLK(13);
+    const uint64_t* keys = reinterpret_cast<const uint64_t*>(stage2);
+#pragma unroll
+    for (int u = 0; u < CPT; ++u) {
+        const int c = tid + u * NT;
+        if (u * NT + wave * 64 < m) {                            // (wavefront-uniform: the walk's bound is a wavefront maximum)
+            const bool valid = c < m;
+            const ulonglong2 e = valid ? stage2[c] : make_ulonglong2(~0ull, 0);
+            const uint32_t inf = (uint32_t)e.y;
+            const uint32_t s0 = valid ? (uint32_t)c - (inf & 0xFFFFu) : 0u;
+            const uint32_t cmax = wave_max_u32(inf >> 16);
+            const uint64_t* bk = keys + 2 * s0;
+            uint32_t below = 0;
+#pragma unroll 2
+            for (uint32_t k = 0; k < cmax; k += 4) {
+                const uint64_t o0 = bk[2 * k], o1 = bk[2 * k + 2], o2 = bk[2 * k + 4], o3 = bk[2 * k + 6];
+                below += (o0 < e.x ? 1u : 0u) + (o1 < e.x ? 1u : 0u) + (o2 < e.x ? 1u : 0u) + (o3 < e.x ? 1u : 0u);
+            }
+            if (valid) comp[s0 + below] = e.x;                   // (comp was last read before barrier 4)
+        }
+    }
+    lds_barrier();                                               // (6)
+    LA_CLK(14);
+    return true;
+}
+
 template <int EC>
 __device__ __forceinline__ bool moved_sort_bins(P64 (&rec)[EC], const SampleLds& L, int tid, uint32_t bucket_limit, int* moved_out) {
     constexpr int NT = kSampleThreads;
     constexpr int CPT = EC >= 8 ? 2 : 1;                         // bins of the small sort per thread
-    constexpr int kCap = 256 * EC;                               // its capacity (a quarter of the round's bins)
-    static_assert(kCap <= CPT * NT && NT == 1024, "capacity");
+    constexpr int kCapN = 256 * EC;                              // its capacity (a quarter of the round's bins) in the narrow form
+    constexpr bool kWide = LA_WIDE_MOVED != 0 && EC >= 4;        // the wide form: twice the capacity, twice the bins per thread, 128 buckets
+    constexpr int kCap = kWide ? 2 * kCapN : kCapN;              // what the side-by-side array holds
+    static_assert(kCapN <= CPT * NT && NT == 1024, "capacity");
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     uint64_t* wmax = reinterpret_cast<uint64_t*>(L.moved);       // [16] a wavefront's largest bin
     uint64_t* wmin = wmax + 16;                                  // [16] its smallest
     uint32_t* wcnt = L.moved + 64;                               // [16] its bins that move
-    uint32_t* cnt2 = L.moved + 80;                               // [64 + 1] bucket counts
-    uint32_t* taken = L.moved + 146;                             // [1] places of the side-by-side array handed out so far
+    uint32_t* cnt2 = L.moved + 80;                               // [128 + 1] bucket counts (64 + 1 in the narrow form)
+    uint32_t* taken = L.moved + 210;                             // [1] places of the side-by-side array handed out so far
     uint64_t* comp = reinterpret_cast<uint64_t*>(L.stage);       // [kCap] the bins that move, in the order of their places; then sorted
     ulonglong2* stage2 = reinterpret_cast<ulonglong2*>(comp + kCap);     // [kCap + kMovedPad] staged by bucket
-    uint64_t* sup = reinterpret_cast<uint64_t*>(stage2 + kCap + kMovedPad);   // [64] the samples in order
-    uint64_t* sup1 = sup + 64;                                   // [8] every eighth of them (sup[7], sup[15] ..)
+    uint64_t* sup = reinterpret_cast<uint64_t*>(stage2 + kCap + kMovedPad);   // [64 | 128] the samples in order
+    uint64_t* sup1 = sup + 128;                                  // [8 | 16] every eighth of them (sup[7], sup[15] ..)
     LA_CLK_START;
     // 1. who stays
     uint64_t v[EC];
@@ -1518,8 +1681,8 @@ __device__ __forceinline__ bool moved_sort_bins(P64 (&rec)[EC], const SampleLds&
         w_lo = ~readlane_u64(incl_m, 63);
     }
     if (lane == 0) { wmax[wave] = w_hi; wmin[wave] = w_lo; }
-    if (tid < 65) cnt2[tid] = 0;
-    if (tid == 65) *taken = 0;
+    if (tid < 129) cnt2[tid] = 0;
+    if (tid == 129) *taken = 0;
     lds_barrier();                                               // (1)
     LA_CLK(7);
     uint64_t pm_w, sm_w;                                         // over the earlier / later wavefronts
@@ -1601,94 +1764,20 @@ __device__ __forceinline__ bool moved_sort_bins(P64 (&rec)[EC], const SampleLds&
             if (lane < m) comp[lane] = p64_value(s);
         }
         lds_barrier();
+    } else if (__builtin_expect(m <= kCapN, 1)) {
+        if (!moved_small_sort<CPT, 64>(comp, stage2, sup, sup1, cnt2, m, tid, bucket_limit LA_CLK_ARG)) return false;
     } else {
-        {
-            // 64 evenly spaced samples (distinct places: m > 64), every wavefront ranks four of them: the number of samples
-            // below one is its place among them
-            const uint64_t smp = comp[((uint32_t)lane * (uint32_t)m + (uint32_t)m / 2u) >> 6];
-#pragma unroll
-            for (int k = 0; k < 64 / (NT / 64); ++k) {
-                const uint64_t s = readlane_u64(smp, wave * (64 / (NT / 64)) + k);
-                const int rank = __builtin_popcountll(__builtin_amdgcn_ballot_w64(smp < s));
-                if (lane == 0) {
-                    sup[rank] = s;
-                    if ((rank & 7) == 7) sup1[rank >> 3] = s;
-                }
-            }
-            if (tid < kMovedPad) stage2[m + tid] = make_ulonglong2(~0ull, 0);     // sentinels behind the staged bins
+        if constexpr (kWide) {
+            // more bins move than the narrow form holds, not more than twice as many (the dense bulk of a power-law topic of
+            // 131 072 .. 262 144 or of ~2 M partitions over 8 192 consumers: 2 050 - 3 100 per round): the same sort with four bins
+            // per thread and 128 buckets -- a round of 27 - 33 k cycles where the sample sort over all bins takes 51 k and the run
+            // merge 55 - 59 k.  Decided per round from what the round's bins say (round 6's first wide form was chosen by the
+            // host from the number of rounds, kept 64 buckets, and lost wherever ~4 000 bins moved).
+            if (m > LA_WIDE_MOVED_LIMIT * EC) return false;
+            if (!moved_small_sort<2 * CPT, 128>(comp, stage2, sup, sup1, cnt2, m, tid, bucket_limit LA_CLK_ARG)) return false;
+        } else {
+            return false;
         }
-        lds_barrier();                                           // (3)
-        LA_CLK(10);
-        uint64_t x[CPT];
-        uint32_t b2[CPT], slot[CPT];
-#pragma unroll
-        for (int u = 0; u < CPT; ++u) {
-            const int c = tid + u * NT;
-            x[u] = ~0ull; b2[u] = 0; slot[u] = 0;
-            if (u * NT + wave * 64 < m) {                        // (wavefront-uniform: a wavefront without a bin skips the phase)
-                const bool valid = c < m;
-                x[u] = comp[valid ? c : 0];
-                // bucket = the number of samples below the bin, in two steps of eight reads each (two dependent trips to
-                // LDS where a binary search makes seven): which eighth of the samples, then where inside it
-                uint32_t c1 = 0, c2 = 0;
-#pragma unroll
-                for (int i = 0; i < 8; ++i) c1 += (sup1[i] < x[u]) ? 1u : 0u;
-                const uint64_t* row = sup + 8u * (c1 < 7u ? c1 : 7u);
-#pragma unroll
-                for (int i = 0; i < 8; ++i) c2 += (row[i] < x[u]) ? 1u : 0u;       // (c1 < 8: row[7] is not below)
-                const uint32_t b = 8u * (c1 < 7u ? c1 : 7u) + c2;
-                b2[u] = b;
-                if (valid) slot[u] = atomicAdd(&cnt2[b], 1u);
-            }
-        }
-        lds_barrier();                                           // (4)
-        LA_CLK(11);
-        // first places of the 65 buckets, the largest bucket: every wavefront for itself (a scan over its lanes), no barrier
-        uint32_t first[CPT], size[CPT];
-        {
-            const uint32_t c = cnt2[lane];
-            const uint32_t incl = wave_incl_scan_u32(c);
-            const uint32_t last = cnt2[64];
-            if (wave_max_u32(max(c, last)) > bucket_limit) return false;         // (workgroup-uniform: same counts everywhere)
-            const uint32_t all = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-#pragma unroll
-            for (int u = 0; u < CPT; ++u) {
-                const uint32_t bl = b2[u] & 63u;
-                const uint32_t f = (uint32_t)__shfl((int)(incl - c), (int)bl), z = (uint32_t)__shfl((int)c, (int)bl);
-                first[u] = b2[u] < 64u ? f : all;
-                size[u] = b2[u] < 64u ? z : last;
-            }
-        }
-        LA_CLK(12);
-#pragma unroll
-        for (int u = 0; u < CPT; ++u) {
-            const int c = tid + u * NT;
-            if (c < m) stage2[first[u] + slot[u]] = make_ulonglong2(x[u], (uint64_t)((size[u] << 16) | slot[u]));
-        }
-        lds_barrier();                                           // (5)
-        LA_CLK(13);
-        const uint64_t* keys = reinterpret_cast<const uint64_t*>(stage2);
-#pragma unroll
-        for (int u = 0; u < CPT; ++u) {
-            const int c = tid + u * NT;
-            if (u * NT + wave * 64 < m) {                        // (wavefront-uniform: the walk's bound is a wavefront maximum)
-                const bool valid = c < m;
-                const ulonglong2 e = valid ? stage2[c] : make_ulonglong2(~0ull, 0);
-                const uint32_t inf = (uint32_t)e.y;
-                const uint32_t s0 = valid ? (uint32_t)c - (inf & 0xFFFFu) : 0u;
-                const uint32_t cmax = wave_max_u32(inf >> 16);
-                const uint64_t* bk = keys + 2 * s0;
-                uint32_t below = 0;
-#pragma unroll 2
-                for (uint32_t k = 0; k < cmax; k += 4) {
-                    const uint64_t o0 = bk[2 * k], o1 = bk[2 * k + 2], o2 = bk[2 * k + 4], o3 = bk[2 * k + 6];
-                    below += (o0 < e.x ? 1u : 0u) + (o1 < e.x ? 1u : 0u) + (o2 < e.x ? 1u : 0u) + (o3 < e.x ? 1u : 0u);
-                }
-                if (valid) comp[s0 + below] = e.x;               // (comp was last read before barrier 4)
-            }
-        }
-        lds_barrier();                                           // (6)
-        LA_CLK(14);
     }
     // 3. back to the places the bins that move came from
     if (wave_moves) {
@@ -1736,8 +1825,44 @@ __device__ void greedy_rounds_packed(const LargeArgs& a, const uint64_t* key, in
         // values in scratch memory (the kernel sits at its 128-register cap) and reloads them in the middle of the chain.
         int tid = tid_fixed;
         asm volatile("" : "+v"(tid));
+        [[maybe_unused]] int path_ = 0, moved_ = 0;
         if (q > 0) {
             bool sorted = false;
+#if LA_ROUND1_REVERSE
+            if constexpr (EC >= 2) {
+                // Round 0 handed the DESCENDING lags to the bins in index order (all totals were 0): where the lags differ the
+                // bins stand in exactly the reverse of the order round 1 needs, and only runs of equal lags (index order = the
+                // right order already) are out of place once the C bins are turned around.  So round 1 turns them around through
+                // LDS and hands the result to the moved-bins sort (cfg5: 82 of 8 192 bins move then) instead of sorting 8 192
+                // bins from scratch -- when most threads' bins descend; a topic of equal lags is in order as it stands.
+                if (q == 1 && use_sample && a.no_moved_sort == 0 && a.no_sample_sort == 0) {
+                    uint32_t* desc_threads = L.moved + 212;
+                    if (tid == 0) *desc_threads = 0;
+                    lds_barrier();
+                    uint64_t v[EC];
+                    bool desc = true;
+#pragma unroll
+                    for (int r = 0; r < EC; ++r) v[r] = p64_value(rec[r]);
+#pragma unroll
+                    for (int r = 1; r < EC; ++r) desc &= v[r - 1] > v[r];
+                    desc &= tid * EC + EC <= C;
+                    const uint64_t votes = __builtin_amdgcn_ballot_w64(desc);
+                    if ((tid & 63) == 0 && votes) atomicAdd(desc_threads, (uint32_t)__builtin_popcountll(votes));
+#pragma unroll
+                    for (int r = 0; r < EC; ++r) s_bin[tid * EC + r] = v[r];
+                    lds_barrier();
+                    if (4u * *desc_threads >= 3u * (uint32_t)(C / EC)) {          // (workgroup-uniform)
+#pragma unroll
+                        for (int r = 0; r < EC; ++r) {
+                            const int i = tid * EC + r;
+                            if (i < C) rec[r] = p64_from(s_bin[C - 1 - i]);
+                        }
+                        next_moved = 1;
+                    }
+                    // (the moved-bins sort's first barrier stands between these reads and its writes to the same memory)
+                }
+            }
+#endif
             if constexpr (EC >= 2) {
                 // few bins move?  A topic that has the property has it round after round (the bulk of a power-law topic);
                 // one that does not (lags spread like the totals) has every bin move in every round: after a look that
@@ -1745,6 +1870,7 @@ __device__ void greedy_rounds_packed(const LargeArgs& a, const uint64_t* key, in
                 if (use_sample && a.no_moved_sort == 0 && q >= next_moved) {
                     int moved = 0;
                     sorted = moved_sort_bins<EC>(rec, L, tid, a.no_sample_sort == 2 ? 20u : kMovedBucket, &moved);
+                    moved_ = moved; if (sorted) path_ = 1;
                     if (sorted || moved <= 512 * EC) moved_wait = 0;
                     else moved_wait = moved_wait ? (moved_wait < 32 ? 2 * moved_wait : 32) : 1;
                     next_moved = q + 1 + moved_wait;
@@ -1755,14 +1881,16 @@ __device__ void greedy_rounds_packed(const LargeArgs& a, const uint64_t* key, in
                 if (!sorted && use_sample && a.no_run_merge == 0 && q >= next_look) {
                     int runs = 0;
                     sorted = merge_runs_bins<EC>(rec, L, tid, &runs);
+                    if (sorted) path_ = 2;
                     int wait = 0;
                     for (int x = runs; x > 2 * kMaxRuns && wait < 16; x >>= 1) ++wait;
                     next_look = q + 1 + wait;
                     if (!sorted) lds_barrier();              // (its LDS use ends before the sample sort's begins)
                 }
-                if (!sorted && use_sample) sorted = sample_sort_bins<EC>(rec, L, tid, a.no_sample_sort == 2 ? 6u : kMaxBucket);
+                if (!sorted && use_sample) { sorted = sample_sort_bins<EC>(rec, L, tid, a.no_sample_sort == 2 ? 6u : kMaxBucket); if (sorted) path_ = 3; }
             }
             if (!sorted) {
+                path_ = 4;
                 // sort the n bins: inside every wavefront first, then merges across wavefronts
                 dpp_fence<EC>(rec);
                 bitonic_sort_tile_p64<64, EC>(rec);
@@ -1777,6 +1905,7 @@ __device__ void greedy_rounds_packed(const LargeArgs& a, const uint64_t* key, in
             }
         }
         // position i of the sorted bins takes partition q*C + i; the next round's lags are fetched now
+        LA_STAMP(q, path_, moved_);
         LA_CLK_START;
         // A thread's EC positions are consecutive (blocked layout), so are its keys and its results: 16 bytes per
         // instruction -- two keys per load, four results per store -- instead of one element each.  This kernel runs on
@@ -1855,6 +1984,7 @@ __device__ void greedy_rounds_packed(const LargeArgs& a, const uint64_t* key, in
         }
         LA_CLK(6);
     }
+    LA_STAMP(rounds < 258 ? rounds : 258, 9, 0);
     if (a.out_total) {
 #pragma unroll
         for (int r = 0; r < EC; ++r) {
@@ -2935,6 +3065,9 @@ extern "C" __attribute__((visibility("default"))) int la_debug_lookback_stats(un
 #endif
 
 #ifdef LA_ROUND_CLOCKS
+extern "C" __attribute__((visibility("default"))) int la_debug_round_stamps(unsigned long long* out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_round_stamp), sizeof(g_round_stamp)) == hipSuccess ? 0 : -3;
+}
 extern "C" __attribute__((visibility("default"))) int la_debug_round_clocks(unsigned long long* out, int reset) {
     hipError_t e = hipMemcpyFromSymbol(out, HIP_SYMBOL(g_round_clocks), sizeof(g_round_clocks));
     if (e == hipSuccess && reset) {

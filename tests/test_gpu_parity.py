@@ -906,12 +906,17 @@ def test_large_rounds_merge_ascending_runs(ctx, p, c, kind):
     (400_000, 8192, "pareto"), (300_000, 4096, "pareto"), (120_000, 2048, "pareto"), (150_000, 5000, "pareto"),
     (200_000, 8192, "bulk16"), (200_000, 8192, "bulk5"), (200_000, 8192, "bulk3"), (100_000, 4000, "bulk16"),
     (60_000, 2048, "bulk5"), (160_000, 8192, "apart"), (90_000, 3000, "apart"), (200_000, 8192, "pairs"),
+    # the wide form of the small sort (more bins move than the narrow form holds, at most twice as many): a power-law topic whose
+    # rounds move 2 050 - 3 100 of 8 192 bins; dense bulks of 2 730 and of exactly 4 096 (the capacity) of 8 192 bins, of 1 365 and
+    # of exactly 2 048 of 4 096 (four bins per thread); consumers that do not fill the workgroup's slots
+    (131_072, 8192, "pareto"), (200_000, 8192, "bulk2"), (100_000, 4096, "bulk3"), (60_000, 4096, "bulk2"), (120_000, 8190, "bulk2"),
 ])
 def test_large_rounds_sort_only_the_bins_that_move(ctx, p, c, kind):
     """Greedy rounds in which few bins change places (moved_sort_bins, la_large.hip) sort only those: the same result as
     with LA_FLAG_NO_MOVED_SORT, as with the run merge off too, as with tight bucket limits (rounds of every form mixed),
     the oracle's.  bulkN: 1 - 1/N of the consumers stand 10^9 apart after the first round, the rest is a dense bulk that
-    reshuffles in every round (N = 3: more than fits, the rounds fall back and the look backs off); apart: nothing ever moves
+    reshuffles in every round (N = 3: more than the narrow form of the small sort holds -- the wide form's case since round 6; N = 2:
+    exactly what the wide form holds); apart: nothing ever moves
     after round 1; pairs: neighbours swap."""
     rng = np.random.default_rng(7 * p + c)
     if kind == "pareto":

@@ -68,6 +68,15 @@ def main():
             print("   cycles per phase (thread 0, %d calls): " % (args.reps + 1) +
                   ", ".join("%s %.1f%%" % (n, 100.0 * clk[i] / tot) for i, n in enumerate(names) if clk[i]) +
                   "; total %.3g = %.0f per round" % (tot, tot / (args.reps + 1) / 127.0))
+        if hasattr(ctx._lib, "la_debug_round_stamps") and os.environ.get("LA_ROUND_STAMPS"):
+            st = (ctypes.c_ulonglong * 520)()
+            ctx._lib.la_debug_round_stamps(st)
+            rounds = (args.partitions + args.consumers - 1) // args.consumers
+            names = {0: "in order", 1: "moved", 2: "run merge", 3: "sample", 4: "network", 9: "end"}
+            # stamp q is taken when round q's bins are in order: the difference to the stamp before is round q - 1's add and stores plus round q's sort
+            print("   round: cycles since the round before was in order, how this round's bins were ordered, bins that moved")
+            for q in range(1, min(rounds, 258) + 1):
+                print("   %3d %7d %-9s %5d" % (q, st[q] - st[q - 1], names.get(st[260 + q] >> 32, "?"), st[260 + q] & 0xFFFFFFFF))
         print("%-13s keys %.3f ms, sort %.3f ms (%d id + %d key passes), ids+greedy %.3f ms, call %.3f ms wall; bit-exact vs round form: %s"
               % (what, k, s, t.id_passes, t.key_passes, g, wall, ok))
     ctx.close()
