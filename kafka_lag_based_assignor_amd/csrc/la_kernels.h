@@ -233,6 +233,8 @@ struct LargeArgs {
     int32_t no_moved_sort;      // LA_FLAG_NO_MOVED_SORT: greedy rounds never sort only the bins that move
     int64_t max_lag_hint;       // LA_FLAG_BOUNDS: 0 <= lag <= max_lag_hint and 0 <= id <= max_id_hint for every partition (the caller's
     int64_t max_id_hint;        // guarantee), or -1: radix passes over digits the bounds rule out are not even launched (round 6)
+    int32_t rounds_follow;      // 1: greedy_rounds_kernel and map_ranks_kernel follow emit_ids_kernel -- the three agree on the narrow form of
+                                // the rounds' lags and results (rounds_io, la_large.hip)
 };
 
 // Once per device at context creation (synchronous): checks the hardware property the radix sort's atomic ranking relies on.

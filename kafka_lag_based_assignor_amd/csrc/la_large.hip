@@ -59,6 +59,13 @@ __device__ __forceinline__ T stream_load(const T* p) {
 #ifndef LA_WIDE_MOVED
 #define LA_WIDE_MOVED 1
 #endif
+// The rounds kernel's lags as 32-bit words and its results as 16-bit consumer indices where they fit (rounds_io).  -DLA_ROUNDS_NARROW_IO=0: off.
+#ifndef LA_ROUNDS_NARROW_IO
+#define LA_ROUNDS_NARROW_IO 1
+#endif
+#ifndef LA_ROUNDS_NARROW_EC
+#define LA_ROUNDS_NARROW_EC 8          // from how many bins per thread on (8: more than 4 096 consumers; at 4 bins per thread it lost 3 %)
+#endif
 #ifndef LA_WIDE_MOVED_LIMIT
 #define LA_WIDE_MOVED_LIMIT 512
 #endif
@@ -995,6 +1002,42 @@ __global__ __launch_bounds__(THREADS, 4) void onesweep_redo_kernel(SortBufs b0, 
 // (one returning LDS atomic per element) is stable only because colliding lanes are served in lane order -- a property of
 // the hardware checked once at la_create on an idle device, not a promise of the ISA.  A violation under load would scramble
 // the order silently; here it raises kStatusOrder (LA_EHIP at the next sync) for 8 B more read per element.
+// ---- what the rounds kernel reads and writes per round (round 6) ---------------------------------------------------------------
+// greedy_rounds_kernel is ONE workgroup on one compute unit, and every round of a topic of C consumers used to pull C sorted 64-bit
+// keys in and push C 32-bit consumer indices out through that unit's address path -- 96 KB per round at 8 192 consumers, in 16-byte
+// pieces that each touch every cache line of a wavefront's stretch: measured with the stores left out and with half the loads
+// (profiles/r06_am_rounds_memory.txt), 1.65 us of a 3.4 us round in which nothing else happens, ~0.2 ms of cfg5's 0.83.  The
+// NARROW form: where the topic has more than 4 096 consumers, its bins pack and no lag needs more than 32 bits, emit_ids_kernel leaves the lags as 32-bit words in
+// the sort's other key buffer and the rounds kernel leaves its results as 16-bit consumer indices in the sort's other value
+// buffer -- both with every round's stretch starting on a multiple of 8 elements (stride `cpad`), so a thread's 8 lags are two
+// aligned 16-byte loads, its 8 results ONE 16-byte store, and a wavefront's accesses are contiguous; map_ranks_kernel, which
+// turns indices into member ranks on the whole chip anyway, reads the 16-bit form.  emit_ids_kernel, greedy_rounds_kernel and
+// map_ranks_kernel each decide from the same sorted keys (the first carries the largest lag, the last the smallest).
+__host__ __device__ inline void rounds_class(int64_t n_cons, int* ec, int* threads);
+struct RoundsIo {
+    int idx_bits;          // the bins pack into (total << idx_bits) | index; 0: they do not (96-bit bins)
+    bool narrow;           // 32-bit lags in, 16-bit indices out, rounds `cpad` elements apart
+    int64_t cpad;          // C rounded up to a multiple of 8
+};
+// only_narrow: the caller wants `narrow` alone (emit_ids_kernel, map_ranks_kernel) -- decided without a look at the keys where it can be
+__device__ __forceinline__ RoundsIo rounds_io(const LargeArgs& a, const uint64_t* key, int64_t P, int64_t C, const bool only_narrow = false) {
+    RoundsIo io{0, false, (C + 7) & ~(int64_t)7};
+    if (P <= 0 || C <= 0) return io;
+    int ec = 1, threads = 64;
+    rounds_class(C, &ec, &threads);
+    if (only_narrow && !(LA_ROUNDS_NARROW_IO != 0 && a.rounds_follow != 0 && ec >= LA_ROUNDS_NARROW_EC && P >= 8)) return io;   // (no key is read)
+    const int n = ec * threads;
+    const int64_t rounds = (P + C - 1) / C;
+    const int64_t lmax = (int64_t)(key[0] ^ kLagKeyFlip), lmin = (int64_t)(key[P - 1] ^ kLagKeyFlip);
+    const int idx_bits = 31 - __builtin_clz(n);                                  // n is a power of two
+    const int lag_bits = lmax > 0 ? 64 - __builtin_clzll((unsigned long long)lmax) : 0;
+    const int round_bits = 64 - __builtin_clzll((unsigned long long)rounds);
+    if (lmin >= 0 && lag_bits + round_bits + idx_bits <= 62) io.idx_bits = idx_bits;
+    // (the last element written is P - 1 + 7 (rounds - 1) < 2 P: both buffers hold twice as many narrow elements as partitions)
+    io.narrow = LA_ROUNDS_NARROW_IO != 0 && a.rounds_follow != 0 && io.idx_bits != 0 && ec >= LA_ROUNDS_NARROW_EC && lag_bits <= 32 && P >= 8;
+    return io;
+}
+
 __global__ __launch_bounds__(256) void emit_ids_kernel(LargeArgs a0, SortBufs b0, const LargeItem* items, char* scratch) {
     LA_PICK_ITEM(a, b, a0, b0, items, scratch, blockIdx.y)
     if ((int64_t)blockIdx.x * blockDim.x >= b.n) return;
@@ -1003,6 +1046,9 @@ __global__ __launch_bounds__(256) void emit_ids_kernel(LargeArgs a0, SortBufs b0
     const uint32_t* val = val_buf(b, fin);
     const uint64_t* key = key_buf(b, fin);
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const RoundsIo io = rounds_io(a, key, b.n, a.n_cons, true);
+    uint32_t* lag32 = reinterpret_cast<uint32_t*>(key_buf(b, fin ^ 1u));          // (narrow form: the rounds' lags)
+    const uint32_t C32 = (uint32_t)a.n_cons;
     bool bad = false;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < b.n; i += stride) {
         const uint32_t v = val[i];
@@ -1010,6 +1056,10 @@ __global__ __launch_bounds__(256) void emit_ids_kernel(LargeArgs a0, SortBufs b0
         if (i > 0) {
             const uint64_t kp = key[i - 1];
             bad |= kp > k || (kp == k && val[i - 1] > v);
+        }
+        if (io.narrow) {
+            const uint32_t q = (uint32_t)i / C32;                                // (b.n < 2^31)
+            lag32[(int64_t)q * io.cpad + ((uint32_t)i - q * C32)] = (uint32_t)(k ^ kLagKeyFlip);
         }
         a.out_pid[a.p0 + i] = (int32_t)(v ^ kPidBias);
         if (fill_rank_minus1) a.out_rank[a.p0 + i] = -1;
@@ -1792,7 +1842,7 @@ __device__ __forceinline__ bool moved_sort_bins(P64 (&rec)[EC], const SampleLds&
 
 template <int EC>
 __device__ void greedy_rounds_packed(const LargeArgs& a, const uint64_t* key, int64_t P, int C, int64_t rounds,
-                                     int idx_bits, void* smem) {
+                                     int idx_bits, void* smem, const uint32_t* lag32, uint16_t* idx16, const int64_t cpad) {
     const int tid = threadIdx.x;
     const int n = EC * blockDim.x;
     constexpr int kSpan = 64 * EC;                       // elements of one wavefront
@@ -1806,13 +1856,18 @@ __device__ void greedy_rounds_packed(const LargeArgs& a, const uint64_t* key, in
     // issued back to back: a branch around a load makes hipcc wait for it before issuing the next one -- eight
     // serialized memory round trips per round here, 6k of a round's 52k cycles; the select happens at the use, a
     // whole round of sorting later.
+    // lag[]: the lags themselves (since round 6: the keys' flip is undone when they arrive, not when they are added).  narrow: the
+    // 32-bit lags emit_ids_kernel left, a round's stretch `cpad` elements after the one before (rounds_io).
+    const bool narrow = EC >= LA_ROUNDS_NARROW_EC && EC >= 4 && lag32 != nullptr;     // (workgroup-uniform; never for fewer bins per thread)
+    const int64_t cap8 = (2 * P - 8) & ~(int64_t)3;                              // the last aligned place a 8-element read may start
     uint64_t lag[EC];
 #pragma unroll
     for (int r = 0; r < EC; ++r) {
         const int i = tid * EC + r;
         // pads (slots beyond the C consumers) sort behind every bin and, like the bins, are all different
         rec[r] = p64_from(i < C ? (uint64_t)i : ((~0ull << idx_bits) | (uint64_t)i));
-        lag[r] = key[i < P ? i : P - 1];
+        if (narrow) lag[r] = lag32[i < cap8 ? i : cap8];                          // (round 0 starts at element 0)
+        else lag[r] = key[i < P ? i : P - 1] ^ kLagKeyFlip;
     }
     [[maybe_unused]] int64_t next_look = 1;              // the next round that looks whether its bins are a few ascending runs
     [[maybe_unused]] int64_t next_moved = 2;             // the next round that looks whether few of its bins move (round 1 sorts
@@ -1911,7 +1966,18 @@ __device__ void greedy_rounds_packed(const LargeArgs& a, const uint64_t* key, in
         // instruction -- two keys per load, four results per store -- instead of one element each.  This kernel runs on
         // ONE CU, whose address path handled 16 narrow instructions per thread and round, 64 cache lines apiece.
         uint64_t next_lag[EC];
-        if constexpr (EC >= 2) {
+        if (narrow) {
+            if constexpr (EC >= 4) {
+                typedef uint32_t U32x4 __attribute__((ext_vector_type(4), aligned(16)));
+                int64_t sb = (q + 1) * cpad + tid * EC;                          // a multiple of 4: 16-byte aligned
+                sb = sb < cap8 ? sb : cap8;                                      // (past the topic: somewhere inside the buffer, never used)
+#pragma unroll
+                for (int r = 0; r < EC; r += 4) {
+                    const U32x4 v = *reinterpret_cast<const U32x4*>(lag32 + sb + r);
+                    next_lag[r] = v.x; next_lag[r + 1] = v.y; next_lag[r + 2] = v.z; next_lag[r + 3] = v.w;
+                }
+            }
+        } else if constexpr (EC >= 2) {
             struct __attribute__((aligned(8))) U64x2 { uint64_t x, y; };
             // No branch around the loads, not even a uniform one (round 3 had `if (P >= 2)` here and hipcc put an
             // s_waitcnt vmcnt(0) between every two of them: four serialized round trips to L2 per round, ~2k cycles).  A
@@ -1922,12 +1988,12 @@ __device__ void greedy_rounds_packed(const LargeArgs& a, const uint64_t* key, in
                 const int64_t s = (q + 1) * C + tid * EC + r;
                 const int64_t base = s < last_pair ? s : last_pair;              // the pair stays inside the array
                 const U64x2 v = *reinterpret_cast<const U64x2*>(key + base);
-                next_lag[r] = base == s ? v.x : v.y;        // s == P - 1: its key is the pair's second word
-                next_lag[r + 1] = v.y;                      // (positions past P - 1 are never used)
+                next_lag[r] = (base == s ? v.x : v.y) ^ kLagKeyFlip;        // s == P - 1: its key is the pair's second word
+                next_lag[r + 1] = v.y ^ kLagKeyFlip;                        // (positions past P - 1 are never used)
             }
         } else {
             const int64_t s = (q + 1) * C + tid;
-            next_lag[0] = key[s < P ? s : P - 1];
+            next_lag[0] = key[s < P ? s : P - 1] ^ kLagKeyFlip;
         }
         int32_t who[EC];
         bool live[EC];
@@ -1936,18 +2002,27 @@ __device__ void greedy_rounds_packed(const LargeArgs& a, const uint64_t* key, in
             // -- no predicates, no 64-bit position arithmetic, two 16-byte stores
 #pragma unroll
             for (int r = 0; r < EC; ++r) {
-                const uint64_t nb = p64_value(rec[r]) + ((lag[r] ^ kLagKeyFlip) << idx_bits);       // Main.java:265
+                const uint64_t nb = p64_value(rec[r]) + (lag[r] << idx_bits);       // Main.java:265
                 rec[r] = p64_from(nb);
                 who[r] = (int32_t)((uint32_t)nb & idx_mask);
                 lag[r] = next_lag[r];
             }
             if constexpr (EC >= 4) {
-                typedef int I32x4 __attribute__((ext_vector_type(4), aligned(4)));
-                int32_t* dst = a.out_rank + a.p0 + q * C + tid * EC;
+                if (narrow) {
+                    // the thread's EC consumer indices as 16-bit words: one aligned store (two 16-byte stores of 32-bit words before)
+                    typedef uint32_t U32xH __attribute__((ext_vector_type(EC / 2), aligned(2 * EC)));
+                    U32xH v;
 #pragma unroll
-                for (int r = 0; r < EC; r += 4) {
-                    const I32x4 v4 = {who[r], who[r + 1], who[r + 2], who[r + 3]};
-                    *reinterpret_cast<I32x4*>(dst + r) = v4;
+                    for (int r = 0; r < EC; r += 2) v[r / 2] = (uint32_t)who[r] | ((uint32_t)who[r + 1] << 16);
+                    *reinterpret_cast<U32xH*>(idx16 + q * cpad + tid * EC) = v;
+                } else {
+                    typedef int I32x4 __attribute__((ext_vector_type(4), aligned(4)));
+                    int32_t* dst = a.out_rank + a.p0 + q * C + tid * EC;
+#pragma unroll
+                    for (int r = 0; r < EC; r += 4) {
+                        const I32x4 v4 = {who[r], who[r + 1], who[r + 2], who[r + 3]};
+                        *reinterpret_cast<I32x4*>(dst + r) = v4;
+                    }
                 }
             }
             LA_CLK(6);
@@ -1958,12 +2033,27 @@ __device__ void greedy_rounds_packed(const LargeArgs& a, const uint64_t* key, in
             const int i = tid * EC + r;
             const int64_t s = q * C + i;
             live[r] = i < C && s < P;
-            const uint64_t nb = p64_value(rec[r]) + ((lag[r] ^ kLagKeyFlip) << idx_bits);       // Main.java:265
+            const uint64_t nb = p64_value(rec[r]) + (lag[r] << idx_bits);       // Main.java:265
             if (live[r]) rec[r] = p64_from(nb);
             who[r] = (int32_t)((uint32_t)nb & idx_mask);    // consumer index; map_ranks_kernel turns it into the rank
             lag[r] = next_lag[r];
         }
-        if constexpr (EC >= 4) {
+        if (EC >= 4 && narrow) {
+            if constexpr (EC >= 4) {
+                uint16_t* dst = idx16 + q * cpad + tid * EC;
+                if (live[EC - 1]) {                         // the last is live: so are all before it
+                    typedef uint32_t U32xH __attribute__((ext_vector_type(EC / 2), aligned(2 * EC)));
+                    U32xH v;
+#pragma unroll
+                    for (int r = 0; r < EC; r += 2) v[r / 2] = (uint32_t)who[r] | ((uint32_t)who[r + 1] << 16);
+                    *reinterpret_cast<U32xH*>(dst) = v;
+                } else {
+#pragma unroll
+                    for (int r = 0; r < EC - 1; ++r)
+                        if (live[r]) dst[r] = (uint16_t)who[r];
+                }
+            }
+        } else if constexpr (EC >= 4) {
             typedef int I32x4 __attribute__((ext_vector_type(4), aligned(4)));
 #pragma unroll
             for (int r = 0; r < EC; r += 4) {
@@ -2014,13 +2104,13 @@ __global__ __launch_bounds__(1024) void greedy_rounds_kernel(LargeArgs a0, SortB
     const int64_t rounds = (P + C - 1) / C;
     {
         // Packed bins (total << idx_bits) | index when nothing can overflow: the keys are sorted, so the
-        // first one carries the largest lag and the last one the smallest.
-        const int64_t lmax = (int64_t)(key[0] ^ kLagKeyFlip), lmin = (int64_t)(key[P - 1] ^ kLagKeyFlip);
-        const int idx_bits = 31 - __builtin_clz(n);                                  // n is a power of two
-        const int lag_bits = lmax > 0 ? 64 - __builtin_clzll((unsigned long long)lmax) : 0;
-        const int round_bits = 64 - __builtin_clzll((unsigned long long)rounds);
-        if (lmin >= 0 && lag_bits + round_bits + idx_bits <= 62) {
-            greedy_rounds_packed<EC>(a, key, P, C, rounds, idx_bits, smem);
+        // first one carries the largest lag and the last one the smallest (rounds_io).
+        const RoundsIo io = rounds_io(a, key, P, C);
+        if (io.idx_bits) {
+            const uint32_t other = b.ctl->cur[kFinal] ^ 1u;
+            greedy_rounds_packed<EC>(a, key, P, C, rounds, io.idx_bits, smem,
+                                     io.narrow ? reinterpret_cast<const uint32_t*>(key_buf(b, other)) : nullptr,
+                                     reinterpret_cast<uint16_t*>(val_buf(b, other)), io.cpad);
             return;
         }
     }
@@ -2299,11 +2389,22 @@ __global__ __launch_bounds__(1024) void greedy_argmin_kernel(LargeArgs a, SortBu
 // The rounds kernels store the chosen consumer's INDEX (position in the topic's rank-sorted list): looking the rank up
 // there would put a dependent global load into every round of the one-workgroup chain (~6 us of 27 per round at
 // 8 192 consumers).  This pass, over all CUs, turns the indices into member ranks.
-__global__ __launch_bounds__(256) void map_ranks_kernel(LargeArgs a0, const LargeItem* items) {
-    LargeArgs a = a0;
-    if (items) { const LargeItem& it = items[blockIdx.y]; a.p0 = it.p0; a.n_part = it.n_part; a.c0 = it.c0; a.n_cons = it.n_cons; }
+__global__ __launch_bounds__(256) void map_ranks_kernel(LargeArgs a0, SortBufs b0, const LargeItem* items, char* scratch) {
+    LA_PICK_ITEM(a, b, a0, b0, items, scratch, blockIdx.y)
     if (a.n_cons == 0) return;                                         // emit_ids_kernel wrote -1: no index to map
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const uint32_t fin = b.ctl->cur[kFinal];
+    const RoundsIo io = rounds_io(a, key_buf(b, fin), a.n_part, a.n_cons, true);
+    if (io.narrow) {
+        // the rounds kernel left 16-bit consumer indices, every round's stretch on a multiple of 8 (rounds_io)
+        const uint16_t* idx16 = reinterpret_cast<const uint16_t*>(val_buf(b, fin ^ 1u));
+        const uint32_t C32 = (uint32_t)a.n_cons;
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.n_part; i += stride) {
+            const uint32_t q = (uint32_t)i / C32;
+            a.out_rank[a.p0 + i] = a.cons_rank[a.c0 + idx16[(int64_t)q * io.cpad + ((uint32_t)i - q * C32)]];
+        }
+        return;
+    }
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < a.n_part; i += stride)
         a.out_rank[a.p0 + i] = a.cons_rank[a.c0 + a.out_rank[a.p0 + i]];
 }
@@ -2325,13 +2426,13 @@ hipError_t launch_rounds(const LargeArgs& a, const SortBufs& b, int threads, hip
     LA_LAUNCH((greedy_rounds_kernel<EC>), dim3(count), dim3(threads), lds, stream, a, b, items, scratch, order);
     if (!items) {
         int grid = (int)((a.n_part + 255) / 256);
-        LA_LAUNCH(map_ranks_kernel, dim3(grid > 2048 ? 2048 : grid), dim3(256), 0, stream, a, (const LargeItem*)nullptr);
+        LA_LAUNCH(map_ranks_kernel, dim3(grid > 2048 ? 2048 : grid), dim3(256), 0, stream, a, b, (const LargeItem*)nullptr, (char*)nullptr);
     }
     return hipGetLastError();
 }
 
 // (EC, threads) of the rounds kernel for a topic with n_cons consumers (1 <= n_cons <= kLargeMaxConsumers)
-inline void rounds_class(int64_t n_cons, int* ec, int* threads) {
+__host__ __device__ inline void rounds_class(int64_t n_cons, int* ec, int* threads) {
     int cp2 = 64;
     while (cp2 < n_cons) cp2 <<= 1;
     if (cp2 <= 1024) { *ec = 1; *threads = cp2; }
@@ -2701,7 +2802,9 @@ hipError_t large_topic_launch(LargeScratch& scratch, const LargeArgs& a, bool ar
         sort_run_passes(b, stream, a.status, nullptr, pass_mask, nullptr, 1, 0, nullptr, kDigits);
     }
     if (profile) (void)hipEventRecord(pf.ev[2], stream);
-    LA_LAUNCH(emit_ids_kernel, dim3(grid), dim3(256), 0, stream, a, b, (const LargeItem*)nullptr, (char*)nullptr);
+    LargeArgs al = a;
+    al.rounds_follow = argmin ? 0 : 1;
+    LA_LAUNCH(emit_ids_kernel, dim3(grid), dim3(256), 0, stream, al, b, (const LargeItem*)nullptr, (char*)nullptr);
     if ((e = hipGetLastError()) != hipSuccess) return e;
     if (a.n_cons == 0) return hipSuccess;
 
@@ -2721,7 +2824,7 @@ hipError_t large_topic_launch(LargeScratch& scratch, const LargeArgs& a, bool ar
     }
     int ec = 1, threads = 64;
     rounds_class(a.n_cons, &ec, &threads);
-    return launch_rounds_class(ec, threads, a, b, stream);
+    return launch_rounds_class(ec, threads, al, b, stream);
 }
 
 hipError_t large_topics_launch(LargeScratch& scratch, const LargeArgs* args, int count, hipStream_t stream) {
@@ -2865,10 +2968,11 @@ hipError_t large_topics_launch(LargeScratch& scratch, const LargeArgs* args, int
         }
     }
     if (profile) (void)hipEventRecord(pf.ev[2], stream);
+    a0.rounds_follow = 1;
     LA_LAUNCH(emit_ids_kernel, dim3(gx, count), dim3(256), 0, stream, a0, b0, d_items, base);
     for (const Cls& c : cls)
         if ((e = launch_rounds_class(c.ec, c.threads, a0, b0, stream, d_items, base, d_order + c.first, c.n)) != hipSuccess) return e;
-    if (!cls.empty()) LA_LAUNCH(map_ranks_kernel, dim3(gx, count), dim3(256), 0, stream, a0, d_items);
+    if (!cls.empty()) LA_LAUNCH(map_ranks_kernel, dim3(gx, count), dim3(256), 0, stream, a0, b0, d_items, base);
     if (profile) (void)hipEventRecord(pf.ev[3], stream);
     return hipGetLastError();
 }
