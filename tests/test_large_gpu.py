@@ -170,3 +170,56 @@ def test_bounds_rule_radix_passes_out_and_a_broken_bound_is_an_error(ctx, p, c, 
             _bounded_call(ctx, w, ml, mi)
         assert e.value.code == N.LA_EINVAL
     _same3(_bounded_call(ctx, w, int(lag.max()), int(ids.max()))[0], exp, "after the errors")
+
+
+# ---- the narrow form of what the rounds kernel reads and writes (round 6: rounds_io, la_large.hip) ---------------------------------
+def _topic_with_lags(lag, c, seed):
+    rng = np.random.default_rng(seed)
+    p = lag.size
+    lag = np.ascontiguousarray(lag, np.int64)
+    return synth.Workload("narrow", 1, np.array([0, p], np.int64), rng.permutation(p).astype(np.int32), np.zeros(p, np.int64),
+                          lag.copy(), np.zeros(p, np.int64), lag, np.array([0, c], np.int64),
+                          np.sort(rng.choice(3 * c + 5, c, replace=False)).astype(np.int32), p, c)
+
+
+@pytest.mark.parametrize("p,c,top", [
+    (8192 * 5, 8192, (1 << 32) - 1),      # consumers fill every slot, full rounds only, the largest lag that still fits 32 bits
+    (8192 * 5, 8192, 1 << 32),            # one bit more: the 64-bit form
+    (8192 * 5 + 3, 8192, 10**6),          # a last round of three partitions
+    (8192 * 5 - 1, 8192, 10**6),          # a last round one partition short
+    (30001, 5001, 10**6),                 # an odd number of consumers: every round's stretch starts off a multiple of 8
+    (4097 * 3, 4097, 10**6),              # the fewest consumers that take the form; P = 3 C
+    (4096 * 6, 4096, 10**6),              # one consumer fewer: four bins per thread, the old form
+    (100, 5000, 10**6),                   # one partial round, far fewer partitions than consumers
+    (8, 8192, 10**6), (7, 8192, 10**6),   # the smallest topic that takes the form, and one that is too small for it
+    (5003, 5000, 0),                      # equal lags: nothing ever moves
+    (120000, 8000, 50),                   # heavy ties
+])
+def test_rounds_kernel_narrow_lags_and_results(ctx, p, c, top):
+    """Topics of more than 4 096 consumers whose bins pack and whose lags fit 32 bits run their greedy rounds on 32-bit lags
+    (left by emit_ids_kernel, every round's stretch on a multiple of 8 elements) and leave 16-bit consumer indices that
+    map_ranks_kernel turns into member ranks; everything else keeps the 64-bit keys and 32-bit indices.  Both forms, their
+    borders, partial rounds and consumer counts that are no multiple of anything, against the oracle -- alone and side by side
+    with other large topics (the launches over items)."""
+    rng = np.random.default_rng(p * 31 + c)
+    lag = rng.integers(0, top + 1, p) if top else np.zeros(p, np.int64)
+    if top:
+        lag[rng.integers(0, p)] = top                                   # the largest lag is really there
+    w = _topic_with_lags(lag, c, p + c)
+    exp = round_form(w.part_off, w.partition_id, w.lag, w.cons_off, w.cons_rank)
+    if p * c <= 300_000_000:
+        _same3(exp, oracle.assign_flat(w.part_off, w.partition_id, w.lag, w.cons_off, w.cons_rank), "round form vs literal")
+    _same3(_device_call(ctx, w), exp, "alone")
+    got = _device_call(ctx, w, want_totals=False)
+    np.testing.assert_array_equal(got[1], exp[1], err_msg="without totals")
+    for fl in (N.LA_FLAG_NO_MOVED_SORT, N.LA_FLAG_SAMPLE_TIGHT, N.LA_FLAG_NO_SAMPLE_SORT):
+        _same3(_device_call(ctx, w, flags=fl), exp, "flag %d" % fl)
+    # side by side with topics of other classes: per-item buffers, one launch per kernel over all of them
+    other = _batch_of([(20000, 3000), (p, c), (70000, 300), (9000, 8192), (50000, 6000)], p + 7, kinds=["u20", "u20", "u40", "u20", "ties"])
+    lag2 = other.lag.copy()
+    lag2[other.part_off[1]:other.part_off[2]] = lag
+    w2 = synth.Workload("narrow batch", other.n_topics, other.part_off, other.partition_id, other.begin, lag2.copy(), other.committed, lag2,
+                        other.cons_off, other.cons_rank, other.max_partitions, other.max_consumers)
+    exp2 = round_form(w2.part_off, w2.partition_id, w2.lag, w2.cons_off, w2.cons_rank)
+    _same3(_device_call(ctx, w2), exp2, "side by side")
+    _same3(ctx.assign_batch_lags(w2.part_off, w2.partition_id, w2.lag, w2.cons_off, w2.cons_rank), exp2, "host entry")
