@@ -1160,7 +1160,7 @@ struct SampleLds {
     uint32_t* misc;       // [32] per-wavefront sums and maxima; [32 .. 32 + 66) second-level bucket counts, flag
     uint32_t* moved;      // [kMovedWords] the moved-bins sort's own words (moved_sort_bins): nothing else touches them
 };
-constexpr int kMovedWords = 256;
+constexpr int kMovedWords = 352;
 
 __host__ __device__ constexpr size_t sample_lds_bytes(int ec) {
     return ((size_t)ec * kSampleThreads + kWalkPad) * 16 + (size_t)kSamplesPerThread * kSampleThreads * (16 + 4) + 64 + (32 + 128) * 4 +
@@ -1684,7 +1684,8 @@ __device__ __forceinline__ bool moved_small_sort(uint64_t* comp, ulonglong2* sta
 }
 
 template <int EC>
-__device__ __forceinline__ bool moved_sort_bins(P64 (&rec)[EC], const SampleLds& L, int tid, uint32_t bucket_limit, int* moved_out) {
+__device__ __forceinline__ bool moved_sort_bins(P64 (&rec)[EC], const SampleLds& L, int tid, uint32_t bucket_limit, int* moved_out,
+                                                const int parity) {
     constexpr int NT = kSampleThreads;
     constexpr int CPT = EC >= 8 ? 2 : 1;                         // bins of the small sort per thread
     constexpr int kCapN = 256 * EC;                              // its capacity (a quarter of the round's bins) in the narrow form
@@ -1693,8 +1694,12 @@ __device__ __forceinline__ bool moved_sort_bins(P64 (&rec)[EC], const SampleLds&
     static_assert(kCapN <= CPT * NT && NT == 1024, "capacity");
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    uint64_t* wmax = reinterpret_cast<uint64_t*>(L.moved);       // [16] a wavefront's largest bin
-    uint64_t* wmin = wmax + 16;                                  // [16] its smallest
+    // [16] a wavefront's largest bin, [16] its smallest, [16] whether its bins ascend: two sets, calls alternate (`parity`) -- a round
+    // in which nothing moves leaves after barrier (1), and the fastest wavefront writes the next call's words while the slowest
+    // still reads this call's
+    uint64_t* wmax = reinterpret_cast<uint64_t*>(L.moved + ((parity & 1) ? 256 : 0));
+    uint64_t* wmin = wmax + 16;
+    uint32_t* wasc = L.moved + 320 + ((parity & 1) ? 16 : 0);
     uint32_t* wcnt = L.moved + 64;                               // [16] its bins that move
     uint32_t* cnt2 = L.moved + 80;                               // [128 + 1] bucket counts (64 + 1 in the narrow form)
     uint32_t* taken = L.moved + 210;                             // [1] places of the side-by-side array handed out so far
@@ -1730,15 +1735,30 @@ __device__ __forceinline__ bool moved_sort_bins(P64 (&rec)[EC], const SampleLds&
         sm_in = ~wave_mirror_u64(wave_shr1_u64(incl_m));
         w_lo = ~readlane_u64(incl_m, 63);
     }
-    if (lane == 0) { wmax[wave] = w_hi; wmin[wave] = w_lo; }
+    if (lane == 0) { wmax[wave] = w_hi; wmin[wave] = w_lo; wasc[wave] = wave_asc ? 1u : 0u; }
     if (tid < 129) cnt2[tid] = 0;
     if (tid == 129) *taken = 0;
     lds_barrier();                                               // (1)
     LA_CLK(7);
+    // the sixteen wavefronts' words, one read each (lane l and its copies in the other rows hold wavefront l & 15's)
+    const uint64_t hi_l = wmax[lane & 15], lo_l = wmin[lane & 15];
+    {
+        // nothing moves at all?  Every wavefront ascends and begins above the one before it: the round's bins are in order, and
+        // the round is over -- no second barrier, no counts (a topic of equal lags, a consumer group that has caught up: every round)
+        const uint32_t as_l = wasc[lane & 15];
+        const uint32_t hb_lo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)hi_l, 0x111, 0xF, 0xF, false);          // row_shr:1
+        const uint32_t hb_hi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(uint32_t)(hi_l >> 32), 0x111, 0xF, 0xF, false);
+        const uint64_t hi_before = ((uint64_t)hb_hi << 32) | hb_lo;                // (a row's first lane: zero)
+        const bool fine = as_l != 0 && hi_before < lo_l;
+        if (__builtin_amdgcn_ballot_w64(!fine) == 0) {
+            *moved_out = 0;
+            return true;
+        }
+    }
     uint64_t pm_w, sm_w;                                         // over the earlier / later wavefronts
     {
-        uint64_t a = lane < wave ? wmax[lane & 15] : 0;
-        uint64_t b = (lane > wave && lane < NT / 64) ? wmin[lane & 15] : ~0ull;
+        uint64_t a = lane < wave ? hi_l : 0;
+        uint64_t b = (lane > wave && lane < NT / 64) ? lo_l : ~0ull;
 #define LA_RED_STEP(J)                                                        \
         {                                                                     \
             const uint64_t oa_ = shfl_xor_u64<J>(a), ob_ = shfl_xor_u64<J>(b); \
@@ -1873,6 +1893,7 @@ __device__ void greedy_rounds_packed(const LargeArgs& a, const uint64_t* key, in
     [[maybe_unused]] int64_t next_moved = 2;             // the next round that looks whether few of its bins move (round 1 sorts
                                                          // what round 0 made of equal bins: every bin moves)
     [[maybe_unused]] int moved_wait = 0;
+    [[maybe_unused]] int moved_calls = 0;                // (the moved-bins sort alternates between two sets of its first words)
     const int tid_fixed = tid;
     for (int64_t q = 0; q < rounds; ++q) {
         // The thread index, opaque once per round: everything a round derives from it (lane predicates, LDS addresses, masks)
@@ -1924,7 +1945,7 @@ __device__ void greedy_rounds_packed(const LargeArgs& a, const uint64_t* key, in
                 // found more than twice what fits, the next one waits 1, 2, 4 .. 32 rounds.
                 if (use_sample && a.no_moved_sort == 0 && q >= next_moved) {
                     int moved = 0;
-                    sorted = moved_sort_bins<EC>(rec, L, tid, a.no_sample_sort == 2 ? 20u : kMovedBucket, &moved);
+                    sorted = moved_sort_bins<EC>(rec, L, tid, a.no_sample_sort == 2 ? 20u : kMovedBucket, &moved, moved_calls++);
                     moved_ = moved; if (sorted) path_ = 1;
                     if (sorted || moved <= 512 * EC) moved_wait = 0;
                     else moved_wait = moved_wait ? (moved_wait < 32 ? 2 * moved_wait : 32) : 1;
