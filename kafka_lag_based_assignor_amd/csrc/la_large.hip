@@ -1018,10 +1018,11 @@ struct RoundsIo {
     int idx_bits;          // the bins pack into (total << idx_bits) | index; 0: they do not (96-bit bins)
     bool narrow;           // 32-bit lags in, 16-bit indices out, rounds `cpad` elements apart
     int64_t cpad;          // C rounded up to a multiple of 8
+    bool zero_tail;        // the smallest lag is zero: the topic's last rounds may hand out zeros only (greedy_rounds_packed)
 };
 // only_narrow: the caller wants `narrow` alone (emit_ids_kernel, map_ranks_kernel) -- decided without a look at the keys where it can be
 __device__ __forceinline__ RoundsIo rounds_io(const LargeArgs& a, const uint64_t* key, int64_t P, int64_t C, const bool only_narrow = false) {
-    RoundsIo io{0, false, (C + 7) & ~(int64_t)7};
+    RoundsIo io{0, false, (C + 7) & ~(int64_t)7, false};
     if (P <= 0 || C <= 0) return io;
     int ec = 1, threads = 64;
     rounds_class(C, &ec, &threads);
@@ -1033,6 +1034,7 @@ __device__ __forceinline__ RoundsIo rounds_io(const LargeArgs& a, const uint64_t
     const int lag_bits = lmax > 0 ? 64 - __builtin_clzll((unsigned long long)lmax) : 0;
     const int round_bits = 64 - __builtin_clzll((unsigned long long)rounds);
     if (lmin >= 0 && lag_bits + round_bits + idx_bits <= 62) io.idx_bits = idx_bits;
+    io.zero_tail = lmin == 0;
     // (the last element written is P - 1 + 7 (rounds - 1) < 2 P: both buffers hold twice as many narrow elements as partitions)
     io.narrow = LA_ROUNDS_NARROW_IO != 0 && a.rounds_follow != 0 && io.idx_bits != 0 && ec >= LA_ROUNDS_NARROW_EC && lag_bits <= 32 && P >= 8;
     return io;
@@ -1862,7 +1864,8 @@ __device__ __forceinline__ bool moved_sort_bins(P64 (&rec)[EC], const SampleLds&
 
 template <int EC>
 __device__ void greedy_rounds_packed(const LargeArgs& a, const uint64_t* key, int64_t P, int C, int64_t rounds,
-                                     int idx_bits, void* smem, const uint32_t* lag32, uint16_t* idx16, const int64_t cpad) {
+                                     int idx_bits, void* smem, const uint32_t* lag32, uint16_t* idx16, const int64_t cpad,
+                                     const bool zero_tail) {
     const int tid = threadIdx.x;
     const int n = EC * blockDim.x;
     constexpr int kSpan = 64 * EC;                       // elements of one wavefront
@@ -1894,6 +1897,34 @@ __device__ void greedy_rounds_packed(const LargeArgs& a, const uint64_t* key, in
                                                          // what round 0 made of equal bins: every bin moves)
     [[maybe_unused]] int moved_wait = 0;
     [[maybe_unused]] int moved_calls = 0;                // (the moved-bins sort alternates between two sets of its first words)
+    // The lags descend, so a round whose FIRST lag is zero hands out zeros only, and so does every round behind it: nothing is
+    // added any more, the order the bins stand in when that round begins is final and the rounds behind it only write it down again
+    // -- no order check, no barrier.  (A consumer group that has caught up on most partitions: the long tail of a big topic's
+    // rounds.)  Which round that is, is found ONCE, before the loop -- 64 rounds probed per step by the lanes of every wavefront for
+    // itself: two or three dependent loads -- because anything added to the loop for it cost every topic (a load of the next
+    // round's first lag per round, scalar, vector or by one lane: cfg5 +7 %: one more instruction through the one compute unit's
+    // address path per wavefront and round, or a memory round trip inside the next LDS barrier's lgkmcnt(0)).
+    int64_t first_zero_round = rounds;                   // (workgroup-uniform)
+    if (zero_tail) {                                     // (the topic's smallest lag is zero at all)
+        const int lane = tid & 63;
+        int64_t lo = 0, hi = rounds;                     // rounds below lo begin with a lag > 0; round hi (if any) with zero
+        while (lo < hi) {
+            const int64_t step = (hi - lo + 63) / 64;
+            const int64_t r = lo + lane * step;
+            uint64_t first = 0;
+            if (r < hi) {
+                if (narrow) { const int64_t f = r * cpad; first = lag32[f < cap8 ? f : cap8]; }
+                else first = key[r * (int64_t)C] ^ kLagKeyFlip;
+            }
+            const uint64_t zeros = __builtin_amdgcn_ballot_w64(first == 0);      // (lanes beyond hi count as zero)
+            if (zeros == 0) { lo = lo + 63 * step + 1; continue; }                // (cannot happen while 64 * step >= hi - lo; kept for safety)
+            const int k = __builtin_ctzll(zeros);
+            hi = lo + k * step < hi ? lo + k * step : hi;
+            lo = k > 0 ? lo + (int64_t)(k - 1) * step + 1 : lo;
+            if (k == 0) hi = lo;
+        }
+        first_zero_round = lo;
+    }
     const int tid_fixed = tid;
     for (int64_t q = 0; q < rounds; ++q) {
         // The thread index, opaque once per round: everything a round derives from it (lane predicates, LDS addresses, masks)
@@ -1902,7 +1933,7 @@ __device__ void greedy_rounds_packed(const LargeArgs& a, const uint64_t* key, in
         int tid = tid_fixed;
         asm volatile("" : "+v"(tid));
         [[maybe_unused]] int path_ = 0, moved_ = 0;
-        if (q > 0) {
+        if (q > 0 && q <= first_zero_round) {
             bool sorted = false;
 #if LA_ROUND1_REVERSE
             if constexpr (EC >= 2) {
@@ -2131,7 +2162,7 @@ __global__ __launch_bounds__(1024) void greedy_rounds_kernel(LargeArgs a0, SortB
             const uint32_t other = b.ctl->cur[kFinal] ^ 1u;
             greedy_rounds_packed<EC>(a, key, P, C, rounds, io.idx_bits, smem,
                                      io.narrow ? reinterpret_cast<const uint32_t*>(key_buf(b, other)) : nullptr,
-                                     reinterpret_cast<uint16_t*>(val_buf(b, other)), io.cpad);
+                                     reinterpret_cast<uint16_t*>(val_buf(b, other)), io.cpad, io.zero_tail);
             return;
         }
     }

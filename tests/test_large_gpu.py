@@ -223,3 +223,40 @@ def test_rounds_kernel_narrow_lags_and_results(ctx, p, c, top):
     exp2 = round_form(w2.part_off, w2.partition_id, w2.lag, w2.cons_off, w2.cons_rank)
     _same3(_device_call(ctx, w2), exp2, "side by side")
     _same3(ctx.assign_batch_lags(w2.part_off, w2.partition_id, w2.lag, w2.cons_off, w2.cons_rank), exp2, "host entry")
+
+
+@pytest.mark.parametrize("p,c,nonzero,top", [
+    (100_000, 600, 0, 0),                 # every lag zero: the order of round 0 is final
+    (100_000, 600, 1, 10**6),             # one partition with a lag
+    (100_000, 600, 599, 10**6), (100_000, 600, 600, 10**6), (100_000, 600, 601, 10**6),   # the zeros begin around a round's border
+    (100_000, 600, 31_337, 10**6),        # ... in the middle of round 52
+    (100_000, 600, 99_999, 10**6),        # only the last partition has none
+    (60_000, 3000, 7000, 50),             # four bins per thread, heavy ties before the zeros
+    (200_000, 8192, 20_000, 10**6),       # the narrow form (32-bit lags in, 16-bit indices out)
+    (200_000, 8192, 20_000, 1 << 40),     # 64-bit keys
+    (200_000, 5000, 4999, 10**6),         # consumers that do not fill the slots; zeros from round 1 on
+    (9000, 8192, 100, 10**6),             # two rounds, the second partial
+])
+def test_rounds_behind_the_last_lag_only_write_the_final_order_down(ctx, p, c, nonzero, top):
+    """The lags descend: a greedy round whose first lag is zero hands out zeros only, and so does every round behind it -- the order
+    the bins stand in is final, and those rounds skip their order check (found once per topic, before the rounds; greedy_rounds_packed).
+    A consumer group that has caught up on most of a big topic's partitions.  Against the oracle, alone and inside an item launch."""
+    rng = np.random.default_rng(p + 13 * c + nonzero)
+    lag = np.zeros(p, np.int64)
+    if nonzero:
+        lag[:nonzero] = rng.integers(1, top + 1, nonzero)
+        lag = rng.permutation(lag)
+    w = _topic_with_lags(lag, c, p + c + nonzero)
+    exp = round_form(w.part_off, w.partition_id, w.lag, w.cons_off, w.cons_rank)
+    if p * c <= 300_000_000:
+        _same3(exp, oracle.assign_flat(w.part_off, w.partition_id, w.lag, w.cons_off, w.cons_rank), "round form vs literal")
+    _same3(_device_call(ctx, w), exp, "alone")
+    for fl in (N.LA_FLAG_NO_MOVED_SORT, N.LA_FLAG_SAMPLE_TIGHT):
+        _same3(_device_call(ctx, w, flags=fl), exp, "flag %d" % fl)
+    other = _batch_of([(20000, 3000), (p, c), (70000, 300)], p + 7, kinds=["u20", "u20", "zero"])
+    lag2 = other.lag.copy()
+    lag2[other.part_off[1]:other.part_off[2]] = lag
+    w2 = synth.Workload("zero tail batch", other.n_topics, other.part_off, other.partition_id, other.begin, lag2.copy(), other.committed, lag2,
+                        other.cons_off, other.cons_rank, other.max_partitions, other.max_consumers)
+    exp2 = round_form(w2.part_off, w2.partition_id, w2.lag, w2.cons_off, w2.cons_rank)
+    _same3(_device_call(ctx, w2), exp2, "side by side")
