@@ -603,6 +603,27 @@ __device__ __forceinline__ void greedy_one_wave_key32(const BlockArgs& a, uint64
     }
 }
 
+// The rounds behind a topic's last lag (block path, the two one-wavefront greedy forms that leave their winners in the slots).  The
+// sorted lags descend: from the first round whose FIRST lag is zero on, nothing is added to any bin, the order of the bins is final
+// and every further round repeats that round's winners -- a consumer group that has caught up on most of a topic's partitions runs
+// 2 of its 500 rounds.  zero = the word a lag of zero stands as (a slot: 0; a sorted key: kLagKeyFlip).  Out: *P_run = the partitions
+// the greedy has to run over (whole rounds, the first all-zero round included), *tail_from = that round's first position: position
+// i >= *P_run has the winner of position *tail_from + i % C.  Ends with a barrier (every thread of the workgroup calls it).
+__device__ __forceinline__ void zero_tail_rounds(const uint64_t* s_key, const uint64_t zero, uint32_t* s_word, const int P, const int C,
+                                                 const int tid, const int nt, int* P_run, int* tail_from) {
+    *P_run = P;
+    *tail_from = 0;
+    if (tid == 0) *s_word = (uint32_t)P;
+    lds_barrier();
+    if (s_key[P - 1] != zero) return;                                   // (workgroup-uniform) no lag of zero at all
+    for (int i = tid; i < P; i += nt)
+        if (s_key[i] == zero && (i == 0 || s_key[i - 1] != zero)) *s_word = (uint32_t)i;       // one writer: the first zero
+    lds_barrier();
+    const int z = (int)*s_word;
+    const int fz = (z + C - 1) / C;                                     // the first round that hands out zeros only
+    if ((fz + 1) * C < P) { *P_run = (fz + 1) * C; *tail_from = fz * C; }
+}
+
 // LDS byte address of a __shared__ object (what ds_* instructions take)
 __device__ __forceinline__ uint32_t lds_address(const void* p) {
     return (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) char*)p;
@@ -1061,22 +1082,25 @@ __global__ __launch_bounds__(1024) void block_topic_kernel(BlockArgs a) {
 
     // ---- greedy rounds --------------------------------------------------------------------------------
     if (slots) {
+        int P_run, tail_from;
+        zero_tail_rounds(s_key, 0ull, s_or + 3, P, C, tid, nt, &P_run, &tail_from);
         if (tid < kWave) {
             switch (n_c) {
-                case 1: greedy_one_wave_slots<1>(a, s_key, c0, P, C, idx_bits, tid); break;
-                case 2: greedy_one_wave_slots<2>(a, s_key, c0, P, C, idx_bits, tid); break;
-                case 4: greedy_one_wave_slots<4>(a, s_key, c0, P, C, idx_bits, tid); break;
-                case 8: greedy_one_wave_slots<8>(a, s_key, c0, P, C, idx_bits, tid); break;
-                case 16: greedy_one_wave_slots<16>(a, s_key, c0, P, C, idx_bits, tid); break;
-                case 32: greedy_one_wave_slots<32>(a, s_key, c0, P, C, idx_bits, tid); break;
-                default: greedy_one_wave_slots<64>(a, s_key, c0, P, C, idx_bits, tid); break;
+                case 1: greedy_one_wave_slots<1>(a, s_key, c0, P_run, C, idx_bits, tid); break;
+                case 2: greedy_one_wave_slots<2>(a, s_key, c0, P_run, C, idx_bits, tid); break;
+                case 4: greedy_one_wave_slots<4>(a, s_key, c0, P_run, C, idx_bits, tid); break;
+                case 8: greedy_one_wave_slots<8>(a, s_key, c0, P_run, C, idx_bits, tid); break;
+                case 16: greedy_one_wave_slots<16>(a, s_key, c0, P_run, C, idx_bits, tid); break;
+                case 32: greedy_one_wave_slots<32>(a, s_key, c0, P_run, C, idx_bits, tid); break;
+                default: greedy_one_wave_slots<64>(a, s_key, c0, P_run, C, idx_bits, tid); break;
             }
         }
         lds_barrier();
         LA_BCLK(4);
-        // the winners (consumer positions, low word of each slot) -> member ranks, every wavefront, coalesced
+        // the winners (consumer positions, low word of each slot) -> member ranks, every wavefront, coalesced; the rounds behind
+        // the last lag repeat the last round that ran
         const uint32_t* won = reinterpret_cast<const uint32_t*>(s_key);
-        for (int i = tid; i < P; i += nt) a.out_rank[p0 + i] = s_rank[won[2 * i]];
+        for (int i = tid; i < P; i += nt) a.out_rank[p0 + i] = s_rank[won[2 * (i < P_run ? i : tail_from + i % C)]];
         LA_BCLK(5);
         return;
     }
@@ -1095,16 +1119,17 @@ __global__ __launch_bounds__(1024) void block_topic_kernel(BlockArgs a) {
         if (packed && n_c > kWave && a.key32_greedy && (n_c == 2 * kWave || a.key32_greedy >= 2)) {
             // 128 / 256 bins: ONE wavefront, the bins stay where they are (LDS), the order comes from 32-bit keys
             if (tid == 0) s_key[P] = kLagKeyFlip;                       // "lag 0" for idle slots and rounds past the topic (P + 1: scratch)
-            lds_barrier();
+            int P_run, tail_from;
+            zero_tail_rounds(s_key, kLagKeyFlip, s_or + 3, P, C, tid, nt, &P_run, &tail_from);       // (with the barrier the sentinel needs)
             if (tid < kWave) {
-                if (n_c == 2 * kWave) greedy_one_wave_key32<2>(a, s_key, s_tot, s_idx, c0, P, C, idx_bits, lag_bits, tid);
-                else greedy_one_wave_key32<4>(a, s_key, s_tot, s_idx, c0, P, C, idx_bits, lag_bits, tid);
+                if (n_c == 2 * kWave) greedy_one_wave_key32<2>(a, s_key, s_tot, s_idx, c0, P_run, C, idx_bits, lag_bits, tid);
+                else greedy_one_wave_key32<4>(a, s_key, s_tot, s_idx, c0, P_run, C, idx_bits, lag_bits, tid);
             }
             lds_barrier();
             LA_BCLK(4);
             // the winners (consumer positions, low word of each slot) -> member ranks, every wavefront, coalesced
             const uint32_t* won = reinterpret_cast<const uint32_t*>(s_key);
-            for (int i = tid; i < P; i += nt) a.out_rank[p0 + i] = s_rank[won[2 * i]];
+            for (int i = tid; i < P; i += nt) a.out_rank[p0 + i] = s_rank[won[2 * (i < P_run ? i : tail_from + i % C)]];
             LA_BCLK(5);
             return;
         }

@@ -165,3 +165,31 @@ print("ok")
         out = subprocess.run([sys.executable, "-c", code % (ROOT, os.path.join(ROOT, "tests"))], env=env, capture_output=True,
                              text=True, timeout=600)
         assert out.returncode == 0 and "ok" in out.stdout, (mode, out.stdout[-1500:], out.stderr[-1500:])
+
+
+# ---- the rounds behind a topic's last lag (round 6: zero_tail_rounds, la_block.hip) -------------------------------------------------
+@pytest.mark.parametrize("p,c", [(8000, 16), (5000, 50), (3000, 64), (1500, 1), (10000, 128), (8000, 100), (6000, 200), (16384, 64), (2500, 7)])
+@pytest.mark.parametrize("nonzero", ["none", "one", "c-1", "c", "c+1", "mid", "p-c", "p-1"])
+def test_block_rounds_behind_the_last_lag_repeat_the_final_order(ctx, p, c, nonzero):
+    """A consumer group that has caught up on most of a topic's partitions: the sorted lags end in zeros, and from the first round
+    whose first lag is zero on every round repeats that round's winners (the two one-wavefront greedy forms that leave their
+    winners in the slots: up to 64 consumers, and 65 - 256 through 32-bit keys).  The zeros beginning at, before and behind a
+    round's border; alone, many topics in one launch, and through the host entry."""
+    k = {"none": 0, "one": 1, "c-1": c - 1, "c": c, "c+1": c + 1, "mid": (p // (2 * c)) * c + c // 2 + 1, "p-c": p - c, "p-1": p - 1}[nonzero]
+    k = max(0, min(k, p))
+    rng = np.random.default_rng(p * 7 + c + k)
+    t = 5
+    part_off = np.arange(t + 1, dtype=np.int64) * p
+    cons_off = np.arange(t + 1, dtype=np.int64) * c
+    lag = np.zeros(t * p, np.int64)
+    for i in range(t):
+        kk = k if i != 3 else max(0, k - 1)                              # (one topic a partition off)
+        seg = np.zeros(p, np.int64)
+        seg[:kk] = rng.integers(1, (1 << 30) if i % 2 else 40, kk)      # wide lags / heavy ties before the zeros
+        lag[i * p:(i + 1) * p] = rng.permutation(seg)
+    pid = np.concatenate([rng.permutation(p) for _ in range(t)]).astype(np.int32)
+    ranks = np.concatenate([np.sort(rng.choice(3 * c + 5, c, replace=False)) for _ in range(t)]).astype(np.int32)
+    exp = oracle.assign_flat(part_off, pid, lag, cons_off, ranks)
+    w = synth.Workload("caught up", t, part_off, pid, np.zeros(t * p, np.int64), lag.copy(), np.zeros(t * p, np.int64), lag, cons_off, ranks, p, c)
+    _same3(_device_call(ctx, w), exp, "device entry")
+    _same3(ctx.assign_batch_lags(part_off, pid, lag, cons_off, ranks), exp, "host entry")

@@ -15,6 +15,9 @@ def run(t, p, c, algo=N.LA_ALGO_AUTO, reps=5, lag_bits=int(__import__("os").envi
     cons_off = np.arange(t + 1, dtype=np.int64) * c
     pid = torch.argsort(torch.rand(t, p, device=dev), dim=1).to(torch.int32).reshape(-1).contiguous()
     lag = torch.randint(0, 1 << lag_bits, (n,), device=dev, dtype=torch.int64)
+    zf = float(__import__("os").environ.get("ZERO_FRAC", "0"))        # a consumer group that has caught up on this share of the partitions
+    if zf > 0:
+        lag = torch.where(torch.rand(n, device=dev) < zf, torch.zeros_like(lag), lag)
     ranks = torch.arange(c, device=dev, dtype=torch.int32).repeat(t).contiguous()
     d_po, d_co = torch.from_numpy(part_off).to(dev), torch.from_numpy(cons_off).to(dev)
     out_pid = torch.empty(n, device=dev, dtype=torch.int32); out_rank = torch.empty(n, device=dev, dtype=torch.int32)
