@@ -466,6 +466,39 @@ def run_configs(torch, N, ctx, dev, stream):
             torch.cuda.empty_cache()
         except Exception as exc:  # noqa: BLE001 -- a reported extra
             out[name] = {"error": str(exc)}
+    # The same two single-topic configs as a consumer group that has CAUGHT UP would hand them over: 99 % of the partitions with
+    # committed == end (lag 0).  Not a BASELINE row: the state big topics are in most of the time, and the one in which the rounds
+    # behind the last lag only repeat the final order (round 6).
+    caught = {}
+    for name in ("cfg2b", "cfg5"):
+        try:
+            w0 = synth.config(name)
+            rng = np.random.default_rng(99)
+            idle = rng.random(w0.n_partitions) < 0.99
+            committed = np.where(idle, w0.end, w0.committed)
+            w = synth.Workload(name + " caught up", w0.n_topics, w0.part_off, w0.partition_id, w0.begin, w0.end, committed,
+                               np.where(idle, 0, w0.lag), w0.cons_off, w0.cons_rank, w0.max_partitions, w0.max_consumers)
+            sh = DeviceShard(torch, N, dev, w, 0, w.n_topics, False, "auto")
+            set_bytes = 36 * sh.n + 8 * sh.k
+            copies = [sh] + [DeviceShard(torch, N, dev, w, 0, w.n_topics, False, "auto") for _ in range(rotation_for(set_bytes) - 1)]
+            ms, calls = timed_calls(torch, ctx, [x.batch for x in copies], stream, settle_ms=40.0)
+            if len(copies) > 1:
+                ctx.assign_batch_device(sh.batch, stream)
+                ctx.sync(stream)
+            n = sh.n
+            got = (sh.out_pid[:n].cpu().numpy(), sh.out_rank[:n].cpu().numpy(), sh.out_total[: sh.k].cpu().numpy())
+            lag = oracle.compute_lags(w.begin, w.end, w.committed, False)
+            exp = round_form(w.part_off, w.partition_id, lag, w.cons_off, w.cons_rank)
+            caught[name] = {"ms_per_call": round(ms, 5), "calls_timed": calls, "lagging_partitions": int((lag > 0).sum()),
+                            "bit_exact": bool(all(np.array_equal(g, e) for g, e in zip(got, exp))),
+                            "against": "oracle/round_form.py", "config_ms_per_call": out.get(name, {}).get("ms_per_call")}
+            del sh, copies
+            torch.cuda.empty_cache()
+        except Exception as exc:  # noqa: BLE001 -- a reported extra
+            caught[name] = {"error": str(exc)}
+    caught["what"] = ("cfg2b / cfg5 with 99 % of the partitions caught up (committed == end): the rounds behind the last lag repeat "
+                      "the final order instead of being played; config_ms_per_call = the same shape with every partition lagging")
+    out["caught_up"] = caught
     out["what"] = ("every single-GPU BASELINE.json config at full size, device-resident, earliest mode: ms per "
                    "la_assign_batch_device call from one HIP-event pair around a settled back-to-back block of calls that ROTATE "
                    "over `rotation.sets` distinct resident copies of the config (inputs and result buffers; 768 MB between two "

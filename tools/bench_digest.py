@@ -19,7 +19,11 @@ def main(path):
             print(" ", k, {a: b for a, b in v.items() if not isinstance(b, str) or a == "error"})
     cfgs = d.get("configs") or {}
     print("  configs (ms, frac, bit_exact, sha256 == frozen, copies)", {k: (v.get("ms_per_call"), v.get("frac"), v.get("bit_exact"), v.get("sha256_matches_frozen_literal_oracle"),
-                            (v.get("rotation") or {}).get("sets")) for k, v in cfgs.items() if isinstance(v, dict)})
+                            (v.get("rotation") or {}).get("sets")) for k, v in cfgs.items() if isinstance(v, dict) and k != "caught_up"})
+    cu = cfgs.get("caught_up") or {}
+    if cu:
+        print("  caught up (ms, ms with every partition lagging, bit_exact)", {k: (v.get("ms_per_call"), v.get("config_ms_per_call"), v.get("bit_exact"), v.get("error"))
+                                                                          for k, v in cu.items() if isinstance(v, dict)})
     sc = d.get("small_call") or {}
     if "rows" in sc:
         print("  small_call", [(x["partitions"], x["gpu_call_us"], x["cpu_oracle_us"]) for x in sc["rows"]],
