@@ -615,7 +615,7 @@ __device__ __forceinline__ void zero_tail_rounds(const uint64_t* s_key, const ui
     *tail_from = 0;
     if (tid == 0) *s_word = (uint32_t)P;
     lds_barrier();
-    if (s_key[P - 1] != zero) return;                                   // (workgroup-uniform) no lag of zero at all
+    if (P <= 0 || s_key[P - 1] != zero) return;                         // (workgroup-uniform) no lag of zero at all
     for (int i = tid; i < P; i += nt)
         if (s_key[i] == zero && (i == 0 || s_key[i - 1] != zero)) *s_word = (uint32_t)i;       // one writer: the first zero
     lds_barrier();
